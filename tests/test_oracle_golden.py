@@ -1,0 +1,168 @@
+"""The CPU oracle (oracle/taco_oracle.c) against the golden vectors captured from the reference's own torch
+sub-models (tests/golden/make_golden.py).  Tolerances, all stated here:
+
+  * 0 ulp (bit-exact) wherever the reference's arithmetic is +,-,*,/ only;
+  * <= 1 ulp where the reference's CPU build uses torch.sqrt (its vectorised sqrt is not correctly rounded;
+    the oracle's is);
+  * <= 5e-7 absolute on angles that go through atan2/asin/sin/cos (the oracle uses its own polynomial
+    implementations so that CPU and GPU agree bit-for-bit; they are within 2 ulp of torch's);
+  * integer done flags: exact.
+"""
+import numpy as np
+
+from oracle import oracle as O
+from util import assert_bits_equal, assert_ulp
+
+TWO_PI = np.float32(2 * np.pi)
+
+
+def test_quaternion_helpers(golden):
+    q = golden("quat")
+    assert_bits_equal(O.quat_mul(q["q"], q["p"]), q["mul"], "quat_mul TU:19-40")
+    assert_bits_equal(O.quat_rotate_inv(q["q"], q["v"]), q["rot_inv"], "quat_rotate(conj) TU:58-68")
+    conj = q["q"].copy()
+    conj[:, :3] *= -1
+    assert_bits_equal(conj, q["conj"], "quat_conjugate TU:84-88")
+    assert_bits_equal(O.quat_mul(conj, q["p"]), q["rel"], "relative_quat_body FA:356")
+    assert_bits_equal(O.quat_to_matrix(q["q"]), q["mat"], "quaternion_to_matrix TJ:389-416")
+    np.testing.assert_allclose(O.euler_xyz_v1(q["q"]), q["rpy"], rtol=0, atol=5e-7, err_msg="get_euler_xyz_v1 TU:175-196")
+    np.testing.assert_allclose(O.quat_from_euler_xyz(q["e"]), q["from_euler"], rtol=0, atol=2e-7, err_msg="quat_from_euler_xyz TU:199-213")
+    np.testing.assert_allclose(O.quat_diff_rad(q["q"], q["p"]), q["diff_rad"], rtol=0, atol=5e-7, err_msg="quat_diff_rad TJ:145-164")
+
+
+def test_rate_pid(golden):
+    p = golden("pid")
+    T, n, _ = p["des"].shape
+    prev = np.zeros((n, 3), np.float32)
+    integ = np.zeros((n, 3), np.float32)
+    for t in range(T):
+        if t == int(p["reset_step"]):
+            prev[p["reset_ids"]] = 0
+            integ[p["reset_ids"]] = 0
+        out = O.pid_step(float(p["dt"]), p["des"][t], p["cur"][t], prev, integ)
+        assert_bits_equal(out, p["out"][t], f"pid out t={t}")
+        assert_bits_equal(prev, p["prev"][t], f"pid previous_error t={t}")
+        assert_bits_equal(integ, p["integ"][t], f"pid integral t={t}")
+    # SURVEY Appendix A smoke values
+    prev = np.zeros((1, 3), np.float32); integ = np.zeros((1, 3), np.float32)
+    o1 = O.pid_step(0.001, [[1, -2, 0.5]], [[0.2, 0.1, -0.3]], prev, integ)
+    np.testing.assert_allclose(o1, [[8.8, -42.0, 64.0]], rtol=1e-6)
+    o2 = O.pid_step(0.001, [[1, -2, 0.5]], [[0.25, 0.0, -0.3]], prev, integ)
+    np.testing.assert_allclose(o2, [[-1.75, -20.0, 64.0]], rtol=1e-4)
+
+
+def test_allocator_and_real2sim(golden):
+    a = golden("alloc")
+    thr, u_after = O.allocator(a["u"])
+    assert_bits_equal(thr, a["thr"], "control_allocator CTRL/fpv_dynamics.py:35-46")
+    assert_bits_equal(u_after, a["u_after"], "u[:,3] in-place clip")
+    fs, ts = O.real2sim(a["f_real"], a["t_real"])
+    assert_bits_equal(fs, a["f_sim"], "real2sim forces")
+    assert_bits_equal(ts, a["t_sim"], "real2sim torques")
+    thr, _ = O.allocator([[500., 10, -20, 400], [900, 300, 300, 300], [50, 0, 0, 0], [1000, 0, 0, 0]])
+    np.testing.assert_array_equal(thr, [[220, 760, 280, 740], [100, 100, 100, 1000], [100] * 4, [1000] * 4])
+
+
+def test_battery(golden):
+    b = golden("battery")
+    E = b["E0"].copy(); u1 = np.zeros_like(E); t = np.zeros_like(E)
+    Vs = []
+    for k in range(b["Pm"].shape[0]):
+        Vs.append(O.battery_step(True, float(b["dt"]), b["Pm"][k], E, u1, t))
+    Vs = np.stack(Vs)[b["V_keep_idx"]]
+    assert np.isnan(b["V"]).any(), "fixture must contain the sqrt(<0) NaN case"
+    assert_ulp(Vs, b["V"], 1, "battery voltage (torch.sqrt is not correctly rounded)")
+    assert_bits_equal(E, b["E_end"], "E_c after 2000 steps")
+    assert_bits_equal(u1, b["u1_end"], "u_1 after 2000 steps")
+    assert_bits_equal(t, b["t_end"], "time after 2000 steps")
+    z = np.zeros(4, np.float32)
+    assert_bits_equal(O.battery_step(False, 0.001, np.ones(4, np.float32), z.copy(), z.copy(), z.copy()), b["V_off"], "battery off = 26.1 V")
+
+
+def test_rotor_first_order_lag(golden):
+    r = golden("rotor")
+    om = r["om0"].copy()
+    oms = []
+    for k in range(r["thr"].shape[0]):
+        O.rotor_step(r["V0"] + np.float32(0.001 * k), r["thr"][k], r["tau"], r["para"], om)
+        oms.append(om.copy())
+    assert_bits_equal(np.stack(oms)[r["keep_idx"]], r["omega"], "RotorDynamics.sim_process CTRL/thrust_dynamics.py:98-104")
+
+
+def test_aero(golden):
+    a = golden("aero")
+    rf, rt, bf = O.aero(a["cf_ct"], a["d"], a["kt"], a["vb"], a["om"])
+    assert_bits_equal(rf, a["rf"], "rotor force")
+    assert_bits_equal(rt, a["rt"], "rotor torque")
+    assert_bits_equal(bf, a["bf"], "body drag force")
+    assert not a["bt"].any()
+
+
+def test_rewards_and_done_flags(golden):
+    w = golden("reward")
+    ml = float(w["max_len"])
+    r, d = O.reward_pos(w["rel_pos_b"], w["pos"], w["q"], w["qt"], w["prog"], ml)
+    np.testing.assert_allclose(r, w["r_pos"], rtol=1e-6, atol=0)
+    np.testing.assert_array_equal(d, w["d_pos"])
+    r, d = O.reward_rotate(w["rel_pos"], w["rel_v"], w["pos"], w["q"], w["cmd"], w["prog"], ml)
+    assert_ulp(r, w["r_rot"], 2, "rotating reward")
+    np.testing.assert_array_equal(d, w["d_rot"])
+    r, d = O.reward_flip(w["rel_pos_b"], w["relq"], w["pos"], w["cmd"], w["prog"], ml)
+    assert_ulp(r, w["r_flip"], 1, "flip reward")
+    np.testing.assert_array_equal(d, w["d_flip"])
+    assert w["d_pos"].any() and not w["d_pos"].all(), "fixture must exercise both flag values"
+
+
+def test_observation_frame(golden):
+    o = golden("obs")
+    for task, key in ((0, "f_pos"), (1, "f_rot"), (2, "f_flip")):
+        fr, fc = O.obs_frame(task, o["p"], o["q"], o["v"], o["w"], o["pt"], o["qt"], o["V"], o["act"], o["cmd"], o["flip_radian"], o["roll_cont"])
+        assert_bits_equal(fr, o[key], f"26-D frame {key} FA:415-421")
+    assert_bits_equal(fc, o["flip_cmd"], "flip command FA:831-832")
+
+
+def test_rand_float_and_reset_quats(golden):
+    import math
+    r = golden("reset")
+    for col, (name, lo, hi) in enumerate((("pm2", -2.0, 2.0), ("pmpi", -math.pi, math.pi), ("u0_400", 0.0, 400.0), ("u0_2p2", 0.0, 2.2),
+                                          ("pm6", -6.0, 6.0), ("dr095", 1 - 0.05 * 0.7, 1 + 0.05 * 0.7), ("tau", 0.017 - 0.001, 0.017 + 0.001),
+                                          ("noise", 1 - 10 / 700, 1 + 10 / 700))):
+        assert_bits_equal(O.rand_float(lo, hi, r["u"][:, col]), r[name], f"torch_rand_float {name} TU:216-219")
+    z = np.zeros(len(r["e"]), np.float32)
+    np.testing.assert_allclose(O.quat_from_euler_xyz(r["e"]), r["quat_xyz"], rtol=0, atol=2e-7)
+    np.testing.assert_allclose(O.quat_from_euler_xyz(np.stack([r["e"][:, 0], z, z], 1)), r["quat_roll_only"], rtol=0, atol=2e-7)
+    np.testing.assert_allclose(O.quat_from_euler_xyz(np.stack([z, z, r["e"][:, 2]], 1)), r["quat_yaw_only"], rtol=0, atol=2e-7)
+
+
+def test_composed_substep_chain(golden):
+    """rows C -> H'' chained exactly as mid_physics_step does, over a prescribed rigid-body trajectory."""
+    c = golden("chain")
+    T, n = c["q"].shape[:2]
+    dt = float(c["dt"])
+    rpy_old = O.euler_xyz_v1(c["q"][0]); rpy_cont = rpy_old.copy()
+    prev = np.zeros((n, 3), np.float32); integ = np.zeros((n, 3), np.float32)
+    E = c["E0"].copy(); u1 = np.zeros(n, np.float32); tt = np.zeros(n, np.float32); om = c["om0"].copy()
+    for t in range(T):
+        q, v, w, a = c["q"][t], c["v"][t], c["w"][t], c["act"][t]
+        rpy = O.euler_xyz_v1(q)
+        d = rpy - rpy_old
+        d = np.where(d > 1, d - TWO_PI, d); d = np.where(d < -1, d + TWO_PI, d)
+        rpy_cont = rpy_cont + d; rpy_old = rpy
+        vb = O.quat_rotate_inv(q, v); wb = O.quat_rotate_inv(q, w)
+        u = np.zeros((n, 4), np.float32)
+        u[:, 0] = (a[:, 0] + np.float32(1)) / np.float32(2) * np.float32(1000)
+        u[:, 1:] = O.pid_step(dt, a[:, 1:] * np.float32(20), wb, prev, integ)
+        thr, u = O.allocator(u)
+        V = O.battery_step(True, dt, O.power(om), E, u1, tt)
+        O.rotor_step(V, thr, c["tau"], c["para"], om)
+        rf, rt, bf = O.aero(c["cf_ct"], c["d"], c["kt"], vb, om)
+        fs, ts = O.real2sim(rf, rt)
+        np.testing.assert_allclose(rpy, c["rpy"][t], rtol=0, atol=5e-7)
+        np.testing.assert_allclose(rpy_cont, c["rpy_cont"][t], rtol=0, atol=1e-5)
+        assert_bits_equal(vb, c["vb"][t], f"v_body t={t}"); assert_bits_equal(wb, c["wb"][t], f"w_body t={t}")
+        assert_bits_equal(u, c["u"][t], f"u t={t}"); assert_bits_equal(thr, c["thr"][t], f"throttle t={t}")
+        assert_ulp(V, c["V"][t], 1, f"V t={t}")
+        np.testing.assert_allclose(om, c["om"][t], rtol=3e-7); np.testing.assert_allclose(fs, c["f_sim"][t], rtol=6e-7)
+        np.testing.assert_allclose(ts, c["t_sim"][t], rtol=6e-7); assert_bits_equal(bf, c["body_f"][t], f"body force t={t}")
+    assert np.abs(c["rpy_cont"][-1] - c["rpy"][-1]).max() > 3, "fixture must cross the +-pi euler wrap"
+    np.testing.assert_allclose(E, c["E_end"], rtol=1e-7)
