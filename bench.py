@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the fused VecTask.step() on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one VecTask.step() of the whole batch = ONE taco_step launch through the C ABI (plus, for N > 1, the
+per-step RCCL all-gather of the packed obs|reward|done|time-out block).  Workload at N = 1: BASELINE configs[1]
+(task_mode=pos, 4 096 envs, rotor_response_time=0.017).  For N > 1 every rank holds 4 096 envs (weak scaling; global
+env ids are disjoint contiguous slices), value = N * 4096 * K / max-over-ranks time.
+Inputs (the action stream a_t = clamp(0.3 N(0,1) + (-0.45,0,0,0), -1, 1)) are resident in HBM before the timed region.
+
+Extra objects on the JSON line: "roofline" (step kernel vs HBM peak, 820 algorithmic bytes per env-step),
+"cpu_baseline" (the CPU oracle timed on this host's cores on a bounded sample; rank 0, N = 1 only), "parity"
+(HIP vs oracle on the first steps of this very workload), "large_n" (the same kernel at 262 144 envs, where the HBM
+roofline is the meaningful bound).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_ENV_STEP = 820.0   # 205 fp32 words (88 read + 117 written), len_obs = len_states = 1
+HBM_PEAK_GBPS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s"
+
+
+def make_actions(n, steps, seed, device):
+    import torch
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    a = 0.3 * torch.randn((steps, n, 4), generator=g, dtype=torch.float32)
+    a[:, :, 0] -= 0.45
+    return a.clamp_(-1, 1).to(device)
+
+
+def time_kernel_launches(env, acts, steps, torch):
+    """Average duration of the step kernel: HIP events (torch.cuda.Event on the launch stream = torch's current stream)
+    bracketing each launch; returns microseconds."""
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    na = acts.shape[0]
+    for t in range(steps):
+        starts[t].record()
+        env.step_raw(acts[t % na])
+        ends[t].record()
+    torch.cuda.synchronize()
+    d = sorted(s.elapsed_time(e) * 1e3 for s, e in zip(starts, ends))
+    return sum(d) / len(d), d[len(d) // 2]
+
+
+def cpu_baseline(cfg, budget_s=12.0):
+    """The CPU oracle (oracle/, kind 'port') on this host: all cores through OpenMP, bounded by wall time."""
+    import numpy as np
+    from taco_amd import config
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    flat = config.flat_cfg(cfg)
+    n = flat["num_envs"]
+    orc = O.OracleEnv(flat, threads=threads)
+    rng = np.random.default_rng(0)
+    acts = np.clip(0.3 * rng.standard_normal((64, n, 4)) + np.array([-0.45, 0, 0, 0]), -1, 1).astype(np.float32)
+    for t in range(5):
+        orc.step(acts[t])
+    t0 = time.perf_counter()
+    steps = 0
+    while time.perf_counter() - t0 < budget_s:
+        for _ in range(10):
+            orc.step(acts[steps % 64])
+            steps += 1
+    dt = time.perf_counter() - t0
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": f"{steps} steps x {n} envs of the same workload through the CPU oracle (OpenMP over envs), {dt:.1f} s on {model or 'host CPU'}"}
+
+
+def parity_check(cfg, steps=60):
+    import numpy as np
+    import torch
+    from taco_amd import config
+    from taco_amd.vec_env import FpvBase
+    from oracle import oracle as O
+    flat = config.flat_cfg(cfg)
+    n = flat["num_envs"]
+    env = FpvBase(cfg, copy_outputs=False)
+    orc = O.OracleEnv(flat, threads=min(os.cpu_count() or 1, 16))
+    acts = make_actions(n, steps, 1234, "cuda")
+    acts_h = acts.cpu().numpy()
+    linf = 0.0
+    flags_equal = True
+    bits_equal = True
+    for t in range(steps):
+        env.step_raw(acts[t])
+        orc.step(acts_h[t])
+        if t % 10 == 9 or t == steps - 1:
+            g = env.get_state().cpu().numpy()
+            o = orc.get_state().view(np.float32)
+            fin = np.isfinite(g[:13]) & np.isfinite(o[:13])
+            linf = max(linf, float(np.abs(g[:13] - o[:13])[fin].max()))
+            bits_equal &= bool((g.view(np.uint32) == o.view(np.uint32)).all())
+            flags_equal &= bool((env.reset_buf.cpu().numpy() == orc.reset_buf).all())
+            bits_equal &= bool((env.obs_buf.cpu().numpy().view(np.uint32) == orc.obs_buf.view(np.uint32)).all())
+            bits_equal &= bool((env.rew_buf.cpu().numpy().view(np.uint32) == orc.rew_buf.view(np.uint32)).all())
+    return {"steps": steps, "envs": n, "traj_linf_vs_oracle": linf, "done_flags_equal": flags_equal, "all_words_bit_equal": bits_equal}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU (BASELINE configs[1]: 4096)")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the per-step RCCL all-gather")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-large-n", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from taco_amd import config
+    from taco_amd.vec_env import FpvBase
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    n_local = args.envs
+    n_global = n_local * world
+    cfg = config.baseline_config(1, num_envs=n_global)
+    if world > 1:
+        from taco_amd.dist import ShardedEnv
+        env = ShardedEnv(cfg, rank=rank, world_size=world, device=dev, gather=not args.no_gather)
+        step = env.step_gathered
+    else:
+        env = FpvBase(cfg, sim_device=str(dev), rl_device=str(dev), copy_outputs=False)
+        step = env.step_raw
+    n_act = 64
+    acts = make_actions(n_local, n_act, 1000 + rank, dev)
+
+    for t in range(args.warmup):
+        step(acts[t % n_act])
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for t in range(args.steps):
+        step(acts[t % n_act])
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    value = n_global * args.steps / elapsed
+
+    out = None
+    if rank == 0:
+        base = env.env if world > 1 else env
+        k_avg_us, k_med_us = time_kernel_launches(base, acts, min(args.steps, 500), torch)
+        achieved = ALGO_BYTES_PER_ENV_STEP * n_local / (k_avg_us * 1e-6) / 1e9
+        grid, block = base.launch_geometry()
+        out = {
+            "metric": "env-steps/s at 4096 envs per GPU, fpv_asymmetry.step() hot path (task_mode=pos)",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: task_mode=pos, 4096 envs per GPU, rotor_response_time=0.017, delay_time=20, "
+                                   "dt=0.001 x 10 substeps, PhysX-substeps=2, random pose/vel/target, battery on",
+                       "envs_per_gpu": n_local, "envs_total": n_global, "parallelism": f"env-sharded x{world}",
+                       "collective": ("none" if world == 1 or args.no_gather else "1 RCCL all-gather of [obs|rew|done|timeout] per step"),
+                       "kernel": base.lib.taco_step_kernel_name().decode(), "grid": grid, "block": block},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": None, "kernel_avg_us": k_avg_us, "kernel_median_us": k_med_us,
+                         "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
+                         "note": "4096 envs = 64 wavefronts on 256 CUs: latency-bound regime, see large_n for the bandwidth regime"},
+            "gpu_event_ms_per_step": ev0.elapsed_time(ev1) / args.steps,
+        }
+        if world == 1:
+            if not args.no_large_n:
+                big_n = 262144
+                benv = FpvBase(config.baseline_config(1, num_envs=big_n), sim_device=str(dev), rl_device=str(dev), copy_outputs=False)
+                bacts = make_actions(big_n, 4, 7, dev)
+                for t in range(20):
+                    benv.step_raw(bacts[t % 4])
+                torch.cuda.synchronize()
+                b_avg, b_med = time_kernel_launches(benv, bacts, 100, torch)
+                bg, bb = benv.launch_geometry()
+                ach = ALGO_BYTES_PER_ENV_STEP * big_n / (b_avg * 1e-6) / 1e9
+                out["large_n"] = {"envs": big_n, "kernel_avg_us": b_avg, "env_steps_per_s": big_n / (b_avg * 1e-6), "achieved_GBps": ach,
+                                  "frac_of_hbm_peak": ach / HBM_PEAK_GBPS, "grid": bg, "block": bb}
+                del benv
+            out["parity"] = parity_check(config.baseline_config(1, num_envs=n_local))
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(config.baseline_config(1, num_envs=n_local))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

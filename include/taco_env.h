@@ -1,0 +1,174 @@
+/*
+ * taco_env.h -- C ABI of libtaco_env.so: the MI355X-native drop-in for the reference's fpv_asymmetry.step() hot path.
+ *
+ * What this boundary replaces in the reference (paths under yinzikang/taco):
+ *   - the Isaac Gym tensor API the task drives on every step (python/isaacgym/gymtorch.py:60-104 wrap_tensor /
+ *     unwrap_tensor over python/isaacgym/_bindings/src/gymtorch/gymtorch.cpp:33-158, and the gymapi calls
+ *     refresh_actor_root_state_tensor / apply_rigid_body_force_tensors / simulate / set_actor_root_state_tensor_indexed
+ *     at IsaacGymEnvs/isaacgymenvs/tasks/fpv_asymmetry.py:335-336, :633-635, :506-508 and
+ *     tasks/base/vec_task_asymmetry.py:313), and
+ *   - the ~2 400 per-step torch launches of fpv_asymmetry.py / tasks/control/ (SURVEY.md section 3.1),
+ * by ONE kernel launch per VecTask.step().
+ *
+ * Ownership is inverted with respect to gymtorch (where the simulator owns the memory and torch borrows it): the caller
+ * (PyTorch-ROCm, or any HIP program) allocates every buffer; the library borrows raw device pointers for the duration
+ * of a call and never allocates device memory, never synchronises the host and never calls exit().  All work is
+ * enqueued on the caller's HIP stream.  Signatures use plain pointers and sizes only (no torch types).
+ *
+ * Errors: every function returns TACO_OK (0) or a negative taco_status; taco_last_error() returns a thread-local
+ * message (the reference prints "***" messages and calls quit(), vec_task_asymmetry.py:268-270).
+ * Threading: calls on one handle are not re-entrant; different handles are independent.
+ */
+#ifndef TACO_ENV_H
+#define TACO_ENV_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TACO_ABI_VERSION 1
+
+typedef enum taco_status {
+    TACO_OK = 0,
+    TACO_ERR_INVALID_ARG = -1,  /* null pointer, bad size, unsupported cfg value */
+    TACO_ERR_HIP = -2,          /* a HIP runtime call failed; message holds hipGetErrorString */
+    TACO_ERR_WORKSPACE = -3,    /* workspace too small / misaligned */
+    TACO_ERR_STATE = -4         /* call order violated (e.g. step before init) */
+} taco_status;
+
+/* task_mode: registry keys "Fpv_pos" / "Fpv_rotate" / "Fpv_flip" / "Fpv_mix" (tasks/__init__.py:30-39) */
+enum { TACO_TASK_POS = 0, TACO_TASK_ROTATE = 1, TACO_TASK_FLIP = 2, TACO_TASK_MIX = 3 };
+
+/* One bit per boolean cfg key the hot path reads (fpv_asymmetry.py:63-112). */
+enum {
+    TACO_F_RANDOM_COPTER_POS = 1u << 0,
+    TACO_F_RANDOM_COPTER_QUAT = 1u << 1,
+    TACO_F_RANDOM_COPTER_VEL = 1u << 2,
+    TACO_F_RANDOM_TARGET_POS = 1u << 3,
+    TACO_F_RANDOM_TARGET_YAW = 1u << 4,
+    TACO_F_BATTERY_CONSUMPTION = 1u << 5,
+    TACO_F_RANDOM_VOLTAGE = 1u << 6,
+    TACO_F_ROTOR_NOISE = 1u << 7,
+    TACO_F_ROTOR_DELAY = 1u << 8,
+    TACO_F_ROTOR_RESPONSE = 1u << 9,
+    TACO_F_RANDOM_ROTORDYNAMIC_COE = 1u << 10,
+    TACO_F_RANDOM_ROTOR_DELAY = 1u << 11,
+    TACO_F_RANDOM_ROTOR_RESPONSE = 1u << 12,
+    TACO_F_RANDOM_ROTOR_SPEED = 1u << 13,
+    TACO_F_RANDOM_AERODYNAMIC_COE = 1u << 14,
+    TACO_F_RANDOM_DELAY_TIME = 1u << 15,  /* cfg key "ramdom_delay_time" (sic, fpv_asymmetry.py:89) */
+    TACO_F_RANDOM_DEPLOY_TIME = 1u << 16, /* cfg key "ramdom_deploy_time" (sic, fpv_asymmetry.py:90) */
+    TACO_F_RANDOM_COMMAND = 1u << 17,
+    TACO_F_OBSERVATION_NOISE = 1u << 18
+};
+
+typedef struct taco_cfg {
+    int32_t num_envs;         /* envs on this handle (cfg["env"]["numEnvs"], or this rank's shard of it) */
+    int32_t env_offset;       /* global id of local env 0: keys the random streams and the FpvMix thirds */
+    int32_t num_envs_global;  /* numEnvs of the whole job (fpv_asymmetry.py:924-926) */
+    int32_t task_mode;        /* TACO_TASK_* */
+    int32_t len_obs;          /* cfg["env"]["lenObservations"] */
+    int32_t len_states;       /* cfg["env"]["lenStates"] */
+    int32_t control_freq_inv; /* cfg["env"]["controlFrequencyInv"]; must be 10 (the delay line hard-codes 10 slots/action) */
+    int32_t substeps;         /* cfg["sim"]["substeps"], 1..8 */
+    int32_t max_episode_length;
+    int32_t delay_time;       /* ms, 0..90 (delay_time_max is 100, fpv_asymmetry.py:87,329) */
+    uint32_t flags;           /* TACO_F_* */
+    uint32_t _pad;
+    uint64_t seed;
+    double dt;                /* cfg["sim"]["dt"] */
+    double rotor_response_time;
+    double difficulty;        /* writable at run time through taco_set_difficulty (ppo_asymmetry.py:173-175) */
+    double clip_actions, clip_obs, clip_states; /* +inf = none (vec_task_asymmetry.py:98-100) */
+    double mass;              /* composite mass of the 9 welded bodies [kg] */
+    double inertia[3];        /* composite principal inertia about the chassis origin [kg m^2] */
+    double arm_x, arm_y;      /* rotor offsets (+-arm_x, +-arm_y) [m] (assets/xml/fpv_without_duct.xml:8-33) */
+    double gravity_z;         /* -9.81 (fpv_asymmetry.py:214-217) */
+} taco_cfg;
+
+/* ---- State blob (taco_get_state / taco_set_state; parity tests + checkpoint/restore).
+ * [TACO_BLOB_ROWS][num_envs] 32-bit words, field-major.  Rows 65 and 66 are int32, all others float.
+ * Rows 67.. are the pending-action delay line (actions_remained_buffer, fpv_asymmetry.py:189) in LOGICAL order,
+ * row = 67 + slot*4 + channel, slot 0 = the action applied in the next 1-ms substep. */
+enum {
+    TACO_S_POS = 0,        /* 3  copter position (root state 0:3)            */
+    TACO_S_QUAT = 3,       /* 4  copter attitude xyzw (3:7)                   */
+    TACO_S_LINVEL = 7,     /* 3  world-frame linear velocity (7:10)           */
+    TACO_S_ANGVEL = 10,    /* 3  world-frame angular velocity (10:13)         */
+    TACO_S_TGT_POS = 13,   /* 3                                               */
+    TACO_S_TGT_QUAT = 16,  /* 4                                               */
+    TACO_S_RPY_OLD = 20,   /* 3  copter_rpy_old                               */
+    TACO_S_RPY_CONT = 23,  /* 3  copter_rpy_continuous                        */
+    TACO_S_PID_PREV = 26,  /* 3  angvel_control.previous_error                */
+    TACO_S_PID_INT = 29,   /* 3  angvel_control.integral                      */
+    TACO_S_BAT_E = 32, TACO_S_BAT_U1 = 33, TACO_S_BAT_T = 34, TACO_S_BAT_V = 35,
+    TACO_S_OMEGA = 36,     /* 4  rotor_speed (noised value that is fed back)  */
+    TACO_S_ACT = 40,       /* 4  actions                                      */
+    TACO_S_ACT_OLD = 44,   /* 4  actions_old                                  */
+    TACO_S_CMD = 48,       /* 2  command                                      */
+    TACO_S_FLIP_RADIAN = 50,
+    TACO_S_TAU = 51,       /* 4  rotor response_time                          */
+    TACO_S_OPARA = 55,     /* 5  rotor omega_para                             */
+    TACO_S_CF = 60, TACO_S_CT = 61, TACO_S_DX = 62, TACO_S_DY = 63, TACO_S_KT = 64, /* aero parameters */
+    TACO_S_PROGRESS = 65,  /* int32 progress_buf                              */
+    TACO_S_DELAY_LEN = 66, /* int32 actions_remained_length                   */
+    TACO_NUM_FIELDS = 67,
+    TACO_RING_SLOTS = 100,
+    TACO_BLOB_ROWS = 67 + 400
+};
+
+typedef struct taco_env taco_env;
+
+/* ABI version of the loaded library (== TACO_ABI_VERSION of the header it was built from). */
+int taco_abi_version(void);
+/* Thread-local text of the last error on this thread ("" if none). */
+const char *taco_last_error(void);
+
+/* Bytes of device workspace taco_create needs for `cfg` (SoA state + delay-line ring; 256-byte aligned). */
+size_t taco_workspace_bytes(const taco_cfg *cfg);
+
+/* Replaces FpvBase.__init__ -> VecTask.__init__ -> create_sim/prepare_sim (fpv_asymmetry.py:54-200,
+ * vec_task_asymmetry.py:146-200) for the state the hot path owns.  `workspace` is caller-allocated device memory of
+ * at least taco_workspace_bytes(cfg); it is initialised asynchronously on `stream` (hipStream_t, may be NULL). */
+int taco_create(const taco_cfg *cfg, int device, void *workspace, size_t workspace_bytes, void *stream, taco_env **out);
+void taco_destroy(taco_env *env);
+
+/* Replaces VecTask.step (vec_task_asymmetry.py:290-334): reset dispatch + domain randomisation, delay line,
+ * 10 x (state refresh, rate PID, allocator, battery, rotor lag, aero, rigid-body integrate), observation/state pack,
+ * task reward, done / time-out flags.  All pointers are DEVICE pointers.
+ *   actions     [num_envs][4]            f32 in   (clamped to +-clip_actions inside)
+ *   obs_buf     [num_envs][len_obs][26]  f32 in/out  persistent frame stack, newest frame last, unclamped
+ *   states_buf  [num_envs][len_states][26] f32 in/out
+ *   rew_buf     [num_envs]               f32 out
+ *   reset_buf   [num_envs]               i64 in/out  non-zero on entry = reset this env first (ones before step 1)
+ *   timeout_buf [num_envs]               u8  out     extras["time_outs"]
+ * One kernel launch, asynchronous on `stream`; no host synchronisation. */
+int taco_step(taco_env *env, const float *actions, float *obs_buf, float *states_buf, float *rew_buf, int64_t *reset_buf,
+              uint8_t *timeout_buf, void *stream);
+
+/* Multi-GPU (no counterpart in the reference, which is single-process): bind a DEVICE block
+ * [num_envs][len_obs*26 + 3] f32 that every following taco_step also fills with (obs stack | reward | done | time-out)
+ * per env, so the host layer can publish a rank's results with ONE RCCL all-gather.  NULL unbinds. */
+int taco_bind_gather_block(taco_env *env, float *block);
+
+/* env.difficulty = x (ppo_asymmetry.py:173-175, :376); takes effect at the next taco_step. */
+int taco_set_difficulty(taco_env *env, double difficulty);
+
+/* Number of taco_step calls so far (keys the counter-based random streams); settable for checkpoint/restore. */
+int64_t taco_get_step_count(const taco_env *env);
+int taco_set_step_count(taco_env *env, int64_t n);
+
+/* Copy the per-env state to / from a DEVICE blob of TACO_BLOB_ROWS * num_envs words (layout above). */
+int taco_get_state(taco_env *env, uint32_t *blob, void *stream);
+int taco_set_state(taco_env *env, const uint32_t *blob, void *stream);
+
+/* Diagnostics for bench.py: name of the step kernel (as rocprofv3 reports it) and its launch geometry. */
+const char *taco_step_kernel_name(void);
+int taco_launch_geometry(const taco_env *env, int *grid, int *block);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TACO_ENV_H */

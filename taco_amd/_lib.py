@@ -1,0 +1,122 @@
+"""ctypes binding of libtaco_env.so (include/taco_env.h).  There is NO fallback: if the HIP library is missing or
+fails to load, importing the environment raises -- the product path is the HIP kernel or nothing."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libtaco_env.so")
+
+ABI_VERSION = 1
+NUM_FIELDS = 67
+RING_SLOTS = 100
+BLOB_ROWS = NUM_FIELDS + 4 * RING_SLOTS
+
+TASKS = {"pos": 0, "rotate": 1, "flip": 2, "mix": 3}
+FLAG_BITS = {
+    "random_copter_pos": 0, "random_copter_quat": 1, "random_copter_vel": 2, "random_target_pos": 3,
+    "random_target_yaw": 4, "battery_consumption": 5, "random_voltage": 6, "rotor_noise": 7, "rotor_delay": 8,
+    "rotor_response": 9, "random_rotordynamic_coe": 10, "random_rotor_delay": 11, "random_rotor_response": 12,
+    "random_rotor_speed": 13, "random_aerodynamic_coe": 14, "ramdom_delay_time": 15, "ramdom_deploy_time": 16,
+    "random_command": 17, "observation_noise": 18,
+}
+# every symbol include/taco_env.h declares
+EXPORTS = ["taco_abi_version", "taco_last_error", "taco_workspace_bytes", "taco_create", "taco_destroy", "taco_step",
+           "taco_bind_gather_block", "taco_set_difficulty", "taco_get_step_count", "taco_set_step_count", "taco_get_state", "taco_set_state",
+           "taco_step_kernel_name", "taco_launch_geometry"]
+
+
+class TacoCfg(C.Structure):
+    _fields_ = [
+        ("num_envs", C.c_int32), ("env_offset", C.c_int32), ("num_envs_global", C.c_int32), ("task_mode", C.c_int32),
+        ("len_obs", C.c_int32), ("len_states", C.c_int32), ("control_freq_inv", C.c_int32), ("substeps", C.c_int32),
+        ("max_episode_length", C.c_int32), ("delay_time", C.c_int32), ("flags", C.c_uint32), ("_pad", C.c_uint32),
+        ("seed", C.c_uint64), ("dt", C.c_double), ("rotor_response_time", C.c_double), ("difficulty", C.c_double),
+        ("clip_actions", C.c_double), ("clip_obs", C.c_double), ("clip_states", C.c_double), ("mass", C.c_double),
+        ("inertia", C.c_double * 3), ("arm_x", C.c_double), ("arm_y", C.c_double), ("gravity_z", C.c_double),
+    ]
+
+
+class TacoError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """dlopen libtaco_env.so and declare its prototypes; raises if the HIP extension is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TacoError(f"{LIB_PATH} is missing: build it with `python -m taco_amd.build` (hipcc, gfx950). "
+                        "There is no CPU fallback for the step path.")
+    lib = C.CDLL(LIB_PATH)
+    lib.taco_abi_version.restype = C.c_int
+    lib.taco_last_error.restype = C.c_char_p
+    lib.taco_step_kernel_name.restype = C.c_char_p
+    lib.taco_workspace_bytes.argtypes = [C.POINTER(TacoCfg)]
+    lib.taco_workspace_bytes.restype = C.c_size_t
+    lib.taco_create.argtypes = [C.POINTER(TacoCfg), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.taco_create.restype = C.c_int
+    lib.taco_destroy.argtypes = [C.c_void_p]
+    lib.taco_destroy.restype = None
+    lib.taco_step.argtypes = [C.c_void_p] * 8
+    lib.taco_step.restype = C.c_int
+    lib.taco_bind_gather_block.argtypes = [C.c_void_p, C.c_void_p]
+    lib.taco_bind_gather_block.restype = C.c_int
+    lib.taco_set_difficulty.argtypes = [C.c_void_p, C.c_double]
+    lib.taco_set_difficulty.restype = C.c_int
+    lib.taco_get_step_count.argtypes = [C.c_void_p]
+    lib.taco_get_step_count.restype = C.c_int64
+    lib.taco_set_step_count.argtypes = [C.c_void_p, C.c_int64]
+    lib.taco_set_step_count.restype = C.c_int
+    lib.taco_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.taco_get_state.restype = C.c_int
+    lib.taco_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.taco_set_state.restype = C.c_int
+    lib.taco_launch_geometry.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.taco_launch_geometry.restype = C.c_int
+    if lib.taco_abi_version() != ABI_VERSION:
+        raise TacoError(f"libtaco_env.so ABI {lib.taco_abi_version()} != binding ABI {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise TacoError(f"libtaco_env: status {rc}: {load().taco_last_error().decode()}")
+
+
+def make_cfg(d):
+    """flat dict (taco_amd.config.flat_cfg) -> TacoCfg"""
+    c = TacoCfg()
+    flags = 0
+    for k, bit in FLAG_BITS.items():
+        if d.get(k, False):
+            flags |= 1 << bit
+    c.num_envs = int(d["num_envs"])
+    c.env_offset = int(d.get("env_offset", 0))
+    c.num_envs_global = int(d.get("num_envs_global", d["num_envs"]))
+    c.task_mode = TASKS[d["task_mode"]] if isinstance(d["task_mode"], str) else int(d["task_mode"])
+    c.len_obs = int(d.get("len_obs", 1))
+    c.len_states = int(d.get("len_states", 1))
+    c.control_freq_inv = int(d.get("control_freq_inv", 10))
+    c.substeps = int(d.get("substeps", 2))
+    c.max_episode_length = int(d.get("max_episode_length", 1000))
+    c.delay_time = int(d.get("delay_time", 20))
+    c.flags = flags
+    c.seed = int(d.get("seed", 0))
+    c.dt = float(d.get("dt", 0.001))
+    c.rotor_response_time = float(d.get("rotor_response_time", 0.017))
+    c.difficulty = float(d.get("difficulty", 1.0))
+    c.clip_actions = float(d.get("clip_actions", float("inf")))
+    c.clip_obs = float(d.get("clip_obs", float("inf")))
+    c.clip_states = float(d.get("clip_states", float("inf")))
+    c.mass = float(d["mass"])
+    for i in range(3):
+        c.inertia[i] = float(d["inertia"][i])
+    c.arm_x = float(d["arm_x"])
+    c.arm_y = float(d["arm_y"])
+    c.gravity_z = float(d.get("gravity_z", -9.81))
+    return c

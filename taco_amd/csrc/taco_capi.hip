@@ -1,0 +1,263 @@
+// taco_capi.hip -- C ABI of libtaco_env.so (declared in include/taco_env.h) over the fused step kernel.
+//
+// The library never allocates device memory, never synchronises the host and never calls exit(): the caller owns every
+// buffer (PyTorch-ROCm tensors in the Python host layer), the handle only keeps the configuration, the derived fp32
+// constants and two integers that advance with every step (step counter, ring head).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "taco_step.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, const char *detail = "") {
+    std::snprintf(g_err, sizeof(g_err), fmt, detail);
+    return code;
+}
+int hip_fail(hipError_t e, const char *what) {
+    std::snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return TACO_ERR_HIP;
+}
+
+constexpr int kBlockSmall = 64;   // one wavefront per workgroup: spreads few envs over as many CUs as possible
+constexpr int kBlockLarge = 256;  // >= 64 Ki envs: 4 wavefronts per workgroup
+
+}  // namespace
+
+struct taco_env {
+    taco_cfg cfg;
+    int device;
+    int npad;
+    float *S;
+    float *ring;
+    int64_t step_count;
+    int head;  // physical ring slot of logical slot 0; advances by 10 per step (mod 100)
+    float *gather;  // optional per-rank all-gather block, see taco_bind_gather_block
+    taco::StepParams P;
+};
+
+namespace {
+
+int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+bool cfg_ok(const taco_cfg *c) {
+    if (!c) return fail(0, "cfg is null"), false;
+    if (c->num_envs <= 0) return fail(0, "num_envs must be > 0"), false;
+    if (c->env_offset < 0 || c->num_envs_global < c->env_offset + c->num_envs)
+        return fail(0, "env_offset + num_envs exceeds num_envs_global"), false;
+    if (c->task_mode < TACO_TASK_POS || c->task_mode > TACO_TASK_MIX) return fail(0, "task_mode out of range"), false;
+    if (c->len_obs < 1 || c->len_states < 1) return fail(0, "len_obs / len_states must be >= 1"), false;
+    if (c->control_freq_inv != 10) return fail(0, "control_freq_inv must be 10 (the delay line holds 10 one-ms slots per action)"), false;
+    if (c->substeps < 1 || c->substeps > 8) return fail(0, "substeps must be in 1..8"), false;
+    if (c->delay_time < 0 || c->delay_time > 90) return fail(0, "delay_time must be in 0..90 ms"), false;
+    if (c->max_episode_length < 2) return fail(0, "max_episode_length must be >= 2"), false;
+    if (!(c->dt > 0) || !(c->mass > 0) || !(c->inertia[0] > 0) || !(c->inertia[1] > 0) || !(c->inertia[2] > 0))
+        return fail(0, "dt, mass and inertia must be positive"), false;
+    return true;
+}
+
+// fp32 images of the Python-double expressions of the reference, computed in double exactly where Python would
+void derive(taco_env *e) {
+    const taco_cfg &c = e->cfg;
+    taco::StepParams &P = e->P;
+    const double d = c.difficulty;
+    P.n = c.num_envs; P.npad = e->npad; P.env_offset = c.env_offset; P.task_mode = c.task_mode;
+    P.mix_n1 = (int)((double)c.num_envs_global / 3 * 1);  // fpv_asymmetry.py:924
+    P.mix_n2 = (int)((double)c.num_envs_global / 3 * 2);  // fpv_asymmetry.py:925
+    P.len_obs = c.len_obs; P.len_states = c.len_states; P.substeps = c.substeps; P.max_len = c.max_episode_length;
+    P.delay_time = c.delay_time; P.flags = c.flags;
+    P.seed_lo = (uint32_t)c.seed; P.seed_hi = (uint32_t)(c.seed >> 32);
+    P.dt = (float)c.dt; P.clip_act = (float)c.clip_actions; P.df = (float)d;
+    P.h = (float)(c.dt / (double)c.substeps);
+    P.half_h = (float)(0.5 * (c.dt / (double)c.substeps));
+    P.inv_m = (float)(1.0 / c.mass); P.g = (float)c.gravity_z;
+    P.J0 = (float)c.inertia[0]; P.J1 = (float)c.inertia[1]; P.J2 = (float)c.inertia[2];
+    P.Ji0 = (float)(1.0 / c.inertia[0]); P.Ji1 = (float)(1.0 / c.inertia[1]); P.Ji2 = (float)(1.0 / c.inertia[2]);
+    P.arm_x = (float)c.arm_x; P.arm_y = (float)c.arm_y;
+    // torch_rand_float(lower, upper): (upper - lower) * u + lower
+    P.flip_xy_sc = (float)((0.5 + 1.5 * d) - (-0.5 - 1.5 * d)); P.flip_xy_lo = (float)(-0.5 - 1.5 * d);  // fpv_asymmetry.py:856
+    P.flip_v_sc = (float)((3 * d) - (-3 * d)); P.flip_v_lo = (float)(-3 * d);                             // :870
+    P.dr_sc = (float)((1 + 0.05 * d) - (1 - 0.05 * d)); P.dr_lo = (float)(1 - 0.05 * d);                  // thrust_dynamics.py:119, :207
+    P.tau_sc = (float)((c.rotor_response_time + 0.001) - (c.rotor_response_time - 0.001));               // thrust_dynamics.py:137
+    P.tau_lo = (float)(c.rotor_response_time - 0.001);
+    P.tau_fixed = (float)c.rotor_response_time;
+    P.nq_sc = (float)((d * 0.05) - (-(d * 0.05))); P.nq_lo = (float)(-(d * 0.05));                        // fpv_asymmetry.py:405
+}
+
+// Initial state = what the reference holds after construction, before the first step (fpv_asymmetry.py:124-200,
+// sub-model constructors): actors at (0,0,4) with identity attitude, nominal rotor / aero parameters, zero everything else.
+__global__ void init_state_kernel(float *S, float *ring, int n, int npad, float tau0, int delay_time) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npad) return;
+    for (int f = 0; f < TACO_NUM_FIELDS; ++f) S[(size_t)f * npad + i] = 0.0f;
+    for (int r = 0; r < TACO_RING_SLOTS * 4; ++r) ring[(size_t)r * npad + i] = 0.0f;
+    S[(size_t)(TACO_S_POS + 2) * npad + i] = 4.0f;
+    S[(size_t)(TACO_S_QUAT + 3) * npad + i] = 1.0f;
+    S[(size_t)(TACO_S_TGT_POS + 2) * npad + i] = 4.0f;
+    S[(size_t)(TACO_S_TGT_QUAT + 3) * npad + i] = 1.0f;
+    for (int k = 0; k < 4; ++k) S[(size_t)(TACO_S_TAU + k) * npad + i] = tau0;
+    const float opara[5] = {0.0f, 12.9466f, 0.1872f, -5.1220f, 0.5906f};
+    for (int k = 0; k < 5; ++k) S[(size_t)(TACO_S_OPARA + k) * npad + i] = opara[k];
+    S[(size_t)TACO_S_CF * npad + i] = 1.13e-05f;
+    S[(size_t)TACO_S_CT * npad + i] = 0.05f;
+    S[(size_t)TACO_S_DX * npad + i] = -0.386f;
+    S[(size_t)TACO_S_DY * npad + i] = -0.53f;
+    S[(size_t)TACO_S_KT * npad + i] = 0.009f;
+    S[(size_t)TACO_S_DELAY_LEN * npad + i] = __builtin_bit_cast(float, delay_time);
+    (void)n;
+}
+
+// blob (logical ring order, stride n) <-> workspace (physical ring order, stride npad)
+__global__ void export_state_kernel(const float *S, const float *ring, uint32_t *blob, int n, int npad, int head) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = blockIdx.y;
+    if (i >= n) return;
+    float val;
+    if (row < TACO_NUM_FIELDS) {
+        val = S[(size_t)row * npad + i];
+    } else {
+        const int r = row - TACO_NUM_FIELDS, slot = r >> 2, ch = r & 3;
+        const int ph = (head + slot) % TACO_RING_SLOTS;
+        val = ring[(size_t)(ph * 4 + ch) * npad + i];
+    }
+    blob[(size_t)row * n + i] = __builtin_bit_cast(uint32_t, val);
+}
+__global__ void import_state_kernel(float *S, float *ring, const uint32_t *blob, int n, int npad, int head) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = blockIdx.y;
+    if (i >= n) return;
+    const float val = __builtin_bit_cast(float, blob[(size_t)row * n + i]);
+    if (row < TACO_NUM_FIELDS) {
+        S[(size_t)row * npad + i] = val;
+    } else {
+        const int r = row - TACO_NUM_FIELDS, slot = r >> 2, ch = r & 3;
+        const int ph = (head + slot) % TACO_RING_SLOTS;
+        ring[(size_t)(ph * 4 + ch) * npad + i] = val;
+    }
+}
+
+int block_for(const taco_env *e) { return e->cfg.num_envs >= 65536 ? kBlockLarge : kBlockSmall; }
+
+}  // namespace
+
+extern "C" {
+
+int taco_abi_version(void) { return TACO_ABI_VERSION; }
+const char *taco_last_error(void) { return g_err; }
+const char *taco_step_kernel_name(void) { return "taco_step_kernel"; }
+
+size_t taco_workspace_bytes(const taco_cfg *cfg) {
+    if (!cfg || cfg->num_envs <= 0) return 0;
+    const size_t npad = (size_t)round_up(cfg->num_envs, 64);
+    return (size_t)(TACO_NUM_FIELDS + TACO_RING_SLOTS * 4) * npad * sizeof(float);
+}
+
+int taco_create(const taco_cfg *cfg, int device, void *workspace, size_t workspace_bytes, void *stream, taco_env **out) {
+    g_err[0] = 0;
+    if (!out) return fail(TACO_ERR_INVALID_ARG, "out is null");
+    *out = nullptr;
+    if (!cfg_ok(cfg)) return TACO_ERR_INVALID_ARG;
+    if (!workspace) return fail(TACO_ERR_WORKSPACE, "workspace is null");
+    if (workspace_bytes < taco_workspace_bytes(cfg)) return fail(TACO_ERR_WORKSPACE, "workspace smaller than taco_workspace_bytes(cfg)");
+    if (((uintptr_t)workspace & 255u) != 0) return fail(TACO_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+    hipError_t he = hipSetDevice(device);
+    if (he != hipSuccess) return hip_fail(he, "hipSetDevice");
+    taco_env *e = new (std::nothrow) taco_env();
+    if (!e) return fail(TACO_ERR_INVALID_ARG, "out of host memory");
+    e->cfg = *cfg;
+    e->device = device;
+    e->npad = round_up(cfg->num_envs, 64);
+    e->S = (float *)workspace;
+    e->ring = e->S + (size_t)TACO_NUM_FIELDS * e->npad;
+    e->step_count = 0;
+    e->head = 0;
+    e->gather = nullptr;
+    std::memset(&e->P, 0, sizeof(e->P));
+    derive(e);
+    hipLaunchKernelGGL(init_state_kernel, dim3((e->npad + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->S, e->ring, cfg->num_envs,
+                       e->npad, (float)cfg->rotor_response_time, cfg->delay_time);
+    he = hipGetLastError();
+    if (he != hipSuccess) { delete e; return hip_fail(he, "init_state_kernel launch"); }
+    *out = e;
+    return TACO_OK;
+}
+
+void taco_destroy(taco_env *env) { delete env; }
+
+int taco_step(taco_env *e, const float *actions, float *obs_buf, float *states_buf, float *rew_buf, int64_t *reset_buf,
+              uint8_t *timeout_buf, void *stream) {
+    if (!e) return fail(TACO_ERR_INVALID_ARG, "env is null");
+    if (!actions || !obs_buf || !states_buf || !rew_buf || !reset_buf || !timeout_buf)
+        return fail(TACO_ERR_INVALID_ARG, "taco_step: null buffer pointer");
+    if (((uintptr_t)actions & 15u) != 0) return fail(TACO_ERR_INVALID_ARG, "actions must be 16-byte aligned");
+    taco::StepParams P = e->P;
+    P.S = e->S; P.ring = e->ring;
+    P.act_in = actions; P.obs = obs_buf; P.states = states_buf; P.rew = rew_buf;
+    P.reset = (long long *)reset_buf; P.timeout = timeout_buf;
+    P.gather = e->gather;
+    P.step = (uint32_t)e->step_count;
+    P.head = e->head;
+    const int n = e->cfg.num_envs;
+    if (block_for(e) == kBlockLarge)
+        hipLaunchKernelGGL(taco::taco_step_kernel<kBlockLarge>, dim3((n + kBlockLarge - 1) / kBlockLarge), dim3(kBlockLarge), 0, (hipStream_t)stream, P);
+    else
+        hipLaunchKernelGGL(taco::taco_step_kernel<kBlockSmall>, dim3((n + kBlockSmall - 1) / kBlockSmall), dim3(kBlockSmall), 0, (hipStream_t)stream, P);
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) return hip_fail(he, "taco_step_kernel launch");
+    e->step_count += 1;
+    e->head = (e->head + 10) % TACO_RING_SLOTS;
+    return TACO_OK;
+}
+
+int taco_set_difficulty(taco_env *e, double difficulty) {
+    if (!e) return fail(TACO_ERR_INVALID_ARG, "env is null");
+    e->cfg.difficulty = difficulty;
+    derive(e);
+    return TACO_OK;
+}
+
+int taco_bind_gather_block(taco_env *e, float *block) {
+    if (!e) return fail(TACO_ERR_INVALID_ARG, "env is null");
+    e->gather = block;
+    return TACO_OK;
+}
+
+int64_t taco_get_step_count(const taco_env *e) { return e ? e->step_count : -1; }
+int taco_set_step_count(taco_env *e, int64_t n) {
+    if (!e || n < 0) return fail(TACO_ERR_INVALID_ARG, "taco_set_step_count: bad argument");
+    e->step_count = n;
+    return TACO_OK;
+}
+
+int taco_get_state(taco_env *e, uint32_t *blob, void *stream) {
+    if (!e || !blob) return fail(TACO_ERR_INVALID_ARG, "taco_get_state: null argument");
+    const int n = e->cfg.num_envs;
+    hipLaunchKernelGGL(export_state_kernel, dim3((n + 255) / 256, TACO_BLOB_ROWS), dim3(256), 0, (hipStream_t)stream, e->S, e->ring, blob, n,
+                       e->npad, e->head);
+    hipError_t he = hipGetLastError();
+    return he == hipSuccess ? TACO_OK : hip_fail(he, "export_state_kernel launch");
+}
+
+int taco_set_state(taco_env *e, const uint32_t *blob, void *stream) {
+    if (!e || !blob) return fail(TACO_ERR_INVALID_ARG, "taco_set_state: null argument");
+    const int n = e->cfg.num_envs;
+    hipLaunchKernelGGL(import_state_kernel, dim3((n + 255) / 256, TACO_BLOB_ROWS), dim3(256), 0, (hipStream_t)stream, e->S, e->ring, blob, n,
+                       e->npad, e->head);
+    hipError_t he = hipGetLastError();
+    return he == hipSuccess ? TACO_OK : hip_fail(he, "import_state_kernel launch");
+}
+
+int taco_launch_geometry(const taco_env *e, int *grid, int *block) {
+    if (!e || !grid || !block) return fail(TACO_ERR_INVALID_ARG, "taco_launch_geometry: null argument");
+    *block = block_for(e);
+    *grid = (e->cfg.num_envs + *block - 1) / *block;
+    return TACO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,142 @@
+// taco_math.hpp -- device-side scalar math for the fused step kernel (gfx950).
+//
+// Everything here is built from IEEE-754 fp32 +,-,*,fma, correctly rounded / and sqrt, and integer ops only, so a
+// result depends on nothing but the inputs (no ocml transcendental, no fast-math approximation instruction).  That is
+// what lets the kernel's trajectories, rewards and done flags be compared BIT-FOR-BIT with an independent CPU
+// implementation of the same published algorithms (Cephes-style single-precision kernels, Philox4x32-10).
+// The translation unit is compiled with -ffp-contract=off: an fma happens only where this file writes fma().
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace taco {
+
+#define TD __device__ __forceinline__
+
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kTwoPi = 6.28318530717958647692f;
+constexpr float kHalfPi = 1.57079632679489661923f;
+constexpr float kQuarterPi = 0.78539816339744830962f;
+
+TD float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+TD float absf(float x) { return __builtin_fabsf(x); }
+TD uint32_t bits(float f) { return __builtin_bit_cast(uint32_t, f); }
+TD float from_bits(uint32_t u) { return __builtin_bit_cast(float, u); }
+TD float with_sign_of(float mag, float sgn) { return from_bits((bits(mag) & 0x7fffffffu) | (bits(sgn) & 0x80000000u)); }
+TD float nanf32() { return from_bits(0x7fc00000u); }
+
+// torch.clamp semantics: min(max(x, lo), hi); a NaN x stays NaN
+TD float clampf(float x, float lo, float hi) {
+    float t = (x < lo) ? lo : x;
+    return (t > hi) ? hi : t;
+}
+
+// ---- sin / cos: k = rint(x * 2/pi); 3-term Cody-Waite reduction; minimax kernels on |r| <= pi/4
+TD float sin_poly(float r) {
+    float z = r * r;
+    float p = fma(fma(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    return fma(p * z, r, r);
+}
+TD float cos_poly(float r) {
+    float z = r * r;
+    float p = fma(fma(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+    return fma(p * z, z, fma(-0.5f, z, 1.0f));
+}
+TD void sincos(float x, float &s, float &c) {
+    if (!(absf(x) < 1048576.0f)) { s = c = nanf32(); return; }
+    float k = __builtin_rintf(x * 0.63661977236758134308f);
+    float r = fma(-k, 1.5703125f, x);
+    r = fma(-k, 4.837512969970703125e-4f, r);
+    r = fma(-k, 7.54978995489188216e-8f, r);
+    float sr = sin_poly(r), cr = cos_poly(r);
+    int n = (int)k & 3;
+    float ss = (n & 1) ? cr : sr;
+    float cc = (n & 1) ? sr : cr;
+    s = (n & 2) ? -ss : ss;
+    c = ((n + 1) & 2) ? -cc : cc;
+}
+
+// ---- atan2: octant reduction with one division, odd minimax polynomial on |t| <= tan(pi/8)
+TD float atan2(float y, float x) {
+    if (x != x || y != y) return nanf32();
+    float ax = absf(x), ay = absf(y);
+    float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+    float r;
+    if (mx == 0.0f) {
+        r = 0.0f;
+    } else {
+        bool big = mn > 0.41421356237309503f * mx;
+        float num = big ? mn - mx : mn;
+        float den = big ? mn + mx : mx;
+        float t = num / den;
+        float z = t * t;
+        float p = fma(fma(fma(8.05374449538e-2f, z, -1.38776856032e-1f), z, 1.99777106478e-1f), z, -3.33329491539e-1f);
+        r = fma(p * z, t, t);
+        if (big) r = kQuarterPi + r;
+    }
+    if (ay > ax) r = kHalfPi - r;
+    if (bits(x) & 0x80000000u) r = kPi - r;
+    return with_sign_of(r, y);
+}
+
+// ---- asin on [-1, 1]
+TD float asin(float x) {
+    float a = absf(x);
+    if (!(a <= 1.0f)) return nanf32();
+    bool big = a > 0.5f;
+    float z = big ? 0.5f * (1.0f - a) : a * a;
+    float s = big ? __builtin_sqrtf(z) : a;
+    float p = fma(fma(fma(fma(4.2163199048e-2f, z, 2.4181311049e-2f), z, 4.5470025998e-2f), z, 7.4953002686e-2f), z, 1.6666752422e-1f);
+    float r = fma(s * z, p, s);
+    if (big) r = kHalfPi - (r + r);
+    return with_sign_of(r, x);
+}
+
+// ---- natural log of a normal positive finite float (Box-Muller only)
+TD float log(float x) {
+    uint32_t u = bits(x);
+    int e = (int)((u >> 23) & 0xffu) - 126;
+    float m = from_bits((u & 0x007fffffu) | 0x3f000000u);
+    if (m < 0.70710678118654752440f) { e -= 1; m = m + m - 1.0f; } else { m = m - 1.0f; }
+    float z = m * m;
+    float p = 7.0376836292e-2f;
+    p = fma(p, m, -1.1514610310e-1f);
+    p = fma(p, m, 1.1676998740e-1f);
+    p = fma(p, m, -1.2420140846e-1f);
+    p = fma(p, m, 1.4249322787e-1f);
+    p = fma(p, m, -1.6668057665e-1f);
+    p = fma(p, m, 2.0000714765e-1f);
+    p = fma(p, m, -2.4999993993e-1f);
+    p = fma(p, m, 3.3333331174e-1f);
+    float fe = (float)e;
+    float y = (m * z) * p;
+    y = fma(-2.12194440e-4f, fe, y);
+    y = fma(-0.5f, z, y);
+    return fma(0.693359375f, fe, m + y);
+}
+
+// ---- Philox4x32-10 (Salmon et al., SC'11).  counter = (global env id, step index, stream, block), key = seed
+struct U4 { uint32_t x, y, z, w; };
+TD U4 philox(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        c0 = h1 ^ c1 ^ k0;
+        c1 = l1;
+        c2 = h0 ^ c3 ^ k1;
+        c3 = l0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return U4{c0, c1, c2, c3};
+}
+// 24-bit uniform in [0, 1)
+TD float uniform(uint32_t b) { return (float)(b >> 8) * 5.9604644775390625e-8f; }
+
+// norms / cross products with the accumulation shape the reference's CPU kernels use (see DESIGN.md "arithmetic")
+TD float norm2(float a, float b) { return __builtin_sqrtf(fma(b, b, a * a)); }
+TD float norm3(float a, float b, float c) { return __builtin_sqrtf(fma(c, c, fma(b, b, a * a))); }
+TD float cross_term(float a1, float b2, float a2, float b1) { return fma(a1, b2, -(a2 * b1)); }
+
+}  // namespace taco

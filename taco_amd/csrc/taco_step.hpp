@@ -1,0 +1,726 @@
+// taco_step.hpp -- the fused VecTask.step() kernel for gfx950 (MI355X).
+//
+// One lane = one env.  All persistent per-env state lives in HBM as a structure of arrays (field-major,
+// stride npad = num_envs rounded up to 64), so every state load/store of a wavefront is one fully coalesced 256-byte
+// access.  One launch performs, for every env: reset + domain randomisation (if its reset flag is set), the
+// pending-action delay line, 10 x [euler unwrap, body rates, rate PID, allocator, battery sag, rotor first-order
+// lag, aero, rigid-body integrate], then the relative state, the 26-D observation / state frames (transposed through a
+// per-wavefront LDS tile so the [env][frame][26] rows are written with coalesced stores), the task reward and the
+// done / time-out flags.  No MFMA: this is element-wise ODE integration, the largest contraction is 4x4 . 4.
+//
+// Reference lines restated by each block are cited inline (FA = isaacgymenvs/tasks/fpv_asymmetry.py,
+// VT = tasks/base/vec_task_asymmetry.py, CTRL = tasks/control/, TU = python/isaacgym/torch_utils.py,
+// TJ = isaacgymenvs/utils/torch_jit_utils.py).
+#pragma once
+#include "taco_math.hpp"
+#include "../../include/taco_env.h"
+
+namespace taco {
+
+struct StepParams {
+    // device pointers
+    float *S;            // [TACO_NUM_FIELDS][npad] state words
+    float *ring;         // [100][4][npad] pending-action ring, PHYSICAL slot order (logical slot s lives at (head+s)%100)
+    const float *act_in; // [n][4]
+    float *obs;          // [n][len_obs][26]
+    float *states;       // [n][len_states][26]
+    float *rew;          // [n]
+    long long *reset;    // [n] in/out
+    uint8_t *timeout;    // [n]
+    float *gather;       // optional [n][len_obs*26 + 3] f32: obs stack | reward | done | time-out (one all-gather block per rank)
+    // geometry / cfg
+    int n, npad, env_offset, task_mode, mix_n1, mix_n2, len_obs, len_states, substeps, max_len, delay_time, head;
+    uint32_t flags, seed_lo, seed_hi, step;
+    // fp32 images of the Python doubles the reference feeds into tensor ops
+    float dt, clip_act, df;
+    float h, half_h, inv_m, g, J0, J1, J2, Ji0, Ji1, Ji2, arm_x, arm_y;
+    float flip_xy_sc, flip_xy_lo, flip_v_sc, flip_v_lo, dr_sc, dr_lo, tau_sc, tau_lo, tau_fixed, nq_sc, nq_lo;
+};
+
+enum : uint32_t { STREAM_RESET = 1, STREAM_CMD = 2, STREAM_DEPLOY = 3, STREAM_ROTOR = 4, STREAM_OBS = 5 };
+
+struct V3 { float x, y, z; };
+struct Q4 { float x, y, z, w; };
+
+// TU:19-40 quat_mul
+TD Q4 quat_mul(Q4 a, Q4 b) {
+    float ww = (a.z + a.x) * (b.x + b.y);
+    float yy = (a.w - a.y) * (b.w + b.z);
+    float zz = (a.w + a.y) * (b.w - b.z);
+    float xx = ww + yy + zz;
+    float qq = 0.5f * (xx + (a.z - a.x) * (b.x - b.y));
+    Q4 o;
+    o.w = qq - ww + (a.z - a.y) * (b.y - b.z);
+    o.x = qq - xx + (a.x + a.w) * (b.x + b.w);
+    o.y = qq - yy + (a.w - a.x) * (b.y + b.z);
+    o.z = qq - zz + (a.z + a.y) * (b.w - b.x);
+    return o;
+}
+TD Q4 conj(Q4 q) { return Q4{-q.x, -q.y, -q.z, q.w}; }
+// TU:58-68 quat_rotate(q, v)
+TD V3 quat_rotate(Q4 q, V3 v) {
+    float s = 2.0f * (q.w * q.w) - 1.0f;
+    float cx = cross_term(q.y, v.z, q.z, v.y);
+    float cy = cross_term(q.z, v.x, q.x, v.z);
+    float cz = cross_term(q.x, v.y, q.y, v.x);
+    float dot = q.x * v.x + q.y * v.y + q.z * v.z;
+    V3 o;
+    o.x = v.x * s + cx * q.w * 2.0f + q.x * dot * 2.0f;
+    o.y = v.y * s + cy * q.w * 2.0f + q.y * dot * 2.0f;
+    o.z = v.z * s + cz * q.w * 2.0f + q.z * dot * 2.0f;
+    return o;
+}
+// TU:175-196 get_euler_xyz_v1
+TD V3 euler_xyz_v1(Q4 q) {
+    V3 e;
+    float sinr_cosp = 2.0f * (q.w * q.x + q.y * q.z);
+    float cosr_cosp = q.w * q.w - q.x * q.x - q.y * q.y + q.z * q.z;
+    e.x = atan2(sinr_cosp, cosr_cosp);
+    float sinp = 2.0f * (q.w * q.y - q.z * q.x);
+    if (absf(sinp) >= 1.0f) e.y = kHalfPi * (sinp > 0.0f ? 1.0f : (sinp < 0.0f ? -1.0f : 0.0f));
+    else e.y = asin(sinp);
+    float siny_cosp = 2.0f * (q.w * q.z + q.x * q.y);
+    float cosy_cosp = q.w * q.w + q.x * q.x - q.y * q.y - q.z * q.z;
+    e.z = atan2(siny_cosp, cosy_cosp);
+    return e;
+}
+// TU:199-213 quat_from_euler_xyz
+TD Q4 quat_from_euler(float roll, float pitch, float yaw) {
+    float cy, sy, cr, sr, cp, sp;
+    sincos(yaw * 0.5f, sy, cy);
+    sincos(roll * 0.5f, sr, cr);
+    sincos(pitch * 0.5f, sp, cp);
+    Q4 q;
+    q.w = cy * cr * cp + sy * sr * sp;
+    q.x = cy * sr * cp - sy * cr * sp;
+    q.y = cy * cr * sp + sy * sr * cp;
+    q.z = sy * cr * cp - cy * sr * sp;
+    return q;
+}
+// TJ:389-416 quaternion_to_matrix, row-major
+TD void quat_to_matrix(Q4 q, float m[9]) {
+    float i = q.x, j = q.y, k = q.z, r = q.w;
+    float two_s = 2.0f / (((i * i + j * j) + k * k) + r * r);
+    m[0] = 1.0f - two_s * (j * j + k * k);
+    m[1] = two_s * (i * j - k * r);
+    m[2] = two_s * (i * k + j * r);
+    m[3] = two_s * (i * j + k * r);
+    m[4] = 1.0f - two_s * (i * i + k * k);
+    m[5] = two_s * (j * k - i * r);
+    m[6] = two_s * (i * k - j * r);
+    m[7] = two_s * (j * k + i * r);
+    m[8] = 1.0f - two_s * (i * i + j * j);
+}
+// unwrap step of refresh_state FA:339-347
+TD void unwrap(float rpy, float &old, float &cont) {
+    float d = rpy - old;
+    d = (d > 1.0f) ? d - kTwoPi : d;
+    d = (d < -1.0f) ? d + kTwoPi : d;
+    cont = cont + d;
+    old = rpy;
+}
+// CTRL/angvel_control.py:67-88, one axis
+TD float pid_axis(float dt, float kp, float des, float cur, float &prev, float &integ) {
+    float e = clampf(des - cur, -400.0f, 400.0f);
+    float pv = (prev == 0.0f) ? e : prev;
+    float P = kp * e;
+    float I = clampf(integ + e * dt, -500.0f, 500.0f);
+    float I_term = 0.0f * I;
+    float deriv = (e - pv) / dt;
+    float D = clampf(0.5f * deriv, -150.0f, 150.0f);
+    float FF = 0.0f * des;
+    integ = I;
+    prev = e;
+    return 0.4f * (P + I_term + D + FF);
+}
+TD float two_level(float d) { return 1.0f / (1.0f + d * d) + 1.0f / (1.0f + 10.0f * d * d); }
+
+// round(N(0,1)) clamped to +-lim by inverse CDF on one uniform (distribution of FA:324 / FA:576)
+TD int rounded_normal(float u, int lim) {
+    int k = -3;
+    k += (u >= 0.0062096653f);
+    k += (u >= 0.0668072013f);
+    k += (u >= 0.3085375387f);
+    k += (u >= 0.6914624613f);
+    k += (u >= 0.9331927987f);
+    k += (u >= 0.9937903347f);
+    return k < -lim ? -lim : (k > lim ? lim : k);
+}
+
+// One gym.simulate(dt) for one free rigid body: `substeps` sub-iterations of semi-implicit Euler with the closed-form
+// quaternion update, body-frame wrench held constant (replaces VT:313 + FA:633-635; spec in DESIGN.md "row I").
+TD void integrate(const StepParams &P, V3 &p, Q4 &q, V3 &v, V3 &w, V3 F, V3 tq) {
+    for (int it = 0; it < P.substeps; ++it) {
+        float xx = q.x * q.x, yy = q.y * q.y, zz = q.z * q.z;
+        float xy = q.x * q.y, xz = q.x * q.z, yz = q.y * q.z;
+        float wx = q.w * q.x, wy = q.w * q.y, wz = q.w * q.z;
+        float R00 = fma(-2.0f, yy + zz, 1.0f), R01 = 2.0f * (xy - wz), R02 = 2.0f * (xz + wy);
+        float R10 = 2.0f * (xy + wz), R11 = fma(-2.0f, xx + zz, 1.0f), R12 = 2.0f * (yz - wx);
+        float R20 = 2.0f * (xz - wy), R21 = 2.0f * (yz + wx), R22 = fma(-2.0f, xx + yy, 1.0f);
+        float b0 = fma(R20, w.z, fma(R10, w.y, R00 * w.x));
+        float b1 = fma(R21, w.z, fma(R11, w.y, R01 * w.x));
+        float b2 = fma(R22, w.z, fma(R12, w.y, R02 * w.x));
+        float L0 = P.J0 * b0, L1 = P.J1 * b1, L2 = P.J2 * b2;
+        float g0 = fma(b1, L2, -(b2 * L1));
+        float g1 = fma(b2, L0, -(b0 * L2));
+        float g2 = fma(b0, L1, -(b1 * L0));
+        b0 = fma(P.h, P.Ji0 * (tq.x - g0), b0);
+        b1 = fma(P.h, P.Ji1 * (tq.y - g1), b1);
+        b2 = fma(P.h, P.Ji2 * (tq.z - g2), b2);
+        w.x = fma(R02, b2, fma(R01, b1, R00 * b0));
+        w.y = fma(R12, b2, fma(R11, b1, R10 * b0));
+        w.z = fma(R22, b2, fma(R21, b1, R20 * b0));
+        float a0 = fma(R02, F.z, fma(R01, F.y, R00 * F.x)) * P.inv_m;
+        float a1 = fma(R12, F.z, fma(R11, F.y, R10 * F.x)) * P.inv_m;
+        float a2 = fma(fma(R22, F.z, fma(R21, F.y, R20 * F.x)), P.inv_m, P.g);
+        v.x = fma(P.h, a0, v.x);
+        v.y = fma(P.h, a1, v.y);
+        v.z = fma(P.h, a2, v.z);
+        p.x = fma(P.h, v.x, p.x);
+        p.y = fma(P.h, v.y, p.y);
+        p.z = fma(P.h, v.z, p.z);
+        float w2 = fma(w.z, w.z, fma(w.y, w.y, w.x * w.x));
+        float A2 = (P.half_h * P.half_h) * w2;
+        float k, c;
+        if (A2 <= 0.25f) {
+            float sp = fma(fma(fma(fma(2.7557319224e-6f, A2, -1.9841269841e-4f), A2, 8.3333333333e-3f), A2, -1.6666666667e-1f), A2, 1.0f);
+            c = fma(fma(fma(fma(2.4801587302e-5f, A2, -1.3888888889e-3f), A2, 4.1666666667e-2f), A2, -0.5f), A2, 1.0f);
+            k = P.half_h * sp;
+        } else if (A2 == A2) {
+            float wn = __builtin_sqrtf(w2);
+            float s;
+            sincos(P.half_h * wn, s, c);
+            k = s / wn;
+        } else {
+            k = c = nanf32();
+        }
+        float dx = w.x * k, dy = w.y * k, dz = w.z * k;
+        float nx = fma(c, q.x, fma(dx, q.w, fma(dy, q.z, -(dz * q.y))));
+        float ny = fma(c, q.y, fma(dy, q.w, fma(dz, q.x, -(dx * q.z))));
+        float nz = fma(c, q.z, fma(dz, q.w, fma(dx, q.y, -(dy * q.x))));
+        float nw = fma(c, q.w, -fma(dx, q.x, fma(dy, q.y, dz * q.z)));
+        float n2 = fma(nw, nw, fma(nz, nz, fma(ny, ny, nx * nx)));
+        float inv;
+        if (absf(n2 - 1.0f) <= 0.015625f) {
+            float hn = 0.5f * n2;
+            float y0 = 1.5f - hn;
+            float y1 = y0 * fma(-hn, y0 * y0, 1.5f);
+            inv = y1 * fma(-hn, y1 * y1, 1.5f);
+        } else {
+            inv = 1.0f / __builtin_sqrtf(n2);
+        }
+        q.x = nx * inv; q.y = ny * inv; q.z = nz * inv; q.w = nw * inv;
+    }
+}
+
+#define SF(f) P.S[(size_t)(f) * P.npad + i]
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void taco_step_kernel(const StepParams P) {
+    constexpr int TILE_LD = 27;  // 26 + 1 pad: lane l writes words l*27+k -> bank (27l + k) % 32, conflict-free per half-wave
+    __shared__ float tile_all[BLOCK / 64][64 * TILE_LD];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    float *tile = tile_all[wv];
+    const int i_raw = blockIdx.x * BLOCK + threadIdx.x;
+    const bool active = i_raw < P.n;
+    const int i = active ? i_raw : P.n - 1;  // tail lanes shadow the last env and store nothing
+    const int gid = P.env_offset + i;
+    const uint32_t fl = P.flags;
+    const int grp = (P.task_mode != TACO_TASK_MIX) ? P.task_mode
+                    : (gid < P.mix_n1 ? TACO_TASK_POS : (gid < P.mix_n2 ? TACO_TASK_ROTATE : TACO_TASK_FLIP));
+    const bool mix = P.task_mode == TACO_TASK_MIX;
+
+    // ------------------------------------------------------------------ load state (coalesced SoA rows)
+    V3 p{SF(TACO_S_POS), SF(TACO_S_POS + 1), SF(TACO_S_POS + 2)};
+    Q4 q{SF(TACO_S_QUAT), SF(TACO_S_QUAT + 1), SF(TACO_S_QUAT + 2), SF(TACO_S_QUAT + 3)};
+    V3 v{SF(TACO_S_LINVEL), SF(TACO_S_LINVEL + 1), SF(TACO_S_LINVEL + 2)};
+    V3 w{SF(TACO_S_ANGVEL), SF(TACO_S_ANGVEL + 1), SF(TACO_S_ANGVEL + 2)};
+    V3 pt{SF(TACO_S_TGT_POS), SF(TACO_S_TGT_POS + 1), SF(TACO_S_TGT_POS + 2)};
+    Q4 qt{SF(TACO_S_TGT_QUAT), SF(TACO_S_TGT_QUAT + 1), SF(TACO_S_TGT_QUAT + 2), SF(TACO_S_TGT_QUAT + 3)};
+    float rpy_old[3], rpy_cont[3], pid_prev[3], pid_int[3], omega[4], act[4], act_old[4], tau[4], opara[5];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        rpy_old[k] = SF(TACO_S_RPY_OLD + k); rpy_cont[k] = SF(TACO_S_RPY_CONT + k);
+        pid_prev[k] = SF(TACO_S_PID_PREV + k); pid_int[k] = SF(TACO_S_PID_INT + k);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { omega[k] = SF(TACO_S_OMEGA + k); act[k] = SF(TACO_S_ACT + k); tau[k] = SF(TACO_S_TAU + k); }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) opara[k] = SF(TACO_S_OPARA + k);
+    float bat_E = SF(TACO_S_BAT_E), bat_u1 = SF(TACO_S_BAT_U1), bat_t = SF(TACO_S_BAT_T), bat_V = SF(TACO_S_BAT_V);
+    float cmd0 = SF(TACO_S_CMD), cmd1 = SF(TACO_S_CMD + 1), flip_radian = SF(TACO_S_FLIP_RADIAN);
+    float cf = SF(TACO_S_CF), ct = SF(TACO_S_CT), dx = SF(TACO_S_DX), dy = SF(TACO_S_DY), kt = SF(TACO_S_KT);
+    int progress = __builtin_bit_cast(int, SF(TACO_S_PROGRESS));
+    int dlen = __builtin_bit_cast(int, SF(TACO_S_DELAY_LEN));
+    const float4 a_in = reinterpret_cast<const float4 *>(P.act_in)[i];
+
+    // ------------------------------------------------------------------ pre_physics_step FA:317-332
+    const bool is_reset = P.reset[i] != 0;
+    const bool at_time = progress == 500;  // reset_command_condition FA:595-598, before progress is zeroed
+    if (is_reset) {
+        // ---- reset_idx FA:475-517.  37 uniforms of STREAM_RESET = 10 Philox blocks
+        float u[40];
+#pragma unroll
+        for (int b = 0; b < 10; ++b) {
+            U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, P.step, STREAM_RESET, (uint32_t)b);
+            u[4 * b] = uniform(r.x); u[4 * b + 1] = uniform(r.y); u[4 * b + 2] = uniform(r.z); u[4 * b + 3] = uniform(r.w);
+        }
+        // reset_copter_idx: FA:725-756 pos, :783-812 rotate, :850-884 flip, :981-1056 mix (pos-style ranges for all groups)
+        if (grp == TACO_TASK_FLIP && !mix) {
+            if (fl & TACO_F_RANDOM_COPTER_POS) {
+                p.x = P.flip_xy_sc * u[0] + P.flip_xy_lo;
+                p.y = P.flip_xy_sc * u[1] + P.flip_xy_lo;
+                p.z = 3.0f + P.df * (4.0f * u[2] + -2.0f);
+            } else {
+                p.x = 1.0f * u[0] + -0.5f;
+                p.y = 1.0f * u[1] + -0.5f;
+                p.z = 3.0f;
+            }
+        } else if (grp == TACO_TASK_ROTATE && !mix && !(fl & TACO_F_RANDOM_COPTER_POS)) {
+            p.x = 1.0f * u[0] + -0.5f;
+            p.y = 1.0f * u[1] + -0.5f;
+            p.z = 2.5f;
+        } else if (fl & TACO_F_RANDOM_COPTER_POS) {
+            p.x = 4.0f * u[0] + -2.0f;
+            p.y = 4.0f * u[1] + -2.0f;
+            p.z = 2.5f + (4.0f * u[2] + -2.0f);
+        } else {
+            p.x = 0.0f; p.y = 0.0f; p.z = 2.5f;
+        }
+        if (fl & TACO_F_RANDOM_COPTER_QUAT) {  // rand_quat FA:698-704 (flip: limits (pi, 0, 0))
+            const float pi_sc = (float)(3.14159265358979323846 - (-3.14159265358979323846)), pi_lo = (float)(-3.14159265358979323846);
+            float l_sc = (grp == TACO_TASK_FLIP) ? 0.0f : pi_sc;
+            float l_lo = (grp == TACO_TASK_FLIP) ? -0.0f : pi_lo;
+            q = quat_from_euler(pi_sc * u[3] + pi_lo, l_sc * u[4] + l_lo, l_sc * u[5] + l_lo);
+        } else {
+            q = Q4{0.0f, 0.0f, 0.0f, 1.0f};
+        }
+        if (grp == TACO_TASK_FLIP) {
+            if (fl & TACO_F_RANDOM_COPTER_VEL) {
+                v.x = P.flip_v_sc * u[6] + P.flip_v_lo; v.y = P.flip_v_sc * u[7] + P.flip_v_lo; v.z = P.flip_v_sc * u[8] + P.flip_v_lo;
+                w.x = 10.0f * (u[12] < 0.5f ? -1.0f : 1.0f);  // w.y, w.z keep their values (FA:876, :1047)
+            } else {
+                v = V3{0.0f, 0.0f, 0.0f};
+                if (mix) w = V3{0.0f, 0.0f, 0.0f};  // FA:1050; standalone FpvFlip leaves angvel untouched (FA:877-878)
+            }
+        } else if (fl & TACO_F_RANDOM_COPTER_VEL) {
+            v.x = 3.0f * (2.0f * u[6] + -1.0f); v.y = 3.0f * (2.0f * u[7] + -1.0f); v.z = 3.0f * (2.0f * u[8] + -1.0f);
+            w.x = 3.0f * (2.0f * u[9] + -1.0f); w.y = 3.0f * (2.0f * u[10] + -1.0f); w.z = 3.0f * (2.0f * u[11] + -1.0f);
+        } else {
+            v = V3{0.0f, 0.0f, 0.0f};
+            w = V3{0.0f, 0.0f, 0.0f};
+        }
+        V3 e0 = euler_xyz_v1(q);
+        rpy_old[0] = rpy_cont[0] = e0.x; rpy_old[1] = rpy_cont[1] = e0.y; rpy_old[2] = rpy_cont[2] = e0.z;
+        // reset_controller_idx FA:550-558
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pid_prev[k] = pid_int[k] = 0.0f;
+        bat_u1 = 0.0f; bat_t = 0.0f;
+        bat_E = (fl & TACO_F_RANDOM_VOLTAGE) ? (float)2.2 * u[17] + 0.0f : 0.0f;
+        const float opara_init[5] = {0.0f, 12.9466f, 0.1872f, -5.1220f, 0.5906f};
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            opara[k] = (fl & TACO_F_RANDOM_ROTORDYNAMIC_COE) ? opara_init[k] * (P.dr_sc * u[18 + k] + P.dr_lo) : opara_init[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (fl & TACO_F_ROTOR_RESPONSE) tau[k] = (fl & TACO_F_RANDOM_ROTOR_RESPONSE) ? P.tau_sc * u[23 + k] + P.tau_lo : P.tau_fixed * 1.0f;
+            else tau[k] = 0.001f * 1.0f;
+            omega[k] = (fl & TACO_F_RANDOM_ROTOR_SPEED) ? 400.0f * u[27 + k] + 0.0f : 0.0f;
+        }
+        if (fl & TACO_F_RANDOM_AERODYNAMIC_COE) {
+            cf = 1.13e-05f * (P.dr_sc * u[31] + P.dr_lo);
+            ct = 0.05f * (P.dr_sc * u[32] + P.dr_lo);
+            dx = -0.386f * (P.dr_sc * u[33] + P.dr_lo);
+            dy = -0.53f * (P.dr_sc * u[34] + P.dr_lo);
+            kt = 0.009f * (P.dr_sc * u[35] + P.dr_lo);
+        }
+        // reset_env_idx FA:560-581
+        bat_V = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) act[k] = 0.0f;
+        if (active) {
+            for (int s = 0; s < TACO_RING_SLOTS * 4; ++s) P.ring[(size_t)s * P.npad + i] = 0.0f;
+        }
+        if (fl & TACO_F_RANDOM_DELAY_TIME) {
+            int L = P.delay_time - rounded_normal(u[36], 3);
+            dlen = L < 0 ? 0 : L;
+        } else {
+            dlen = P.delay_time;
+        }
+        // reset_target_idx FA:523-548
+        if (fl & TACO_F_RANDOM_TARGET_POS) {
+            pt.x = P.df * (4.0f * u[13] + -2.0f);
+            pt.y = P.df * (4.0f * u[14] + -2.0f);
+            pt.z = 3.0f + P.df * (4.0f * u[15] + -2.0f);
+        } else {
+            pt = V3{0.0f, 0.0f, 3.0f};
+        }
+        const float pi_sc = (float)(3.14159265358979323846 - (-3.14159265358979323846)), pi_lo = (float)(-3.14159265358979323846);
+        float yaw = (fl & TACO_F_RANDOM_TARGET_YAW) ? pi_sc * u[16] + pi_lo : 0.0f;
+        qt = quat_from_euler(0.0f, 0.0f, yaw);
+    }
+    if (is_reset || at_time) {  // reset_command_idx: FA:758-759, :814-821, :886-917, :1058-1112
+        if (grp == TACO_TASK_POS) {
+            cmd0 = 0.0f; cmd1 = 0.0f;
+        } else {
+            U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, P.step, STREAM_CMD, 0u);
+            if (grp == TACO_TASK_ROTATE) {
+                cmd0 = 1.0f;
+                cmd1 = (fl & TACO_F_RANDOM_COMMAND) ? 12.0f * uniform(r.x) + -6.0f : 1.0f;
+            } else {
+                if (at_time) {
+                    float uu = uniform(r.y), t = 0.0f;
+                    if (uu < 1.0f / 8) t = -3.0f;
+                    if (uu >= 1.0f / 8 && uu < 2.0f / 8) t = -2.0f;
+                    if (uu >= 2.0f / 8 && uu < 3.0f / 8) t = -1.0f;
+                    if (uu >= 5.0f / 8 && uu < 6.0f / 8) t = 1.0f;
+                    if (uu >= 6.0f / 8 && uu < 7.0f / 8) t = 2.0f;
+                    if (uu >= 7.0f / 8) t = 3.0f;
+                    flip_radian = flip_radian + kTwoPi * t;
+                }
+                if (is_reset) flip_radian = (w.x > 5.0f) ? kTwoPi : -kTwoPi;
+                cmd0 = -1.0f;
+            }
+        }
+    }
+    if (is_reset) progress = 0;  // FA:510-511
+#pragma unroll
+    for (int k = 0; k < 4; ++k) act_old[k] = act[k];
+    act[0] = clampf(a_in.x, -P.clip_act, P.clip_act);  // VT:304
+    act[1] = clampf(a_in.y, -P.clip_act, P.clip_act);
+    act[2] = clampf(a_in.z, -P.clip_act, P.clip_act);
+    act[3] = clampf(a_in.w, -P.clip_act, P.clip_act);
+    int T = 10;
+    if (fl & TACO_F_RANDOM_DEPLOY_TIME) {
+        U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, P.step, STREAM_DEPLOY, 0u);
+        T = 10 - rounded_normal(uniform(r.x), 1);
+    }
+    // The 10 slots this step consumes: logical 0..9, physical (head+s)%100 -- uniform across the wave, so coalesced.
+    // Slots the write below covers are overlaid from registers instead of being re-read.
+    float ad[10][4];
+#pragma unroll
+    for (int s = 0; s < 10; ++s) {
+        int ph = P.head + s; ph = ph >= TACO_RING_SLOTS ? ph - TACO_RING_SLOTS : ph;
+        const bool fresh = (s >= dlen) && (s < dlen + T);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float old = is_reset ? 0.0f : P.ring[(size_t)(ph * 4 + k) * P.npad + i];
+            ad[s][k] = fresh ? act[k] : old;
+        }
+    }
+    if (active) {  // FA:327-330: write the action into logical slots [L, L+T) & [0,100)
+        for (int j = 0; j < 11; ++j) {
+            int sl = dlen + j;
+            if (j < T && sl < TACO_RING_SLOTS) {
+                int ph = P.head + sl; ph = ph >= TACO_RING_SLOTS ? ph - TACO_RING_SLOTS : ph;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) P.ring[(size_t)(ph * 4 + k) * P.npad + i] = act[k];
+            }
+        }
+    }
+    dlen += T;
+
+    // ------------------------------------------------------------------ 10 x (mid_physics_step + simulate) VT:309-313
+    const bool bat_on = (fl & TACO_F_BATTERY_CONSUMPTION) != 0;
+#pragma unroll 1
+    for (int ks = 0; ks < 10; ++ks) {
+        // refresh_state, the part the inner loop consumes FA:339-350
+        V3 e = euler_xyz_v1(q);
+        unwrap(e.x, rpy_old[0], rpy_cont[0]);
+        unwrap(e.y, rpy_old[1], rpy_cont[1]);
+        unwrap(e.z, rpy_old[2], rpy_cont[2]);
+        Q4 cq = conj(q);
+        V3 vb = quat_rotate(cq, v);
+        V3 wb = quat_rotate(cq, w);
+        // delayed action FA:366: slot min(L-1, ks); L >= 9 here, so only ks == 9 can be clipped (to slot 8)
+        float d0, d1, d2, d3;
+        {
+            int idx = (dlen - 1 < ks) ? dlen - 1 : ks;
+            d0 = ad[0][0]; d1 = ad[0][1]; d2 = ad[0][2]; d3 = ad[0][3];
+#pragma unroll
+            for (int s = 1; s < 10; ++s) {
+                const bool hit = idx == s;
+                d0 = hit ? ad[s][0] : d0; d1 = hit ? ad[s][1] : d1; d2 = hit ? ad[s][2] : d2; d3 = hit ? ad[s][3] : d3;
+            }
+        }
+        // angular_vel_control FA:637-650
+        float u0 = (d0 + 1.0f) / 2.0f * 1000.0f;
+        float u1 = pid_axis(P.dt, 27.5f, d1 * 20.0f, wb.x, pid_prev[0], pid_int[0]);
+        float u2 = pid_axis(P.dt, 50.0f, d2 * 20.0f, wb.y, pid_prev[1], pid_int[1]);
+        float u3 = pid_axis(P.dt, 200.0f, d3 * 20.0f, wb.z, pid_prev[2], pid_int[2]);
+        // control_allocator CTRL/fpv_dynamics.py:35-46
+        u3 = clampf(u3, -u0 / 2.0f, u0 / 2.0f);
+        float f0 = ((u0 * 1.0f + u1 * -1.0f) + u2 * 1.0f) + u3 * -1.0f;
+        float f1 = ((u0 * 1.0f + u1 * -1.0f) + u2 * -1.0f) + u3 * 1.0f;
+        float f2 = ((u0 * 1.0f + u1 * 1.0f) + u2 * -1.0f) + u3 * -1.0f;
+        float f3 = ((u0 * 1.0f + u1 * 1.0f) + u2 * 1.0f) + u3 * 1.0f;
+        float mx = f0 - 1000.0f, t1 = f1 - 1000.0f, t2 = f2 - 1000.0f, t3 = f3 - 1000.0f;
+        mx = (t1 > mx || t1 != t1) ? t1 : mx;
+        mx = (t2 > mx || t2 != t2) ? t2 : mx;
+        mx = (t3 > mx || t3 != t3) ? t3 : mx;
+        float ex = (mx < 0.0f) ? 0.0f : mx;
+        float thr[4] = {clampf(f0 - ex, 100.0f, 1000.0f), clampf(f1 - ex, 100.0f, 1000.0f), clampf(f2 - ex, 100.0f, 1000.0f),
+                        clampf(f3 - ex, 100.0f, 1000.0f)};
+        // mechanical power FA:614
+        float Pm;
+        {
+            float b = omega[0] * 2.0f * kPi / 4500.0f; Pm = 400.0f * ((b * b) * b);
+            b = omega[1] * 2.0f * kPi / 4500.0f; Pm = Pm + 400.0f * ((b * b) * b);
+            b = omega[2] * 2.0f * kPi / 4500.0f; Pm = Pm + 400.0f * ((b * b) * b);
+            b = omega[3] * 2.0f * kPi / 4500.0f; Pm = Pm + 400.0f * ((b * b) * b);
+        }
+        // Battery_Dynamics.sim_process CTRL/battery_dynamics.py:47-75
+        if (bat_on) {
+            bat_t = bat_t + P.dt;
+            float p_c = Pm / 0.75f / 9000.0f;
+            bat_E = bat_E + p_c * P.dt;
+            float P_avg = bat_E / bat_t;
+            float r0_ = 0.0015778f + -7.7608e-5f * P_avg + (float)(0.0069498 * 1500.0);
+            float r0 = (r0_ > 4.5f) ? r0_ : 4.5f;
+            float uo = 4.35f + -0.1102178f * bat_E + 0.0103368f * (bat_E * bat_E) + -4.3778e-4f * ((bat_E * bat_E) * bat_E);
+            float u1_dot = (0.00104846f * p_c - bat_u1) / 3.3f;
+            bat_u1 = bat_u1 + u1_dot * P.dt;
+            float dd = uo - bat_u1;
+            float rad = dd * dd - 4.0f * r0 * p_c;
+            bat_V = 0.5f * (dd + __builtin_sqrtf(rad)) * 6.0f;
+        } else {
+            bat_V = 4.35f * 6.0f;
+        }
+        // RotorDynamics.sim_process CTRL/thrust_dynamics.py:98-104
+        {
+            float y = (bat_V - 23.0f) / 3.0f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float x = thr[k] / 1000.0f;
+                float target = (opara[0] * 1.0f + opara[1] * x + opara[2] * y + opara[3] * (x * x) + opara[4] * x * y) * 100.0f;
+                omega[k] = omega[k] + (1.0f / tau[k]) * 0.001f * (target - omega[k]);
+            }
+        }
+        if (fl & TACO_F_ROTOR_NOISE) {  // CTRL/thrust_dynamics.py:68-78
+            U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, P.step, STREAM_ROTOR, (uint32_t)ks);
+            const float n_sc = (float)((1 + 10.0 / 700) - (1 - 10.0 / 700)), n_lo = (float)(1 - 10.0 / 700);
+            omega[0] = omega[0] * (n_sc * uniform(r.x) + n_lo);
+            omega[1] = omega[1] * (n_sc * uniform(r.y) + n_lo);
+            omega[2] = omega[2] * (n_sc * uniform(r.z) + n_lo);
+            omega[3] = omega[3] * (n_sc * uniform(r.w) + n_lo);
+        }
+        // AeroDynamics.sim_process CTRL/thrust_dynamics.py:173-199 + real->sim re-index CTRL/fpv_dynamics.py:48-56
+        float rf[4], rt[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { rf[k] = cf * omega[k] * omega[k]; rt[k] = ct * rf[k]; }
+        float vxy = norm2(vb.x, vb.y);
+        V3 F{0.0f, 0.0f, 0.0f}, tq{0.0f, 0.0f, 0.0f};
+        if (!is_reset) {  // FA:629-630
+            const float fs0 = rf[2], fs1 = rf[3], fs2 = rf[0], fs3 = rf[1];
+            const float ts0 = -rt[2], ts1 = rt[3], ts2 = -rt[0], ts3 = rt[1];
+            F.x = dx * vb.x;
+            F.y = dy * vb.y;
+            F.z = kt * vxy * vxy + ((fs0 + fs1) + (fs2 + fs3));
+            tq.x = P.arm_y * ((fs0 + fs1) - (fs2 + fs3));
+            tq.y = -P.arm_x * ((fs0 - fs1) - (fs2 - fs3));
+            tq.z = (ts0 + ts1) + (ts2 + ts3);
+        }
+        integrate(P, p, q, v, w, F, tq);
+    }
+
+    // ------------------------------------------------------------------ post_physics_step FA:374-388
+    progress += 1;
+    if (active) {
+        // FA:378 leaves logical slots [90,100) untouched by the shift.  With the ring advancing by 10 (host side), the new
+        // logical [90,100) are the physical slots just consumed, so they must be given the values of the old logical
+        // [90,100) (= new [80,90)); a slot this step's action write covered is taken from registers, not re-read.
+        const int wr_lo = dlen - T;  // the write above covered logical [wr_lo, dlen)
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            int src = P.head + 90 + j; src = src >= TACO_RING_SLOTS ? src - TACO_RING_SLOTS : src;
+            int dst = P.head + j;  // old logical j == new logical 90+j
+            dst = dst >= TACO_RING_SLOTS ? dst - TACO_RING_SLOTS : dst;
+            const bool fresh = (90 + j >= wr_lo) && (90 + j < dlen);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float old = P.ring[(size_t)(src * 4 + k) * P.npad + i];
+                P.ring[(size_t)(dst * 4 + k) * P.npad + i] = fresh ? act[k] : old;
+            }
+        }
+    }
+    dlen = dlen - 10 < 0 ? 0 : dlen - 10;
+    {
+        V3 e = euler_xyz_v1(q);
+        unwrap(e.x, rpy_old[0], rpy_cont[0]);
+        unwrap(e.y, rpy_old[1], rpy_cont[1]);
+        unwrap(e.z, rpy_old[2], rpy_cont[2]);
+    }
+    // relative quantities FA:354-360 (target velocities are identically zero)
+    const Q4 cq = conj(q);
+    const V3 rel_pos{pt.x - p.x, pt.y - p.y, pt.z - p.z};
+    const V3 rel_v{0.0f - v.x, 0.0f - v.y, 0.0f - v.z};
+    const V3 rel_w{0.0f - w.x, 0.0f - w.y, 0.0f - w.z};
+    const V3 rel_pos_b = quat_rotate(cq, rel_pos);
+    const Q4 rel_q_b = quat_mul(cq, qt);
+    const V3 rel_v_b = quat_rotate(cq, rel_v);
+    const V3 rel_w_b = quat_rotate(cq, rel_w);
+    if (grp == TACO_TASK_FLIP) cmd1 = clampf(flip_radian - rpy_cont[0], -kTwoPi, kTwoPi);  // FA:831-832 / :930-931
+
+    // 26-D frame FA:415-421 + task tails
+    float fr[26];
+    float m[9];
+    quat_to_matrix(rel_q_b, m);
+    const float tilt00 = m[0];  // R00 of the noise-free relative attitude: the flip reward's x_tiltage
+    fr[0] = rel_pos_b.x / 3.0f; fr[1] = rel_pos_b.y / 3.0f; fr[2] = rel_pos_b.z / 3.0f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) fr[3 + k] = m[k];
+    fr[12] = rel_v_b.x / 2.0f; fr[13] = rel_v_b.y / 2.0f; fr[14] = rel_v_b.z / 2.0f;
+    fr[15] = rel_w_b.x / kPi; fr[16] = rel_w_b.y / kPi; fr[17] = rel_w_b.z / kPi;
+    fr[18] = (bat_V - 23.0f) / 3.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) fr[19 + k] = act[k];
+    fr[23] = 4.0f * clampf(p.z, 0.0f, 0.5f) - 1.0f;
+    fr[24] = cmd0;
+    fr[25] = (grp == TACO_TASK_POS) ? cmd1 : (grp == TACO_TASK_ROTATE ? cmd1 / 6.0f : cmd1 / 2.0f / kPi);
+
+    // ---- frame stacks: rows of this wave's 64 envs are contiguous -> stream them as one flat range.
+    // word d of the range belongs to env d / row, offset j = d % row; j < row-26 is history (old word d+26), the
+    // rest is the new frame, read back from the LDS tile (transposes lane-major registers into env-major rows).
+    const int wave_env0 = blockIdx.x * BLOCK + wv * 64;
+    const int wave_envs = (P.n - wave_env0) < 64 ? (P.n - wave_env0) : 64;  // may be <= 0 for a fully idle wave
+    auto stream_rows = [&](float *buf, int len, float *mirror, int mirror_row) {
+        const int row = len * 26, hist = row - 26;
+        const int total = wave_envs * row;
+        float *base = buf + (size_t)wave_env0 * row;
+        float *mbase = mirror ? mirror + (size_t)wave_env0 * mirror_row : nullptr;
+        int d = lane;
+        int env = 0, j = lane;
+        while (j >= row) { j -= row; ++env; }
+        for (; d < total; d += 64) {
+            float val = (j < hist) ? base[d + 26] : tile[env * TILE_LD + (j - hist)];
+            base[d] = val;
+            if (mbase) mbase[env * mirror_row + j] = val;
+            j += 64;
+            while (j >= row) { j -= row; ++env; }
+        }
+    };
+    // states first (noise-free frame), then obs (possibly noised)
+#pragma unroll
+    for (int k = 0; k < 26; ++k) tile[lane * TILE_LD + k] = fr[k];
+    __syncthreads();
+    stream_rows(P.states, P.len_states, nullptr, 0);
+    __syncthreads();
+    if (fl & TACO_F_OBSERVATION_NOISE) {  // FA:402-410
+        float nrm[12];
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr) {  // uniforms 4..15 of STREAM_OBS = blocks 1..3, two Box-Muller pairs per block
+            U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, P.step, STREAM_OBS, (uint32_t)(1 + pr));
+            float ua = 1.0f - uniform(r.x), ub = uniform(r.y);
+            float rad = __builtin_sqrtf(-2.0f * log(ua));
+            float sn, cs;
+            sincos(kTwoPi * ub, sn, cs);
+            nrm[4 * pr] = rad * cs; nrm[4 * pr + 1] = rad * sn;
+            ua = 1.0f - uniform(r.z); ub = uniform(r.w);
+            rad = __builtin_sqrtf(-2.0f * log(ua));
+            sincos(kTwoPi * ub, sn, cs);
+            nrm[4 * pr + 2] = rad * cs; nrm[4 * pr + 3] = rad * sn;
+        }
+        U4 r0 = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, P.step, STREAM_OBS, 0u);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) fr[k] = fr[k] + P.df * (nrm[k] * (float)(0.06 / 3 / 3) + 0.0f);
+        Q4 nq = quat_from_euler(P.nq_sc * uniform(r0.x) + P.nq_lo, P.nq_sc * uniform(r0.y) + P.nq_lo, P.nq_sc * uniform(r0.z) + P.nq_lo);
+        quat_to_matrix(quat_mul(rel_q_b, nq), m);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) fr[3 + k] = m[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) fr[12 + k] = fr[12 + k] + P.df * (nrm[3 + k] * (float)(0.1 / 3 / 2) + 0.0f);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) fr[15 + k] = fr[15 + k] + P.df * (nrm[6 + k] * (float)(60.0 / 3 / 180) + 0.0f);
+        fr[18] = fr[18] + P.df * (nrm[9] * (float)(0.06 / 3) + 0.0f);
+        fr[23] = fr[23] + P.df * (nrm[10] * (float)(0.06 / 3 / 3) + 0.0f);
+#pragma unroll
+        for (int k = 0; k < 26; ++k) tile[lane * TILE_LD + k] = fr[k];
+        __syncthreads();
+    }
+    const int gather_row = P.len_obs * 26 + 3;
+    stream_rows(P.obs, P.len_obs, P.gather, gather_row);
+
+    // ------------------------------------------------------------------ compute_reward CTRL/task_reward.py
+    float rew, pos_dist;
+    if (grp == TACO_TASK_POS) {  // :20-47
+        pos_dist = norm3(rel_pos_b.x, rel_pos_b.y, rel_pos_b.z);
+        float pr = 1.0f / (1.0f + pos_dist * pos_dist) + 1.0f / (1.0f + 10.0f * pos_dist * pos_dist);
+        Q4 mq = quat_mul(q, conj(qt));  // quat_diff_rad TJ:145-164
+        float nn = norm3(mq.x, mq.y, mq.z);
+        nn = (nn > 1.0f) ? 1.0f : nn;
+        float qd = 2.0f * asin(nn);
+        float rr = 1.0f / (1.0f + qd * qd) + 1.0f / (1.0f + 10.0f * qd * qd);
+        rew = pr * rr / 100.0f;
+    } else if (grp == TACO_TASK_ROTATE) {  // :50-104
+        float nx0 = -rel_pos.x, nx1 = -rel_pos.y, nx2 = 0.0f;
+        float nn = norm3(nx0, nx1, nx2) + 1e-8f;
+        nx0 = nx0 / nn; nx1 = nx1 / nn; nx2 = nx2 / nn;
+        float ny0 = cross_term(0.0f, nx2, 1.0f, nx1), ny1 = cross_term(1.0f, nx0, 0.0f, nx2), ny2 = cross_term(0.0f, nx1, 0.0f, nx0);
+        float yn = norm3(ny0, ny1, ny2) + 1e-8f;
+        ny0 = ny0 / yn; ny1 = ny1 / yn; ny2 = ny2 / yn;
+        float hori = norm2(rel_pos.x, rel_pos.y) - 1.2f;
+        float vert = absf(rel_pos.z);
+        pos_dist = __builtin_sqrtf(hori * hori + vert * vert);
+        float pr = 1.0f / (1.0f + pos_dist * pos_dist) + 1.0f / (1.0f + 10.0f * pos_dist * pos_dist);
+        float normal = (rel_v.x * nx0 + rel_v.y * nx1) + rel_v.z * nx2;
+        float tang = (rel_v.x * ny0 + rel_v.y * ny1) + rel_v.z * ny2;
+        float ld = norm3(normal - 0.0f, tang - cmd1, rel_v.z - 0.0f);
+        float lr = 1.0f / (1.0f + ld * ld) + 1.0f / (1.0f + 10.0f * ld * ld);
+        float hm[9];
+        quat_to_matrix(q, hm);
+        float ddir = 1.0f + (nx0 * hm[0] + nx1 * hm[3]) / norm2(hm[0], hm[3]);
+        float dr = 1.0f / (1.0f + ddir * ddir) + 1.0f / (1.0f + 10.0f * ddir * ddir);
+        rew = pr * lr * dr / 100.0f;
+    } else {  // :107-143
+        pos_dist = norm3(rel_pos_b.x, rel_pos_b.y, rel_pos_b.z);
+        float pr = 1.0f / (1.0f + 1.0f * pos_dist) + 1.0f / (1.0f + 10.0f * pos_dist);
+        float xr = 1.0f / (1.0f + 10.0f * (1.0f - tilt00));
+        float cd = cmd1 / 2.0f / kPi;
+        float cr = 1.0f / (1.0f + cd * cd) + 1.0f / (1.0f + 10.0f * cd * cd);
+        rew = pr * xr * cr / 100.0f;
+    }
+    long long die = 0;
+    if (p.z < 0.1f) die = 1;
+    if (pos_dist > 10.0f) die = 1;
+    const float max_len_f = (float)P.max_len;
+    const long long rs = ((float)progress >= max_len_f - 1.0f) ? 1 : die;
+    const bool tmo = (progress >= P.max_len - 1) && (rs != 0);  // VT:323
+
+    // ------------------------------------------------------------------ store
+    if (active) {
+        P.rew[i] = rew;
+        P.reset[i] = rs;
+        P.timeout[i] = tmo ? 1 : 0;
+        if (P.gather) {
+            float *gr = P.gather + (size_t)i * gather_row + (gather_row - 3);
+            gr[0] = rew; gr[1] = (float)rs; gr[2] = tmo ? 1.0f : 0.0f;
+        }
+        SF(TACO_S_POS) = p.x; SF(TACO_S_POS + 1) = p.y; SF(TACO_S_POS + 2) = p.z;
+        SF(TACO_S_QUAT) = q.x; SF(TACO_S_QUAT + 1) = q.y; SF(TACO_S_QUAT + 2) = q.z; SF(TACO_S_QUAT + 3) = q.w;
+        SF(TACO_S_LINVEL) = v.x; SF(TACO_S_LINVEL + 1) = v.y; SF(TACO_S_LINVEL + 2) = v.z;
+        SF(TACO_S_ANGVEL) = w.x; SF(TACO_S_ANGVEL + 1) = w.y; SF(TACO_S_ANGVEL + 2) = w.z;
+        if (is_reset) {
+            SF(TACO_S_TGT_POS) = pt.x; SF(TACO_S_TGT_POS + 1) = pt.y; SF(TACO_S_TGT_POS + 2) = pt.z;
+            SF(TACO_S_TGT_QUAT) = qt.x; SF(TACO_S_TGT_QUAT + 1) = qt.y; SF(TACO_S_TGT_QUAT + 2) = qt.z; SF(TACO_S_TGT_QUAT + 3) = qt.w;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) SF(TACO_S_TAU + k) = tau[k];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) SF(TACO_S_OPARA + k) = opara[k];
+            SF(TACO_S_CF) = cf; SF(TACO_S_CT) = ct; SF(TACO_S_DX) = dx; SF(TACO_S_DY) = dy; SF(TACO_S_KT) = kt;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            SF(TACO_S_RPY_OLD + k) = rpy_old[k]; SF(TACO_S_RPY_CONT + k) = rpy_cont[k];
+            SF(TACO_S_PID_PREV + k) = pid_prev[k]; SF(TACO_S_PID_INT + k) = pid_int[k];
+        }
+        SF(TACO_S_BAT_E) = bat_E; SF(TACO_S_BAT_U1) = bat_u1; SF(TACO_S_BAT_T) = bat_t; SF(TACO_S_BAT_V) = bat_V;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { SF(TACO_S_OMEGA + k) = omega[k]; SF(TACO_S_ACT + k) = act[k]; SF(TACO_S_ACT_OLD + k) = act_old[k]; }
+        SF(TACO_S_CMD) = cmd0; SF(TACO_S_CMD + 1) = cmd1; SF(TACO_S_FLIP_RADIAN) = flip_radian;
+        SF(TACO_S_PROGRESS) = __builtin_bit_cast(float, progress);
+        SF(TACO_S_DELAY_LEN) = __builtin_bit_cast(float, dlen);
+    }
+}
+
+}  // namespace taco

@@ -1,0 +1,207 @@
+"""Python host layer: the reference's VecTask surface over the HIP step library.
+
+Mirrors what the PPO loop sees of `FpvBase(VecTask)` (fpv_asymmetry.py:34-211, vec_task_asymmetry.py:48-139, :231-254,
+:290-375): constructor signature, `num_envs / num_obs / len_obs / num_states / len_states / num_acts`,
+`observation_space / state_space / action_space`, writable `difficulty`, `obs_buf / states_buf / rew_buf / reset_buf /
+progress_buf / timeout_buf`, `reset()`, `step()`, `reset_done()`, `reset_idx()`.
+
+PyTorch is plumbing here: it owns device memory (the library borrows `data_ptr()`s) and provides the stream.  Every
+`step()` is ONE kernel launch through the C ABI; there is no torch fallback for the arithmetic.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import flat_cfg
+
+
+class Box:
+    """Three-attribute stand-in for gym.spaces.Box (gym is not a dependency of the hot path)."""
+
+    def __init__(self, low, high):
+        self.low = np.asarray(low, dtype=np.float32)
+        self.high = np.asarray(high, dtype=np.float32)
+        self.shape = self.low.shape
+
+    def __repr__(self):
+        return f"Box{self.shape}"
+
+
+def _stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class FpvBase:
+    """Vectorised FPV environment; subclasses only fix `task_mode` (registry names of tasks/__init__.py:30-39)."""
+
+    task_mode = None
+    num_commands = 2
+
+    def __init__(self, cfg, rl_device="cuda:0", sim_device="cuda:0", graphics_device_id=-1, headless=True,
+                 virtual_screen_capture=False, force_render=False, env_offset=0, num_envs_local=None, copy_outputs=True):
+        self.cfg = cfg
+        if self.task_mode is not None:
+            cfg["task_mode"] = self.task_mode
+        self.lib = _lib.load()  # raises if libtaco_env.so is missing: no fallback
+        self.device = torch.device(sim_device)
+        if self.device.type != "cuda":
+            raise _lib.TacoError("the step kernel runs on an MI355X; sim_device must be a cuda:N (HIP) device")
+        self.rl_device = torch.device(rl_device)
+        self.headless = headless
+        self.copy_outputs = copy_outputs
+        self._flat = flat_cfg(cfg, env_offset=env_offset, num_envs_local=num_envs_local)
+        self._c = _lib.make_cfg(self._flat)
+
+        env = cfg["env"]
+        self.num_envs = self._c.num_envs
+        self.num_envs_global = self._c.num_envs_global
+        self.env_offset = self._c.env_offset
+        self.num_agents = 1
+        self.num_acts = self.num_actions = env["numActions"] = 4
+        self.num_obs = env["numObservations"] = 18 + 1 + self.num_acts + 1 + self.num_commands  # 26, fpv_asymmetry.py:107
+        self.num_states = env["numStates"] = self.num_obs
+        self.len_obs = self._c.len_obs
+        self.len_states = self._c.len_states
+        self.control_freq_inv = self._c.control_freq_inv
+        self.max_episode_length = self._c.max_episode_length
+        self.clip_obs = env.get("clipObservations", math.inf)
+        self.clip_states = env.get("clipStates", math.inf)
+        self.clip_actions = env.get("clipActions", math.inf)
+        self.dt = self._c.dt
+        self.obs_space = Box(np.full((self.len_obs, self.num_obs), -np.inf), np.full((self.len_obs, self.num_obs), np.inf))
+        self.state_space = Box(np.full((self.len_states, self.num_states), -np.inf), np.full((self.len_states, self.num_states), np.inf))
+        self.act_space = Box(-np.ones(self.num_acts), np.ones(self.num_acts))
+
+        # allocate_buffers, vec_task_asymmetry.py:231-254
+        dev = self.device
+        self.obs_buf = torch.zeros((self.num_envs, self.len_obs, self.num_obs), device=dev, dtype=torch.float32)
+        self.states_buf = torch.zeros((self.num_envs, self.len_states, self.num_states), device=dev, dtype=torch.float32)
+        self.rew_buf = torch.zeros(self.num_envs, device=dev, dtype=torch.float32)
+        self.reset_buf = torch.ones(self.num_envs, device=dev, dtype=torch.long)
+        self.timeout_buf = torch.zeros(self.num_envs, device=dev, dtype=torch.bool)
+        self.extras = {}
+        self.obs_dict = {}
+
+        nbytes = self.lib.taco_workspace_bytes(C.byref(self._c))
+        self._workspace = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        self._h = C.c_void_p()
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.taco_create(C.byref(self._c), dev.index or 0, C.c_void_p(self._workspace.data_ptr()), nbytes,
+                                            _stream_ptr(dev), C.byref(self._h)))
+        self._difficulty = float(cfg["difficulty"])
+
+    # ---- spaces / attributes the callers read (train_fpv_asymmetry_ppo.py:372-393, ppo_asymmetry.py:42-52)
+    @property
+    def observation_space(self):
+        return self.obs_space
+
+    @property
+    def action_space(self):
+        return self.act_space
+
+    @property
+    def difficulty(self):
+        return self._difficulty
+
+    @difficulty.setter
+    def difficulty(self, value):  # ppo_asymmetry.py:173-175 writes env.difficulty every epoch
+        self._difficulty = float(value)
+        self.cfg["difficulty"] = self._difficulty
+        _lib.check(self.lib.taco_set_difficulty(self._h, self._difficulty))
+
+    @property
+    def progress_buf(self):
+        return self.get_state()[_lib.NUM_FIELDS - 2].view(torch.int32).to(torch.long)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self.lib.taco_destroy(h)
+            self._h = None
+
+    # ---- VecTask API
+    def _outputs(self):
+        obs = torch.clamp(self.obs_buf, -self.clip_obs, self.clip_obs) if (self.copy_outputs or math.isfinite(self.clip_obs)) else self.obs_buf
+        st = torch.clamp(self.states_buf, -self.clip_states, self.clip_states) if (self.copy_outputs or math.isfinite(self.clip_states)) else self.states_buf
+        self.obs_dict["obs"] = obs.to(self.rl_device)
+        self.obs_dict["states"] = st.to(self.rl_device)
+        return self.obs_dict
+
+    def reset(self):
+        """vec_task_asymmetry.py:352-361: returns the (zero) buffers; the real reset happens inside the first step()."""
+        return self._outputs()
+
+    def step_raw(self, actions):
+        """One taco_step launch on the current stream; updates obs_buf/states_buf/rew_buf/reset_buf/timeout_buf in place."""
+        if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.device != self.device:
+            actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
+        if actions.shape != (self.num_envs, self.num_acts):
+            raise ValueError(f"actions must be [{self.num_envs}, {self.num_acts}], got {tuple(actions.shape)}")
+        rc = self.lib.taco_step(self._h, actions.data_ptr(), self.obs_buf.data_ptr(), self.states_buf.data_ptr(), self.rew_buf.data_ptr(),
+                                self.reset_buf.data_ptr(), self.timeout_buf.data_ptr(), _stream_ptr(self.device).value)
+        _lib.check(rc)
+
+    def step(self, actions):
+        """vec_task_asymmetry.py:290-334."""
+        self.step_raw(actions)
+        self.extras["time_outs"] = self.timeout_buf.to(self.rl_device)
+        return self._outputs(), self.rew_buf.to(self.rl_device), self.reset_buf.to(self.rl_device), self.extras
+
+    def reset_idx(self, env_ids):
+        """Mark envs for reset; like the reference, the re-initialisation itself runs at the start of the next step()."""
+        self.reset_buf[env_ids] = 1
+
+    def reset_done(self):
+        """vec_task_asymmetry.py:363-375 (reset itself is deferred to the next step, see reset_idx)."""
+        done_env_ids = self.reset_buf.nonzero(as_tuple=False).flatten()
+        return self._outputs(), done_env_ids
+
+    def zero_actions(self):
+        return torch.zeros((self.num_envs, self.num_acts), dtype=torch.float32, device=self.rl_device)
+
+    # ---- state blob (parity tests, checkpoint / restore)
+    def get_state(self):
+        blob = torch.empty((_lib.BLOB_ROWS, self.num_envs), device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.taco_get_state(self._h, blob.data_ptr(), _stream_ptr(self.device).value))
+        return blob
+
+    def set_state(self, blob):
+        blob = blob.to(device=self.device).contiguous()
+        assert blob.shape == (_lib.BLOB_ROWS, self.num_envs) and blob.element_size() == 4
+        _lib.check(self.lib.taco_set_state(self._h, blob.data_ptr(), _stream_ptr(self.device).value))
+
+    @property
+    def step_count(self):
+        return self.lib.taco_get_step_count(self._h)
+
+    @step_count.setter
+    def step_count(self, n):
+        _lib.check(self.lib.taco_set_step_count(self._h, int(n)))
+
+    def launch_geometry(self):
+        g, b = C.c_int(), C.c_int()
+        _lib.check(self.lib.taco_launch_geometry(self._h, C.byref(g), C.byref(b)))
+        return g.value, b.value
+
+
+class FpvPos(FpvBase):
+    task_mode = "pos"
+
+
+class FpvRotate(FpvBase):
+    task_mode = "rotate"
+
+
+class FpvFlip(FpvBase):
+    task_mode = "flip"
+
+
+class FpvMix(FpvBase):
+    task_mode = "mix"
+
+
+# tasks/__init__.py:30-39
+isaacgym_task_map = {"Fpv_pos": FpvPos, "Fpv_rotate": FpvRotate, "Fpv_flip": FpvFlip, "Fpv_mix": FpvMix}

@@ -1,0 +1,108 @@
+"""GPU parity: the HIP step kernel (through the C ABI / taco_amd.vec_env) against the CPU oracle on identical seeded
+inputs.  Bar: every state word, observation, reward and flag BIT-EXACT after every step (the kernel and the oracle
+implement the same IEEE-754 operation sequence; see DESIGN.md "arithmetic contract").  The north-star tolerance
+(trajectory L-inf <= 1e-5 over 1 000 steps, integer flags exact) is asserted as well, as the weaker documented bar.
+"""
+import numpy as np
+import pytest
+import torch
+
+from taco_amd import config
+from util import assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def action_stream(n, steps, seed):
+    """a_t = clamp(0.3*N(0,1) + (-0.45,0,0,0), -1, 1)"""
+    rng = np.random.default_rng(seed)
+    a = 0.3 * rng.standard_normal((steps, n, 4)).astype(np.float32)
+    a[:, :, 0] -= 0.45
+    return np.clip(a, -1, 1).astype(np.float32)
+
+
+def run_pair(cfg, steps, seed=0, check_every=1, hover_bias=False):
+    from oracle import oracle as O
+    from taco_amd.vec_env import FpvBase
+    flat = config.flat_cfg(cfg)
+    n = flat["num_envs"]
+    env = FpvBase(cfg, copy_outputs=False)
+    orc = O.OracleEnv(flat, threads=8)
+    acts = action_stream(n, steps, seed)
+    if hover_bias:
+        acts[:, :, 0] = np.clip(acts[:, :, 0] + 0.25, -1, 1)
+    acts_d = torch.from_numpy(acts).cuda()
+    max_err = 0.0
+    n_done = 0
+    for t in range(steps):
+        env.step_raw(acts_d[t])
+        orc.step(acts[t])
+        if t % check_every == 0 or t == steps - 1:
+            what = f"step {t}"
+            assert_bits_equal(env.reset_buf.cpu().numpy(), orc.reset_buf, what + " reset_buf")
+            assert_bits_equal(env.timeout_buf.cpu().numpy().astype(np.uint8), orc.timeout_buf, what + " timeout_buf")
+            assert_bits_equal(env.rew_buf.cpu().numpy(), orc.rew_buf, what + " rew_buf")
+            assert_bits_equal(env.obs_buf.cpu().numpy(), orc.obs_buf, what + " obs_buf")
+            assert_bits_equal(env.states_buf.cpu().numpy(), orc.states_buf, what + " states_buf")
+            gb = env.get_state().cpu().numpy()
+            ob = orc.get_state().view(np.float32)
+            assert_bits_equal(gb.view(np.uint32)[65:67], ob.view(np.uint32)[65:67], what + " progress / delay length")
+            assert_bits_equal(gb[:65], ob[:65], what + " state fields")
+            assert_bits_equal(gb[67:], ob[67:], what + " delay line")
+            fin = np.isfinite(ob[:13]) & np.isfinite(gb[:13])
+            max_err = max(max_err, float(np.abs(gb[:13] - ob[:13])[fin].max()))
+        n_done += int(orc.reset_buf.sum())
+    assert max_err <= 1e-5, "north-star bar: root-state trajectory L-inf <= 1e-5"
+    return n_done
+
+
+def test_pos_plumbing_config0():
+    """BASELINE configs[0]: pos, 64 envs, all randomisation off, battery off."""
+    run_pair(config.baseline_config(0), steps=300)
+
+
+def test_pos_config1_4096_envs_1000_steps():
+    """BASELINE configs[1] at full size, 1 000 steps (north-star horizon); episodes end and re-randomise on the way."""
+    done = run_pair(config.baseline_config(1), steps=1000, check_every=50)
+    assert done > 1000, "the run must exercise resets"
+
+
+def test_rotate_config2():
+    run_pair(config.baseline_config(2, num_envs=1024), steps=600, check_every=25, hover_bias=True)
+
+
+def test_flip_config3():
+    run_pair(config.baseline_config(3, num_envs=1024), steps=600, check_every=25, hover_bias=True)
+
+
+def test_mix_all_randomisation_config4():
+    """BASELINE configs[4] flags: every random_* on, observation/rotor noise, random delay + deploy time, lenStates 5;
+    1 000 envs so the thirds are uneven (333/666)."""
+    run_pair(config.baseline_config(4, num_envs=1000), steps=700, check_every=25, hover_bias=True)
+
+
+def test_ragged_sizes_and_large_block():
+    for n in (1, 63, 65, 200):
+        run_pair(config.baseline_config(1, num_envs=n), steps=40)
+    run_pair(config.baseline_config(4, num_envs=65536 + 77), steps=12, check_every=4)  # 256-thread workgroups, ragged tail
+
+
+def test_clipping_and_substeps():
+    cfg = config.baseline_config(1, num_envs=256)
+    cfg["env"]["clipActions"] = 0.5
+    cfg["sim"]["substeps"] = 4
+    cfg["env"]["maxEpisodeLength"] = 120
+    cfg["env"]["lenObservations"] = 3
+    cfg["env"]["lenStates"] = 2
+    run_pair(cfg, steps=260)
+
+
+def test_delay_line_overflow_regime():
+    """delay_time = 85 with random deploy time: L + T crosses 100, the mask write is truncated and the stale tail of the
+    dense buffer is read (SURVEY section 7 'delay-line overflow').  The ring must reproduce the dense buffer exactly."""
+    cfg = config.baseline_config(1, num_envs=512)
+    cfg["delay_time"] = 85
+    cfg["ramdom_deploy_time"] = True
+    cfg["ramdom_delay_time"] = True
+    from oracle import oracle as O
+    run_pair(cfg, steps=400, check_every=10, hover_bias=True)
