@@ -1,0 +1,92 @@
+"""The C-ABI shared library: loads without a GPU, exports every symbol include/taco_env.h declares, agrees with the
+ctypes binding on struct layout, and reports argument errors through status codes + taco_last_error (no compute calls)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+from taco_amd import _lib, config
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "taco_env.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from taco_amd import build
+    build.build()
+    return _lib.load()
+
+
+def declared_functions():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(taco_[a-z_]+)\s*\(", txt)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = declared_functions()
+    assert len(names) >= 13
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/taco_env.h but not exported"
+    assert sorted(_lib.EXPORTS) == names, "binding list out of sync with the header"
+    assert lib.taco_abi_version() == 1
+    assert lib.taco_step_kernel_name() == b"taco_step_kernel"
+
+
+def test_struct_layout_matches_the_header():
+    """compile a 10-line C program against the header and compare sizeof/offsetof with the ctypes Structure"""
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "taco_env.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu %d %d\n", sizeof(taco_cfg), offsetof(taco_cfg, flags), offsetof(taco_cfg, seed), offsetof(taco_cfg, dt),
+         offsetof(taco_cfg, mass), offsetof(taco_cfg, inertia), offsetof(taco_cfg, gravity_z), TACO_NUM_FIELDS, TACO_BLOB_ROWS);
+  return 0; }'''
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "t.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "t")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", exe, c])
+        got = [int(x) for x in subprocess.check_output([exe]).split()]
+    T = _lib.TacoCfg
+    assert got == [C.sizeof(T), T.flags.offset, T.seed.offset, T.dt.offset, T.mass.offset, T.inertia.offset, T.gravity_z.offset,
+                   _lib.NUM_FIELDS, _lib.BLOB_ROWS]
+
+
+def test_workspace_size_and_argument_errors(lib):
+    c = _lib.make_cfg(config.flat_cfg(config.baseline_config(1)))
+    assert lib.taco_workspace_bytes(C.byref(c)) == (67 + 400) * 4096 * 4
+    c65 = _lib.make_cfg(config.flat_cfg(config.baseline_config(1, num_envs=65)))
+    assert lib.taco_workspace_bytes(C.byref(c65)) == (67 + 400) * 128 * 4      # padded to whole wavefronts
+    assert lib.taco_workspace_bytes(None) == 0
+    h = C.c_void_p()
+    # invalid configuration / workspace are rejected before any HIP call
+    bad = _lib.make_cfg(dict(config.flat_cfg(config.baseline_config(1)), control_freq_inv=4))
+    assert lib.taco_create(C.byref(bad), 0, None, 0, None, C.byref(h)) == -1
+    assert b"control_freq_inv" in lib.taco_last_error()
+    assert lib.taco_create(C.byref(c), 0, None, 0, None, C.byref(h)) == -3
+    assert b"workspace" in lib.taco_last_error() and not h.value
+    assert lib.taco_create(C.byref(c), 0, C.c_void_p(256), 16, None, C.byref(h)) == -3
+    assert lib.taco_step(None, None, None, None, None, None, None, None) == -1
+    assert lib.taco_set_difficulty(None, 1.0) == -1
+    assert lib.taco_get_step_count(None) == -1
+    with pytest.raises(_lib.TacoError):
+        _lib.check(lib.taco_get_state(None, None, None))
+
+
+def test_product_does_not_reach_into_the_oracle():
+    """the product tree must never import, include or link anything under oracle/"""
+    pkg = os.path.join(ROOT, "taco_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f"{f} imports oracle"
+                assert "oracle/" not in txt and "taco_oracle" not in txt, f"{f} refers to oracle/"
+    out = subprocess.check_output(["ldd", _lib.LIB_PATH]).decode()
+    assert "oracle" not in out

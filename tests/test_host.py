@@ -1,0 +1,81 @@
+"""Host-side logic that needs no GPU: config authoring / flattening, sharding arithmetic, gather block packing,
+and the 'fail loudly' contract of the Python layer."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from taco_amd import config, dist, _lib
+
+
+def test_composite_body_from_mjcf_numbers():
+    m, J = config.composite_body()
+    assert abs(m - (0.46 + 8e-7)) < 1e-12
+    assert abs(J[0] - (5e-4 + 8e-7 + 1e-7 * (8 * 0.059 ** 2 + 4 * 0.02 ** 2))) < 1e-15
+    assert abs(J[2] - (8e-4 + 8e-7 + 8e-7 * (0.047 ** 2 + 0.059 ** 2))) < 1e-15
+    m2, J2 = config.composite_body("with_duct")
+    assert m2 > 0.57 and J2[1] > 0.00147
+
+
+def test_flat_cfg_reads_the_reference_key_set():
+    cfg = config.default_cfg("rotate", 512, env_lenStates=5, delay_time=40, sim_substeps=4)
+    f = config.flat_cfg(cfg)
+    assert f["task_mode"] == "rotate" and f["num_envs"] == f["num_envs_global"] == 512
+    assert f["len_obs"] == 1 and f["len_states"] == 5 and f["substeps"] == 4 and f["delay_time"] == 40
+    assert f["control_freq_inv"] == 10 and f["dt"] == 0.001 and math.isinf(f["clip_obs"])
+    for k in _lib.FLAG_BITS:
+        assert k in f, k
+    c = _lib.make_cfg(f)
+    assert c.flags & (1 << _lib.FLAG_BITS["random_command"]) and not c.flags & (1 << _lib.FLAG_BITS["observation_noise"])
+    with pytest.raises(ValueError):
+        config.flat_cfg(dict(cfg, delay_time_max=50))
+    f2 = config.flat_cfg(cfg, env_offset=128, num_envs_local=64)
+    assert (f2["num_envs"], f2["env_offset"], f2["num_envs_global"]) == (64, 128, 512)
+
+
+def test_baseline_configs_are_the_five_of_baseline_json():
+    modes = [config.baseline_config(i)["task_mode"] for i in range(5)]
+    sizes = [config.baseline_config(i)["env"]["numEnvs"] for i in range(5)]
+    assert modes == ["pos", "pos", "rotate", "flip", "mix"] and sizes == [64, 4096, 16384, 65536, 262144]
+    c4 = config.baseline_config(4)
+    assert c4["observation_noise"] and c4["rotor_noise"] and c4["ramdom_deploy_time"] and c4["env"]["lenStates"] == 5
+
+
+def test_shard_bounds_cover_the_range_contiguously():
+    for n, w in ((4096, 8), (10, 3), (7, 8), (262144, 8), (1000, 6)):
+        b = [dist.shard_bounds(n, w, r) for r in range(w)]
+        assert b[0][0] == 0 and b[-1][1] == n
+        assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+        assert max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) <= 1
+
+
+def test_gather_block_pack_unpack_roundtrip():
+    g = torch.Generator().manual_seed(0)
+    for len_obs in (1, 3):
+        obs = torch.randn(17, len_obs, 26, generator=g)
+        rew = torch.randn(17, generator=g)
+        done = torch.randint(0, 2, (17,), generator=g)
+        tmo = torch.randint(0, 2, (17,), generator=g).bool() & (done != 0)
+        blk = dist.pack_block(obs, rew, done, tmo)
+        assert blk.shape == (17, dist.block_row(len_obs))
+        o, r, d, t = dist.unpack_block(blk, len_obs)
+        assert torch.equal(o, obs) and torch.equal(r, rew) and torch.equal(d, done) and torch.equal(t, tmo)
+        assert d.dtype == torch.long and t.dtype == torch.bool
+
+
+def test_python_layer_fails_loudly_without_a_hip_device():
+    from taco_amd.vec_env import FpvPos, isaacgym_task_map
+    assert set(isaacgym_task_map) == {"Fpv_pos", "Fpv_rotate", "Fpv_flip", "Fpv_mix"}
+    with pytest.raises(_lib.TacoError):
+        FpvPos(config.baseline_config(0), rl_device="cpu", sim_device="cpu")   # no CPU fallback for the step path
+    if not torch.cuda.is_available():
+        with pytest.raises(Exception):
+            FpvPos(config.baseline_config(0), rl_device="cuda:0", sim_device="cuda:0")
+
+
+def test_missing_library_is_an_error_not_a_fallback(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libtaco_env.so")
+    with pytest.raises(_lib.TacoError, match="no CPU fallback"):
+        _lib.load()
