@@ -108,7 +108,8 @@ def parity_check(cfg, steps=60):
             o = orc.get_state().view(np.float32)
             fin = np.isfinite(g[:13]) & np.isfinite(o[:13])
             linf = max(linf, float(np.abs(g[:13] - o[:13])[fin].max()))
-            bits_equal &= bool((g.view(np.uint32) == o.view(np.uint32)).all())
+            keep = np.r_[0:20, 26:g.shape[0]]   # rows 20..25 (rpy_old / rpy_continuous) are tracked for flip envs only
+            bits_equal &= bool((g.view(np.uint32)[keep] == o.view(np.uint32)[keep]).all())
             flags_equal &= bool((env.reset_buf.cpu().numpy() == orc.reset_buf).all())
             bits_equal &= bool((env.obs_buf.cpu().numpy().view(np.uint32) == orc.obs_buf.view(np.uint32)).all())
             bits_equal &= bool((env.rew_buf.cpu().numpy().view(np.uint32) == orc.rew_buf.view(np.uint32)).all())

@@ -3,7 +3,8 @@
     python -m taco_amd.build [--force]
 
 hipcc cross-compiles without a GPU.  -ffp-contract=off is part of the kernel's numerical contract (see
-csrc/taco_math.hpp): fused multiply-adds appear only where the source writes fma().
+csrc/taco_math.hpp): fused multiply-adds appear only where the source writes fma().  -fno-slp-vectorize keeps the
+compiler from pairing scalar fp32 ops into v_pk_* (no faster on gfx950, costs ~30 VGPRs in register-pair shuffles).
 """
 import os
 import subprocess
@@ -15,7 +16,7 @@ LIB = os.path.join(HERE, "libtaco_env.so")
 SOURCES = ["taco_capi.hip"]
 DEPS = ["taco_capi.hip", "taco_step.hpp", "taco_math.hpp", os.path.join("..", "..", "include", "taco_env.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
          "-Wall", "-Wno-unused-function"]
 
 

@@ -49,6 +49,7 @@ int round_up(int x, int m) { return (x + m - 1) / m * m; }
 bool cfg_ok(const taco_cfg *c) {
     if (!c) return fail(0, "cfg is null"), false;
     if (c->num_envs <= 0) return fail(0, "num_envs must be > 0"), false;
+    if (c->num_envs > 2000000) return fail(0, "num_envs must be <= 2 000 000 per handle (32-bit buffer offsets); shard larger jobs"), false;
     if (c->env_offset < 0 || c->num_envs_global < c->env_offset + c->num_envs)
         return fail(0, "env_offset + num_envs exceeds num_envs_global"), false;
     if (c->task_mode < TACO_TASK_POS || c->task_mode > TACO_TASK_MIX) return fail(0, "task_mode out of range"), false;
@@ -202,6 +203,8 @@ int taco_step(taco_env *e, const float *actions, float *obs_buf, float *states_b
     P.reset = (long long *)reset_buf; P.timeout = timeout_buf;
     P.gather = e->gather;
     P.step = (uint32_t)e->step_count;
+    P.s_bytes = (uint32_t)((size_t)TACO_NUM_FIELDS * e->npad * sizeof(float));
+    P.ring_bytes = (uint32_t)((size_t)TACO_RING_SLOTS * 4 * e->npad * sizeof(float));
     P.head = e->head;
     const int n = e->cfg.num_envs;
     if (block_for(e) == kBlockLarge)

@@ -31,6 +31,7 @@ struct StepParams {
     // geometry / cfg
     int n, npad, env_offset, task_mode, mix_n1, mix_n2, len_obs, len_states, substeps, max_len, delay_time, head;
     uint32_t flags, seed_lo, seed_hi, step;
+    uint32_t s_bytes, ring_bytes;  // sizes of S and ring for the buffer descriptors (range-checked accesses)
     // fp32 images of the Python doubles the reference feeds into tensor ops
     float dt, clip_act, df;
     float h, half_h, inv_m, g, J0, J1, J2, Ji0, Ji1, Ji2, arm_x, arm_y;
@@ -38,6 +39,18 @@ struct StepParams {
 };
 
 enum : uint32_t { STREAM_RESET = 1, STREAM_CMD = 2, STREAM_DEPLOY = 3, STREAM_ROTOR = 4, STREAM_OBS = 5 };
+
+
+// ---- memory access.  State and ring rows are reached through 128-bit buffer descriptors: one VGPR holds the lane's byte
+// offset (4*i) for EVERY row, the row offset (field * npad * 4) rides in the scalar soffset operand.  With plain 64-bit
+// pointers each of the 67 + 40 row addresses would occupy a VGPR pair for the whole kernel (measured: > 130 VGPRs).
+// Out-of-range accesses are dropped / return 0 by the hardware range check instead of faulting.
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+TD rsrc_t make_rsrc(const void *base, uint32_t bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000); }
+TD float buf_ld(rsrc_t r, uint32_t voff, uint32_t soff) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0)); }
+TD void buf_st(rsrc_t r, float v, uint32_t voff, uint32_t soff) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, voff, soff, 0); }
+TD float as_f(int x) { return __builtin_bit_cast(float, x); }
+TD int as_i(float x) { return __builtin_bit_cast(int, x); }
 
 struct V3 { float x, y, z; };
 struct Q4 { float x, y, z, w; };
@@ -213,153 +226,212 @@ TD void integrate(const StepParams &P, V3 &p, Q4 &q, V3 &v, V3 &w, V3 F, V3 tq) 
     }
 }
 
-#define SF(f) P.S[(size_t)(f) * P.npad + i]
 
+// reset_idx for one env (FA:475-517), in the reference's call order: reset_copter_idx -> reset_controller_idx ->
+// reset_env_idx -> reset_target_idx.  Every new value goes straight to the env's SoA words; the 37 uniforms come from
+// 10 Philox blocks of STREAM_RESET, each generated where it is consumed.
+#define RS(f, val) buf_st(rS, (val), voff, (uint32_t)(f) * row_bytes)
+TD void reset_env(const StepParams &P, rsrc_t rS, rsrc_t rR, uint32_t voff, uint32_t row_bytes, int gid, int grp, bool mix, bool active) {
+    if (!active) return;
+    const uint32_t fl = P.flags;
+    auto block = [&](uint32_t b, float &u0, float &u1, float &u2, float &u3) {
+        U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, P.step, STREAM_RESET, b);
+        u0 = uniform(r.x); u1 = uniform(r.y); u2 = uniform(r.z); u3 = uniform(r.w);
+    };
+    float u0, u1, u2, u3, u4, u5, u6, u7;
+    const float pi_sc = (float)(3.14159265358979323846 - (-3.14159265358979323846)), pi_lo = (float)(-3.14159265358979323846);
+    // ---- reset_copter_idx: FA:725-756 pos, :783-812 rotate, :850-884 flip, :981-1056 mix (pos-style ranges for all groups)
+    block(0, u0, u1, u2, u3);  // uniforms 0..3: pos x y z, euler a
+    block(1, u4, u5, u6, u7);  // uniforms 4..7: euler b c, linvel x y
+    V3 p;
+    if (grp == TACO_TASK_FLIP && !mix) {
+        if (fl & TACO_F_RANDOM_COPTER_POS) {
+            p.x = P.flip_xy_sc * u0 + P.flip_xy_lo;
+            p.y = P.flip_xy_sc * u1 + P.flip_xy_lo;
+            p.z = 3.0f + P.df * (4.0f * u2 + -2.0f);
+        } else {
+            p.x = 1.0f * u0 + -0.5f;
+            p.y = 1.0f * u1 + -0.5f;
+            p.z = 3.0f;
+        }
+    } else if (grp == TACO_TASK_ROTATE && !mix && !(fl & TACO_F_RANDOM_COPTER_POS)) {
+        p.x = 1.0f * u0 + -0.5f;
+        p.y = 1.0f * u1 + -0.5f;
+        p.z = 2.5f;
+    } else if (fl & TACO_F_RANDOM_COPTER_POS) {
+        p.x = 4.0f * u0 + -2.0f;
+        p.y = 4.0f * u1 + -2.0f;
+        p.z = 2.5f + (4.0f * u2 + -2.0f);
+    } else {
+        p.x = 0.0f; p.y = 0.0f; p.z = 2.5f;
+    }
+    RS(TACO_S_POS, p.x); RS(TACO_S_POS + 1, p.y); RS(TACO_S_POS + 2, p.z);
+    Q4 q{0.0f, 0.0f, 0.0f, 1.0f};
+    if (fl & TACO_F_RANDOM_COPTER_QUAT) {  // rand_quat FA:698-704 (flip: limits (pi, 0, 0))
+        const float l_sc = (grp == TACO_TASK_FLIP) ? 0.0f : pi_sc;
+        const float l_lo = (grp == TACO_TASK_FLIP) ? -0.0f : pi_lo;
+        q = quat_from_euler(pi_sc * u3 + pi_lo, l_sc * u4 + l_lo, l_sc * u5 + l_lo);
+    }
+    RS(TACO_S_QUAT, q.x); RS(TACO_S_QUAT + 1, q.y); RS(TACO_S_QUAT + 2, q.z); RS(TACO_S_QUAT + 3, q.w);
+    {
+        const V3 e0 = euler_xyz_v1(q);  // FA:752-754
+        RS(TACO_S_RPY_OLD, e0.x); RS(TACO_S_RPY_OLD + 1, e0.y); RS(TACO_S_RPY_OLD + 2, e0.z);
+        RS(TACO_S_RPY_CONT, e0.x); RS(TACO_S_RPY_CONT + 1, e0.y); RS(TACO_S_RPY_CONT + 2, e0.z);
+    }
+    {
+        float a0, a1, a2, a3, b0, b1, b2, b3;
+        block(2, a0, a1, a2, a3);  // uniforms 8..11: linvel z, angvel x y z
+        block(3, b0, b1, b2, b3);  // uniforms 12..15: flip sign, target x y z
+        if (grp == TACO_TASK_FLIP) {
+            if (fl & TACO_F_RANDOM_COPTER_VEL) {
+                RS(TACO_S_LINVEL, P.flip_v_sc * u6 + P.flip_v_lo);
+                RS(TACO_S_LINVEL + 1, P.flip_v_sc * u7 + P.flip_v_lo);
+                RS(TACO_S_LINVEL + 2, P.flip_v_sc * a0 + P.flip_v_lo);
+                RS(TACO_S_ANGVEL, 10.0f * (b0 < 0.5f ? -1.0f : 1.0f));  // w.y, w.z keep their values (FA:876, :1047)
+            } else {
+                RS(TACO_S_LINVEL, 0.0f); RS(TACO_S_LINVEL + 1, 0.0f); RS(TACO_S_LINVEL + 2, 0.0f);
+                if (mix) { RS(TACO_S_ANGVEL, 0.0f); RS(TACO_S_ANGVEL + 1, 0.0f); RS(TACO_S_ANGVEL + 2, 0.0f); }  // FA:1050 vs FA:877-878
+            }
+        } else if (fl & TACO_F_RANDOM_COPTER_VEL) {
+            RS(TACO_S_LINVEL, 3.0f * (2.0f * u6 + -1.0f));
+            RS(TACO_S_LINVEL + 1, 3.0f * (2.0f * u7 + -1.0f));
+            RS(TACO_S_LINVEL + 2, 3.0f * (2.0f * a0 + -1.0f));
+            RS(TACO_S_ANGVEL, 3.0f * (2.0f * a1 + -1.0f));
+            RS(TACO_S_ANGVEL + 1, 3.0f * (2.0f * a2 + -1.0f));
+            RS(TACO_S_ANGVEL + 2, 3.0f * (2.0f * a3 + -1.0f));
+        } else {
+            RS(TACO_S_LINVEL, 0.0f); RS(TACO_S_LINVEL + 1, 0.0f); RS(TACO_S_LINVEL + 2, 0.0f);
+            RS(TACO_S_ANGVEL, 0.0f); RS(TACO_S_ANGVEL + 1, 0.0f); RS(TACO_S_ANGVEL + 2, 0.0f);
+        }
+        // ---- reset_target_idx FA:523-548
+        if (fl & TACO_F_RANDOM_TARGET_POS) {
+            RS(TACO_S_TGT_POS, P.df * (4.0f * b1 + -2.0f));
+            RS(TACO_S_TGT_POS + 1, P.df * (4.0f * b2 + -2.0f));
+            RS(TACO_S_TGT_POS + 2, 3.0f + P.df * (4.0f * b3 + -2.0f));
+        } else {
+            RS(TACO_S_TGT_POS, 0.0f); RS(TACO_S_TGT_POS + 1, 0.0f); RS(TACO_S_TGT_POS + 2, 3.0f);
+        }
+    }
+    {
+        float c0, c1, c2, c3, d0, d1, d2, d3;
+        block(4, c0, c1, c2, c3);  // uniforms 16..19: target yaw, battery E, omega_para 0 1
+        block(5, d0, d1, d2, d3);  // uniforms 20..23: omega_para 2 3 4, tau 0
+        const float yaw = (fl & TACO_F_RANDOM_TARGET_YAW) ? pi_sc * c0 + pi_lo : 0.0f;
+        const Q4 qt = quat_from_euler(0.0f, 0.0f, yaw);
+        RS(TACO_S_TGT_QUAT, qt.x); RS(TACO_S_TGT_QUAT + 1, qt.y); RS(TACO_S_TGT_QUAT + 2, qt.z); RS(TACO_S_TGT_QUAT + 3, qt.w);
+        // ---- reset_controller_idx FA:550-558
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { RS(TACO_S_PID_PREV + k, 0.0f); RS(TACO_S_PID_INT + k, 0.0f); }
+        RS(TACO_S_BAT_U1, 0.0f); RS(TACO_S_BAT_T, 0.0f); RS(TACO_S_BAT_V, 0.0f);
+        RS(TACO_S_BAT_E, (fl & TACO_F_RANDOM_VOLTAGE) ? (float)2.2 * c1 + 0.0f : 0.0f);
+        const bool rc = (fl & TACO_F_RANDOM_ROTORDYNAMIC_COE) != 0;
+        RS(TACO_S_OPARA + 0, rc ? 0.0f * (P.dr_sc * c2 + P.dr_lo) : 0.0f);
+        RS(TACO_S_OPARA + 1, rc ? 12.9466f * (P.dr_sc * c3 + P.dr_lo) : 12.9466f);
+        RS(TACO_S_OPARA + 2, rc ? 0.1872f * (P.dr_sc * d0 + P.dr_lo) : 0.1872f);
+        RS(TACO_S_OPARA + 3, rc ? -5.1220f * (P.dr_sc * d1 + P.dr_lo) : -5.1220f);
+        RS(TACO_S_OPARA + 4, rc ? 0.5906f * (P.dr_sc * d2 + P.dr_lo) : 0.5906f);
+        float e0, e1, e2, e3, f0, f1, f2, f3;
+        block(6, e0, e1, e2, e3);  // uniforms 24..27: tau 1 2 3, omega0 0
+        block(7, f0, f1, f2, f3);  // uniforms 28..31: omega0 1 2 3, cf
+        const float tu[4] = {d3, e0, e1, e2};
+        const float ou[4] = {e3, f0, f1, f2};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float t;
+            if (fl & TACO_F_ROTOR_RESPONSE) t = (fl & TACO_F_RANDOM_ROTOR_RESPONSE) ? P.tau_sc * tu[k] + P.tau_lo : P.tau_fixed * 1.0f;
+            else t = 0.001f * 1.0f;
+            RS(TACO_S_TAU + k, t);
+            RS(TACO_S_OMEGA + k, (fl & TACO_F_RANDOM_ROTOR_SPEED) ? 400.0f * ou[k] + 0.0f : 0.0f);
+        }
+        float g0, g1, g2, g3, h0, h1, h2, h3;
+        block(8, g0, g1, g2, g3);  // uniforms 32..35: ct, dx, dy, kt
+        block(9, h0, h1, h2, h3);  // uniform 36: delay length
+        if (fl & TACO_F_RANDOM_AERODYNAMIC_COE) {  // CTRL/thrust_dynamics.py:201-210 (a no-op when the flag is off)
+            RS(TACO_S_CF, 1.13e-05f * (P.dr_sc * f3 + P.dr_lo));
+            RS(TACO_S_CT, 0.05f * (P.dr_sc * g0 + P.dr_lo));
+            RS(TACO_S_DX, -0.386f * (P.dr_sc * g1 + P.dr_lo));
+            RS(TACO_S_DY, -0.53f * (P.dr_sc * g2 + P.dr_lo));
+            RS(TACO_S_KT, 0.009f * (P.dr_sc * g3 + P.dr_lo));
+        }
+        // ---- reset_env_idx FA:560-581
+        int L = P.delay_time;
+        if (fl & TACO_F_RANDOM_DELAY_TIME) {
+            L = P.delay_time - rounded_normal(h0, 3);
+            L = L < 0 ? 0 : L;
+        }
+        RS(TACO_S_DELAY_LEN, as_f(L));
+        RS(TACO_S_PROGRESS, as_f(0));  // FA:510-511
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { RS(TACO_S_ACT + k, 0.0f); RS(TACO_S_ACT_OLD + k, 0.0f); }
+    for (int s = 0; s < TACO_RING_SLOTS * 4; ++s) buf_st(rR, 0.0f, voff, (uint32_t)s * row_bytes);
+}
+#undef RS
+
+#define SLD(f) buf_ld(rS, voff, (uint32_t)(f) * row_bytes)
+#define SST(f, val) buf_st(rS, (val), voff, (uint32_t)(f) * row_bytes)
+
+// Two instantiations: BLOCK = 64 for the latency regime (few envs: one wavefront per workgroup, spread over as many CUs
+// as possible, registers unconstrained) and BLOCK = 256 for the throughput regime, where the register budget is capped
+// at 128 VGPRs so that 4 wavefronts per SIMD hide each other's dependent-issue latency.
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void taco_step_kernel(const StepParams P) {
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 256 ? 4 : 1, BLOCK >= 256 ? 4 : 8))) void taco_step_kernel(const StepParams P) {
     constexpr int TILE_LD = 27;  // 26 + 1 pad: lane l writes words l*27+k -> bank (27l + k) % 32, conflict-free per half-wave
-    __shared__ float tile_all[BLOCK / 64][64 * TILE_LD];
+    // Per-wavefront LDS scratch, used for two things one after the other:
+    //   substeps : the 10 pending-action slots this step consumes, slots[s][lane] as float4 (10 KiB) -- keeps 40 values
+    //              out of the register file and lets substep k fetch its action with one ds_read_b128;
+    //   post-step: the 64 x 26 frame tile that transposes lane-major registers into env-major rows (6.75 KiB).
+    constexpr int WAVE_LDS_WORDS = 10 * 64 * 4;
+    static_assert(WAVE_LDS_WORDS >= 64 * TILE_LD, "tile must fit in the per-wave scratch");
+    __shared__ __attribute__((aligned(16))) float lds_all[BLOCK / 64][WAVE_LDS_WORDS];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
-    float *tile = tile_all[wv];
+    float *tile = lds_all[wv];
+    float4 *slots = reinterpret_cast<float4 *>(lds_all[wv]);
     const int i_raw = blockIdx.x * BLOCK + threadIdx.x;
     const bool active = i_raw < P.n;
     const int i = active ? i_raw : P.n - 1;  // tail lanes shadow the last env and store nothing
     const int gid = P.env_offset + i;
+    const uint32_t voff = (uint32_t)i * 4u;            // this lane's byte offset inside every SoA row
+    const uint32_t row_bytes = (uint32_t)P.npad * 4u;  // one SoA row
+    const rsrc_t rS = make_rsrc(P.S, P.s_bytes);
+    const rsrc_t rR = make_rsrc(P.ring, P.ring_bytes);
     const uint32_t fl = P.flags;
     const int grp = (P.task_mode != TACO_TASK_MIX) ? P.task_mode
                     : (gid < P.mix_n1 ? TACO_TASK_POS : (gid < P.mix_n2 ? TACO_TASK_ROTATE : TACO_TASK_FLIP));
     const bool mix = P.task_mode == TACO_TASK_MIX;
-
-    // ------------------------------------------------------------------ load state (coalesced SoA rows)
-    V3 p{SF(TACO_S_POS), SF(TACO_S_POS + 1), SF(TACO_S_POS + 2)};
-    Q4 q{SF(TACO_S_QUAT), SF(TACO_S_QUAT + 1), SF(TACO_S_QUAT + 2), SF(TACO_S_QUAT + 3)};
-    V3 v{SF(TACO_S_LINVEL), SF(TACO_S_LINVEL + 1), SF(TACO_S_LINVEL + 2)};
-    V3 w{SF(TACO_S_ANGVEL), SF(TACO_S_ANGVEL + 1), SF(TACO_S_ANGVEL + 2)};
-    V3 pt{SF(TACO_S_TGT_POS), SF(TACO_S_TGT_POS + 1), SF(TACO_S_TGT_POS + 2)};
-    Q4 qt{SF(TACO_S_TGT_QUAT), SF(TACO_S_TGT_QUAT + 1), SF(TACO_S_TGT_QUAT + 2), SF(TACO_S_TGT_QUAT + 3)};
-    float rpy_old[3], rpy_cont[3], pid_prev[3], pid_int[3], omega[4], act[4], act_old[4], tau[4], opara[5];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        rpy_old[k] = SF(TACO_S_RPY_OLD + k); rpy_cont[k] = SF(TACO_S_RPY_CONT + k);
-        pid_prev[k] = SF(TACO_S_PID_PREV + k); pid_int[k] = SF(TACO_S_PID_INT + k);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { omega[k] = SF(TACO_S_OMEGA + k); act[k] = SF(TACO_S_ACT + k); tau[k] = SF(TACO_S_TAU + k); }
-#pragma unroll
-    for (int k = 0; k < 5; ++k) opara[k] = SF(TACO_S_OPARA + k);
-    float bat_E = SF(TACO_S_BAT_E), bat_u1 = SF(TACO_S_BAT_U1), bat_t = SF(TACO_S_BAT_T), bat_V = SF(TACO_S_BAT_V);
-    float cmd0 = SF(TACO_S_CMD), cmd1 = SF(TACO_S_CMD + 1), flip_radian = SF(TACO_S_FLIP_RADIAN);
-    float cf = SF(TACO_S_CF), ct = SF(TACO_S_CT), dx = SF(TACO_S_DX), dy = SF(TACO_S_DY), kt = SF(TACO_S_KT);
-    int progress = __builtin_bit_cast(int, SF(TACO_S_PROGRESS));
-    int dlen = __builtin_bit_cast(int, SF(TACO_S_DELAY_LEN));
-    const float4 a_in = reinterpret_cast<const float4 *>(P.act_in)[i];
+    // copter_rpy_continuous is consumed only by the flip command (FA:831, :930); other envs keep their reset-time value
+    const bool track_rpy = grp == TACO_TASK_FLIP;
 
     // ------------------------------------------------------------------ pre_physics_step FA:317-332
     const bool is_reset = P.reset[i] != 0;
-    const bool at_time = progress == 500;  // reset_command_condition FA:595-598, before progress is zeroed
-    if (is_reset) {
-        // ---- reset_idx FA:475-517.  37 uniforms of STREAM_RESET = 10 Philox blocks
-        float u[40];
+    // reset_idx (FA:475-517) runs FIRST and writes the fresh state straight to the SoA rows, so none of its 37 random
+    // draws or temporaries are live once the step proper starts (they would otherwise dominate the register budget).
+    if (is_reset) reset_env(P, rS, rR, voff, row_bytes, gid, grp, mix, active);
+
+    // ------------------------------------------------------------------ load state (coalesced SoA rows)
+    V3 p{SLD(TACO_S_POS), SLD(TACO_S_POS + 1), SLD(TACO_S_POS + 2)};
+    Q4 q{SLD(TACO_S_QUAT), SLD(TACO_S_QUAT + 1), SLD(TACO_S_QUAT + 2), SLD(TACO_S_QUAT + 3)};
+    V3 v{SLD(TACO_S_LINVEL), SLD(TACO_S_LINVEL + 1), SLD(TACO_S_LINVEL + 2)};
+    V3 w{SLD(TACO_S_ANGVEL), SLD(TACO_S_ANGVEL + 1), SLD(TACO_S_ANGVEL + 2)};
+    float rpy_old[3], rpy_cont[3], pid_prev[3], pid_int[3], omega[4], act[4], act_old[4], tau[4], opara[5];
 #pragma unroll
-        for (int b = 0; b < 10; ++b) {
-            U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, P.step, STREAM_RESET, (uint32_t)b);
-            u[4 * b] = uniform(r.x); u[4 * b + 1] = uniform(r.y); u[4 * b + 2] = uniform(r.z); u[4 * b + 3] = uniform(r.w);
-        }
-        // reset_copter_idx: FA:725-756 pos, :783-812 rotate, :850-884 flip, :981-1056 mix (pos-style ranges for all groups)
-        if (grp == TACO_TASK_FLIP && !mix) {
-            if (fl & TACO_F_RANDOM_COPTER_POS) {
-                p.x = P.flip_xy_sc * u[0] + P.flip_xy_lo;
-                p.y = P.flip_xy_sc * u[1] + P.flip_xy_lo;
-                p.z = 3.0f + P.df * (4.0f * u[2] + -2.0f);
-            } else {
-                p.x = 1.0f * u[0] + -0.5f;
-                p.y = 1.0f * u[1] + -0.5f;
-                p.z = 3.0f;
-            }
-        } else if (grp == TACO_TASK_ROTATE && !mix && !(fl & TACO_F_RANDOM_COPTER_POS)) {
-            p.x = 1.0f * u[0] + -0.5f;
-            p.y = 1.0f * u[1] + -0.5f;
-            p.z = 2.5f;
-        } else if (fl & TACO_F_RANDOM_COPTER_POS) {
-            p.x = 4.0f * u[0] + -2.0f;
-            p.y = 4.0f * u[1] + -2.0f;
-            p.z = 2.5f + (4.0f * u[2] + -2.0f);
-        } else {
-            p.x = 0.0f; p.y = 0.0f; p.z = 2.5f;
-        }
-        if (fl & TACO_F_RANDOM_COPTER_QUAT) {  // rand_quat FA:698-704 (flip: limits (pi, 0, 0))
-            const float pi_sc = (float)(3.14159265358979323846 - (-3.14159265358979323846)), pi_lo = (float)(-3.14159265358979323846);
-            float l_sc = (grp == TACO_TASK_FLIP) ? 0.0f : pi_sc;
-            float l_lo = (grp == TACO_TASK_FLIP) ? -0.0f : pi_lo;
-            q = quat_from_euler(pi_sc * u[3] + pi_lo, l_sc * u[4] + l_lo, l_sc * u[5] + l_lo);
-        } else {
-            q = Q4{0.0f, 0.0f, 0.0f, 1.0f};
-        }
-        if (grp == TACO_TASK_FLIP) {
-            if (fl & TACO_F_RANDOM_COPTER_VEL) {
-                v.x = P.flip_v_sc * u[6] + P.flip_v_lo; v.y = P.flip_v_sc * u[7] + P.flip_v_lo; v.z = P.flip_v_sc * u[8] + P.flip_v_lo;
-                w.x = 10.0f * (u[12] < 0.5f ? -1.0f : 1.0f);  // w.y, w.z keep their values (FA:876, :1047)
-            } else {
-                v = V3{0.0f, 0.0f, 0.0f};
-                if (mix) w = V3{0.0f, 0.0f, 0.0f};  // FA:1050; standalone FpvFlip leaves angvel untouched (FA:877-878)
-            }
-        } else if (fl & TACO_F_RANDOM_COPTER_VEL) {
-            v.x = 3.0f * (2.0f * u[6] + -1.0f); v.y = 3.0f * (2.0f * u[7] + -1.0f); v.z = 3.0f * (2.0f * u[8] + -1.0f);
-            w.x = 3.0f * (2.0f * u[9] + -1.0f); w.y = 3.0f * (2.0f * u[10] + -1.0f); w.z = 3.0f * (2.0f * u[11] + -1.0f);
-        } else {
-            v = V3{0.0f, 0.0f, 0.0f};
-            w = V3{0.0f, 0.0f, 0.0f};
-        }
-        V3 e0 = euler_xyz_v1(q);
-        rpy_old[0] = rpy_cont[0] = e0.x; rpy_old[1] = rpy_cont[1] = e0.y; rpy_old[2] = rpy_cont[2] = e0.z;
-        // reset_controller_idx FA:550-558
-#pragma unroll
-        for (int k = 0; k < 3; ++k) pid_prev[k] = pid_int[k] = 0.0f;
-        bat_u1 = 0.0f; bat_t = 0.0f;
-        bat_E = (fl & TACO_F_RANDOM_VOLTAGE) ? (float)2.2 * u[17] + 0.0f : 0.0f;
-        const float opara_init[5] = {0.0f, 12.9466f, 0.1872f, -5.1220f, 0.5906f};
-#pragma unroll
-        for (int k = 0; k < 5; ++k)
-            opara[k] = (fl & TACO_F_RANDOM_ROTORDYNAMIC_COE) ? opara_init[k] * (P.dr_sc * u[18 + k] + P.dr_lo) : opara_init[k];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (fl & TACO_F_ROTOR_RESPONSE) tau[k] = (fl & TACO_F_RANDOM_ROTOR_RESPONSE) ? P.tau_sc * u[23 + k] + P.tau_lo : P.tau_fixed * 1.0f;
-            else tau[k] = 0.001f * 1.0f;
-            omega[k] = (fl & TACO_F_RANDOM_ROTOR_SPEED) ? 400.0f * u[27 + k] + 0.0f : 0.0f;
-        }
-        if (fl & TACO_F_RANDOM_AERODYNAMIC_COE) {
-            cf = 1.13e-05f * (P.dr_sc * u[31] + P.dr_lo);
-            ct = 0.05f * (P.dr_sc * u[32] + P.dr_lo);
-            dx = -0.386f * (P.dr_sc * u[33] + P.dr_lo);
-            dy = -0.53f * (P.dr_sc * u[34] + P.dr_lo);
-            kt = 0.009f * (P.dr_sc * u[35] + P.dr_lo);
-        }
-        // reset_env_idx FA:560-581
-        bat_V = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) act[k] = 0.0f;
-        if (active) {
-            for (int s = 0; s < TACO_RING_SLOTS * 4; ++s) P.ring[(size_t)s * P.npad + i] = 0.0f;
-        }
-        if (fl & TACO_F_RANDOM_DELAY_TIME) {
-            int L = P.delay_time - rounded_normal(u[36], 3);
-            dlen = L < 0 ? 0 : L;
-        } else {
-            dlen = P.delay_time;
-        }
-        // reset_target_idx FA:523-548
-        if (fl & TACO_F_RANDOM_TARGET_POS) {
-            pt.x = P.df * (4.0f * u[13] + -2.0f);
-            pt.y = P.df * (4.0f * u[14] + -2.0f);
-            pt.z = 3.0f + P.df * (4.0f * u[15] + -2.0f);
-        } else {
-            pt = V3{0.0f, 0.0f, 3.0f};
-        }
-        const float pi_sc = (float)(3.14159265358979323846 - (-3.14159265358979323846)), pi_lo = (float)(-3.14159265358979323846);
-        float yaw = (fl & TACO_F_RANDOM_TARGET_YAW) ? pi_sc * u[16] + pi_lo : 0.0f;
-        qt = quat_from_euler(0.0f, 0.0f, yaw);
+    for (int k = 0; k < 3; ++k) {
+        rpy_old[k] = SLD(TACO_S_RPY_OLD + k); rpy_cont[k] = SLD(TACO_S_RPY_CONT + k);
+        pid_prev[k] = SLD(TACO_S_PID_PREV + k); pid_int[k] = SLD(TACO_S_PID_INT + k);
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { omega[k] = SLD(TACO_S_OMEGA + k); act[k] = SLD(TACO_S_ACT + k); tau[k] = SLD(TACO_S_TAU + k); }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) opara[k] = SLD(TACO_S_OPARA + k);
+    float bat_E = SLD(TACO_S_BAT_E), bat_u1 = SLD(TACO_S_BAT_U1), bat_t = SLD(TACO_S_BAT_T), bat_V = SLD(TACO_S_BAT_V);
+    float cmd0 = SLD(TACO_S_CMD), cmd1 = SLD(TACO_S_CMD + 1), flip_radian = SLD(TACO_S_FLIP_RADIAN);
+    const float cf = SLD(TACO_S_CF), ct = SLD(TACO_S_CT), dx = SLD(TACO_S_DX), dy = SLD(TACO_S_DY), kt = SLD(TACO_S_KT);
+    int progress = as_i(SLD(TACO_S_PROGRESS));
+    int dlen = as_i(SLD(TACO_S_DELAY_LEN));
+    const float4 a_in = reinterpret_cast<const float4 *>(P.act_in)[i];
+    const bool at_time = !is_reset && progress == 500;  // reset_command_condition FA:595-598 (a reset env has progress 0 here;
+                                                        // its own progress==500 case is overwritten by the reset branch below)
     if (is_reset || at_time) {  // reset_command_idx: FA:758-759, :814-821, :886-917, :1058-1112
         if (grp == TACO_TASK_POS) {
             cmd0 = 0.0f; cmd1 = 0.0f;
@@ -384,13 +456,17 @@ __global__ __launch_bounds__(BLOCK) void taco_step_kernel(const StepParams P) {
             }
         }
     }
-    if (is_reset) progress = 0;  // FA:510-511
 #pragma unroll
     for (int k = 0; k < 4; ++k) act_old[k] = act[k];
     act[0] = clampf(a_in.x, -P.clip_act, P.clip_act);  // VT:304
     act[1] = clampf(a_in.y, -P.clip_act, P.clip_act);
     act[2] = clampf(a_in.z, -P.clip_act, P.clip_act);
     act[3] = clampf(a_in.w, -P.clip_act, P.clip_act);
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { SST(TACO_S_ACT_OLD + k, act_old[k]); SST(TACO_S_ACT + k, act[k]); }
+        SST(TACO_S_CMD, cmd0); SST(TACO_S_FLIP_RADIAN, flip_radian);
+    }
     int T = 10;
     if (fl & TACO_F_RANDOM_DEPLOY_TIME) {
         U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, P.step, STREAM_DEPLOY, 0u);
@@ -398,15 +474,18 @@ __global__ __launch_bounds__(BLOCK) void taco_step_kernel(const StepParams P) {
     }
     // The 10 slots this step consumes: logical 0..9, physical (head+s)%100 -- uniform across the wave, so coalesced.
     // Slots the write below covers are overlaid from registers instead of being re-read.
-    float ad[10][4];
+    {
 #pragma unroll
-    for (int s = 0; s < 10; ++s) {
-        int ph = P.head + s; ph = ph >= TACO_RING_SLOTS ? ph - TACO_RING_SLOTS : ph;
-        const bool fresh = (s >= dlen) && (s < dlen + T);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float old = is_reset ? 0.0f : P.ring[(size_t)(ph * 4 + k) * P.npad + i];
-            ad[s][k] = fresh ? act[k] : old;
+        for (int s = 0; s < 10; ++s) {
+            int ph = P.head + s; ph = ph >= TACO_RING_SLOTS ? ph - TACO_RING_SLOTS : ph;
+            const bool fresh = (s >= dlen) && (s < dlen + T);
+            const bool keep = !is_reset && !fresh;  // a reset env's ring is all zeros; a fresh slot comes from registers
+            float4 o;
+            o.x = keep ? buf_ld(rR, voff, (uint32_t)(ph * 4 + 0) * row_bytes) : (fresh ? act[0] : 0.0f);
+            o.y = keep ? buf_ld(rR, voff, (uint32_t)(ph * 4 + 1) * row_bytes) : (fresh ? act[1] : 0.0f);
+            o.z = keep ? buf_ld(rR, voff, (uint32_t)(ph * 4 + 2) * row_bytes) : (fresh ? act[2] : 0.0f);
+            o.w = keep ? buf_ld(rR, voff, (uint32_t)(ph * 4 + 3) * row_bytes) : (fresh ? act[3] : 0.0f);
+            slots[s * 64 + lane] = o;
         }
     }
     if (active) {  // FA:327-330: write the action into logical slots [L, L+T) & [0,100)
@@ -415,7 +494,7 @@ __global__ __launch_bounds__(BLOCK) void taco_step_kernel(const StepParams P) {
             if (j < T && sl < TACO_RING_SLOTS) {
                 int ph = P.head + sl; ph = ph >= TACO_RING_SLOTS ? ph - TACO_RING_SLOTS : ph;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) P.ring[(size_t)(ph * 4 + k) * P.npad + i] = act[k];
+                for (int k = 0; k < 4; ++k) buf_st(rR, act[k], (uint32_t)(ph * 4 + k) * row_bytes + voff, 0u);
             }
         }
     }
@@ -426,24 +505,19 @@ __global__ __launch_bounds__(BLOCK) void taco_step_kernel(const StepParams P) {
 #pragma unroll 1
     for (int ks = 0; ks < 10; ++ks) {
         // refresh_state, the part the inner loop consumes FA:339-350
-        V3 e = euler_xyz_v1(q);
-        unwrap(e.x, rpy_old[0], rpy_cont[0]);
-        unwrap(e.y, rpy_old[1], rpy_cont[1]);
-        unwrap(e.z, rpy_old[2], rpy_cont[2]);
+        if (track_rpy) {
+            V3 e = euler_xyz_v1(q);
+            unwrap(e.x, rpy_old[0], rpy_cont[0]);
+            unwrap(e.y, rpy_old[1], rpy_cont[1]);
+            unwrap(e.z, rpy_old[2], rpy_cont[2]);
+        }
         Q4 cq = conj(q);
         V3 vb = quat_rotate(cq, v);
         V3 wb = quat_rotate(cq, w);
         // delayed action FA:366: slot min(L-1, ks); L >= 9 here, so only ks == 9 can be clipped (to slot 8)
-        float d0, d1, d2, d3;
-        {
-            int idx = (dlen - 1 < ks) ? dlen - 1 : ks;
-            d0 = ad[0][0]; d1 = ad[0][1]; d2 = ad[0][2]; d3 = ad[0][3];
-#pragma unroll
-            for (int s = 1; s < 10; ++s) {
-                const bool hit = idx == s;
-                d0 = hit ? ad[s][0] : d0; d1 = hit ? ad[s][1] : d1; d2 = hit ? ad[s][2] : d2; d3 = hit ? ad[s][3] : d3;
-            }
-        }
+        const int idx = (dlen - 1 < ks) ? dlen - 1 : ks;
+        const float4 dact = slots[idx * 64 + lane];
+        const float d0 = dact.x, d1 = dact.y, d2 = dact.z, d3 = dact.w;
         // angular_vel_control FA:637-650
         float u0 = (d0 + 1.0f) / 2.0f * 1000.0f;
         float u1 = pid_axis(P.dt, 27.5f, d1 * 20.0f, wb.x, pid_prev[0], pid_int[0]);
@@ -526,7 +600,32 @@ __global__ __launch_bounds__(BLOCK) void taco_step_kernel(const StepParams P) {
 
     // ------------------------------------------------------------------ post_physics_step FA:374-388
     progress += 1;
+    if (track_rpy) {  // refresh_state FA:382 (euler + unwrap part)
+        V3 e = euler_xyz_v1(q);
+        unwrap(e.x, rpy_old[0], rpy_cont[0]);
+        unwrap(e.y, rpy_old[1], rpy_cont[1]);
+        unwrap(e.z, rpy_old[2], rpy_cont[2]);
+    }
+    const float roll_cont = rpy_cont[0];
     if (active) {
+        // Everything the substep loop evolved goes back to its SoA row NOW, so the registers are free for the
+        // observation / reward code below.
+        SST(TACO_S_POS, p.x); SST(TACO_S_POS + 1, p.y); SST(TACO_S_POS + 2, p.z);
+        SST(TACO_S_QUAT, q.x); SST(TACO_S_QUAT + 1, q.y); SST(TACO_S_QUAT + 2, q.z); SST(TACO_S_QUAT + 3, q.w);
+        SST(TACO_S_LINVEL, v.x); SST(TACO_S_LINVEL + 1, v.y); SST(TACO_S_LINVEL + 2, v.z);
+        SST(TACO_S_ANGVEL, w.x); SST(TACO_S_ANGVEL + 1, w.y); SST(TACO_S_ANGVEL + 2, w.z);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            SST(TACO_S_PID_PREV + k, pid_prev[k]); SST(TACO_S_PID_INT + k, pid_int[k]);
+        }
+        if (track_rpy) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { SST(TACO_S_RPY_OLD + k, rpy_old[k]); SST(TACO_S_RPY_CONT + k, rpy_cont[k]); }
+        }
+        SST(TACO_S_BAT_E, bat_E); SST(TACO_S_BAT_U1, bat_u1); SST(TACO_S_BAT_T, bat_t); SST(TACO_S_BAT_V, bat_V);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) SST(TACO_S_OMEGA + k, omega[k]);
+        SST(TACO_S_PROGRESS, as_f(progress));
         // FA:378 leaves logical slots [90,100) untouched by the shift.  With the ring advancing by 10 (host side), the new
         // logical [90,100) are the physical slots just consumed, so they must be given the values of the old logical
         // [90,100) (= new [80,90)); a slot this step's action write covered is taken from registers, not re-read.
@@ -539,19 +638,16 @@ __global__ __launch_bounds__(BLOCK) void taco_step_kernel(const StepParams P) {
             const bool fresh = (90 + j >= wr_lo) && (90 + j < dlen);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                float old = P.ring[(size_t)(src * 4 + k) * P.npad + i];
-                P.ring[(size_t)(dst * 4 + k) * P.npad + i] = fresh ? act[k] : old;
+                float old = buf_ld(rR, voff, (uint32_t)(src * 4 + k) * row_bytes);
+                buf_st(rR, fresh ? act[k] : old, voff, (uint32_t)(dst * 4 + k) * row_bytes);
             }
         }
+        dlen = dlen - 10 < 0 ? 0 : dlen - 10;
+        SST(TACO_S_DELAY_LEN, as_f(dlen));
     }
-    dlen = dlen - 10 < 0 ? 0 : dlen - 10;
-    {
-        V3 e = euler_xyz_v1(q);
-        unwrap(e.x, rpy_old[0], rpy_cont[0]);
-        unwrap(e.y, rpy_old[1], rpy_cont[1]);
-        unwrap(e.z, rpy_old[2], rpy_cont[2]);
-    }
-    // relative quantities FA:354-360 (target velocities are identically zero)
+    // relative quantities FA:354-360 (target velocities are identically zero); the target pose is only needed from here on
+    const V3 pt{SLD(TACO_S_TGT_POS), SLD(TACO_S_TGT_POS + 1), SLD(TACO_S_TGT_POS + 2)};
+    const Q4 qt{SLD(TACO_S_TGT_QUAT), SLD(TACO_S_TGT_QUAT + 1), SLD(TACO_S_TGT_QUAT + 2), SLD(TACO_S_TGT_QUAT + 3)};
     const Q4 cq = conj(q);
     const V3 rel_pos{pt.x - p.x, pt.y - p.y, pt.z - p.z};
     const V3 rel_v{0.0f - v.x, 0.0f - v.y, 0.0f - v.z};
@@ -560,7 +656,7 @@ __global__ __launch_bounds__(BLOCK) void taco_step_kernel(const StepParams P) {
     const Q4 rel_q_b = quat_mul(cq, qt);
     const V3 rel_v_b = quat_rotate(cq, rel_v);
     const V3 rel_w_b = quat_rotate(cq, rel_w);
-    if (grp == TACO_TASK_FLIP) cmd1 = clampf(flip_radian - rpy_cont[0], -kTwoPi, kTwoPi);  // FA:831-832 / :930-931
+    if (grp == TACO_TASK_FLIP) cmd1 = clampf(flip_radian - roll_cont, -kTwoPi, kTwoPi);  // FA:831-832 / :930-931
 
     // 26-D frame FA:415-421 + task tails
     float fr[26];
@@ -600,7 +696,8 @@ __global__ __launch_bounds__(BLOCK) void taco_step_kernel(const StepParams P) {
             while (j >= row) { j -= row; ++env; }
         }
     };
-    // states first (noise-free frame), then obs (possibly noised)
+    // states first (noise-free frame), then obs (possibly noised).  The barrier also fences the last `slots` reads.
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < 26; ++k) tile[lane * TILE_LD + k] = fr[k];
     __syncthreads();
@@ -696,30 +793,7 @@ __global__ __launch_bounds__(BLOCK) void taco_step_kernel(const StepParams P) {
             float *gr = P.gather + (size_t)i * gather_row + (gather_row - 3);
             gr[0] = rew; gr[1] = (float)rs; gr[2] = tmo ? 1.0f : 0.0f;
         }
-        SF(TACO_S_POS) = p.x; SF(TACO_S_POS + 1) = p.y; SF(TACO_S_POS + 2) = p.z;
-        SF(TACO_S_QUAT) = q.x; SF(TACO_S_QUAT + 1) = q.y; SF(TACO_S_QUAT + 2) = q.z; SF(TACO_S_QUAT + 3) = q.w;
-        SF(TACO_S_LINVEL) = v.x; SF(TACO_S_LINVEL + 1) = v.y; SF(TACO_S_LINVEL + 2) = v.z;
-        SF(TACO_S_ANGVEL) = w.x; SF(TACO_S_ANGVEL + 1) = w.y; SF(TACO_S_ANGVEL + 2) = w.z;
-        if (is_reset) {
-            SF(TACO_S_TGT_POS) = pt.x; SF(TACO_S_TGT_POS + 1) = pt.y; SF(TACO_S_TGT_POS + 2) = pt.z;
-            SF(TACO_S_TGT_QUAT) = qt.x; SF(TACO_S_TGT_QUAT + 1) = qt.y; SF(TACO_S_TGT_QUAT + 2) = qt.z; SF(TACO_S_TGT_QUAT + 3) = qt.w;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) SF(TACO_S_TAU + k) = tau[k];
-#pragma unroll
-            for (int k = 0; k < 5; ++k) SF(TACO_S_OPARA + k) = opara[k];
-            SF(TACO_S_CF) = cf; SF(TACO_S_CT) = ct; SF(TACO_S_DX) = dx; SF(TACO_S_DY) = dy; SF(TACO_S_KT) = kt;
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            SF(TACO_S_RPY_OLD + k) = rpy_old[k]; SF(TACO_S_RPY_CONT + k) = rpy_cont[k];
-            SF(TACO_S_PID_PREV + k) = pid_prev[k]; SF(TACO_S_PID_INT + k) = pid_int[k];
-        }
-        SF(TACO_S_BAT_E) = bat_E; SF(TACO_S_BAT_U1) = bat_u1; SF(TACO_S_BAT_T) = bat_t; SF(TACO_S_BAT_V) = bat_V;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { SF(TACO_S_OMEGA + k) = omega[k]; SF(TACO_S_ACT + k) = act[k]; SF(TACO_S_ACT_OLD + k) = act_old[k]; }
-        SF(TACO_S_CMD) = cmd0; SF(TACO_S_CMD + 1) = cmd1; SF(TACO_S_FLIP_RADIAN) = flip_radian;
-        SF(TACO_S_PROGRESS) = __builtin_bit_cast(float, progress);
-        SF(TACO_S_DELAY_LEN) = __builtin_bit_cast(float, dlen);
+        SST(TACO_S_CMD + 1, cmd1);
     }
 }
 
