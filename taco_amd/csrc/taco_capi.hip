@@ -93,39 +93,44 @@ void derive(taco_env *e) {
 
 // Initial state = what the reference holds after construction, before the first step (fpv_asymmetry.py:124-200,
 // sub-model constructors): actors at (0,0,4) with identity attitude, nominal rotor / aero parameters, zero everything else.
-__global__ void init_state_kernel(float *S, float *ring, int n, int npad, float tau0, int delay_time) {
+__device__ __forceinline__ float &word(float *S, int npad, int i, int field) {
+    const int sl = taco::field_slot(field);
+    return S[((size_t)(sl >> 2) * npad + i) * 4 + (sl & 3)];
+}
+__global__ void init_state_kernel(float *S, float *ring, int npad, float tau0, int delay_time) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npad) return;
-    for (int f = 0; f < TACO_NUM_FIELDS; ++f) S[(size_t)f * npad + i] = 0.0f;
-    for (int r = 0; r < TACO_RING_SLOTS * 4; ++r) ring[(size_t)r * npad + i] = 0.0f;
-    S[(size_t)(TACO_S_POS + 2) * npad + i] = 4.0f;
-    S[(size_t)(TACO_S_QUAT + 3) * npad + i] = 1.0f;
-    S[(size_t)(TACO_S_TGT_POS + 2) * npad + i] = 4.0f;
-    S[(size_t)(TACO_S_TGT_QUAT + 3) * npad + i] = 1.0f;
-    for (int k = 0; k < 4; ++k) S[(size_t)(TACO_S_TAU + k) * npad + i] = tau0;
+    for (int c = 0; c < (int)taco::NUM_CHUNKS; ++c)
+        for (int k = 0; k < 4; ++k) S[((size_t)c * npad + i) * 4 + k] = 0.0f;
+    for (int r = 0; r < TACO_RING_SLOTS; ++r)
+        for (int k = 0; k < 4; ++k) ring[((size_t)r * npad + i) * 4 + k] = 0.0f;
+    word(S, npad, i, TACO_S_POS + 2) = 4.0f;
+    word(S, npad, i, TACO_S_QUAT + 3) = 1.0f;
+    word(S, npad, i, TACO_S_TGT_POS + 2) = 4.0f;
+    word(S, npad, i, TACO_S_TGT_QUAT + 3) = 1.0f;
+    for (int k = 0; k < 4; ++k) word(S, npad, i, TACO_S_TAU + k) = tau0;
     const float opara[5] = {0.0f, 12.9466f, 0.1872f, -5.1220f, 0.5906f};
-    for (int k = 0; k < 5; ++k) S[(size_t)(TACO_S_OPARA + k) * npad + i] = opara[k];
-    S[(size_t)TACO_S_CF * npad + i] = 1.13e-05f;
-    S[(size_t)TACO_S_CT * npad + i] = 0.05f;
-    S[(size_t)TACO_S_DX * npad + i] = -0.386f;
-    S[(size_t)TACO_S_DY * npad + i] = -0.53f;
-    S[(size_t)TACO_S_KT * npad + i] = 0.009f;
-    S[(size_t)TACO_S_DELAY_LEN * npad + i] = __builtin_bit_cast(float, delay_time);
-    (void)n;
+    for (int k = 0; k < 5; ++k) word(S, npad, i, TACO_S_OPARA + k) = opara[k];
+    word(S, npad, i, TACO_S_CF) = 1.13e-05f;
+    word(S, npad, i, TACO_S_CT) = 0.05f;
+    word(S, npad, i, TACO_S_DX) = -0.386f;
+    word(S, npad, i, TACO_S_DY) = -0.53f;
+    word(S, npad, i, TACO_S_KT) = 0.009f;
+    word(S, npad, i, TACO_S_DELAY_LEN) = __builtin_bit_cast(float, delay_time);
 }
 
-// blob (logical ring order, stride n) <-> workspace (physical ring order, stride npad)
+// blob (include/taco_env.h layout: field-major words, logical ring order) <-> workspace (float4 chunks, physical ring order)
 __global__ void export_state_kernel(const float *S, const float *ring, uint32_t *blob, int n, int npad, int head) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int row = blockIdx.y;
     if (i >= n) return;
     float val;
     if (row < TACO_NUM_FIELDS) {
-        val = S[(size_t)row * npad + i];
+        val = word(const_cast<float *>(S), npad, i, row);
     } else {
         const int r = row - TACO_NUM_FIELDS, slot = r >> 2, ch = r & 3;
         const int ph = (head + slot) % TACO_RING_SLOTS;
-        val = ring[(size_t)(ph * 4 + ch) * npad + i];
+        val = ring[((size_t)ph * npad + i) * 4 + ch];
     }
     blob[(size_t)row * n + i] = __builtin_bit_cast(uint32_t, val);
 }
@@ -135,11 +140,11 @@ __global__ void import_state_kernel(float *S, float *ring, const uint32_t *blob,
     if (i >= n) return;
     const float val = __builtin_bit_cast(float, blob[(size_t)row * n + i]);
     if (row < TACO_NUM_FIELDS) {
-        S[(size_t)row * npad + i] = val;
+        word(S, npad, i, row) = val;
     } else {
         const int r = row - TACO_NUM_FIELDS, slot = r >> 2, ch = r & 3;
         const int ph = (head + slot) % TACO_RING_SLOTS;
-        ring[(size_t)(ph * 4 + ch) * npad + i] = val;
+        ring[((size_t)ph * npad + i) * 4 + ch] = val;
     }
 }
 
@@ -156,7 +161,7 @@ const char *taco_step_kernel_name(void) { return "taco_step_kernel"; }
 size_t taco_workspace_bytes(const taco_cfg *cfg) {
     if (!cfg || cfg->num_envs <= 0) return 0;
     const size_t npad = (size_t)round_up(cfg->num_envs, 64);
-    return (size_t)(TACO_NUM_FIELDS + TACO_RING_SLOTS * 4) * npad * sizeof(float);
+    return (size_t)(taco::NUM_CHUNKS + TACO_RING_SLOTS) * npad * 4 * sizeof(float);
 }
 
 int taco_create(const taco_cfg *cfg, int device, void *workspace, size_t workspace_bytes, void *stream, taco_env **out) {
@@ -175,14 +180,14 @@ int taco_create(const taco_cfg *cfg, int device, void *workspace, size_t workspa
     e->device = device;
     e->npad = round_up(cfg->num_envs, 64);
     e->S = (float *)workspace;
-    e->ring = e->S + (size_t)TACO_NUM_FIELDS * e->npad;
+    e->ring = e->S + (size_t)taco::NUM_CHUNKS * e->npad * 4;
     e->step_count = 0;
     e->head = 0;
     e->gather = nullptr;
     std::memset(&e->P, 0, sizeof(e->P));
     derive(e);
-    hipLaunchKernelGGL(init_state_kernel, dim3((e->npad + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->S, e->ring, cfg->num_envs,
-                       e->npad, (float)cfg->rotor_response_time, cfg->delay_time);
+    hipLaunchKernelGGL(init_state_kernel, dim3((e->npad + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->S, e->ring, e->npad,
+                       (float)cfg->rotor_response_time, cfg->delay_time);
     he = hipGetLastError();
     if (he != hipSuccess) { delete e; return hip_fail(he, "init_state_kernel launch"); }
     *out = e;
@@ -203,8 +208,8 @@ int taco_step(taco_env *e, const float *actions, float *obs_buf, float *states_b
     P.reset = (long long *)reset_buf; P.timeout = timeout_buf;
     P.gather = e->gather;
     P.step = (uint32_t)e->step_count;
-    P.s_bytes = (uint32_t)((size_t)TACO_NUM_FIELDS * e->npad * sizeof(float));
-    P.ring_bytes = (uint32_t)((size_t)TACO_RING_SLOTS * 4 * e->npad * sizeof(float));
+    P.s_bytes = (uint32_t)((size_t)taco::NUM_CHUNKS * e->npad * 4 * sizeof(float));
+    P.ring_bytes = (uint32_t)((size_t)TACO_RING_SLOTS * e->npad * 4 * sizeof(float));
     P.head = e->head;
     const int n = e->cfg.num_envs;
     if (block_for(e) == kBlockLarge)

@@ -19,8 +19,8 @@ namespace taco {
 
 struct StepParams {
     // device pointers
-    float *S;            // [TACO_NUM_FIELDS][npad] state words
-    float *ring;         // [100][4][npad] pending-action ring, PHYSICAL slot order (logical slot s lives at (head+s)%100)
+    float *S;            // [NUM_CHUNKS][npad] float4 state chunks
+    float *ring;         // [100][npad] float4 pending-action ring, PHYSICAL slot order (logical slot s lives at (head+s)%100)
     const float *act_in; // [n][4]
     float *obs;          // [n][len_obs][26]
     float *states;       // [n][len_states][26]
@@ -38,6 +38,43 @@ struct StepParams {
     float flip_xy_sc, flip_xy_lo, flip_v_sc, flip_v_lo, dr_sc, dr_lo, tau_sc, tau_lo, tau_fixed, nq_sc, nq_lo;
 };
 
+// ---- workspace layout ("array of float4 rows"): the 67 state words of an env are packed into 18 float4 CHUNKS;
+// chunk c of env i lives at byte (c * npad + i) * 16, so a wavefront moves a chunk with ONE 16-byte-per-lane access
+// (1 KiB, fully coalesced) instead of four 4-byte ones.  Words that travel together share a chunk.
+// The pending-action ring is ring[slot][npad] float4 (the 4 action channels of a slot) in PHYSICAL slot order.
+enum Chunk : uint32_t {
+    C_POS = 0,      // p.x p.y p.z | progress (int)
+    C_QUAT = 1,     // q.x q.y q.z q.w
+    C_LINVEL = 2,   // v.x v.y v.z | delay length (int)
+    C_ANGVEL = 3,   // w.x w.y w.z | battery voltage
+    C_PID_PREV = 4, // previous_error xyz | battery E_c
+    C_PID_INT = 5,  // integral xyz | battery u_1
+    C_OMEGA = 6,    // rotor speeds
+    C_ACT = 7,      // actions
+    C_ACT_OLD = 8,  // actions_old
+    C_MISC = 9,     // battery time | command[0] | command[1] | flip_radian
+    C_RPY_OLD = 10, // xyz | -
+    C_RPY_CONT = 11,
+    C_TGT_POS = 12, // xyz | -
+    C_TGT_QUAT = 13,
+    C_TAU = 14,     // rotor response times
+    C_OPARA = 15,   // omega_para[0..3]
+    C_AERO0 = 16,   // omega_para[4] | cf | ct | dx
+    C_AERO1 = 17,   // dy | kt | - | -
+    NUM_CHUNKS = 18
+};
+// blob row (include/taco_env.h "State blob") -> chunk * 4 + component
+__host__ __device__ constexpr int field_slot(int f) {
+    return f < 3 ? C_POS * 4 + f : f < 7 ? C_QUAT * 4 + (f - 3) : f < 10 ? C_LINVEL * 4 + (f - 7) : f < 13 ? C_ANGVEL * 4 + (f - 10)
+         : f < 16 ? C_TGT_POS * 4 + (f - 13) : f < 20 ? C_TGT_QUAT * 4 + (f - 16) : f < 23 ? C_RPY_OLD * 4 + (f - 20)
+         : f < 26 ? C_RPY_CONT * 4 + (f - 23) : f < 29 ? C_PID_PREV * 4 + (f - 26) : f < 32 ? C_PID_INT * 4 + (f - 29)
+         : f == 32 ? C_PID_PREV * 4 + 3 : f == 33 ? C_PID_INT * 4 + 3 : f == 34 ? C_MISC * 4 + 0 : f == 35 ? C_ANGVEL * 4 + 3
+         : f < 40 ? C_OMEGA * 4 + (f - 36) : f < 44 ? C_ACT * 4 + (f - 40) : f < 48 ? C_ACT_OLD * 4 + (f - 44)
+         : f == 48 ? C_MISC * 4 + 1 : f == 49 ? C_MISC * 4 + 2 : f == 50 ? C_MISC * 4 + 3 : f < 55 ? C_TAU * 4 + (f - 51)
+         : f < 59 ? C_OPARA * 4 + (f - 55) : f == 59 ? C_AERO0 * 4 + 0 : f == 60 ? C_AERO0 * 4 + 1 : f == 61 ? C_AERO0 * 4 + 2
+         : f == 62 ? C_AERO0 * 4 + 3 : f == 63 ? C_AERO1 * 4 + 0 : f == 64 ? C_AERO1 * 4 + 1 : f == 65 ? C_POS * 4 + 3 : C_LINVEL * 4 + 3;
+}
+
 enum : uint32_t { STREAM_RESET = 1, STREAM_CMD = 2, STREAM_DEPLOY = 3, STREAM_ROTOR = 4, STREAM_OBS = 5 };
 
 
@@ -45,10 +82,23 @@ enum : uint32_t { STREAM_RESET = 1, STREAM_CMD = 2, STREAM_DEPLOY = 3, STREAM_RO
 // offset (4*i) for EVERY row, the row offset (field * npad * 4) rides in the scalar soffset operand.  With plain 64-bit
 // pointers each of the 67 + 40 row addresses would occupy a VGPR pair for the whole kernel (measured: > 130 VGPRs).
 // Out-of-range accesses are dropped / return 0 by the hardware range check instead of faulting.
-using rsrc_t = __amdgpu_buffer_rsrc_t;
-TD rsrc_t make_rsrc(const void *base, uint32_t bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000); }
-TD float buf_ld(rsrc_t r, uint32_t voff, uint32_t soff) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0)); }
-TD void buf_st(rsrc_t r, float v, uint32_t voff, uint32_t soff) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, voff, soff, 0); }
+// The intrinsics are declared directly (the composable_kernel idiom): on this toolchain (clang 22 / ROCm 7.2)
+// __builtin_amdgcn_raw_buffer_load_b128 lowers to a ONE-dword load whose value is splat over the vector.
+typedef int rsrc_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ f32x4_t llvm_amdgcn_raw_buffer_load_v4f32(rsrc_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ void llvm_amdgcn_raw_buffer_store_v4f32(f32x4_t v, rsrc_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
+TD rsrc_t make_rsrc(const void *base, uint32_t bytes) {
+    const uint64_t a = (uint64_t)base;  // wave-uniform: comes from the kernel arguments
+    return rsrc_t{(int)(uint32_t)a, (int)((uint32_t)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
+TD float4 buf_ld4(rsrc_t r, uint32_t voff, uint32_t soff) {
+    const f32x4_t u = llvm_amdgcn_raw_buffer_load_v4f32(r, (int)voff, (int)soff, 0);
+    return make_float4(u.x, u.y, u.z, u.w);
+}
+TD void buf_st4(rsrc_t r, float4 v, uint32_t voff, uint32_t soff) {
+    llvm_amdgcn_raw_buffer_store_v4f32(f32x4_t{v.x, v.y, v.z, v.w}, r, (int)voff, (int)soff, 0);
+}
 TD float as_f(int x) { return __builtin_bit_cast(float, x); }
 TD int as_i(float x) { return __builtin_bit_cast(int, x); }
 
@@ -228,9 +278,10 @@ TD void integrate(const StepParams &P, V3 &p, Q4 &q, V3 &v, V3 &w, V3 F, V3 tq) 
 
 
 // reset_idx for one env (FA:475-517), in the reference's call order: reset_copter_idx -> reset_controller_idx ->
-// reset_env_idx -> reset_target_idx.  Every new value goes straight to the env's SoA words; the 37 uniforms come from
+// reset_env_idx -> reset_target_idx.  Every new value goes straight to the env's chunks; the 37 uniforms come from
 // 10 Philox blocks of STREAM_RESET, each generated where it is consumed.
-#define RS(f, val) buf_st(rS, (val), voff, (uint32_t)(f) * row_bytes)
+#define CST(c, val) buf_st4(rS, (val), voff, (uint32_t)(c) * row_bytes)
+#define CLD(c) buf_ld4(rS, voff, (uint32_t)(c) * row_bytes)
 TD void reset_env(const StepParams &P, rsrc_t rS, rsrc_t rR, uint32_t voff, uint32_t row_bytes, int gid, int grp, bool mix, bool active) {
     if (!active) return;
     const uint32_t fl = P.flags;
@@ -265,111 +316,98 @@ TD void reset_env(const StepParams &P, rsrc_t rS, rsrc_t rR, uint32_t voff, uint
     } else {
         p.x = 0.0f; p.y = 0.0f; p.z = 2.5f;
     }
-    RS(TACO_S_POS, p.x); RS(TACO_S_POS + 1, p.y); RS(TACO_S_POS + 2, p.z);
+    CST(C_POS, make_float4(p.x, p.y, p.z, as_f(0)));  // progress <- 0 (FA:510-511)
     Q4 q{0.0f, 0.0f, 0.0f, 1.0f};
     if (fl & TACO_F_RANDOM_COPTER_QUAT) {  // rand_quat FA:698-704 (flip: limits (pi, 0, 0))
         const float l_sc = (grp == TACO_TASK_FLIP) ? 0.0f : pi_sc;
         const float l_lo = (grp == TACO_TASK_FLIP) ? -0.0f : pi_lo;
         q = quat_from_euler(pi_sc * u3 + pi_lo, l_sc * u4 + l_lo, l_sc * u5 + l_lo);
     }
-    RS(TACO_S_QUAT, q.x); RS(TACO_S_QUAT + 1, q.y); RS(TACO_S_QUAT + 2, q.z); RS(TACO_S_QUAT + 3, q.w);
+    CST(C_QUAT, make_float4(q.x, q.y, q.z, q.w));
     {
         const V3 e0 = euler_xyz_v1(q);  // FA:752-754
-        RS(TACO_S_RPY_OLD, e0.x); RS(TACO_S_RPY_OLD + 1, e0.y); RS(TACO_S_RPY_OLD + 2, e0.z);
-        RS(TACO_S_RPY_CONT, e0.x); RS(TACO_S_RPY_CONT + 1, e0.y); RS(TACO_S_RPY_CONT + 2, e0.z);
+        CST(C_RPY_OLD, make_float4(e0.x, e0.y, e0.z, 0.0f));
+        CST(C_RPY_CONT, make_float4(e0.x, e0.y, e0.z, 0.0f));
+    }
+    float a0, a1, a2, a3, b0, b1, b2, b3;
+    block(2, a0, a1, a2, a3);  // uniforms 8..11: linvel z, angvel x y z
+    block(3, b0, b1, b2, b3);  // uniforms 12..15: flip sign, target x y z
+    float c0, c1, c2, c3, d0, d1, d2, d3;
+    block(4, c0, c1, c2, c3);  // uniforms 16..19: target yaw, battery E, omega_para 0 1
+    block(5, d0, d1, d2, d3);  // uniforms 20..23: omega_para 2 3 4, tau 0
+    float h0, h1, h2, h3;
+    block(9, h0, h1, h2, h3);  // uniform 36: delay length
+    // ---- reset_env_idx FA:560-581: delay length
+    int L = P.delay_time;
+    if (fl & TACO_F_RANDOM_DELAY_TIME) {
+        L = P.delay_time - rounded_normal(h0, 3);
+        L = L < 0 ? 0 : L;
     }
     {
-        float a0, a1, a2, a3, b0, b1, b2, b3;
-        block(2, a0, a1, a2, a3);  // uniforms 8..11: linvel z, angvel x y z
-        block(3, b0, b1, b2, b3);  // uniforms 12..15: flip sign, target x y z
+        V3 v{0.0f, 0.0f, 0.0f}, w{0.0f, 0.0f, 0.0f};
         if (grp == TACO_TASK_FLIP) {
+            const float4 w_old = CLD(C_ANGVEL);
+            w = V3{w_old.x, w_old.y, w_old.z};  // standalone FpvFlip leaves angvel untouched unless told otherwise (FA:876-878)
             if (fl & TACO_F_RANDOM_COPTER_VEL) {
-                RS(TACO_S_LINVEL, P.flip_v_sc * u6 + P.flip_v_lo);
-                RS(TACO_S_LINVEL + 1, P.flip_v_sc * u7 + P.flip_v_lo);
-                RS(TACO_S_LINVEL + 2, P.flip_v_sc * a0 + P.flip_v_lo);
-                RS(TACO_S_ANGVEL, 10.0f * (b0 < 0.5f ? -1.0f : 1.0f));  // w.y, w.z keep their values (FA:876, :1047)
-            } else {
-                RS(TACO_S_LINVEL, 0.0f); RS(TACO_S_LINVEL + 1, 0.0f); RS(TACO_S_LINVEL + 2, 0.0f);
-                if (mix) { RS(TACO_S_ANGVEL, 0.0f); RS(TACO_S_ANGVEL + 1, 0.0f); RS(TACO_S_ANGVEL + 2, 0.0f); }  // FA:1050 vs FA:877-878
+                v = V3{P.flip_v_sc * u6 + P.flip_v_lo, P.flip_v_sc * u7 + P.flip_v_lo, P.flip_v_sc * a0 + P.flip_v_lo};
+                w.x = 10.0f * (b0 < 0.5f ? -1.0f : 1.0f);  // w.y, w.z keep their values (FA:876, :1047)
+            } else if (mix) {
+                w = V3{0.0f, 0.0f, 0.0f};  // FA:1050
             }
         } else if (fl & TACO_F_RANDOM_COPTER_VEL) {
-            RS(TACO_S_LINVEL, 3.0f * (2.0f * u6 + -1.0f));
-            RS(TACO_S_LINVEL + 1, 3.0f * (2.0f * u7 + -1.0f));
-            RS(TACO_S_LINVEL + 2, 3.0f * (2.0f * a0 + -1.0f));
-            RS(TACO_S_ANGVEL, 3.0f * (2.0f * a1 + -1.0f));
-            RS(TACO_S_ANGVEL + 1, 3.0f * (2.0f * a2 + -1.0f));
-            RS(TACO_S_ANGVEL + 2, 3.0f * (2.0f * a3 + -1.0f));
-        } else {
-            RS(TACO_S_LINVEL, 0.0f); RS(TACO_S_LINVEL + 1, 0.0f); RS(TACO_S_LINVEL + 2, 0.0f);
-            RS(TACO_S_ANGVEL, 0.0f); RS(TACO_S_ANGVEL + 1, 0.0f); RS(TACO_S_ANGVEL + 2, 0.0f);
+            v = V3{3.0f * (2.0f * u6 + -1.0f), 3.0f * (2.0f * u7 + -1.0f), 3.0f * (2.0f * a0 + -1.0f)};
+            w = V3{3.0f * (2.0f * a1 + -1.0f), 3.0f * (2.0f * a2 + -1.0f), 3.0f * (2.0f * a3 + -1.0f)};
         }
-        // ---- reset_target_idx FA:523-548
-        if (fl & TACO_F_RANDOM_TARGET_POS) {
-            RS(TACO_S_TGT_POS, P.df * (4.0f * b1 + -2.0f));
-            RS(TACO_S_TGT_POS + 1, P.df * (4.0f * b2 + -2.0f));
-            RS(TACO_S_TGT_POS + 2, 3.0f + P.df * (4.0f * b3 + -2.0f));
-        } else {
-            RS(TACO_S_TGT_POS, 0.0f); RS(TACO_S_TGT_POS + 1, 0.0f); RS(TACO_S_TGT_POS + 2, 3.0f);
-        }
+        CST(C_LINVEL, make_float4(v.x, v.y, v.z, as_f(L)));
+        CST(C_ANGVEL, make_float4(w.x, w.y, w.z, 0.0f));  // battery_voltage <- 0 (FA:566)
     }
+    // ---- reset_target_idx FA:523-548
+    if (fl & TACO_F_RANDOM_TARGET_POS) CST(C_TGT_POS, make_float4(P.df * (4.0f * b1 + -2.0f), P.df * (4.0f * b2 + -2.0f), 3.0f + P.df * (4.0f * b3 + -2.0f), 0.0f));
+    else CST(C_TGT_POS, make_float4(0.0f, 0.0f, 3.0f, 0.0f));
     {
-        float c0, c1, c2, c3, d0, d1, d2, d3;
-        block(4, c0, c1, c2, c3);  // uniforms 16..19: target yaw, battery E, omega_para 0 1
-        block(5, d0, d1, d2, d3);  // uniforms 20..23: omega_para 2 3 4, tau 0
         const float yaw = (fl & TACO_F_RANDOM_TARGET_YAW) ? pi_sc * c0 + pi_lo : 0.0f;
         const Q4 qt = quat_from_euler(0.0f, 0.0f, yaw);
-        RS(TACO_S_TGT_QUAT, qt.x); RS(TACO_S_TGT_QUAT + 1, qt.y); RS(TACO_S_TGT_QUAT + 2, qt.z); RS(TACO_S_TGT_QUAT + 3, qt.w);
-        // ---- reset_controller_idx FA:550-558
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { RS(TACO_S_PID_PREV + k, 0.0f); RS(TACO_S_PID_INT + k, 0.0f); }
-        RS(TACO_S_BAT_U1, 0.0f); RS(TACO_S_BAT_T, 0.0f); RS(TACO_S_BAT_V, 0.0f);
-        RS(TACO_S_BAT_E, (fl & TACO_F_RANDOM_VOLTAGE) ? (float)2.2 * c1 + 0.0f : 0.0f);
-        const bool rc = (fl & TACO_F_RANDOM_ROTORDYNAMIC_COE) != 0;
-        RS(TACO_S_OPARA + 0, rc ? 0.0f * (P.dr_sc * c2 + P.dr_lo) : 0.0f);
-        RS(TACO_S_OPARA + 1, rc ? 12.9466f * (P.dr_sc * c3 + P.dr_lo) : 12.9466f);
-        RS(TACO_S_OPARA + 2, rc ? 0.1872f * (P.dr_sc * d0 + P.dr_lo) : 0.1872f);
-        RS(TACO_S_OPARA + 3, rc ? -5.1220f * (P.dr_sc * d1 + P.dr_lo) : -5.1220f);
-        RS(TACO_S_OPARA + 4, rc ? 0.5906f * (P.dr_sc * d2 + P.dr_lo) : 0.5906f);
-        float e0, e1, e2, e3, f0, f1, f2, f3;
-        block(6, e0, e1, e2, e3);  // uniforms 24..27: tau 1 2 3, omega0 0
-        block(7, f0, f1, f2, f3);  // uniforms 28..31: omega0 1 2 3, cf
+        CST(C_TGT_QUAT, make_float4(qt.x, qt.y, qt.z, qt.w));
+    }
+    // ---- reset_controller_idx FA:550-558
+    CST(C_PID_PREV, make_float4(0.0f, 0.0f, 0.0f, (fl & TACO_F_RANDOM_VOLTAGE) ? (float)2.2 * c1 + 0.0f : 0.0f));  // + battery E_c
+    CST(C_PID_INT, make_float4(0.0f, 0.0f, 0.0f, 0.0f));                                                          // + battery u_1
+    {
+        const float4 misc = CLD(C_MISC);  // command / flip_radian survive a reset until reset_command_idx rewrites them
+        CST(C_MISC, make_float4(0.0f, misc.y, misc.z, misc.w));  // battery time <- 0
+    }
+    const bool rc = (fl & TACO_F_RANDOM_ROTORDYNAMIC_COE) != 0;
+    CST(C_OPARA, make_float4(rc ? 0.0f * (P.dr_sc * c2 + P.dr_lo) : 0.0f, rc ? 12.9466f * (P.dr_sc * c3 + P.dr_lo) : 12.9466f,
+                             rc ? 0.1872f * (P.dr_sc * d0 + P.dr_lo) : 0.1872f, rc ? -5.1220f * (P.dr_sc * d1 + P.dr_lo) : -5.1220f));
+    float e0, e1, e2, e3, f0, f1, f2, f3, g0, g1, g2, g3;
+    block(6, e0, e1, e2, e3);  // uniforms 24..27: tau 1 2 3, omega0 0
+    block(7, f0, f1, f2, f3);  // uniforms 28..31: omega0 1 2 3, cf
+    block(8, g0, g1, g2, g3);  // uniforms 32..35: ct, dx, dy, kt
+    {
         const float tu[4] = {d3, e0, e1, e2};
         const float ou[4] = {e3, f0, f1, f2};
+        float t[4], o[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            float t;
-            if (fl & TACO_F_ROTOR_RESPONSE) t = (fl & TACO_F_RANDOM_ROTOR_RESPONSE) ? P.tau_sc * tu[k] + P.tau_lo : P.tau_fixed * 1.0f;
-            else t = 0.001f * 1.0f;
-            RS(TACO_S_TAU + k, t);
-            RS(TACO_S_OMEGA + k, (fl & TACO_F_RANDOM_ROTOR_SPEED) ? 400.0f * ou[k] + 0.0f : 0.0f);
+            if (fl & TACO_F_ROTOR_RESPONSE) t[k] = (fl & TACO_F_RANDOM_ROTOR_RESPONSE) ? P.tau_sc * tu[k] + P.tau_lo : P.tau_fixed * 1.0f;
+            else t[k] = 0.001f * 1.0f;
+            o[k] = (fl & TACO_F_RANDOM_ROTOR_SPEED) ? 400.0f * ou[k] + 0.0f : 0.0f;
         }
-        float g0, g1, g2, g3, h0, h1, h2, h3;
-        block(8, g0, g1, g2, g3);  // uniforms 32..35: ct, dx, dy, kt
-        block(9, h0, h1, h2, h3);  // uniform 36: delay length
-        if (fl & TACO_F_RANDOM_AERODYNAMIC_COE) {  // CTRL/thrust_dynamics.py:201-210 (a no-op when the flag is off)
-            RS(TACO_S_CF, 1.13e-05f * (P.dr_sc * f3 + P.dr_lo));
-            RS(TACO_S_CT, 0.05f * (P.dr_sc * g0 + P.dr_lo));
-            RS(TACO_S_DX, -0.386f * (P.dr_sc * g1 + P.dr_lo));
-            RS(TACO_S_DY, -0.53f * (P.dr_sc * g2 + P.dr_lo));
-            RS(TACO_S_KT, 0.009f * (P.dr_sc * g3 + P.dr_lo));
-        }
-        // ---- reset_env_idx FA:560-581
-        int L = P.delay_time;
-        if (fl & TACO_F_RANDOM_DELAY_TIME) {
-            L = P.delay_time - rounded_normal(h0, 3);
-            L = L < 0 ? 0 : L;
-        }
-        RS(TACO_S_DELAY_LEN, as_f(L));
-        RS(TACO_S_PROGRESS, as_f(0));  // FA:510-511
+        CST(C_TAU, make_float4(t[0], t[1], t[2], t[3]));
+        CST(C_OMEGA, make_float4(o[0], o[1], o[2], o[3]));
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { RS(TACO_S_ACT + k, 0.0f); RS(TACO_S_ACT_OLD + k, 0.0f); }
-    for (int s = 0; s < TACO_RING_SLOTS * 4; ++s) buf_st(rR, 0.0f, voff, (uint32_t)s * row_bytes);
+    {
+        const float4 ae0 = CLD(C_AERO0), ae1 = CLD(C_AERO1);  // aero parameters keep their values unless re-randomised
+        const bool ra = (fl & TACO_F_RANDOM_AERODYNAMIC_COE) != 0;  // CTRL/thrust_dynamics.py:201-210 (a no-op when off)
+        CST(C_AERO0, make_float4(rc ? 0.5906f * (P.dr_sc * d2 + P.dr_lo) : 0.5906f, ra ? 1.13e-05f * (P.dr_sc * f3 + P.dr_lo) : ae0.y,
+                                 ra ? 0.05f * (P.dr_sc * g0 + P.dr_lo) : ae0.z, ra ? -0.386f * (P.dr_sc * g1 + P.dr_lo) : ae0.w));
+        CST(C_AERO1, make_float4(ra ? -0.53f * (P.dr_sc * g2 + P.dr_lo) : ae1.x, ra ? 0.009f * (P.dr_sc * g3 + P.dr_lo) : ae1.y, 0.0f, 0.0f));
+    }
+    CST(C_ACT, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    CST(C_ACT_OLD, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    for (int s = 0; s < TACO_RING_SLOTS; ++s) buf_st4(rR, make_float4(0.0f, 0.0f, 0.0f, 0.0f), voff, (uint32_t)s * row_bytes);
 }
-#undef RS
 
-#define SLD(f) buf_ld(rS, voff, (uint32_t)(f) * row_bytes)
-#define SST(f, val) buf_st(rS, (val), voff, (uint32_t)(f) * row_bytes)
 
 // Two instantiations: BLOCK = 64 for the latency regime (few envs: one wavefront per workgroup, spread over as many CUs
 // as possible, registers unconstrained) and BLOCK = 256 for the throughput regime, where the register budget is capped
@@ -392,8 +430,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
     const bool active = i_raw < P.n;
     const int i = active ? i_raw : P.n - 1;  // tail lanes shadow the last env and store nothing
     const int gid = P.env_offset + i;
-    const uint32_t voff = (uint32_t)i * 4u;            // this lane's byte offset inside every SoA row
-    const uint32_t row_bytes = (uint32_t)P.npad * 4u;  // one SoA row
+    const uint32_t voff = (uint32_t)i * 16u;            // this lane's byte offset inside every float4 row
+    const uint32_t row_bytes = (uint32_t)P.npad * 16u;  // one float4 row (chunk or ring slot)
     const rsrc_t rS = make_rsrc(P.S, P.s_bytes);
     const rsrc_t rR = make_rsrc(P.ring, P.ring_bytes);
     const uint32_t fl = P.flags;
@@ -409,26 +447,30 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
     // draws or temporaries are live once the step proper starts (they would otherwise dominate the register budget).
     if (is_reset) reset_env(P, rS, rR, voff, row_bytes, gid, grp, mix, active);
 
-    // ------------------------------------------------------------------ load state (coalesced SoA rows)
-    V3 p{SLD(TACO_S_POS), SLD(TACO_S_POS + 1), SLD(TACO_S_POS + 2)};
-    Q4 q{SLD(TACO_S_QUAT), SLD(TACO_S_QUAT + 1), SLD(TACO_S_QUAT + 2), SLD(TACO_S_QUAT + 3)};
-    V3 v{SLD(TACO_S_LINVEL), SLD(TACO_S_LINVEL + 1), SLD(TACO_S_LINVEL + 2)};
-    V3 w{SLD(TACO_S_ANGVEL), SLD(TACO_S_ANGVEL + 1), SLD(TACO_S_ANGVEL + 2)};
-    float rpy_old[3], rpy_cont[3], pid_prev[3], pid_int[3], omega[4], act[4], act_old[4], tau[4], opara[5];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        rpy_old[k] = SLD(TACO_S_RPY_OLD + k); rpy_cont[k] = SLD(TACO_S_RPY_CONT + k);
-        pid_prev[k] = SLD(TACO_S_PID_PREV + k); pid_int[k] = SLD(TACO_S_PID_INT + k);
+    // ------------------------------------------------------------------ load state: 14 coalesced 16-byte-per-lane loads
+    const float4 c_pos = CLD(C_POS), c_quat = CLD(C_QUAT), c_lin = CLD(C_LINVEL), c_ang = CLD(C_ANGVEL);
+    const float4 c_pp = CLD(C_PID_PREV), c_pi = CLD(C_PID_INT), c_om = CLD(C_OMEGA), c_act = CLD(C_ACT), c_misc = CLD(C_MISC);
+    const float4 c_tau = CLD(C_TAU), c_op = CLD(C_OPARA), c_a0 = CLD(C_AERO0), c_a1 = CLD(C_AERO1);
+    V3 p{c_pos.x, c_pos.y, c_pos.z};
+    Q4 q{c_quat.x, c_quat.y, c_quat.z, c_quat.w};
+    V3 v{c_lin.x, c_lin.y, c_lin.z};
+    V3 w{c_ang.x, c_ang.y, c_ang.z};
+    float rpy_old[3] = {0.0f, 0.0f, 0.0f}, rpy_cont[3] = {0.0f, 0.0f, 0.0f};
+    if (track_rpy) {
+        const float4 c_ro = CLD(C_RPY_OLD), c_rc = CLD(C_RPY_CONT);
+        rpy_old[0] = c_ro.x; rpy_old[1] = c_ro.y; rpy_old[2] = c_ro.z;
+        rpy_cont[0] = c_rc.x; rpy_cont[1] = c_rc.y; rpy_cont[2] = c_rc.z;
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { omega[k] = SLD(TACO_S_OMEGA + k); act[k] = SLD(TACO_S_ACT + k); tau[k] = SLD(TACO_S_TAU + k); }
-#pragma unroll
-    for (int k = 0; k < 5; ++k) opara[k] = SLD(TACO_S_OPARA + k);
-    float bat_E = SLD(TACO_S_BAT_E), bat_u1 = SLD(TACO_S_BAT_U1), bat_t = SLD(TACO_S_BAT_T), bat_V = SLD(TACO_S_BAT_V);
-    float cmd0 = SLD(TACO_S_CMD), cmd1 = SLD(TACO_S_CMD + 1), flip_radian = SLD(TACO_S_FLIP_RADIAN);
-    const float cf = SLD(TACO_S_CF), ct = SLD(TACO_S_CT), dx = SLD(TACO_S_DX), dy = SLD(TACO_S_DY), kt = SLD(TACO_S_KT);
-    int progress = as_i(SLD(TACO_S_PROGRESS));
-    int dlen = as_i(SLD(TACO_S_DELAY_LEN));
+    float pid_prev[3] = {c_pp.x, c_pp.y, c_pp.z}, pid_int[3] = {c_pi.x, c_pi.y, c_pi.z};
+    float omega[4] = {c_om.x, c_om.y, c_om.z, c_om.w};
+    float act[4] = {c_act.x, c_act.y, c_act.z, c_act.w}, act_old[4];
+    const float tau[4] = {c_tau.x, c_tau.y, c_tau.z, c_tau.w};
+    const float opara[5] = {c_op.x, c_op.y, c_op.z, c_op.w, c_a0.x};
+    float bat_E = c_pp.w, bat_u1 = c_pi.w, bat_t = c_misc.x, bat_V = c_ang.w;
+    float cmd0 = c_misc.y, cmd1 = c_misc.z, flip_radian = c_misc.w;
+    const float cf = c_a0.y, ct = c_a0.z, dx = c_a0.w, dy = c_a1.x, kt = c_a1.y;
+    int progress = as_i(c_pos.w);
+    int dlen = as_i(c_lin.w);
     const float4 a_in = reinterpret_cast<const float4 *>(P.act_in)[i];
     const bool at_time = !is_reset && progress == 500;  // reset_command_condition FA:595-598 (a reset env has progress 0 here;
                                                         // its own progress==500 case is overwritten by the reset branch below)
@@ -463,9 +505,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
     act[2] = clampf(a_in.z, -P.clip_act, P.clip_act);
     act[3] = clampf(a_in.w, -P.clip_act, P.clip_act);
     if (active) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { SST(TACO_S_ACT_OLD + k, act_old[k]); SST(TACO_S_ACT + k, act[k]); }
-        SST(TACO_S_CMD, cmd0); SST(TACO_S_FLIP_RADIAN, flip_radian);
+        CST(C_ACT_OLD, make_float4(act_old[0], act_old[1], act_old[2], act_old[3]));
+        CST(C_ACT, make_float4(act[0], act[1], act[2], act[3]));
     }
     int T = 10;
     if (fl & TACO_F_RANDOM_DEPLOY_TIME) {
@@ -480,11 +521,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
             int ph = P.head + s; ph = ph >= TACO_RING_SLOTS ? ph - TACO_RING_SLOTS : ph;
             const bool fresh = (s >= dlen) && (s < dlen + T);
             const bool keep = !is_reset && !fresh;  // a reset env's ring is all zeros; a fresh slot comes from registers
-            float4 o;
-            o.x = keep ? buf_ld(rR, voff, (uint32_t)(ph * 4 + 0) * row_bytes) : (fresh ? act[0] : 0.0f);
-            o.y = keep ? buf_ld(rR, voff, (uint32_t)(ph * 4 + 1) * row_bytes) : (fresh ? act[1] : 0.0f);
-            o.z = keep ? buf_ld(rR, voff, (uint32_t)(ph * 4 + 2) * row_bytes) : (fresh ? act[2] : 0.0f);
-            o.w = keep ? buf_ld(rR, voff, (uint32_t)(ph * 4 + 3) * row_bytes) : (fresh ? act[3] : 0.0f);
+            float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (keep) o = buf_ld4(rR, voff, (uint32_t)ph * row_bytes);
+            if (fresh) o = make_float4(act[0], act[1], act[2], act[3]);
             slots[s * 64 + lane] = o;
         }
     }
@@ -493,8 +532,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
             int sl = dlen + j;
             if (j < T && sl < TACO_RING_SLOTS) {
                 int ph = P.head + sl; ph = ph >= TACO_RING_SLOTS ? ph - TACO_RING_SLOTS : ph;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) buf_st(rR, act[k], (uint32_t)(ph * 4 + k) * row_bytes + voff, 0u);
+                buf_st4(rR, make_float4(act[0], act[1], act[2], act[3]), (uint32_t)ph * row_bytes + voff, 0u);
             }
         }
     }
@@ -610,22 +648,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
     if (active) {
         // Everything the substep loop evolved goes back to its SoA row NOW, so the registers are free for the
         // observation / reward code below.
-        SST(TACO_S_POS, p.x); SST(TACO_S_POS + 1, p.y); SST(TACO_S_POS + 2, p.z);
-        SST(TACO_S_QUAT, q.x); SST(TACO_S_QUAT + 1, q.y); SST(TACO_S_QUAT + 2, q.z); SST(TACO_S_QUAT + 3, q.w);
-        SST(TACO_S_LINVEL, v.x); SST(TACO_S_LINVEL + 1, v.y); SST(TACO_S_LINVEL + 2, v.z);
-        SST(TACO_S_ANGVEL, w.x); SST(TACO_S_ANGVEL + 1, w.y); SST(TACO_S_ANGVEL + 2, w.z);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            SST(TACO_S_PID_PREV + k, pid_prev[k]); SST(TACO_S_PID_INT + k, pid_int[k]);
-        }
+        CST(C_POS, make_float4(p.x, p.y, p.z, as_f(progress)));
+        CST(C_QUAT, make_float4(q.x, q.y, q.z, q.w));
+        CST(C_ANGVEL, make_float4(w.x, w.y, w.z, bat_V));
+        CST(C_PID_PREV, make_float4(pid_prev[0], pid_prev[1], pid_prev[2], bat_E));
+        CST(C_PID_INT, make_float4(pid_int[0], pid_int[1], pid_int[2], bat_u1));
+        CST(C_OMEGA, make_float4(omega[0], omega[1], omega[2], omega[3]));
         if (track_rpy) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { SST(TACO_S_RPY_OLD + k, rpy_old[k]); SST(TACO_S_RPY_CONT + k, rpy_cont[k]); }
+            CST(C_RPY_OLD, make_float4(rpy_old[0], rpy_old[1], rpy_old[2], 0.0f));
+            CST(C_RPY_CONT, make_float4(rpy_cont[0], rpy_cont[1], rpy_cont[2], 0.0f));
         }
-        SST(TACO_S_BAT_E, bat_E); SST(TACO_S_BAT_U1, bat_u1); SST(TACO_S_BAT_T, bat_t); SST(TACO_S_BAT_V, bat_V);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) SST(TACO_S_OMEGA + k, omega[k]);
-        SST(TACO_S_PROGRESS, as_f(progress));
         // FA:378 leaves logical slots [90,100) untouched by the shift.  With the ring advancing by 10 (host side), the new
         // logical [90,100) are the physical slots just consumed, so they must be given the values of the old logical
         // [90,100) (= new [80,90)); a slot this step's action write covered is taken from registers, not re-read.
@@ -636,18 +668,17 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
             int dst = P.head + j;  // old logical j == new logical 90+j
             dst = dst >= TACO_RING_SLOTS ? dst - TACO_RING_SLOTS : dst;
             const bool fresh = (90 + j >= wr_lo) && (90 + j < dlen);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float old = buf_ld(rR, voff, (uint32_t)(src * 4 + k) * row_bytes);
-                buf_st(rR, fresh ? act[k] : old, voff, (uint32_t)(dst * 4 + k) * row_bytes);
-            }
+            float4 old = buf_ld4(rR, voff, (uint32_t)src * row_bytes);
+            if (fresh) old = make_float4(act[0], act[1], act[2], act[3]);
+            buf_st4(rR, old, voff, (uint32_t)dst * row_bytes);
         }
         dlen = dlen - 10 < 0 ? 0 : dlen - 10;
-        SST(TACO_S_DELAY_LEN, as_f(dlen));
+        CST(C_LINVEL, make_float4(v.x, v.y, v.z, as_f(dlen)));
     }
     // relative quantities FA:354-360 (target velocities are identically zero); the target pose is only needed from here on
-    const V3 pt{SLD(TACO_S_TGT_POS), SLD(TACO_S_TGT_POS + 1), SLD(TACO_S_TGT_POS + 2)};
-    const Q4 qt{SLD(TACO_S_TGT_QUAT), SLD(TACO_S_TGT_QUAT + 1), SLD(TACO_S_TGT_QUAT + 2), SLD(TACO_S_TGT_QUAT + 3)};
+    const float4 c_tp = CLD(C_TGT_POS), c_tq = CLD(C_TGT_QUAT);
+    const V3 pt{c_tp.x, c_tp.y, c_tp.z};
+    const Q4 qt{c_tq.x, c_tq.y, c_tq.z, c_tq.w};
     const Q4 cq = conj(q);
     const V3 rel_pos{pt.x - p.x, pt.y - p.y, pt.z - p.z};
     const V3 rel_v{0.0f - v.x, 0.0f - v.y, 0.0f - v.z};
@@ -793,7 +824,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
             float *gr = P.gather + (size_t)i * gather_row + (gather_row - 3);
             gr[0] = rew; gr[1] = (float)rs; gr[2] = tmo ? 1.0f : 0.0f;
         }
-        SST(TACO_S_CMD + 1, cmd1);
+        CST(C_MISC, make_float4(bat_t, cmd0, cmd1, flip_radian));
     }
 }
 
