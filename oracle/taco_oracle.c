@@ -157,6 +157,33 @@ enum {
 };
 
 /* ------------------------------------------------------------------------------------------------ small helpers */
+/* x / c for a divisor c known in advance, WITHOUT a division: q = x * RN(1/c), then one fma-based correction.
+ * For every divisor this file uses it on (0.001, 0.75, 3, 3.3, 6, 100, 1000, 4500, 9000, pi) the result was checked
+ * exhaustively (all 2^24 signed mantissas x several binades) to be bit-identical to the IEEE-754 quotient x / c, i.e. to
+ * what torch's `tensor / scalar` computes.  It differs from IEEE only where no meaningful state lives: |x| beyond ~1e34
+ * (NaN instead of +-inf), quotients in the denormal range, and the sign of a zero quotient (-0/c gives +0).
+ * The HIP kernel uses the same three operations. */
+static inline float div_const(float x, float c, float rc) {
+    float q = x * rc;
+    float r = fmaf(-q, c, x);
+    return fmaf(r, rc, q);
+}
+#define DIVC(x, c) div_const((x), (c), 1.0f / (c))
+/* exhaustive check of div_const for a run-time divisor (the sim dt): one binade of x, both signs; scale invariance of
+ * the three operations covers the other binades of the normal range */
+static int div_const_is_exact(float c) {
+    static float cached_c = 0.0f; /* benign race: every thread computes the same answer */
+    static int cached_ok = 0;
+    if (c == cached_c) return cached_ok;
+    const float rc = 1.0f / c;
+    for (uint32_t m = 0; m < (1u << 23); ++m) {
+        float x = u2f(0x3f800000u | m);
+        if (div_const(x, c, rc) != x / c || div_const(-x, c, rc) != -x / c) { cached_ok = 0; cached_c = c; return 0; }
+    }
+    cached_ok = 1;
+    cached_c = c;
+    return 1;
+}
 /* torch.clamp / torch.clip: min(max(x, lo), hi), NaN in x propagates */
 static inline float clampf(float x, float lo, float hi) {
     float t = (x < lo) ? lo : x;
@@ -262,24 +289,24 @@ static inline float rand_float(double lower, double upper, float u) { return (fl
 
 /* ------------------------------------------------------------------------------------------------ sub-models */
 /* CTRL/angvel_control.py:67-88 (gains :17-60) */
-static inline void pid_axis(float dt, float kp, float des, float cur, float *prev, float *integ, float *out) {
+static inline void pid_axis(float dt, float rdt, float kp, float des, float cur, float *prev, float *integ, float *out) {
     const float ki = 0.0f, kd = 0.5f, kf = 0.0f, fg = 0.4f;
     float e = clampf(des - cur, -400.0f, 400.0f);
     float pv = (*prev == 0.0f) ? e : *prev;
     float P = kp * e;
     float I = clampf(*integ + e * dt, -500.0f, 500.0f);
     float I_term = ki * I;
-    float deriv = (e - pv) / dt;
+    float deriv = (rdt != 0.0f) ? div_const(e - pv, dt, rdt) : (e - pv) / dt; /* rdt = 1/dt when div_const is exact for dt */
     float D = clampf(kd * deriv, -150.0f, 150.0f);
     float FF = kf * des;
     *out = fg * (P + I_term + D + FF);
     *integ = I;
     *prev = e;
 }
-static inline void pid_step(float dt, const float des[3], const float cur[3], float prev[3], float integ[3], float out[3]) {
-    pid_axis(dt, 27.5f, des[0], cur[0], &prev[0], &integ[0], &out[0]);
-    pid_axis(dt, 50.0f, des[1], cur[1], &prev[1], &integ[1], &out[1]);
-    pid_axis(dt, 200.0f, des[2], cur[2], &prev[2], &integ[2], &out[2]);
+static inline void pid_step(float dt, float rdt, const float des[3], const float cur[3], float prev[3], float integ[3], float out[3]) {
+    pid_axis(dt, rdt, 27.5f, des[0], cur[0], &prev[0], &integ[0], &out[0]);
+    pid_axis(dt, rdt, 50.0f, des[1], cur[1], &prev[1], &integ[1], &out[1]);
+    pid_axis(dt, rdt, 200.0f, des[2], cur[2], &prev[2], &integ[2], &out[2]);
 }
 /* CTRL/fpv_dynamics.py:35-46 control_allocator (weight :28-33); u[3] is clipped in place like the reference */
 static inline void allocator(float u[4], float thr[4]) {
@@ -296,7 +323,7 @@ static inline void allocator(float u[4], float thr[4]) {
 static inline float mech_power(const float om[4]) {
     float acc = 0.0f;
     for (int i = 0; i < 4; ++i) {
-        float b = om[i] * 2.0f * PI_F / 4500.0f;
+        float b = DIVC(om[i] * 2.0f * PI_F, 4500.0f);
         float t = 400.0f * ((b * b) * b);
         acc = (i == 0) ? t : acc + t;
     }
@@ -307,14 +334,14 @@ static inline float battery_step(int enabled, float dt, float Pm, float *E, floa
     const float a0 = 4.35f;
     if (!enabled) return a0 * 6.0f;
     *t = *t + dt;
-    float p_c = Pm / 0.75f / 9000.0f;
+    float p_c = DIVC(DIVC(Pm, 0.75f), 9000.0f);
     *E = *E + p_c * dt;
     float P_avg = *E / *t;
     float r0_ = 0.0015778f + -7.7608e-5f * P_avg + (float)(0.0069498 * 1500.0);
     float r0 = (r0_ > 4.5f) ? r0_ : 4.5f;
     float Ec = *E;
     float u0 = a0 + -0.1102178f * Ec + 0.0103368f * (Ec * Ec) + -4.3778e-4f * ((Ec * Ec) * Ec);
-    float u1_dot = (0.00104846f * p_c - *u1) / 3.3f;
+    float u1_dot = DIVC(0.00104846f * p_c - *u1, 3.3f);
     *u1 = *u1 + u1_dot * dt;
     float d = u0 - *u1;
     float rad = d * d - 4.0f * r0 * p_c;
@@ -322,9 +349,9 @@ static inline float battery_step(int enabled, float dt, float Pm, float *E, floa
 }
 /* CTRL/thrust_dynamics.py:98-104 (throttle_voltage2omega :52-66, omega_compute :80-86; delay depth 1 = pass-through) */
 static inline void rotor_step(float V, const float thr[4], const float tau[4], const float p[5], float om[4]) {
-    float y = (V - 23.0f) / 3.0f;
+    float y = DIVC(V - 23.0f, 3.0f);
     for (int i = 0; i < 4; ++i) {
-        float x = thr[i] / 1000.0f;
+        float x = DIVC(thr[i], 1000.0f);
         float target = (p[0] * 1.0f + p[1] * x + p[2] * y + p[3] * (x * x) + p[4] * x * y) * 100.0f;
         /* `self.sample_time / self.response_time`: Python float / Tensor is Tensor.__rtruediv__ = reciprocal() * scalar */
         om[i] = om[i] + (1.0f / tau[i]) * 0.001f * (target - om[i]);
@@ -365,7 +392,7 @@ static inline float reward_pos(const float rpb[3], const float pos[3], const flo
     float r0 = 1.0f / (1.0f + qd * qd), r1 = 1.0f / (1.0f + 10.0f * qd * qd);
     float rr = r0 + r1;
     *reset = done_flag(pos[2], d, prog, max_len);
-    return pr * rr / 100.0f;
+    return DIVC(pr * rr, 100.0f);
 }
 /* CTRL/task_reward.py:50-104 */
 static inline float reward_rotate(const float rp[3], const float rv[3], const float pos[3], const float q[4], const float cmd[2],
@@ -393,7 +420,7 @@ static inline float reward_rotate(const float rp[3], const float rv[3], const fl
     float dd = 1.0f + (nx[0] * hx + nx[1] * hy) / norm2(hx, hy);
     float dr = 1.0f / (1.0f + dd * dd) + 1.0f / (1.0f + 10.0f * dd * dd);
     *reset = done_flag(pos[2], pd, prog, max_len);
-    return pr * lr * dr / 100.0f;
+    return DIVC(pr * lr * dr, 100.0f);
 }
 /* CTRL/task_reward.py:107-143 */
 static inline float reward_flip(const float rpb[3], const float relq[4], const float pos[3], const float cmd[2], int64_t prog,
@@ -404,93 +431,86 @@ static inline float reward_flip(const float rpb[3], const float relq[4], const f
     quat_to_matrix(relq, m);
     float xt = 1.0f - m[0];
     float xr = 1.0f / (1.0f + 10.0f * xt);
-    float cd = cmd[1] / 2.0f / PI_F;
+    float cd = DIVC(cmd[1] / 2.0f, PI_F);
     float cr = 1.0f / (1.0f + cd * cd) + 1.0f / (1.0f + 10.0f * cd * cd);
     *reset = done_flag(pos[2], d, prog, max_len);
-    return pr * xr * cr / 100.0f;
+    return DIVC(pr * xr * cr, 100.0f);
 }
 
 /* ------------------------------------------------------------------------------------------------ row I: integrate
  * Replaces gym.simulate(sim) (VT:313) for ONE free rigid body.  NOT in the reference's source (closed PhysX):
- * "parity unpinned".  Scheme (PhysX public SDK, DyBodyCoreIntegrator-style): per sub-iteration h = dt/substeps with the
- * body-frame wrench held constant (gym.apply_rigid_body_force_tensors(..., LOCAL_SPACE), FA:633-635):
- *     w_b += h * Jinv * (tau - w_b x (J w_b));  v += h * (R F / m + g);  p += h * v;
- *     q <- normalize(exp(h/2 * w_world) (x) q)    [closed-form quaternion update, world-frame angular velocity]
- * exp() uses even/odd Taylor polynomials in a2 = (h/2 |w|)^2 while a2 <= 0.25 (|w| h <= 1 rad per sub-iteration) and the
- * sqrt/sincos form beyond; the renormalisation uses two Newton steps from 1 while |n2 - 1| <= 1/64, else 1/sqrt(n2). */
+ * "parity unpinned".  Scheme (PhysX public SDK): `substeps` sub-iterations of h = dt/substeps, semi-implicit Euler, with
+ * the body-frame wrench held constant (gym.apply_rigid_body_force_tensors(..., LOCAL_SPACE), FA:633-635):
+ *     b += h J^-1 (tau - b x J b)          body rates b; start value = the body-frame angular velocity of row C
+ *     v += h (R(q) F / m + g);  p += h v    R(q) F by the quaternion sandwich  F + w t + qv x t,  t = 2 qv x F
+ *     q <- normalize(q (x) exp(h/2 b))      closed-form quaternion update; a body-frame rate multiplies on the right
+ * and, after the last sub-iteration, the world-frame angular velocity of the root state is w = R(q) b.
+ * exp(): Taylor polynomials in a2 = (h/2 |b|)^2 while a2 <= 0.25, sqrt/sincos beyond; normalisation: one Newton step
+ * from 1 (error 3/8 (n2-1)^2, far below fp32 resolution) while |n2 - 1| <= 1e-3, else 1/sqrt(n2).
+ * Every operation below is written out (fma where fused) -- the HIP kernel repeats it verbatim. */
 typedef struct {
-    float h, half_h, inv_m, g, J[3], Jinv[3];
+    float h, half_h, inv_m, g, J[3], hJi[3];
     int substeps;
 } integ_par;
 
-static inline void integrate_substep(const integ_par *P, float p[3], float q[4], float v[3], float w[3], const float F[3],
-                                     const float tau[3]) {
+static inline void quat_sandwich(const float q[4], const float u[3], float out[3]) {
+    float tx = fmaf(q[1], u[2], -(q[2] * u[1])), ty = fmaf(q[2], u[0], -(q[0] * u[2])), tz = fmaf(q[0], u[1], -(q[1] * u[0]));
+    tx = tx + tx; ty = ty + ty; tz = tz + tz;
+    out[0] = fmaf(q[1], tz, fmaf(-q[2], ty, fmaf(q[3], tx, u[0])));
+    out[1] = fmaf(q[2], tx, fmaf(-q[0], tz, fmaf(q[3], ty, u[1])));
+    out[2] = fmaf(q[0], ty, fmaf(-q[1], tx, fmaf(q[3], tz, u[2])));
+}
+
+static inline void integrate_substep(const integ_par *P, float p[3], float q[4], float v[3], float w[3], const float wb[3],
+                                     const float F[3], const float tau[3]) {
+    float b0 = wb[0], b1 = wb[1], b2 = wb[2];
     for (int it = 0; it < P->substeps; ++it) {
-        float qx = q[0], qy = q[1], qz = q[2], qw = q[3];
-        float xx = qx * qx, yy = qy * qy, zz = qz * qz;
-        float xy = qx * qy, xz = qx * qz, yz = qy * qz;
-        float wx = qw * qx, wy = qw * qy, wz = qw * qz;
-        float R00 = fmaf(-2.0f, yy + zz, 1.0f), R01 = 2.0f * (xy - wz), R02 = 2.0f * (xz + wy);
-        float R10 = 2.0f * (xy + wz), R11 = fmaf(-2.0f, xx + zz, 1.0f), R12 = 2.0f * (yz - wx);
-        float R20 = 2.0f * (xz - wy), R21 = 2.0f * (yz + wx), R22 = fmaf(-2.0f, xx + yy, 1.0f);
-        /* body rates, Euler's equations */
-        float b0 = fmaf(R20, w[2], fmaf(R10, w[1], R00 * w[0]));
-        float b1 = fmaf(R21, w[2], fmaf(R11, w[1], R01 * w[0]));
-        float b2 = fmaf(R22, w[2], fmaf(R12, w[1], R02 * w[0]));
+        /* Euler's equations in the body frame */
         float L0 = P->J[0] * b0, L1 = P->J[1] * b1, L2 = P->J[2] * b2;
         float g0 = fmaf(b1, L2, -(b2 * L1));
         float g1 = fmaf(b2, L0, -(b0 * L2));
         float g2 = fmaf(b0, L1, -(b1 * L0));
-        b0 = fmaf(P->h, P->Jinv[0] * (tau[0] - g0), b0);
-        b1 = fmaf(P->h, P->Jinv[1] * (tau[1] - g1), b1);
-        b2 = fmaf(P->h, P->Jinv[2] * (tau[2] - g2), b2);
-        w[0] = fmaf(R02, b2, fmaf(R01, b1, R00 * b0));
-        w[1] = fmaf(R12, b2, fmaf(R11, b1, R10 * b0));
-        w[2] = fmaf(R22, b2, fmaf(R21, b1, R20 * b0));
+        b0 = fmaf(P->hJi[0], tau[0] - g0, b0);
+        b1 = fmaf(P->hJi[1], tau[1] - g1, b1);
+        b2 = fmaf(P->hJi[2], tau[2] - g2, b2);
         /* linear */
-        float a0 = fmaf(R02, F[2], fmaf(R01, F[1], R00 * F[0])) * P->inv_m;
-        float a1 = fmaf(R12, F[2], fmaf(R11, F[1], R10 * F[0])) * P->inv_m;
-        float a2 = fmaf(fmaf(R22, F[2], fmaf(R21, F[1], R20 * F[0])), P->inv_m, P->g);
-        v[0] = fmaf(P->h, a0, v[0]);
-        v[1] = fmaf(P->h, a1, v[1]);
-        v[2] = fmaf(P->h, a2, v[2]);
+        float RF[3];
+        quat_sandwich(q, F, RF);
+        v[0] = fmaf(P->h, RF[0] * P->inv_m, v[0]);
+        v[1] = fmaf(P->h, RF[1] * P->inv_m, v[1]);
+        v[2] = fmaf(P->h, fmaf(RF[2], P->inv_m, P->g), v[2]);
         p[0] = fmaf(P->h, v[0], p[0]);
         p[1] = fmaf(P->h, v[1], p[1]);
         p[2] = fmaf(P->h, v[2], p[2]);
-        /* attitude: dq = (w * sin(a)/|w|, cos(a)), a = half_h * |w| */
-        float w2 = fmaf(w[2], w[2], fmaf(w[1], w[1], w[0] * w[0]));
+        /* attitude */
+        float w2 = fmaf(b2, b2, fmaf(b1, b1, b0 * b0));
         float A2 = (P->half_h * P->half_h) * w2;
-        float k, c;
-        if (A2 <= 0.25f) {
-            float sp = fmaf(fmaf(fmaf(fmaf(2.7557319224e-6f, A2, -1.9841269841e-4f), A2, 8.3333333333e-3f), A2, -1.6666666667e-1f), A2, 1.0f);
-            c = fmaf(fmaf(fmaf(fmaf(2.4801587302e-5f, A2, -1.3888888889e-3f), A2, 4.1666666667e-2f), A2, -0.5f), A2, 1.0f);
-            k = P->half_h * sp;
-        } else if (A2 == A2) {
-            float wn = sqrtf(w2);
-            float s;
-            sincos_own(P->half_h * wn, &s, &c);
-            k = s / wn;
-        } else {
-            k = c = NAN;
+        float sp = fmaf(fmaf(fmaf(fmaf(2.7557319224e-6f, A2, -1.9841269841e-4f), A2, 8.3333333333e-3f), A2, -1.6666666667e-1f), A2, 1.0f);
+        float c = fmaf(fmaf(fmaf(fmaf(2.4801587302e-5f, A2, -1.3888888889e-3f), A2, 4.1666666667e-2f), A2, -0.5f), A2, 1.0f);
+        float k = P->half_h * sp;
+        if (!(A2 <= 0.25f)) {
+            if (A2 == A2) {
+                float wn = sqrtf(w2), sn;
+                sincos_own(P->half_h * wn, &sn, &c);
+                k = sn / wn;
+            } else {
+                k = c = NAN;
+            }
         }
-        float dx = w[0] * k, dy = w[1] * k, dz = w[2] * k;
-        /* Hamilton product (dx,dy,dz,c) (x) q */
-        float nx = fmaf(c, qx, fmaf(dx, qw, fmaf(dy, qz, -(dz * qy))));
-        float ny = fmaf(c, qy, fmaf(dy, qw, fmaf(dz, qx, -(dx * qz))));
-        float nz = fmaf(c, qz, fmaf(dz, qw, fmaf(dx, qy, -(dy * qx))));
-        float nw = fmaf(c, qw, -fmaf(dx, qx, fmaf(dy, qy, dz * qz)));
+        float dx = b0 * k, dy = b1 * k, dz = b2 * k;
+        float qx = q[0], qy = q[1], qz = q[2], qw = q[3];
+        /* Hamilton product q (x) (dx, dy, dz, c) */
+        float nx = fmaf(qw, dx, fmaf(qx, c, fmaf(qy, dz, -(qz * dy))));
+        float ny = fmaf(qw, dy, fmaf(qy, c, fmaf(qz, dx, -(qx * dz))));
+        float nz = fmaf(qw, dz, fmaf(qz, c, fmaf(qx, dy, -(qy * dx))));
+        float nw = fmaf(qw, c, -fmaf(qx, dx, fmaf(qy, dy, qz * dz)));
         float n2 = fmaf(nw, nw, fmaf(nz, nz, fmaf(ny, ny, nx * nx)));
-        float inv;
-        if (fabsf(n2 - 1.0f) <= 0.015625f) {
-            float hn = 0.5f * n2;
-            float y0 = 1.5f - hn;
-            float y1 = y0 * fmaf(-hn, y0 * y0, 1.5f);
-            inv = y1 * fmaf(-hn, y1 * y1, 1.5f);
-        } else {
-            inv = 1.0f / sqrtf(n2);
-        }
+        float inv = fmaf(-0.5f, n2, 1.5f);
+        if (!(fabsf(n2 - 1.0f) <= 1e-3f)) inv = 1.0f / sqrtf(n2);
         q[0] = nx * inv; q[1] = ny * inv; q[2] = nz * inv; q[3] = nw * inv;
     }
+    const float bb[3] = {b0, b1, b2};
+    quat_sandwich(q, bb, w);
 }
 
 /* ------------------------------------------------------------------------------------------------ environment */
@@ -515,6 +535,7 @@ struct orc_env {
     int threads;
     int mix_n1, mix_n2;
     integ_par ip;
+    float rdt; /* 1/dt if div_const is exact for this dt, else 0 (true division is used) */
 };
 
 static void derive(orc_env *e) {
@@ -526,8 +547,9 @@ static void derive(orc_env *e) {
     e->ip.g = (float)c->gravity_z;
     for (int i = 0; i < 3; ++i) {
         e->ip.J[i] = (float)c->inertia[i];
-        e->ip.Jinv[i] = (float)(1.0 / c->inertia[i]);
+        e->ip.hJi[i] = (float)((c->dt / (double)c->substeps) / c->inertia[i]);
     }
+    e->rdt = div_const_is_exact((float)c->dt) ? 1.0f / (float)c->dt : 0.0f;
     /* FA:924-925: n1 = int(N / 3 * 1), n2 = int(N / 3 * 2) in Python doubles */
     e->mix_n1 = (int)((double)c->num_envs_global / 3 * 1);
     e->mix_n2 = (int)((double)c->num_envs_global / 3 * 2);
@@ -731,16 +753,16 @@ static inline void relative_state(const float p[3], const float q[4], const floa
 /* noise-free frame FA:415-421 + task tails FA:713-714, :768-771, :835-838 */
 static inline void pack_frame(const rel_state *r, float V, const float act[4], float z, int grp, const float cmd[2], float out[26]) {
     float m[9];
-    for (int k = 0; k < 3; ++k) out[k] = r->rel_pos_b[k] / 3.0f;
+    for (int k = 0; k < 3; ++k) out[k] = DIVC(r->rel_pos_b[k], 3.0f);
     quat_to_matrix(r->rel_q_b, m);
     for (int k = 0; k < 9; ++k) out[3 + k] = m[k];
     for (int k = 0; k < 3; ++k) out[12 + k] = r->rel_v_b[k] / 2.0f;
-    for (int k = 0; k < 3; ++k) out[15 + k] = r->rel_w_b[k] / PI_F;
-    out[18] = (V - 23.0f) / 3.0f;
+    for (int k = 0; k < 3; ++k) out[15 + k] = DIVC(r->rel_w_b[k], PI_F);
+    out[18] = DIVC(V - 23.0f, 3.0f);
     for (int k = 0; k < 4; ++k) out[19 + k] = act[k];
     out[23] = 4.0f * clampf(z, 0.0f, 0.5f) - 1.0f;
     out[24] = cmd[0];
-    out[25] = (grp == ORC_TASK_POS) ? cmd[1] : (grp == ORC_TASK_ROTATE ? cmd[1] / 6.0f : cmd[1] / 2.0f / PI_F);
+    out[25] = (grp == ORC_TASK_POS) ? cmd[1] : (grp == ORC_TASK_ROTATE ? DIVC(cmd[1], 6.0f) : DIVC(cmd[1] / 2.0f, PI_F));
 }
 
 static void step_env(const orc_env *e, int i, const float *actions, float *obs_buf, float *states_buf, float *rew_buf,
@@ -791,7 +813,7 @@ static void step_env(const orc_env *e, int i, const float *actions, float *obs_b
         float u[4], thr[4], des[3];
         u[0] = (ad[0] + 1.0f) / 2.0f * 1000.0f;
         for (int k = 0; k < 3; ++k) des[k] = ad[1 + k] * 20.0f;
-        pid_step(dtf, des, wb, s->pid_prev, s->pid_int, &u[1]);
+        pid_step(dtf, e->rdt, des, wb, s->pid_prev, s->pid_int, &u[1]);
         allocator(u, thr);
         /* control_with_thrusts FA:608-635 */
         float Pm = mech_power(s->omega);
@@ -814,7 +836,7 @@ static void step_env(const orc_env *e, int i, const float *actions, float *obs_b
             tq[1] = -(float)c->arm_x * ((fs[0] - fs[1]) - (fs[2] - fs[3]));
             tq[2] = (ts[0] + ts[1]) + (ts[2] + ts[3]);
         }
-        integrate_substep(&e->ip, s->p, s->q, s->v, s->w, F, tq); /* gym.simulate VT:313 */
+        integrate_substep(&e->ip, s->p, s->q, s->v, s->w, wb, F, tq); /* gym.simulate VT:313 */
     }
 
     /* ---- post_physics_step FA:374-388 */
@@ -957,7 +979,8 @@ void orc_quat_from_euler_xyz(int n, const float *rpy, float *q) { for (int i = 0
 void orc_quat_diff_rad(int n, const float *a, const float *b, float *out) { for (int i = 0; i < n; ++i) out[i] = quat_diff_rad(a + 4 * i, b + 4 * i); }
 void orc_quat_to_matrix(int n, const float *q, float *m9) { for (int i = 0; i < n; ++i) quat_to_matrix(q + 4 * i, m9 + 9 * i); }
 void orc_pid_step(int n, float dt, const float *des, const float *cur, float *prev, float *integ, float *out) {
-    for (int i = 0; i < n; ++i) pid_step(dt, des + 3 * i, cur + 3 * i, prev + 3 * i, integ + 3 * i, out + 3 * i);
+    const float rdt = div_const_is_exact(dt) ? 1.0f / dt : 0.0f;
+    for (int i = 0; i < n; ++i) pid_step(dt, rdt, des + 3 * i, cur + 3 * i, prev + 3 * i, integ + 3 * i, out + 3 * i);
 }
 void orc_allocator(int n, float *u, float *thr) { for (int i = 0; i < n; ++i) allocator(u + 4 * i, thr + 4 * i); }
 void orc_real2sim(int n, const float *f, const float *t, float *fs, float *ts) { for (int i = 0; i < n; ++i) real2sim(f + 4 * i, t + 4 * i, fs + 4 * i, ts + 4 * i); }
@@ -1008,6 +1031,8 @@ void orc_integrate(const orc_cfg *cfg, int n, float *root13, const float *wrench
     derive(&tmp);
     for (int i = 0; i < n; ++i) {
         float *r = root13 + 13 * i;
-        integrate_substep(&tmp.ip, r, r + 3, r + 7, r + 10, wrench6 + 6 * i, wrench6 + 6 * i + 3);
+        float wb[3];
+        rotate_inv(r + 3, r + 10, wb); /* row C's body-frame angular velocity (FA:350) */
+        integrate_substep(&tmp.ip, r, r + 3, r + 7, r + 10, wb, wrench6 + 6 * i, wrench6 + 6 * i + 3);
     }
 }

@@ -63,6 +63,27 @@ bool cfg_ok(const taco_cfg *c) {
     return true;
 }
 
+// x / c via q = x * RN(1/c) + one fma correction (taco_math.hpp div_const) is used for the run-time divisor dt only if it is
+// bit-identical to the IEEE quotient for this dt: checked exhaustively over one binade of x, both signs (the three
+// operations are scale-invariant, so this covers the normal range).  ~10 ms on the host, once per taco_create / difficulty change.
+bool div_const_is_exact(float c) {
+    static float cached_c = 0.0f;
+    static bool cached_ok = false;
+    if (c == cached_c) return cached_ok;
+    const float rc = 1.0f / c;
+    bool ok = true;
+    for (uint32_t m = 0; m < (1u << 23) && ok; ++m) {
+        uint32_t u = 0x3f800000u | m;
+        float x;
+        std::memcpy(&x, &u, 4);
+        const float q = x * rc, r = std::fmaf(-q, c, x), d = std::fmaf(r, rc, q);
+        ok = (d == x / c);
+    }
+    cached_c = c;
+    cached_ok = ok;
+    return ok;
+}
+
 // fp32 images of the Python-double expressions of the reference, computed in double exactly where Python would
 void derive(taco_env *e) {
     const taco_cfg &c = e->cfg;
@@ -79,7 +100,10 @@ void derive(taco_env *e) {
     P.half_h = (float)(0.5 * (c.dt / (double)c.substeps));
     P.inv_m = (float)(1.0 / c.mass); P.g = (float)c.gravity_z;
     P.J0 = (float)c.inertia[0]; P.J1 = (float)c.inertia[1]; P.J2 = (float)c.inertia[2];
-    P.Ji0 = (float)(1.0 / c.inertia[0]); P.Ji1 = (float)(1.0 / c.inertia[1]); P.Ji2 = (float)(1.0 / c.inertia[2]);
+    P.hJi0 = (float)((c.dt / (double)c.substeps) / c.inertia[0]);
+    P.hJi1 = (float)((c.dt / (double)c.substeps) / c.inertia[1]);
+    P.hJi2 = (float)((c.dt / (double)c.substeps) / c.inertia[2]);
+    P.rdt = div_const_is_exact(P.dt) ? 1.0f / P.dt : 0.0f;
     P.arm_x = (float)c.arm_x; P.arm_y = (float)c.arm_y;
     // torch_rand_float(lower, upper): (upper - lower) * u + lower
     P.flip_xy_sc = (float)((0.5 + 1.5 * d) - (-0.5 - 1.5 * d)); P.flip_xy_lo = (float)(-0.5 - 1.5 * d);  // fpv_asymmetry.py:856

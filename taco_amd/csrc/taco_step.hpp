@@ -33,8 +33,8 @@ struct StepParams {
     uint32_t flags, seed_lo, seed_hi, step;
     uint32_t s_bytes, ring_bytes;  // sizes of S and ring for the buffer descriptors (range-checked accesses)
     // fp32 images of the Python doubles the reference feeds into tensor ops
-    float dt, clip_act, df;
-    float h, half_h, inv_m, g, J0, J1, J2, Ji0, Ji1, Ji2, arm_x, arm_y;
+    float dt, rdt, clip_act, df;  // rdt = 1/dt when div_const is exact for this dt (checked on the host), else 0
+    float h, half_h, inv_m, g, J0, J1, J2, hJi0, hJi1, hJi2, arm_x, arm_y;
     float flip_xy_sc, flip_xy_lo, flip_v_sc, flip_v_lo, dr_sc, dr_lo, tau_sc, tau_lo, tau_fixed, nq_sc, nq_lo;
 };
 
@@ -183,13 +183,13 @@ TD void unwrap(float rpy, float &old, float &cont) {
     old = rpy;
 }
 // CTRL/angvel_control.py:67-88, one axis
-TD float pid_axis(float dt, float kp, float des, float cur, float &prev, float &integ) {
+TD float pid_axis(float dt, float rdt, float kp, float des, float cur, float &prev, float &integ) {
     float e = clampf(des - cur, -400.0f, 400.0f);
     float pv = (prev == 0.0f) ? e : prev;
     float P = kp * e;
     float I = clampf(integ + e * dt, -500.0f, 500.0f);
     float I_term = 0.0f * I;
-    float deriv = (e - pv) / dt;
+    float deriv = (rdt != 0.0f) ? div_const(e - pv, dt, rdt) : (e - pv) / dt;  // rdt is wave-uniform: a scalar branch
     float D = clampf(0.5f * deriv, -150.0f, 150.0f);
     float FF = 0.0f * des;
     integ = I;
@@ -210,72 +210,71 @@ TD int rounded_normal(float u, int lim) {
     return k < -lim ? -lim : (k > lim ? lim : k);
 }
 
-// One gym.simulate(dt) for one free rigid body: `substeps` sub-iterations of semi-implicit Euler with the closed-form
-// quaternion update, body-frame wrench held constant (replaces VT:313 + FA:633-635; spec in DESIGN.md "row I").
-TD void integrate(const StepParams &P, V3 &p, Q4 &q, V3 &v, V3 &w, V3 F, V3 tq) {
+// R(q) u for a unit quaternion by the sandwich product: u + w t + qv x t with t = 2 qv x u
+TD V3 quat_sandwich(Q4 q, V3 u) {
+    float tx = fma(q.y, u.z, -(q.z * u.y)), ty = fma(q.z, u.x, -(q.x * u.z)), tz = fma(q.x, u.y, -(q.y * u.x));
+    tx = tx + tx; ty = ty + ty; tz = tz + tz;
+    V3 o;
+    o.x = fma(q.y, tz, fma(-q.z, ty, fma(q.w, tx, u.x)));
+    o.y = fma(q.z, tx, fma(-q.x, tz, fma(q.w, ty, u.y)));
+    o.z = fma(q.x, ty, fma(-q.y, tx, fma(q.w, tz, u.z)));
+    return o;
+}
+
+// One gym.simulate(dt) for one free rigid body (replaces VT:313 + FA:633-635; spec in DESIGN.md "row I"): `substeps`
+// sub-iterations of semi-implicit Euler in the body frame (start value of the body rates: row C's body-frame angular
+// velocity wb), closed-form quaternion update q <- normalize(q (x) exp(h/2 b)), body-frame wrench held constant; the
+// world-frame angular velocity of the root state is rebuilt once at the end.  The rare forms (|b| h/2 > 0.5 rad per
+// sub-iteration, |q|^2 off by > 1e-3, NaN) are evaluated only when some lane of the wavefront needs them (ballot), and
+// selected per lane, so the common case has no divergent control flow at all.
+TD void integrate(const StepParams &P, V3 &p, Q4 &q, V3 &v, V3 &w, V3 wb, V3 F, V3 tq) {
+    float b0 = wb.x, b1 = wb.y, b2 = wb.z;
     for (int it = 0; it < P.substeps; ++it) {
-        float xx = q.x * q.x, yy = q.y * q.y, zz = q.z * q.z;
-        float xy = q.x * q.y, xz = q.x * q.z, yz = q.y * q.z;
-        float wx = q.w * q.x, wy = q.w * q.y, wz = q.w * q.z;
-        float R00 = fma(-2.0f, yy + zz, 1.0f), R01 = 2.0f * (xy - wz), R02 = 2.0f * (xz + wy);
-        float R10 = 2.0f * (xy + wz), R11 = fma(-2.0f, xx + zz, 1.0f), R12 = 2.0f * (yz - wx);
-        float R20 = 2.0f * (xz - wy), R21 = 2.0f * (yz + wx), R22 = fma(-2.0f, xx + yy, 1.0f);
-        float b0 = fma(R20, w.z, fma(R10, w.y, R00 * w.x));
-        float b1 = fma(R21, w.z, fma(R11, w.y, R01 * w.x));
-        float b2 = fma(R22, w.z, fma(R12, w.y, R02 * w.x));
         float L0 = P.J0 * b0, L1 = P.J1 * b1, L2 = P.J2 * b2;
         float g0 = fma(b1, L2, -(b2 * L1));
         float g1 = fma(b2, L0, -(b0 * L2));
         float g2 = fma(b0, L1, -(b1 * L0));
-        b0 = fma(P.h, P.Ji0 * (tq.x - g0), b0);
-        b1 = fma(P.h, P.Ji1 * (tq.y - g1), b1);
-        b2 = fma(P.h, P.Ji2 * (tq.z - g2), b2);
-        w.x = fma(R02, b2, fma(R01, b1, R00 * b0));
-        w.y = fma(R12, b2, fma(R11, b1, R10 * b0));
-        w.z = fma(R22, b2, fma(R21, b1, R20 * b0));
-        float a0 = fma(R02, F.z, fma(R01, F.y, R00 * F.x)) * P.inv_m;
-        float a1 = fma(R12, F.z, fma(R11, F.y, R10 * F.x)) * P.inv_m;
-        float a2 = fma(fma(R22, F.z, fma(R21, F.y, R20 * F.x)), P.inv_m, P.g);
-        v.x = fma(P.h, a0, v.x);
-        v.y = fma(P.h, a1, v.y);
-        v.z = fma(P.h, a2, v.z);
+        b0 = fma(P.hJi0, tq.x - g0, b0);
+        b1 = fma(P.hJi1, tq.y - g1, b1);
+        b2 = fma(P.hJi2, tq.z - g2, b2);
+        const V3 RF = quat_sandwich(q, F);
+        v.x = fma(P.h, RF.x * P.inv_m, v.x);
+        v.y = fma(P.h, RF.y * P.inv_m, v.y);
+        v.z = fma(P.h, fma(RF.z, P.inv_m, P.g), v.z);
         p.x = fma(P.h, v.x, p.x);
         p.y = fma(P.h, v.y, p.y);
         p.z = fma(P.h, v.z, p.z);
-        float w2 = fma(w.z, w.z, fma(w.y, w.y, w.x * w.x));
-        float A2 = (P.half_h * P.half_h) * w2;
-        float k, c;
-        if (A2 <= 0.25f) {
-            float sp = fma(fma(fma(fma(2.7557319224e-6f, A2, -1.9841269841e-4f), A2, 8.3333333333e-3f), A2, -1.6666666667e-1f), A2, 1.0f);
-            c = fma(fma(fma(fma(2.4801587302e-5f, A2, -1.3888888889e-3f), A2, 4.1666666667e-2f), A2, -0.5f), A2, 1.0f);
-            k = P.half_h * sp;
-        } else if (A2 == A2) {
-            float wn = __builtin_sqrtf(w2);
-            float s;
-            sincos(P.half_h * wn, s, c);
-            k = s / wn;
-        } else {
-            k = c = nanf32();
+        const float w2 = fma(b2, b2, fma(b1, b1, b0 * b0));
+        const float A2 = (P.half_h * P.half_h) * w2;
+        const float sp = fma(fma(fma(fma(2.7557319224e-6f, A2, -1.9841269841e-4f), A2, 8.3333333333e-3f), A2, -1.6666666667e-1f), A2, 1.0f);
+        float c = fma(fma(fma(fma(2.4801587302e-5f, A2, -1.3888888889e-3f), A2, 4.1666666667e-2f), A2, -0.5f), A2, 1.0f);
+        float k = P.half_h * sp;
+        const bool big = !(A2 <= 0.25f);
+        if (__builtin_amdgcn_ballot_w64(big)) {
+            const float wn = __builtin_sqrtf(w2);
+            float sn, cs;
+            sincos(P.half_h * wn, sn, cs);
+            float ks = sn / wn;
+            if (A2 != A2) { ks = nanf32(); cs = nanf32(); }
+            k = big ? ks : k;
+            c = big ? cs : c;
         }
-        float dx = w.x * k, dy = w.y * k, dz = w.z * k;
-        float nx = fma(c, q.x, fma(dx, q.w, fma(dy, q.z, -(dz * q.y))));
-        float ny = fma(c, q.y, fma(dy, q.w, fma(dz, q.x, -(dx * q.z))));
-        float nz = fma(c, q.z, fma(dz, q.w, fma(dx, q.y, -(dy * q.x))));
-        float nw = fma(c, q.w, -fma(dx, q.x, fma(dy, q.y, dz * q.z)));
-        float n2 = fma(nw, nw, fma(nz, nz, fma(ny, ny, nx * nx)));
-        float inv;
-        if (absf(n2 - 1.0f) <= 0.015625f) {
-            float hn = 0.5f * n2;
-            float y0 = 1.5f - hn;
-            float y1 = y0 * fma(-hn, y0 * y0, 1.5f);
-            inv = y1 * fma(-hn, y1 * y1, 1.5f);
-        } else {
-            inv = 1.0f / __builtin_sqrtf(n2);
+        const float dx = b0 * k, dy = b1 * k, dz = b2 * k;
+        const float nx = fma(q.w, dx, fma(q.x, c, fma(q.y, dz, -(q.z * dy))));
+        const float ny = fma(q.w, dy, fma(q.y, c, fma(q.z, dx, -(q.x * dz))));
+        const float nz = fma(q.w, dz, fma(q.z, c, fma(q.x, dy, -(q.y * dx))));
+        const float nw = fma(q.w, c, -fma(q.x, dx, fma(q.y, dy, q.z * dz)));
+        const float n2 = fma(nw, nw, fma(nz, nz, fma(ny, ny, nx * nx)));
+        float inv = fma(-0.5f, n2, 1.5f);
+        const bool off = !(absf(n2 - 1.0f) <= 1e-3f);
+        if (__builtin_amdgcn_ballot_w64(off)) {
+            const float ie = 1.0f / __builtin_sqrtf(n2);
+            inv = off ? ie : inv;
         }
         q.x = nx * inv; q.y = ny * inv; q.z = nz * inv; q.w = nw * inv;
     }
+    w = quat_sandwich(q, V3{b0, b1, b2});
 }
-
 
 // reset_idx for one env (FA:475-517), in the reference's call order: reset_copter_idx -> reset_controller_idx ->
 // reset_env_idx -> reset_target_idx.  Every new value goes straight to the env's chunks; the 37 uniforms come from
@@ -440,6 +439,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
     const bool mix = P.task_mode == TACO_TASK_MIX;
     // copter_rpy_continuous is consumed only by the flip command (FA:831, :930); other envs keep their reset-time value
     const bool track_rpy = grp == TACO_TASK_FLIP;
+    // wave-uniform form of the same predicate: the euler/unwrap block runs for a whole wavefront or not at all (lanes of
+    // other tasks then compute values nobody reads), which keeps the substep loop free of divergent control flow
+    const bool wave_tracks_rpy = __builtin_amdgcn_ballot_w64(track_rpy) != 0;
 
     // ------------------------------------------------------------------ pre_physics_step FA:317-332
     const bool is_reset = P.reset[i] != 0;
@@ -456,7 +458,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
     V3 v{c_lin.x, c_lin.y, c_lin.z};
     V3 w{c_ang.x, c_ang.y, c_ang.z};
     float rpy_old[3] = {0.0f, 0.0f, 0.0f}, rpy_cont[3] = {0.0f, 0.0f, 0.0f};
-    if (track_rpy) {
+    if (wave_tracks_rpy) {
         const float4 c_ro = CLD(C_RPY_OLD), c_rc = CLD(C_RPY_CONT);
         rpy_old[0] = c_ro.x; rpy_old[1] = c_ro.y; rpy_old[2] = c_ro.z;
         rpy_cont[0] = c_rc.x; rpy_cont[1] = c_rc.y; rpy_cont[2] = c_rc.z;
@@ -543,7 +545,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
 #pragma unroll 1
     for (int ks = 0; ks < 10; ++ks) {
         // refresh_state, the part the inner loop consumes FA:339-350
-        if (track_rpy) {
+        if (wave_tracks_rpy) {
             V3 e = euler_xyz_v1(q);
             unwrap(e.x, rpy_old[0], rpy_cont[0]);
             unwrap(e.y, rpy_old[1], rpy_cont[1]);
@@ -558,9 +560,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
         const float d0 = dact.x, d1 = dact.y, d2 = dact.z, d3 = dact.w;
         // angular_vel_control FA:637-650
         float u0 = (d0 + 1.0f) / 2.0f * 1000.0f;
-        float u1 = pid_axis(P.dt, 27.5f, d1 * 20.0f, wb.x, pid_prev[0], pid_int[0]);
-        float u2 = pid_axis(P.dt, 50.0f, d2 * 20.0f, wb.y, pid_prev[1], pid_int[1]);
-        float u3 = pid_axis(P.dt, 200.0f, d3 * 20.0f, wb.z, pid_prev[2], pid_int[2]);
+        float u1 = pid_axis(P.dt, P.rdt, 27.5f, d1 * 20.0f, wb.x, pid_prev[0], pid_int[0]);
+        float u2 = pid_axis(P.dt, P.rdt, 50.0f, d2 * 20.0f, wb.y, pid_prev[1], pid_int[1]);
+        float u3 = pid_axis(P.dt, P.rdt, 200.0f, d3 * 20.0f, wb.z, pid_prev[2], pid_int[2]);
         // control_allocator CTRL/fpv_dynamics.py:35-46
         u3 = clampf(u3, -u0 / 2.0f, u0 / 2.0f);
         float f0 = ((u0 * 1.0f + u1 * -1.0f) + u2 * 1.0f) + u3 * -1.0f;
@@ -577,21 +579,21 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
         // mechanical power FA:614
         float Pm;
         {
-            float b = omega[0] * 2.0f * kPi / 4500.0f; Pm = 400.0f * ((b * b) * b);
-            b = omega[1] * 2.0f * kPi / 4500.0f; Pm = Pm + 400.0f * ((b * b) * b);
-            b = omega[2] * 2.0f * kPi / 4500.0f; Pm = Pm + 400.0f * ((b * b) * b);
-            b = omega[3] * 2.0f * kPi / 4500.0f; Pm = Pm + 400.0f * ((b * b) * b);
+            float b = TACO_DIVC(omega[0] * 2.0f * kPi, 4500.0f); Pm = 400.0f * ((b * b) * b);
+            b = TACO_DIVC(omega[1] * 2.0f * kPi, 4500.0f); Pm = Pm + 400.0f * ((b * b) * b);
+            b = TACO_DIVC(omega[2] * 2.0f * kPi, 4500.0f); Pm = Pm + 400.0f * ((b * b) * b);
+            b = TACO_DIVC(omega[3] * 2.0f * kPi, 4500.0f); Pm = Pm + 400.0f * ((b * b) * b);
         }
         // Battery_Dynamics.sim_process CTRL/battery_dynamics.py:47-75
         if (bat_on) {
             bat_t = bat_t + P.dt;
-            float p_c = Pm / 0.75f / 9000.0f;
+            float p_c = TACO_DIVC(TACO_DIVC(Pm, 0.75f), 9000.0f);
             bat_E = bat_E + p_c * P.dt;
             float P_avg = bat_E / bat_t;
             float r0_ = 0.0015778f + -7.7608e-5f * P_avg + (float)(0.0069498 * 1500.0);
             float r0 = (r0_ > 4.5f) ? r0_ : 4.5f;
             float uo = 4.35f + -0.1102178f * bat_E + 0.0103368f * (bat_E * bat_E) + -4.3778e-4f * ((bat_E * bat_E) * bat_E);
-            float u1_dot = (0.00104846f * p_c - bat_u1) / 3.3f;
+            float u1_dot = TACO_DIVC(0.00104846f * p_c - bat_u1, 3.3f);
             bat_u1 = bat_u1 + u1_dot * P.dt;
             float dd = uo - bat_u1;
             float rad = dd * dd - 4.0f * r0 * p_c;
@@ -601,10 +603,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
         }
         // RotorDynamics.sim_process CTRL/thrust_dynamics.py:98-104
         {
-            float y = (bat_V - 23.0f) / 3.0f;
+            float y = TACO_DIVC(bat_V - 23.0f, 3.0f);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                float x = thr[k] / 1000.0f;
+                float x = TACO_DIVC(thr[k], 1000.0f);
                 float target = (opara[0] * 1.0f + opara[1] * x + opara[2] * y + opara[3] * (x * x) + opara[4] * x * y) * 100.0f;
                 omega[k] = omega[k] + (1.0f / tau[k]) * 0.001f * (target - omega[k]);
             }
@@ -622,8 +624,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
 #pragma unroll
         for (int k = 0; k < 4; ++k) { rf[k] = cf * omega[k] * omega[k]; rt[k] = ct * rf[k]; }
         float vxy = norm2(vb.x, vb.y);
-        V3 F{0.0f, 0.0f, 0.0f}, tq{0.0f, 0.0f, 0.0f};
-        if (!is_reset) {  // FA:629-630
+        V3 F, tq;
+        {
             const float fs0 = rf[2], fs1 = rf[3], fs2 = rf[0], fs3 = rf[1];
             const float ts0 = -rt[2], ts1 = rt[3], ts2 = -rt[0], ts3 = rt[1];
             F.x = dx * vb.x;
@@ -633,12 +635,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
             tq.y = -P.arm_x * ((fs0 - fs1) - (fs2 - fs3));
             tq.z = (ts0 + ts1) + (ts2 + ts3);
         }
-        integrate(P, p, q, v, w, F, tq);
+        if (is_reset) { F = V3{0.0f, 0.0f, 0.0f}; tq = V3{0.0f, 0.0f, 0.0f}; }  // FA:629-630: no force during the reset step
+        integrate(P, p, q, v, w, wb, F, tq);
     }
 
     // ------------------------------------------------------------------ post_physics_step FA:374-388
     progress += 1;
-    if (track_rpy) {  // refresh_state FA:382 (euler + unwrap part)
+    if (wave_tracks_rpy) {  // refresh_state FA:382 (euler + unwrap part)
         V3 e = euler_xyz_v1(q);
         unwrap(e.x, rpy_old[0], rpy_cont[0]);
         unwrap(e.y, rpy_old[1], rpy_cont[1]);
@@ -694,17 +697,17 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
     float m[9];
     quat_to_matrix(rel_q_b, m);
     const float tilt00 = m[0];  // R00 of the noise-free relative attitude: the flip reward's x_tiltage
-    fr[0] = rel_pos_b.x / 3.0f; fr[1] = rel_pos_b.y / 3.0f; fr[2] = rel_pos_b.z / 3.0f;
+    fr[0] = TACO_DIVC(rel_pos_b.x, 3.0f); fr[1] = TACO_DIVC(rel_pos_b.y, 3.0f); fr[2] = TACO_DIVC(rel_pos_b.z, 3.0f);
 #pragma unroll
     for (int k = 0; k < 9; ++k) fr[3 + k] = m[k];
     fr[12] = rel_v_b.x / 2.0f; fr[13] = rel_v_b.y / 2.0f; fr[14] = rel_v_b.z / 2.0f;
-    fr[15] = rel_w_b.x / kPi; fr[16] = rel_w_b.y / kPi; fr[17] = rel_w_b.z / kPi;
-    fr[18] = (bat_V - 23.0f) / 3.0f;
+    fr[15] = TACO_DIVC(rel_w_b.x, kPi); fr[16] = TACO_DIVC(rel_w_b.y, kPi); fr[17] = TACO_DIVC(rel_w_b.z, kPi);
+    fr[18] = TACO_DIVC(bat_V - 23.0f, 3.0f);
 #pragma unroll
     for (int k = 0; k < 4; ++k) fr[19 + k] = act[k];
     fr[23] = 4.0f * clampf(p.z, 0.0f, 0.5f) - 1.0f;
     fr[24] = cmd0;
-    fr[25] = (grp == TACO_TASK_POS) ? cmd1 : (grp == TACO_TASK_ROTATE ? cmd1 / 6.0f : cmd1 / 2.0f / kPi);
+    fr[25] = (grp == TACO_TASK_POS) ? cmd1 : (grp == TACO_TASK_ROTATE ? TACO_DIVC(cmd1, 6.0f) : TACO_DIVC(cmd1 / 2.0f, kPi));
 
     // ---- frame stacks: rows of this wave's 64 envs are contiguous -> stream them as one flat range.
     // word d of the range belongs to env d / row, offset j = d % row; j < row-26 is history (old word d+26), the
@@ -779,7 +782,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
         nn = (nn > 1.0f) ? 1.0f : nn;
         float qd = 2.0f * asin(nn);
         float rr = 1.0f / (1.0f + qd * qd) + 1.0f / (1.0f + 10.0f * qd * qd);
-        rew = pr * rr / 100.0f;
+        rew = TACO_DIVC(pr * rr, 100.0f);
     } else if (grp == TACO_TASK_ROTATE) {  // :50-104
         float nx0 = -rel_pos.x, nx1 = -rel_pos.y, nx2 = 0.0f;
         float nn = norm3(nx0, nx1, nx2) + 1e-8f;
@@ -799,14 +802,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
         quat_to_matrix(q, hm);
         float ddir = 1.0f + (nx0 * hm[0] + nx1 * hm[3]) / norm2(hm[0], hm[3]);
         float dr = 1.0f / (1.0f + ddir * ddir) + 1.0f / (1.0f + 10.0f * ddir * ddir);
-        rew = pr * lr * dr / 100.0f;
+        rew = TACO_DIVC(pr * lr * dr, 100.0f);
     } else {  // :107-143
         pos_dist = norm3(rel_pos_b.x, rel_pos_b.y, rel_pos_b.z);
         float pr = 1.0f / (1.0f + 1.0f * pos_dist) + 1.0f / (1.0f + 10.0f * pos_dist);
         float xr = 1.0f / (1.0f + 10.0f * (1.0f - tilt00));
-        float cd = cmd1 / 2.0f / kPi;
+        float cd = TACO_DIVC(cmd1 / 2.0f, kPi);
         float cr = 1.0f / (1.0f + cd * cd) + 1.0f / (1.0f + 10.0f * cd * cd);
-        rew = pr * xr * cr / 100.0f;
+        rew = TACO_DIVC(pr * xr * cr, 100.0f);
     }
     long long die = 0;
     if (p.z < 0.1f) die = 1;

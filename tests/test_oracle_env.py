@@ -71,7 +71,8 @@ def test_integrator_constant_spin_matches_closed_form():
         root = O.integrate(dict(BODY, dt=0.001, substeps=2), root, z)
     ang = 2 * np.arctan2(root[0, 5], root[0, 6])
     np.testing.assert_allclose(ang, 20.0 * 0.1, rtol=1e-5)
-    np.testing.assert_allclose(root[0, 10:13], [0, 0, 20.0], atol=1e-5)
+    # |q|^2 sits within ~1e-7 of 1 (fp32), and both frame changes scale with |q|^2: ~5e-8 relative drift per substep
+    np.testing.assert_allclose(root[0, 10:13], [0, 0, 20.0], atol=3e-4)
 
 
 def test_integrator_torque_free_tumble_conserves_momentum_and_energy():
