@@ -150,8 +150,11 @@ int taco_step(taco_env *env, const float *actions, float *obs_buf, float *states
               uint8_t *timeout_buf, void *stream);
 
 /* Multi-GPU (no counterpart in the reference, which is single-process): bind a DEVICE block
- * [num_envs][len_obs*26 + 3] f32 that every following taco_step also fills with (obs stack | reward | done | time-out)
- * per env, so the host layer can publish a rank's results with ONE RCCL all-gather.  NULL unbinds. */
+ * [num_envs][taco_gather_row_floats(len_obs)] f32, 128-byte aligned, that every following taco_step also fills with
+ * (obs stack [len_obs*26] | reward | done | time-out | zero padding) per env, so the host layer can publish a rank's
+ * results with ONE RCCL all-gather.  Rows are padded to a multiple of 32 floats (one or more whole 128-byte lines per
+ * env).  NULL unbinds. */
+int taco_gather_row_floats(int len_obs);
 int taco_bind_gather_block(taco_env *env, float *block);
 
 /* env.difficulty = x (ppo_asymmetry.py:173-175, :376); takes effect at the next taco_step. */

@@ -21,7 +21,7 @@ FLAG_BITS = {
 }
 # every symbol include/taco_env.h declares
 EXPORTS = ["taco_abi_version", "taco_last_error", "taco_workspace_bytes", "taco_create", "taco_destroy", "taco_step",
-           "taco_bind_gather_block", "taco_set_difficulty", "taco_get_step_count", "taco_set_step_count", "taco_get_state", "taco_set_state",
+           "taco_gather_row_floats", "taco_bind_gather_block", "taco_set_difficulty", "taco_get_step_count", "taco_set_step_count", "taco_get_state", "taco_set_state",
            "taco_step_kernel_name", "taco_launch_geometry"]
 
 
@@ -63,6 +63,8 @@ def load():
     lib.taco_destroy.restype = None
     lib.taco_step.argtypes = [C.c_void_p] * 8
     lib.taco_step.restype = C.c_int
+    lib.taco_gather_row_floats.argtypes = [C.c_int]
+    lib.taco_gather_row_floats.restype = C.c_int
     lib.taco_bind_gather_block.argtypes = [C.c_void_p, C.c_void_p]
     lib.taco_bind_gather_block.restype = C.c_int
     lib.taco_set_difficulty.argtypes = [C.c_void_p, C.c_double]

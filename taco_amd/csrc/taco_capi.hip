@@ -54,6 +54,8 @@ bool cfg_ok(const taco_cfg *c) {
         return fail(0, "env_offset + num_envs exceeds num_envs_global"), false;
     if (c->task_mode < TACO_TASK_POS || c->task_mode > TACO_TASK_MIX) return fail(0, "task_mode out of range"), false;
     if (c->len_obs < 1 || c->len_states < 1) return fail(0, "len_obs / len_states must be >= 1"), false;
+    if ((size_t)c->num_envs * (size_t)(c->len_obs > c->len_states ? c->len_obs : c->len_states) * 104 >= 0xffffffffull)
+        return fail(0, "num_envs * len * 104 bytes must stay below 4 GiB (32-bit buffer offsets); shard the job"), false;
     if (c->control_freq_inv != 10) return fail(0, "control_freq_inv must be 10 (the delay line holds 10 one-ms slots per action)"), false;
     if (c->substeps < 1 || c->substeps > 8) return fail(0, "substeps must be in 1..8"), false;
     if (c->delay_time < 0 || c->delay_time > 90) return fail(0, "delay_time must be in 0..90 ms"), false;
@@ -178,6 +180,8 @@ int block_for(const taco_env *e) { return e->cfg.num_envs >= 65536 ? kBlockLarge
 
 extern "C" {
 
+int taco_gather_row_floats(int len_obs);
+
 int taco_abi_version(void) { return TACO_ABI_VERSION; }
 const char *taco_last_error(void) { return g_err; }
 const char *taco_step_kernel_name(void) { return "taco_step_kernel"; }
@@ -226,6 +230,7 @@ int taco_step(taco_env *e, const float *actions, float *obs_buf, float *states_b
     if (!actions || !obs_buf || !states_buf || !rew_buf || !reset_buf || !timeout_buf)
         return fail(TACO_ERR_INVALID_ARG, "taco_step: null buffer pointer");
     if (((uintptr_t)actions & 15u) != 0) return fail(TACO_ERR_INVALID_ARG, "actions must be 16-byte aligned");
+    const size_t n_envs = (size_t)e->cfg.num_envs;
     taco::StepParams P = e->P;
     P.S = e->S; P.ring = e->ring;
     P.act_in = actions; P.obs = obs_buf; P.states = states_buf; P.rew = rew_buf;
@@ -234,6 +239,10 @@ int taco_step(taco_env *e, const float *actions, float *obs_buf, float *states_b
     P.step = (uint32_t)e->step_count;
     P.s_bytes = (uint32_t)((size_t)taco::NUM_CHUNKS * e->npad * 4 * sizeof(float));
     P.ring_bytes = (uint32_t)((size_t)TACO_RING_SLOTS * e->npad * 4 * sizeof(float));
+    P.obs_bytes = (uint32_t)((size_t)n_envs * e->cfg.len_obs * 26 * sizeof(float));
+    P.states_bytes = (uint32_t)((size_t)n_envs * e->cfg.len_states * 26 * sizeof(float));
+    P.gather_row = (uint32_t)taco_gather_row_floats(e->cfg.len_obs);
+    P.gather_bytes = (uint32_t)((size_t)n_envs * P.gather_row * sizeof(float));
     P.head = e->head;
     const int n = e->cfg.num_envs;
     if (block_for(e) == kBlockLarge)
@@ -253,6 +262,8 @@ int taco_set_difficulty(taco_env *e, double difficulty) {
     derive(e);
     return TACO_OK;
 }
+
+int taco_gather_row_floats(int len_obs) { return (len_obs * 26 + 3 + 31) / 32 * 32; }
 
 int taco_bind_gather_block(taco_env *e, float *block) {
     if (!e) return fail(TACO_ERR_INVALID_ARG, "env is null");

@@ -32,6 +32,7 @@ struct StepParams {
     int n, npad, env_offset, task_mode, mix_n1, mix_n2, len_obs, len_states, substeps, max_len, delay_time, head;
     uint32_t flags, seed_lo, seed_hi, step;
     uint32_t s_bytes, ring_bytes;  // sizes of S and ring for the buffer descriptors (range-checked accesses)
+    uint32_t obs_bytes, states_bytes, gather_bytes, gather_row;  // gather_row = floats per env in the gather block (multiple of 32)
     // fp32 images of the Python doubles the reference feeds into tensor ops
     float dt, rdt, clip_act, df;  // rdt = 1/dt when div_const is exact for this dt (checked on the host), else 0
     float h, half_h, inv_m, g, J0, J1, J2, hJi0, hJi1, hJi2, arm_x, arm_y;
@@ -88,6 +89,10 @@ typedef int rsrc_t __attribute__((ext_vector_type(4)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 __device__ f32x4_t llvm_amdgcn_raw_buffer_load_v4f32(rsrc_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 __device__ void llvm_amdgcn_raw_buffer_store_v4f32(f32x4_t v, rsrc_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ f32x2_t llvm_amdgcn_raw_buffer_load_v2f32(rsrc_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
+__device__ void llvm_amdgcn_raw_buffer_store_v2f32(f32x2_t v, rsrc_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2f32");
+__device__ void llvm_amdgcn_raw_buffer_store_f32(float v, rsrc_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.f32");
 TD rsrc_t make_rsrc(const void *base, uint32_t bytes) {
     const uint64_t a = (uint64_t)base;  // wave-uniform: comes from the kernel arguments
     return rsrc_t{(int)(uint32_t)a, (int)((uint32_t)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
@@ -413,13 +418,12 @@ TD void reset_env(const StepParams &P, rsrc_t rS, rsrc_t rR, uint32_t voff, uint
 // at 128 VGPRs so that 4 wavefronts per SIMD hide each other's dependent-issue latency.
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 256 ? 4 : 1, BLOCK >= 256 ? 4 : 8))) void taco_step_kernel(const StepParams P) {
-    constexpr int TILE_LD = 27;  // 26 + 1 pad: lane l writes words l*27+k -> bank (27l + k) % 32, conflict-free per half-wave
     // Per-wavefront LDS scratch, used for two things one after the other:
     //   substeps : the 10 pending-action slots this step consumes, slots[s][lane] as float4 (10 KiB) -- keeps 40 values
     //              out of the register file and lets substep k fetch its action with one ds_read_b128;
-    //   post-step: the 64 x 26 frame tile that transposes lane-major registers into env-major rows (6.75 KiB).
+    //   post-step: the 64 x 26 frame tile that transposes lane-major registers into env-major bytes (6.5 KiB).
     constexpr int WAVE_LDS_WORDS = 10 * 64 * 4;
-    static_assert(WAVE_LDS_WORDS >= 64 * TILE_LD, "tile must fit in the per-wave scratch");
+    static_assert(WAVE_LDS_WORDS >= 64 * 26, "tile must fit in the per-wave scratch");
     __shared__ __attribute__((aligned(16))) float lds_all[BLOCK / 64][WAVE_LDS_WORDS];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
@@ -538,10 +542,30 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
             }
         }
     }
+    if (active) {
+        const int dlen_after = dlen + T;
+        // (done here, ahead of the substeps, so that its loads and stores drain while the substep loop computes)
+        // FA:378 leaves logical slots [90,100) untouched by the shift.  With the ring advancing by 10 (host side), the new
+        // logical [90,100) are the physical slots just consumed, so they must be given the values of the old logical
+        // [90,100) (= new [80,90)); a slot this step's action write covered is taken from registers, not re-read.
+        const int wr_lo = dlen;  // the write above covered logical [dlen, dlen + T)
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            int src = P.head + 90 + j; src = src >= TACO_RING_SLOTS ? src - TACO_RING_SLOTS : src;
+            int dst = P.head + j;  // old logical j == new logical 90+j
+            dst = dst >= TACO_RING_SLOTS ? dst - TACO_RING_SLOTS : dst;
+            const bool fresh = (90 + j >= wr_lo) && (90 + j < dlen_after);
+            float4 old = buf_ld4(rR, voff, (uint32_t)src * row_bytes);
+            if (fresh) old = make_float4(act[0], act[1], act[2], act[3]);
+            buf_st4(rR, old, voff, (uint32_t)dst * row_bytes);
+        }
+    }
     dlen += T;
 
     // ------------------------------------------------------------------ 10 x (mid_physics_step + simulate) VT:309-313
     const bool bat_on = (fl & TACO_F_BATTERY_CONSUMPTION) != 0;
+    // the target pose is consumed only after the loop; issuing the loads here hides their latency behind the substeps
+    const float4 c_tp = CLD(C_TGT_POS), c_tq = CLD(C_TGT_QUAT);
 #pragma unroll 1
     for (int ks = 0; ks < 10; ++ks) {
         // refresh_state, the part the inner loop consumes FA:339-350
@@ -661,25 +685,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
             CST(C_RPY_OLD, make_float4(rpy_old[0], rpy_old[1], rpy_old[2], 0.0f));
             CST(C_RPY_CONT, make_float4(rpy_cont[0], rpy_cont[1], rpy_cont[2], 0.0f));
         }
-        // FA:378 leaves logical slots [90,100) untouched by the shift.  With the ring advancing by 10 (host side), the new
-        // logical [90,100) are the physical slots just consumed, so they must be given the values of the old logical
-        // [90,100) (= new [80,90)); a slot this step's action write covered is taken from registers, not re-read.
-        const int wr_lo = dlen - T;  // the write above covered logical [wr_lo, dlen)
-#pragma unroll
-        for (int j = 0; j < 10; ++j) {
-            int src = P.head + 90 + j; src = src >= TACO_RING_SLOTS ? src - TACO_RING_SLOTS : src;
-            int dst = P.head + j;  // old logical j == new logical 90+j
-            dst = dst >= TACO_RING_SLOTS ? dst - TACO_RING_SLOTS : dst;
-            const bool fresh = (90 + j >= wr_lo) && (90 + j < dlen);
-            float4 old = buf_ld4(rR, voff, (uint32_t)src * row_bytes);
-            if (fresh) old = make_float4(act[0], act[1], act[2], act[3]);
-            buf_st4(rR, old, voff, (uint32_t)dst * row_bytes);
-        }
         dlen = dlen - 10 < 0 ? 0 : dlen - 10;
         CST(C_LINVEL, make_float4(v.x, v.y, v.z, as_f(dlen)));
     }
     // relative quantities FA:354-360 (target velocities are identically zero); the target pose is only needed from here on
-    const float4 c_tp = CLD(C_TGT_POS), c_tq = CLD(C_TGT_QUAT);
     const V3 pt{c_tp.x, c_tp.y, c_tp.z};
     const Q4 qt{c_tq.x, c_tq.y, c_tq.z, c_tq.w};
     const Q4 cq = conj(q);
@@ -709,34 +718,40 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
     fr[24] = cmd0;
     fr[25] = (grp == TACO_TASK_POS) ? cmd1 : (grp == TACO_TASK_ROTATE ? TACO_DIVC(cmd1, 6.0f) : TACO_DIVC(cmd1 / 2.0f, kPi));
 
-    // ---- frame stacks: rows of this wave's 64 envs are contiguous -> stream them as one flat range.
-    // word d of the range belongs to env d / row, offset j = d % row; j < row-26 is history (old word d+26), the
-    // rest is the new frame, read back from the LDS tile (transposes lane-major registers into env-major rows).
-    const int wave_env0 = blockIdx.x * BLOCK + wv * 64;
-    const int wave_envs = (P.n - wave_env0) < 64 ? (P.n - wave_env0) : 64;  // may be <= 0 for a fully idle wave
-    auto stream_rows = [&](float *buf, int len, float *mirror, int mirror_row) {
-        const int row = len * 26, hist = row - 26;
-        const int total = wave_envs * row;
-        float *base = buf + (size_t)wave_env0 * row;
-        float *mbase = mirror ? mirror + (size_t)wave_env0 * mirror_row : nullptr;
-        int d = lane;
-        int env = 0, j = lane;
-        while (j >= row) { j -= row; ++env; }
-        for (; d < total; d += 64) {
-            float val = (j < hist) ? base[d + 26] : tile[env * TILE_LD + (j - hist)];
-            base[d] = val;
-            if (mbase) mbase[env * mirror_row + j] = val;
-            j += 64;
-            while (j >= row) { j -= row; ++env; }
+    // ---- frame stacks [env][len][26] (newest frame last).  Two store paths:
+    //  len == 1 : the wavefront's 64 rows are one contiguous 6 656-byte range.  The frames go through a per-wave LDS tile
+    //             (lane-major registers -> env-major bytes) and leave as seven fully coalesced 16-byte-per-lane stores.
+    //  len  > 1 : each lane shifts its own row by one frame (8-byte accesses, in place, ascending) and appends the frame.
+    // Stores go through range-checked buffer descriptors, so ragged tails need no special casing.
+    const uint32_t wave_env0 = (uint32_t)(blockIdx.x * BLOCK + wv * 64);
+    auto put_frame = [&](float *buf, uint32_t buf_bytes, int len, const float (&f)[26]) {
+        const rsrc_t rB = make_rsrc(buf, buf_bytes);
+        if (len == 1) {
+            __syncthreads();  // previous users of the scratch (action slots / the other buffer's tile) are done
+            f32x2_t *t2 = reinterpret_cast<f32x2_t *>(tile + lane * 26);  // 104-byte rows: 8-byte aligned
+#pragma unroll
+            for (int k = 0; k < 13; ++k) t2[k] = f32x2_t{f[2 * k], f[2 * k + 1]};
+            __syncthreads();
+            const f32x4_t *t4 = reinterpret_cast<const f32x4_t *>(tile);
+#pragma unroll
+            for (int it = 0; it < 7; ++it) {
+                const uint32_t w4 = (uint32_t)(it * 64 + lane);  // 16-byte word inside the wave's 416-word range
+                if (w4 < 416u) llvm_amdgcn_raw_buffer_store_v4f32(t4[w4], rB, (int)(wave_env0 * 104u + w4 * 16u), 0, 0);
+            }
+        } else if (active) {
+            const uint32_t row0 = (uint32_t)i * (uint32_t)len * 104u;
+            const int pairs = (len - 1) * 13;
+            for (int j = 0; j < pairs; ++j) {
+                const f32x2_t o = llvm_amdgcn_raw_buffer_load_v2f32(rB, (int)(row0 + 104u + (uint32_t)j * 8u), 0, 0);
+                llvm_amdgcn_raw_buffer_store_v2f32(o, rB, (int)(row0 + (uint32_t)j * 8u), 0, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < 13; ++k)
+                llvm_amdgcn_raw_buffer_store_v2f32(f32x2_t{f[2 * k], f[2 * k + 1]}, rB, (int)(row0 + (uint32_t)(pairs + k) * 8u), 0, 0);
         }
     };
-    // states first (noise-free frame), then obs (possibly noised).  The barrier also fences the last `slots` reads.
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 26; ++k) tile[lane * TILE_LD + k] = fr[k];
-    __syncthreads();
-    stream_rows(P.states, P.len_states, nullptr, 0);
-    __syncthreads();
+    // states first (noise-free frame), then obs (possibly noised)
+    put_frame(P.states, P.states_bytes, P.len_states, fr);
     if (fl & TACO_F_OBSERVATION_NOISE) {  // FA:402-410
         float nrm[12];
 #pragma unroll
@@ -765,12 +780,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
         for (int k = 0; k < 3; ++k) fr[15 + k] = fr[15 + k] + P.df * (nrm[6 + k] * (float)(60.0 / 3 / 180) + 0.0f);
         fr[18] = fr[18] + P.df * (nrm[9] * (float)(0.06 / 3) + 0.0f);
         fr[23] = fr[23] + P.df * (nrm[10] * (float)(0.06 / 3 / 3) + 0.0f);
-#pragma unroll
-        for (int k = 0; k < 26; ++k) tile[lane * TILE_LD + k] = fr[k];
-        __syncthreads();
     }
-    const int gather_row = P.len_obs * 26 + 3;
-    stream_rows(P.obs, P.len_obs, P.gather, gather_row);
+    put_frame(P.obs, P.obs_bytes, P.len_obs, fr);
 
     // ------------------------------------------------------------------ compute_reward CTRL/task_reward.py
     float rew, pos_dist;
@@ -824,8 +835,23 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
         P.reset[i] = rs;
         P.timeout[i] = tmo ? 1 : 0;
         if (P.gather) {
-            float *gr = P.gather + (size_t)i * gather_row + (gather_row - 3);
-            gr[0] = rew; gr[1] = (float)rs; gr[2] = tmo ? 1.0f : 0.0f;
+            // one 128-byte-aligned row per env: [obs stack | reward | done | time-out | pad]; the obs stack is re-read from
+            // this lane's own (just written) obs row when there is history, else taken from registers
+            const rsrc_t rG = make_rsrc(P.gather, P.gather_bytes);
+            const rsrc_t rO = make_rsrc(P.obs, P.obs_bytes);
+            const uint32_t g0 = (uint32_t)i * P.gather_row * 4u;
+            const uint32_t hist_pairs = (uint32_t)(P.len_obs - 1) * 13u;
+            for (uint32_t j = 0; j < hist_pairs; ++j) {
+                const f32x2_t o = llvm_amdgcn_raw_buffer_load_v2f32(rO, (int)((uint32_t)i * (uint32_t)P.len_obs * 104u + j * 8u), 0, 0);
+                llvm_amdgcn_raw_buffer_store_v2f32(o, rG, (int)(g0 + j * 8u), 0, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < 13; ++k)
+                llvm_amdgcn_raw_buffer_store_v2f32(f32x2_t{fr[2 * k], fr[2 * k + 1]}, rG, (int)(g0 + (hist_pairs + (uint32_t)k) * 8u), 0, 0);
+            const uint32_t tail = g0 + (uint32_t)P.len_obs * 104u;
+            llvm_amdgcn_raw_buffer_store_f32(rew, rG, (int)tail, 0, 0);
+            llvm_amdgcn_raw_buffer_store_f32((float)rs, rG, (int)(tail + 4u), 0, 0);
+            llvm_amdgcn_raw_buffer_store_f32(tmo ? 1.0f : 0.0f, rG, (int)(tail + 8u), 0, 0);
         }
         CST(C_MISC, make_float4(bat_t, cmd0, cmd1, flip_radian));
     }

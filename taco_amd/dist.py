@@ -19,7 +19,9 @@ def shard_bounds(n_global, world_size, rank):
 
 
 def block_row(len_obs):
-    return len_obs * 26 + 3
+    """floats per env in the gather block: obs stack + reward + done + time-out, padded to whole 128-byte lines
+    (= taco_gather_row_floats of the C ABI)"""
+    return (len_obs * 26 + 3 + 31) // 32 * 32
 
 
 def unpack_block(block, len_obs):
@@ -33,7 +35,13 @@ def unpack_block(block, len_obs):
 def pack_block(obs, rew, done, timeout):
     """Host-side packer with the kernel's block layout (used by the CPU tests, where no kernel fills the block)."""
     n = obs.shape[0]
-    return torch.cat([obs.reshape(n, -1), rew.reshape(n, 1).float(), done.reshape(n, 1).float(), timeout.reshape(n, 1).float()], dim=1).contiguous()
+    row = obs.shape[1] * 26
+    blk = torch.zeros((n, block_row(obs.shape[1])), dtype=torch.float32, device=obs.device)
+    blk[:, :row] = obs.reshape(n, -1)
+    blk[:, row] = rew.float()
+    blk[:, row + 1] = done.float()
+    blk[:, row + 2] = timeout.float()
+    return blk
 
 
 def all_gather_blocks(block, n_global, world_size, group=None):

