@@ -37,18 +37,28 @@ def make_actions(n, steps, seed, device):
 
 
 def time_kernel_launches(env, acts, steps, torch):
-    """Average duration of the step kernel: HIP events (torch.cuda.Event on the launch stream = torch's current stream)
-    bracketing each launch; returns microseconds."""
+    """Duration of the step kernel from HIP events on the launch stream (torch.cuda.Event records on torch's current
+    stream, which is the stream taco_step launches on).  Two estimates, microseconds:
+      back_to_back : one event pair around `steps` consecutive launches / steps  (kernel + inter-kernel gap: an upper bound
+                     that does not pay the event-record overhead per launch; this is what rocprofv3's average tracks)
+      bracketed    : median of per-launch event pairs (adds ~2 us of event overhead at this kernel size)"""
+    na = acts.shape[0]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for t in range(steps):
+        env.step_raw(acts[t % na])
+    e1.record()
+    torch.cuda.synchronize()
+    back_to_back = e0.elapsed_time(e1) * 1e3 / steps
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
     ends = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
-    na = acts.shape[0]
     for t in range(steps):
         starts[t].record()
         env.step_raw(acts[t % na])
         ends[t].record()
     torch.cuda.synchronize()
     d = sorted(s.elapsed_time(e) * 1e3 for s, e in zip(starts, ends))
-    return sum(d) / len(d), d[len(d) // 2]
+    return back_to_back, d[len(d) // 2]
 
 
 def cpu_baseline(cfg, budget_s=12.0):
@@ -199,7 +209,7 @@ def main():
                        "collective": ("none" if world == 1 or args.no_gather else "1 RCCL all-gather of [obs|rew|done|timeout] per step"),
                        "kernel": base.lib.taco_step_kernel_name().decode(), "grid": grid, "block": block},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": None, "kernel_avg_us": k_avg_us, "kernel_median_us": k_med_us,
+                         "traffic": None, "kernel_avg_us": k_avg_us, "kernel_bracketed_median_us": k_med_us,
                          "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
                          "note": "4096 envs = 64 wavefronts on 256 CUs: latency-bound regime, see large_n for the bandwidth regime"},
             "gpu_event_ms_per_step": ev0.elapsed_time(ev1) / args.steps,

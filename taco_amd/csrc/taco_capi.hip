@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -142,7 +143,7 @@ __global__ void init_state_kernel(float *S, float *ring, int npad, float tau0, i
     word(S, npad, i, TACO_S_DX) = -0.386f;
     word(S, npad, i, TACO_S_DY) = -0.53f;
     word(S, npad, i, TACO_S_KT) = 0.009f;
-    word(S, npad, i, TACO_S_DELAY_LEN) = __builtin_bit_cast(float, delay_time);
+    word(S, npad, i, TACO_S_DELAY_LEN) = __builtin_bit_cast(float, delay_time | (delay_time << 16));  // L | Z << 16, see taco_step.hpp
 }
 
 // blob (include/taco_env.h layout: field-major words, logical ring order) <-> workspace (float4 chunks, physical ring order)
@@ -151,12 +152,17 @@ __global__ void export_state_kernel(const float *S, const float *ring, uint32_t 
     const int row = blockIdx.y;
     if (i >= n) return;
     float val;
-    if (row < TACO_NUM_FIELDS) {
+    const int dl = __builtin_bit_cast(int, word(const_cast<float *>(S), npad, i, TACO_S_DELAY_LEN));
+    const int L = dl & 0xffff, Z = (dl >> 16) & 0xff;
+    const bool dense = dl < 0;
+    if (row == TACO_S_DELAY_LEN) {
+        val = __builtin_bit_cast(float, L);
+    } else if (row < TACO_NUM_FIELDS) {
         val = word(const_cast<float *>(S), npad, i, row);
     } else {
         const int r = row - TACO_NUM_FIELDS, slot = r >> 2, ch = r & 3;
         const int ph = (head + slot) % TACO_RING_SLOTS;
-        val = ring[((size_t)ph * npad + i) * 4 + ch];
+        val = (dense || (slot >= Z && slot < L)) ? ring[((size_t)ph * npad + i) * 4 + ch] : 0.0f;  // implied zeros of a non-DENSE env
     }
     blob[(size_t)row * n + i] = __builtin_bit_cast(uint32_t, val);
 }
@@ -164,7 +170,9 @@ __global__ void import_state_kernel(float *S, float *ring, const uint32_t *blob,
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int row = blockIdx.y;
     if (i >= n) return;
-    const float val = __builtin_bit_cast(float, blob[(size_t)row * n + i]);
+    float val = __builtin_bit_cast(float, blob[(size_t)row * n + i]);
+    // an imported delay line is arbitrary content: mark the env DENSE so the literal buffer semantics are followed
+    if (row == TACO_S_DELAY_LEN) val = __builtin_bit_cast(float, (int)((__builtin_bit_cast(uint32_t, val) & 0xffffu) | 0x80000000u));
     if (row < TACO_NUM_FIELDS) {
         word(S, npad, i, row) = val;
     } else {
@@ -174,7 +182,13 @@ __global__ void import_state_kernel(float *S, float *ring, const uint32_t *blob,
     }
 }
 
-int block_for(const taco_env *e) { return e->cfg.num_envs >= 65536 ? kBlockLarge : kBlockSmall; }
+int block_for(const taco_env *e) {
+    if (const char *f = std::getenv("TACO_FORCE_BLOCK")) {  // experiments only
+        const int b = std::atoi(f);
+        if (b == kBlockSmall || b == kBlockLarge) return b;
+    }
+    return e->cfg.num_envs >= 65536 ? kBlockLarge : kBlockSmall;
+}
 
 }  // namespace
 

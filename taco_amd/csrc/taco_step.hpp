@@ -101,8 +101,12 @@ TD float4 buf_ld4(rsrc_t r, uint32_t voff, uint32_t soff) {
     const f32x4_t u = llvm_amdgcn_raw_buffer_load_v4f32(r, (int)voff, (int)soff, 0);
     return make_float4(u.x, u.y, u.z, u.w);
 }
+// 16-byte STORES never use the scalar offset operand: on gfx950 a buffer_store_dwordx4 with an SGPR soffset followed by a
+// VALU write to its data registers can ship the NEW value of the first data dword for the lanes read last (observed:
+// lanes 12-15 of each 16-lane group, non-deterministically).  LLVM's hazard recogniser only guards the no-SGPR-soffset
+// form (GCNHazardRecognizer::createsVALUHazard), so the row offset is folded into the per-lane offset instead.
 TD void buf_st4(rsrc_t r, float4 v, uint32_t voff, uint32_t soff) {
-    llvm_amdgcn_raw_buffer_store_v4f32(f32x4_t{v.x, v.y, v.z, v.w}, r, (int)voff, (int)soff, 0);
+    llvm_amdgcn_raw_buffer_store_v4f32(f32x4_t{v.x, v.y, v.z, v.w}, r, (int)(voff + soff), 0, 0);
 }
 TD float as_f(int x) { return __builtin_bit_cast(float, x); }
 TD int as_i(float x) { return __builtin_bit_cast(int, x); }
@@ -362,7 +366,7 @@ TD void reset_env(const StepParams &P, rsrc_t rS, rsrc_t rR, uint32_t voff, uint
             v = V3{3.0f * (2.0f * u6 + -1.0f), 3.0f * (2.0f * u7 + -1.0f), 3.0f * (2.0f * a0 + -1.0f)};
             w = V3{3.0f * (2.0f * a1 + -1.0f), 3.0f * (2.0f * a2 + -1.0f), 3.0f * (2.0f * a3 + -1.0f)};
         }
-        CST(C_LINVEL, make_float4(v.x, v.y, v.z, as_f(L)));
+        CST(C_LINVEL, make_float4(v.x, v.y, v.z, as_f(L | (L << 16))));  // Z = L: the whole pending line is reset-zeros
         CST(C_ANGVEL, make_float4(w.x, w.y, w.z, 0.0f));  // battery_voltage <- 0 (FA:566)
     }
     // ---- reset_target_idx FA:523-548
@@ -409,7 +413,7 @@ TD void reset_env(const StepParams &P, rsrc_t rS, rsrc_t rR, uint32_t voff, uint
     }
     CST(C_ACT, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
     CST(C_ACT_OLD, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-    for (int s = 0; s < TACO_RING_SLOTS; ++s) buf_st4(rR, make_float4(0.0f, 0.0f, 0.0f, 0.0f), voff, (uint32_t)s * row_bytes);
+    (void)rR;  // the ring is NOT zeroed (FA:574): the delay-line word marks every pending slot as an implied zero
 }
 
 
@@ -476,7 +480,17 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
     float cmd0 = c_misc.y, cmd1 = c_misc.z, flip_radian = c_misc.w;
     const float cf = c_a0.y, ct = c_a0.z, dx = c_a0.w, dy = c_a1.x, kt = c_a1.y;
     int progress = as_i(c_pos.w);
-    int dlen = as_i(c_lin.w);
+    // delay-line word: bits 0..15 L = actions_remained_length, bits 16..23 Z = leading logical slots that are still the
+    // zeros of the last reset, bit 31 DENSE.  While no write of an env has reached the tail slots [90,100) since its reset
+    // (L + T <= 90 always; with delay_time = 20 that is the whole episode), the reference's dense [4,100] buffer is exactly
+    // [Z zeros | written slots up to L | zeros]  -- so the ring needs neither zeroing at reset nor the per-step copy that
+    // preserves the stale tail [90,100) (FA:378).  The first write that touches the tail switches the env to DENSE: the
+    // implied zeros are materialised once and from then on the literal buffer semantics (tail copy, truncated writes,
+    // stale reads) are followed.  Exact in every regime (tests: overflow regime on GPU + dense numpy model of the oracle).
+    const int dl_word = as_i(c_lin.w);
+    int dlen = dl_word & 0xffff;
+    int zlead = (dl_word >> 16) & 0xff;
+    bool dense = dl_word < 0;
     const float4 a_in = reinterpret_cast<const float4 *>(P.act_in)[i];
     const bool at_time = !is_reset && progress == 500;  // reset_command_condition FA:595-598 (a reset env has progress 0 here;
                                                         // its own progress==500 case is overwritten by the reset branch below)
@@ -519,16 +533,28 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
         U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, P.step, STREAM_DEPLOY, 0u);
         T = 10 - rounded_normal(uniform(r.x), 1);
     }
+    if (!dense && dlen + T > TACO_RING_SLOTS - 10) {  // first write that reaches the tail [90,100): materialise the implied zeros
+        if (active) {
+            for (int s = 0; s < TACO_RING_SLOTS; ++s) {
+                if (s < zlead || s >= dlen) {
+                    int ph = P.head + s; ph = ph >= TACO_RING_SLOTS ? ph - TACO_RING_SLOTS : ph;
+                    buf_st4(rR, make_float4(0.0f, 0.0f, 0.0f, 0.0f), (uint32_t)ph * row_bytes + voff, 0u);
+                }
+            }
+        }
+        dense = true;
+        zlead = 0;
+    }
     // The 10 slots this step consumes: logical 0..9, physical (head+s)%100 -- uniform across the wave, so coalesced.
-    // Slots the write below covers are overlaid from registers instead of being re-read.
+    // Slots the write below covers are overlaid from registers instead of being re-read; implied zeros are not read.
     {
 #pragma unroll
         for (int s = 0; s < 10; ++s) {
             int ph = P.head + s; ph = ph >= TACO_RING_SLOTS ? ph - TACO_RING_SLOTS : ph;
             const bool fresh = (s >= dlen) && (s < dlen + T);
-            const bool keep = !is_reset && !fresh;  // a reset env's ring is all zeros; a fresh slot comes from registers
-            float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (keep) o = buf_ld4(rR, voff, (uint32_t)ph * row_bytes);
+            const bool keep = !fresh && (dense || (s >= zlead && s < dlen));
+            float4 o = buf_ld4(rR, voff, (uint32_t)ph * row_bytes);
+            if (!keep) o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (fresh) o = make_float4(act[0], act[1], act[2], act[3]);
             slots[s * 64 + lane] = o;
         }
@@ -542,22 +568,23 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
             }
         }
     }
-    if (active) {
-        const int dlen_after = dlen + T;
-        // (done here, ahead of the substeps, so that its loads and stores drain while the substep loop computes)
-        // FA:378 leaves logical slots [90,100) untouched by the shift.  With the ring advancing by 10 (host side), the new
-        // logical [90,100) are the physical slots just consumed, so they must be given the values of the old logical
-        // [90,100) (= new [80,90)); a slot this step's action write covered is taken from registers, not re-read.
-        const int wr_lo = dlen;  // the write above covered logical [dlen, dlen + T)
+    if (__builtin_amdgcn_ballot_w64(dense && active)) {  // wave-uniform skip: normally no lane is DENSE
+        if (dense && active) {
+            const int dlen_after = dlen + T;
+            // FA:378 leaves logical slots [90,100) untouched by the shift.  With the ring advancing by 10 (host side), the
+            // new logical [90,100) are the physical slots just consumed, so they must be given the values of the old
+            // logical [90,100) (= new [80,90)); a slot this step's action write covered is taken from registers.
+            // Done ahead of the substeps so that its traffic drains while the loop computes.
 #pragma unroll
-        for (int j = 0; j < 10; ++j) {
-            int src = P.head + 90 + j; src = src >= TACO_RING_SLOTS ? src - TACO_RING_SLOTS : src;
-            int dst = P.head + j;  // old logical j == new logical 90+j
-            dst = dst >= TACO_RING_SLOTS ? dst - TACO_RING_SLOTS : dst;
-            const bool fresh = (90 + j >= wr_lo) && (90 + j < dlen_after);
-            float4 old = buf_ld4(rR, voff, (uint32_t)src * row_bytes);
-            if (fresh) old = make_float4(act[0], act[1], act[2], act[3]);
-            buf_st4(rR, old, voff, (uint32_t)dst * row_bytes);
+            for (int j = 0; j < 10; ++j) {
+                int src = P.head + 90 + j; src = src >= TACO_RING_SLOTS ? src - TACO_RING_SLOTS : src;
+                int dst = P.head + j;  // old logical j == new logical 90+j
+                dst = dst >= TACO_RING_SLOTS ? dst - TACO_RING_SLOTS : dst;
+                const bool fresh = (90 + j >= dlen) && (90 + j < dlen_after);
+                float4 old = buf_ld4(rR, voff, (uint32_t)src * row_bytes);
+                if (fresh) old = make_float4(act[0], act[1], act[2], act[3]);
+                buf_st4(rR, old, voff, (uint32_t)dst * row_bytes);
+            }
         }
     }
     dlen += T;
@@ -686,7 +713,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
             CST(C_RPY_CONT, make_float4(rpy_cont[0], rpy_cont[1], rpy_cont[2], 0.0f));
         }
         dlen = dlen - 10 < 0 ? 0 : dlen - 10;
-        CST(C_LINVEL, make_float4(v.x, v.y, v.z, as_f(dlen)));
+        zlead = zlead - 10 < 0 ? 0 : zlead - 10;
+        CST(C_LINVEL, make_float4(v.x, v.y, v.z, as_f((dlen & 0xffff) | (zlead << 16) | (dense ? (int)0x80000000 : 0))));
     }
     // relative quantities FA:354-360 (target velocities are identically zero); the target pose is only needed from here on
     const V3 pt{c_tp.x, c_tp.y, c_tp.z};

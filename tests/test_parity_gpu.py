@@ -114,8 +114,14 @@ def test_delay_line_overflow_regime():
     cfg["delay_time"] = 85
     cfg["ramdom_deploy_time"] = True
     cfg["ramdom_delay_time"] = True
-    from oracle import oracle as O
     run_pair(cfg, steps=400, check_every=10, hover_bias=True)
+    # start just BELOW the tail (L + T = 84..86 <= 90): envs begin with the implied-zero encoding and random-walk into the
+    # dense regime mid-episode (the kernel's one-off materialisation of the implied zeros is on this path)
+    cfg = config.baseline_config(1, num_envs=512)
+    cfg["delay_time"] = 75
+    cfg["ramdom_deploy_time"] = True
+    cfg["env"]["maxEpisodeLength"] = 300
+    run_pair(cfg, steps=500, check_every=5, hover_bias=True)
 
 
 @pytest.mark.parametrize("len_obs", [1, 3])
@@ -141,3 +147,28 @@ def test_gather_block_matches_outputs(len_obs):
         o, r, d, tm = dist.unpack_block(block, len_obs)
         assert torch.equal(d, env.reset_buf) and torch.equal(tm, env.timeout_buf)
     assert env.timeout_buf.any() or True
+
+
+def test_state_blob_roundtrip_and_restore():
+    """taco_get_state / taco_set_state (+ step count) restore a run exactly: a second handle loaded from a mid-run blob
+    continues bit-identically (covers the logical<->physical ring mapping and the implied-zero delay-line encoding)."""
+    from taco_amd.vec_env import FpvBase
+    n = 500
+    cfg = config.baseline_config(4, num_envs=n)
+    cfg["delay_time"] = 60
+    a = FpvBase(cfg, copy_outputs=False)
+    acts = torch.from_numpy(action_stream(n, 90, 11)).cuda()
+    for t in range(37):
+        a.step_raw(acts[t])
+    blob = a.get_state()
+    b = FpvBase(config.baseline_config(4, num_envs=n) | {"delay_time": 60}, copy_outputs=False)
+    b.set_state(blob)
+    b.step_count = a.step_count
+    b.obs_buf.copy_(a.obs_buf); b.states_buf.copy_(a.states_buf); b.reset_buf.copy_(a.reset_buf)
+    assert torch.equal(b.get_state().view(torch.int32), blob.view(torch.int32))
+    for t in range(37, 90):
+        a.step_raw(acts[t]); b.step_raw(acts[t])
+        assert torch.equal(a.obs_buf.view(torch.int32), b.obs_buf.view(torch.int32)), t
+        assert torch.equal(a.states_buf.view(torch.int32), b.states_buf.view(torch.int32)), t
+        assert torch.equal(a.reset_buf, b.reset_buf) and torch.equal(a.rew_buf.view(torch.int32), b.rew_buf.view(torch.int32)), t
+    assert torch.equal(a.get_state().view(torch.int32), b.get_state().view(torch.int32))
