@@ -61,6 +61,19 @@ def time_kernel_launches(env, acts, steps, torch):
     return back_to_back, d[len(d) // 2]
 
 
+def pmc_traffic(n_envs):
+    """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC summary (FETCH_SIZE x2 per the gfx950 note in
+    MI355X_MICROARCH.md + WRITE_SIZE, separate passes; profiles/README.md).  bench.py cannot run rocprofv3 on itself, so the
+    figure is the one measured for the build that produced profiles/; None if no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1])).get("derived", {})
+    key = f"hbm_bytes_per_launch_{n_envs}"
+    return d.get(key), os.path.basename(files[-1])
+
+
 def cpu_baseline(cfg, budget_s=12.0):
     """The CPU oracle (oracle/, kind 'port') on this host: all cores through OpenMP, bounded by wall time."""
     import numpy as np
@@ -198,6 +211,7 @@ def main():
         k_avg_us, k_med_us = time_kernel_launches(base, acts, min(args.steps, 500), torch)
         achieved = ALGO_BYTES_PER_ENV_STEP * n_local / (k_avg_us * 1e-6) / 1e9
         grid, block = base.launch_geometry()
+        traffic, traffic_src = pmc_traffic(n_local)
         out = {
             "metric": "env-steps/s at 4096 envs per GPU, fpv_asymmetry.step() hot path (task_mode=pos)",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -209,7 +223,7 @@ def main():
                        "collective": ("none" if world == 1 or args.no_gather else "1 RCCL all-gather of [obs|rew|done|timeout] per step"),
                        "kernel": base.lib.taco_step_kernel_name().decode(), "grid": grid, "block": block},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": None, "kernel_avg_us": k_avg_us, "kernel_bracketed_median_us": k_med_us,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel_avg_us": k_avg_us, "kernel_bracketed_median_us": k_med_us,
                          "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
                          "note": "4096 envs = 64 wavefronts on 256 CUs: latency-bound regime, see large_n for the bandwidth regime"},
             "gpu_event_ms_per_step": ev0.elapsed_time(ev1) / args.steps,
