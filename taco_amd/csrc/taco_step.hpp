@@ -452,15 +452,27 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
     const bool wave_tracks_rpy = __builtin_amdgcn_ballot_w64(track_rpy) != 0;
 
     // ------------------------------------------------------------------ pre_physics_step FA:317-332
+    // Every load the step needs is issued up front, before the reset flag is known: the flag, the action, the 13 state
+    // chunks and the 10 ring slots of this step are independent, so they share ONE memory round trip.
     const bool is_reset = P.reset[i] != 0;
-    // reset_idx (FA:475-517) runs FIRST and writes the fresh state straight to the SoA rows, so none of its 37 random
-    // draws or temporaries are live once the step proper starts (they would otherwise dominate the register budget).
-    if (is_reset) reset_env(P, rS, rR, voff, row_bytes, gid, grp, mix, active);
-
-    // ------------------------------------------------------------------ load state: 14 coalesced 16-byte-per-lane loads
-    const float4 c_pos = CLD(C_POS), c_quat = CLD(C_QUAT), c_lin = CLD(C_LINVEL), c_ang = CLD(C_ANGVEL);
-    const float4 c_pp = CLD(C_PID_PREV), c_pi = CLD(C_PID_INT), c_om = CLD(C_OMEGA), c_act = CLD(C_ACT), c_misc = CLD(C_MISC);
-    const float4 c_tau = CLD(C_TAU), c_op = CLD(C_OPARA), c_a0 = CLD(C_AERO0), c_a1 = CLD(C_AERO1);
+    const float4 a_in = reinterpret_cast<const float4 *>(P.act_in)[i];
+    float4 c_pos = CLD(C_POS), c_quat = CLD(C_QUAT), c_lin = CLD(C_LINVEL), c_ang = CLD(C_ANGVEL);
+    float4 c_pp = CLD(C_PID_PREV), c_pi = CLD(C_PID_INT), c_om = CLD(C_OMEGA), c_act = CLD(C_ACT), c_misc = CLD(C_MISC);
+    float4 c_tau = CLD(C_TAU), c_op = CLD(C_OPARA), c_a0 = CLD(C_AERO0), c_a1 = CLD(C_AERO1);
+    float4 ring_in[10];
+#pragma unroll
+    for (int s = 0; s < 10; ++s) {
+        int ph = P.head + s; ph = ph >= TACO_RING_SLOTS ? ph - TACO_RING_SLOTS : ph;
+        ring_in[s] = buf_ld4(rR, voff, (uint32_t)ph * row_bytes);  // physical row is wave-uniform: coalesced
+    }
+    // reset_idx (FA:475-517) writes the fresh state straight to the env's chunks (none of its 37 random draws or
+    // temporaries stay live); a wavefront that holds a reset lane then simply loads its chunks again.
+    if (__builtin_amdgcn_ballot_w64(is_reset)) {
+        if (is_reset) reset_env(P, rS, rR, voff, row_bytes, gid, grp, mix, active);
+        c_pos = CLD(C_POS); c_quat = CLD(C_QUAT); c_lin = CLD(C_LINVEL); c_ang = CLD(C_ANGVEL);
+        c_pp = CLD(C_PID_PREV); c_pi = CLD(C_PID_INT); c_om = CLD(C_OMEGA); c_act = CLD(C_ACT); c_misc = CLD(C_MISC);
+        c_tau = CLD(C_TAU); c_op = CLD(C_OPARA); c_a0 = CLD(C_AERO0); c_a1 = CLD(C_AERO1);
+    }
     V3 p{c_pos.x, c_pos.y, c_pos.z};
     Q4 q{c_quat.x, c_quat.y, c_quat.z, c_quat.w};
     V3 v{c_lin.x, c_lin.y, c_lin.z};
@@ -491,7 +503,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
     int dlen = dl_word & 0xffff;
     int zlead = (dl_word >> 16) & 0xff;
     bool dense = dl_word < 0;
-    const float4 a_in = reinterpret_cast<const float4 *>(P.act_in)[i];
     const bool at_time = !is_reset && progress == 500;  // reset_command_condition FA:595-598 (a reset env has progress 0 here;
                                                         // its own progress==500 case is overwritten by the reset branch below)
     if (is_reset || at_time) {  // reset_command_idx: FA:758-759, :814-821, :886-917, :1058-1112
@@ -550,10 +561,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
     {
 #pragma unroll
         for (int s = 0; s < 10; ++s) {
-            int ph = P.head + s; ph = ph >= TACO_RING_SLOTS ? ph - TACO_RING_SLOTS : ph;
             const bool fresh = (s >= dlen) && (s < dlen + T);
             const bool keep = !fresh && (dense || (s >= zlead && s < dlen));
-            float4 o = buf_ld4(rR, voff, (uint32_t)ph * row_bytes);
+            float4 o = ring_in[s];
             if (!keep) o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (fresh) o = make_float4(act[0], act[1], act[2], act[3]);
             slots[s * 64 + lane] = o;
