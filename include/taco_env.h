@@ -126,8 +126,8 @@ int taco_abi_version(void);
 /* Thread-local text of the last error on this thread ("" if none). */
 const char *taco_last_error(void);
 
-/* Bytes of device workspace taco_create needs for `cfg` (18 float4 state chunks + 100 float4 ring slots per env,
- * env count padded to whole wavefronts; the pointer must be 256-byte aligned). */
+/* Bytes of device workspace taco_create needs for `cfg` (17 float4 state chunks + 16 float4 action-history rows +
+ * 100 float4 ring slots per env, env count padded to whole wavefronts; the pointer must be 256-byte aligned). */
 size_t taco_workspace_bytes(const taco_cfg *cfg);
 
 /* Replaces FpvBase.__init__ -> VecTask.__init__ -> create_sim/prepare_sim (fpv_asymmetry.py:54-200,

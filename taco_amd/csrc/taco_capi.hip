@@ -36,9 +36,11 @@ struct taco_env {
     int device;
     int npad;
     float *S;
+    float *hist;
     float *ring;
     int64_t step_count;
     int head;  // physical ring slot of logical slot 0; advances by 10 per step (mod 100)
+    int hh;    // action-history row the next step writes; advances by 1 per step (mod 16)
     float *gather;  // optional per-rank all-gather block, see taco_bind_gather_block
     taco::StepParams P;
 };
@@ -124,11 +126,13 @@ __device__ __forceinline__ float &word(float *S, int npad, int i, int field) {
     const int sl = taco::field_slot(field);
     return S[((size_t)(sl >> 2) * npad + i) * 4 + (sl & 3)];
 }
-__global__ void init_state_kernel(float *S, float *ring, int npad, float tau0, int delay_time) {
+__global__ void init_state_kernel(float *S, float *hist, float *ring, int npad, float tau0, int delay_time) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npad) return;
     for (int c = 0; c < (int)taco::NUM_CHUNKS; ++c)
         for (int k = 0; k < 4; ++k) S[((size_t)c * npad + i) * 4 + k] = 0.0f;
+    for (int r = 0; r < taco::HIST_ROWS; ++r)
+        for (int k = 0; k < 4; ++k) hist[((size_t)r * npad + i) * 4 + k] = 0.0f;
     for (int r = 0; r < TACO_RING_SLOTS; ++r)
         for (int k = 0; k < 4; ++k) ring[((size_t)r * npad + i) * 4 + k] = 0.0f;
     word(S, npad, i, TACO_S_POS + 2) = 4.0f;
@@ -143,42 +147,67 @@ __global__ void init_state_kernel(float *S, float *ring, int npad, float tau0, i
     word(S, npad, i, TACO_S_DX) = -0.386f;
     word(S, npad, i, TACO_S_DY) = -0.53f;
     word(S, npad, i, TACO_S_KT) = 0.009f;
-    word(S, npad, i, TACO_S_DELAY_LEN) = __builtin_bit_cast(float, delay_time | (delay_time << 16));  // L | Z << 16, see taco_step.hpp
+    word(S, npad, i, TACO_S_DELAY_LEN) = __builtin_bit_cast(float, delay_time | (delay_time << 16));  // L | Z << 16: all implied zeros
 }
 
-// blob (include/taco_env.h layout: field-major words, logical ring order) <-> workspace (float4 chunks, physical ring order)
-__global__ void export_state_kernel(const float *S, const float *ring, uint32_t *blob, int n, int npad, int head) {
+// blob (include/taco_env.h layout: field-major words, logical dense delay line) <-> workspace (float4 chunks; pending
+// actions as run queue over the action history, or as the physical slot ring once DENSE)
+__global__ void export_state_kernel(const float *S, const float *hist, const float *ring, uint32_t *blob, int n, int npad, int head, int hh) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int row = blockIdx.y;
     if (i >= n) return;
-    float val;
-    const int dl = __builtin_bit_cast(int, word(const_cast<float *>(S), npad, i, TACO_S_DELAY_LEN));
+    float *Sm = const_cast<float *>(S);
+    const int dl = __builtin_bit_cast(int, word(Sm, npad, i, TACO_S_DELAY_LEN));
     const int L = dl & 0xffff, Z = (dl >> 16) & 0xff;
     const bool dense = dl < 0;
+    float val;
     if (row == TACO_S_DELAY_LEN) {
         val = __builtin_bit_cast(float, L);
+    } else if (row >= TACO_S_ACT && row < TACO_S_ACT + 4) {            // actions = the action of the last step
+        val = hist[((size_t)((hh - 1) & (taco::HIST_ROWS - 1)) * npad + i) * 4 + (row - TACO_S_ACT)];
+    } else if (row >= TACO_S_ACT_OLD && row < TACO_S_ACT_OLD + 4) {    // actions_old = the one before, 0 right after a reset (FA:572-573)
+        const int progress = __builtin_bit_cast(int, word(Sm, npad, i, TACO_S_PROGRESS));
+        val = (progress <= 1) ? 0.0f : hist[((size_t)((hh - 2) & (taco::HIST_ROWS - 1)) * npad + i) * 4 + (row - TACO_S_ACT_OLD)];
     } else if (row < TACO_NUM_FIELDS) {
-        val = word(const_cast<float *>(S), npad, i, row);
+        val = word(Sm, npad, i, row);
     } else {
         const int r = row - TACO_NUM_FIELDS, slot = r >> 2, ch = r & 3;
-        const int ph = (head + slot) % TACO_RING_SLOTS;
-        val = (dense || (slot >= Z && slot < L)) ? ring[((size_t)ph * npad + i) * 4 + ch] : 0.0f;  // implied zeros of a non-DENSE env
+        if (dense) {
+            val = ring[((size_t)((head + slot) % TACO_RING_SLOTS) * npad + i) * 4 + ch];
+        } else {  // expand [Z zeros | run_0 (rem0) | run_1 | ... ] ; beyond L: zeros
+            const int lens = __builtin_bit_cast(int, S[((size_t)taco::C_QUEUE * npad + i) * 4 + 0]);
+            const int mr = __builtin_bit_cast(int, S[((size_t)taco::C_QUEUE * npad + i) * 4 + 1]);
+            const int m = mr & 0xff, rem0 = (mr >> 8) & 0xff;
+            val = 0.0f;
+            int pos = Z;
+            for (int j = 0; j < m && slot >= pos; ++j) {
+                const int len = (j == 0) ? rem0 : taco::run_len(lens, j);
+                if (slot < pos + len) val = hist[((size_t)((hh - (m - j)) & (taco::HIST_ROWS - 1)) * npad + i) * 4 + ch];
+                pos += len;
+            }
+        }
     }
     blob[(size_t)row * n + i] = __builtin_bit_cast(uint32_t, val);
 }
-__global__ void import_state_kernel(float *S, float *ring, const uint32_t *blob, int n, int npad, int head) {
+__global__ void import_state_kernel(float *S, float *hist, float *ring, const uint32_t *blob, int n, int npad, int head, int hh) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int row = blockIdx.y;
     if (i >= n) return;
     float val = __builtin_bit_cast(float, blob[(size_t)row * n + i]);
-    // an imported delay line is arbitrary content: mark the env DENSE so the literal buffer semantics are followed
-    if (row == TACO_S_DELAY_LEN) val = __builtin_bit_cast(float, (int)((__builtin_bit_cast(uint32_t, val) & 0xffffu) | 0x80000000u));
-    if (row < TACO_NUM_FIELDS) {
+    if (row == TACO_S_DELAY_LEN) {
+        // an imported delay line is arbitrary content: the env becomes DENSE (literal slot ring), its run queue empty
+        val = __builtin_bit_cast(float, (int)((__builtin_bit_cast(uint32_t, val) & 0xffffu) | 0x80000000u));
+        for (int k = 0; k < 4; ++k) S[((size_t)taco::C_QUEUE * npad + i) * 4 + k] = 0.0f;
+    }
+    if (row >= TACO_S_ACT && row < TACO_S_ACT + 4) {
+        hist[((size_t)((hh - 1) & (taco::HIST_ROWS - 1)) * npad + i) * 4 + (row - TACO_S_ACT)] = val;
+    } else if (row >= TACO_S_ACT_OLD && row < TACO_S_ACT_OLD + 4) {
+        hist[((size_t)((hh - 2) & (taco::HIST_ROWS - 1)) * npad + i) * 4 + (row - TACO_S_ACT_OLD)] = val;
+    } else if (row < TACO_NUM_FIELDS) {
         word(S, npad, i, row) = val;
     } else {
         const int r = row - TACO_NUM_FIELDS, slot = r >> 2, ch = r & 3;
-        const int ph = (head + slot) % TACO_RING_SLOTS;
-        ring[((size_t)ph * npad + i) * 4 + ch] = val;
+        ring[((size_t)((head + slot) % TACO_RING_SLOTS) * npad + i) * 4 + ch] = val;
     }
 }
 
@@ -203,7 +232,7 @@ const char *taco_step_kernel_name(void) { return "taco_step_kernel"; }
 size_t taco_workspace_bytes(const taco_cfg *cfg) {
     if (!cfg || cfg->num_envs <= 0) return 0;
     const size_t npad = (size_t)round_up(cfg->num_envs, 64);
-    return (size_t)(taco::NUM_CHUNKS + TACO_RING_SLOTS) * npad * 4 * sizeof(float);
+    return (size_t)(taco::NUM_CHUNKS + taco::HIST_ROWS + TACO_RING_SLOTS) * npad * 4 * sizeof(float);
 }
 
 int taco_create(const taco_cfg *cfg, int device, void *workspace, size_t workspace_bytes, void *stream, taco_env **out) {
@@ -222,13 +251,15 @@ int taco_create(const taco_cfg *cfg, int device, void *workspace, size_t workspa
     e->device = device;
     e->npad = round_up(cfg->num_envs, 64);
     e->S = (float *)workspace;
-    e->ring = e->S + (size_t)taco::NUM_CHUNKS * e->npad * 4;
+    e->hist = e->S + (size_t)taco::NUM_CHUNKS * e->npad * 4;
+    e->ring = e->hist + (size_t)taco::HIST_ROWS * e->npad * 4;
     e->step_count = 0;
     e->head = 0;
+    e->hh = 0;
     e->gather = nullptr;
     std::memset(&e->P, 0, sizeof(e->P));
     derive(e);
-    hipLaunchKernelGGL(init_state_kernel, dim3((e->npad + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->S, e->ring, e->npad,
+    hipLaunchKernelGGL(init_state_kernel, dim3((e->npad + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->S, e->hist, e->ring, e->npad,
                        (float)cfg->rotor_response_time, cfg->delay_time);
     he = hipGetLastError();
     if (he != hipSuccess) { delete e; return hip_fail(he, "init_state_kernel launch"); }
@@ -246,7 +277,7 @@ int taco_step(taco_env *e, const float *actions, float *obs_buf, float *states_b
     if (((uintptr_t)actions & 15u) != 0) return fail(TACO_ERR_INVALID_ARG, "actions must be 16-byte aligned");
     const size_t n_envs = (size_t)e->cfg.num_envs;
     taco::StepParams P = e->P;
-    P.S = e->S; P.ring = e->ring;
+    P.S = e->S; P.ring = e->ring; P.hist = e->hist;
     P.act_in = actions; P.obs = obs_buf; P.states = states_buf; P.rew = rew_buf;
     P.reset = (long long *)reset_buf; P.timeout = timeout_buf;
     P.gather = e->gather;
@@ -258,6 +289,8 @@ int taco_step(taco_env *e, const float *actions, float *obs_buf, float *states_b
     P.gather_row = (uint32_t)taco_gather_row_floats(e->cfg.len_obs);
     P.gather_bytes = (uint32_t)((size_t)n_envs * P.gather_row * sizeof(float));
     P.head = e->head;
+    P.hh = e->hh;
+    P.hist_bytes = (uint32_t)((size_t)taco::HIST_ROWS * e->npad * 4 * sizeof(float));
     const int n = e->cfg.num_envs;
     if (block_for(e) == kBlockLarge)
         hipLaunchKernelGGL(taco::taco_step_kernel<kBlockLarge>, dim3((n + kBlockLarge - 1) / kBlockLarge), dim3(kBlockLarge), 0, (hipStream_t)stream, P);
@@ -267,6 +300,7 @@ int taco_step(taco_env *e, const float *actions, float *obs_buf, float *states_b
     if (he != hipSuccess) return hip_fail(he, "taco_step_kernel launch");
     e->step_count += 1;
     e->head = (e->head + 10) % TACO_RING_SLOTS;
+    e->hh = (e->hh + 1) % taco::HIST_ROWS;
     return TACO_OK;
 }
 
@@ -295,8 +329,8 @@ int taco_set_step_count(taco_env *e, int64_t n) {
 int taco_get_state(taco_env *e, uint32_t *blob, void *stream) {
     if (!e || !blob) return fail(TACO_ERR_INVALID_ARG, "taco_get_state: null argument");
     const int n = e->cfg.num_envs;
-    hipLaunchKernelGGL(export_state_kernel, dim3((n + 255) / 256, TACO_BLOB_ROWS), dim3(256), 0, (hipStream_t)stream, e->S, e->ring, blob, n,
-                       e->npad, e->head);
+    hipLaunchKernelGGL(export_state_kernel, dim3((n + 255) / 256, TACO_BLOB_ROWS), dim3(256), 0, (hipStream_t)stream, e->S, e->hist, e->ring, blob, n,
+                       e->npad, e->head, e->hh);
     hipError_t he = hipGetLastError();
     return he == hipSuccess ? TACO_OK : hip_fail(he, "export_state_kernel launch");
 }
@@ -304,8 +338,8 @@ int taco_get_state(taco_env *e, uint32_t *blob, void *stream) {
 int taco_set_state(taco_env *e, const uint32_t *blob, void *stream) {
     if (!e || !blob) return fail(TACO_ERR_INVALID_ARG, "taco_set_state: null argument");
     const int n = e->cfg.num_envs;
-    hipLaunchKernelGGL(import_state_kernel, dim3((n + 255) / 256, TACO_BLOB_ROWS), dim3(256), 0, (hipStream_t)stream, e->S, e->ring, blob, n,
-                       e->npad, e->head);
+    hipLaunchKernelGGL(import_state_kernel, dim3((n + 255) / 256, TACO_BLOB_ROWS), dim3(256), 0, (hipStream_t)stream, e->S, e->hist, e->ring, blob, n,
+                       e->npad, e->head, e->hh);
     hipError_t he = hipGetLastError();
     return he == hipSuccess ? TACO_OK : hip_fail(he, "import_state_kernel launch");
 }

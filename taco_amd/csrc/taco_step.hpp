@@ -21,6 +21,7 @@ struct StepParams {
     // device pointers
     float *S;            // [NUM_CHUNKS][npad] float4 state chunks
     float *ring;         // [100][npad] float4 pending-action ring, PHYSICAL slot order (logical slot s lives at (head+s)%100)
+    float *hist;         // [16][npad] float4 action history, row = step count & 15
     const float *act_in; // [n][4]
     float *obs;          // [n][len_obs][26]
     float *states;       // [n][len_states][26]
@@ -31,7 +32,8 @@ struct StepParams {
     // geometry / cfg
     int n, npad, env_offset, task_mode, mix_n1, mix_n2, len_obs, len_states, substeps, max_len, delay_time, head;
     uint32_t flags, seed_lo, seed_hi, step;
-    uint32_t s_bytes, ring_bytes;  // sizes of S and ring for the buffer descriptors (range-checked accesses)
+    uint32_t s_bytes, ring_bytes, hist_bytes;  // sizes for the buffer descriptors (range-checked accesses)
+    int hh;              // history row this step writes (= number of steps taken so far, mod 16)
     uint32_t obs_bytes, states_bytes, gather_bytes, gather_row;  // gather_row = floats per env in the gather block (multiple of 32)
     // fp32 images of the Python doubles the reference feeds into tensor ops
     float dt, rdt, clip_act, df;  // rdt = 1/dt when div_const is exact for this dt (checked on the host), else 0
@@ -42,39 +44,44 @@ struct StepParams {
 // ---- workspace layout ("array of float4 rows"): the 67 state words of an env are packed into 18 float4 CHUNKS;
 // chunk c of env i lives at byte (c * npad + i) * 16, so a wavefront moves a chunk with ONE 16-byte-per-lane access
 // (1 KiB, fully coalesced) instead of four 4-byte ones.  Words that travel together share a chunk.
-// The pending-action ring is ring[slot][npad] float4 (the 4 action channels of a slot) in PHYSICAL slot order.
+// Pending actions: a run-length queue (C_QUEUE) over the action history hist[16][npad] float4 while an env is in the
+// common regime, the literal slot ring ring[100][npad] float4 (PHYSICAL slot order) once it is DENSE (see the kernel).
 enum Chunk : uint32_t {
     C_POS = 0,      // p.x p.y p.z | progress (int)
     C_QUAT = 1,     // q.x q.y q.z q.w
-    C_LINVEL = 2,   // v.x v.y v.z | delay length (int)
+    C_LINVEL = 2,   // v.x v.y v.z | delay word (see the kernel)
     C_ANGVEL = 3,   // w.x w.y w.z | battery voltage
     C_PID_PREV = 4, // previous_error xyz | battery E_c
     C_PID_INT = 5,  // integral xyz | battery u_1
     C_OMEGA = 6,    // rotor speeds
-    C_ACT = 7,      // actions
-    C_ACT_OLD = 8,  // actions_old
-    C_MISC = 9,     // battery time | command[0] | command[1] | flip_radian
-    C_RPY_OLD = 10, // xyz | -
-    C_RPY_CONT = 11,
-    C_TGT_POS = 12, // xyz | -
-    C_TGT_QUAT = 13,
-    C_TAU = 14,     // rotor response times
-    C_OPARA = 15,   // omega_para[0..3]
-    C_AERO0 = 16,   // omega_para[4] | cf | ct | dx
-    C_AERO1 = 17,   // dy | kt | - | -
-    NUM_CHUNKS = 18
+    C_QUEUE = 7,    // pending-action run queue: run-length codes | count + remainder of the oldest run | - | -
+    C_MISC = 8,     // battery time | command[0] | command[1] | flip_radian
+    C_RPY_OLD = 9,  // xyz | -
+    C_RPY_CONT = 10,
+    C_TGT_POS = 11, // xyz | -
+    C_TGT_QUAT = 12,
+    C_TAU = 13,     // rotor response times
+    C_OPARA = 14,   // omega_para[0..3]
+    C_AERO0 = 15,   // omega_para[4] | cf | ct | dx
+    C_AERO1 = 16,   // dy | kt | - | -
+    NUM_CHUNKS = 17
 };
-// blob row (include/taco_env.h "State blob") -> chunk * 4 + component
+constexpr int HIST_ROWS = 16;  // action history: hist[k][npad] float4, the action of the step whose (count & 15) == k
+// blob row (include/taco_env.h "State blob") -> chunk * 4 + component; -1 for the rows that are not stored as such
+// (actions / actions_old live in the action history, see export_state_kernel)
 __host__ __device__ constexpr int field_slot(int f) {
     return f < 3 ? C_POS * 4 + f : f < 7 ? C_QUAT * 4 + (f - 3) : f < 10 ? C_LINVEL * 4 + (f - 7) : f < 13 ? C_ANGVEL * 4 + (f - 10)
          : f < 16 ? C_TGT_POS * 4 + (f - 13) : f < 20 ? C_TGT_QUAT * 4 + (f - 16) : f < 23 ? C_RPY_OLD * 4 + (f - 20)
          : f < 26 ? C_RPY_CONT * 4 + (f - 23) : f < 29 ? C_PID_PREV * 4 + (f - 26) : f < 32 ? C_PID_INT * 4 + (f - 29)
          : f == 32 ? C_PID_PREV * 4 + 3 : f == 33 ? C_PID_INT * 4 + 3 : f == 34 ? C_MISC * 4 + 0 : f == 35 ? C_ANGVEL * 4 + 3
-         : f < 40 ? C_OMEGA * 4 + (f - 36) : f < 44 ? C_ACT * 4 + (f - 40) : f < 48 ? C_ACT_OLD * 4 + (f - 44)
+         : f < 40 ? C_OMEGA * 4 + (f - 36) : f < 48 ? -1
          : f == 48 ? C_MISC * 4 + 1 : f == 49 ? C_MISC * 4 + 2 : f == 50 ? C_MISC * 4 + 3 : f < 55 ? C_TAU * 4 + (f - 51)
          : f < 59 ? C_OPARA * 4 + (f - 55) : f == 59 ? C_AERO0 * 4 + 0 : f == 60 ? C_AERO0 * 4 + 1 : f == 61 ? C_AERO0 * 4 + 2
          : f == 62 ? C_AERO0 * 4 + 3 : f == 63 ? C_AERO1 * 4 + 0 : f == 64 ? C_AERO1 * 4 + 1 : f == 65 ? C_POS * 4 + 3 : C_LINVEL * 4 + 3;
 }
+// delay word (C_LINVEL.w): bits 0..15 L, bits 16..23 Z, bit 31 DENSE.  queue words (C_QUEUE.x/.y): run-length codes (T - 9,
+// two bits per run, oldest run in bits 1:0) and  m | rem0 << 8  (number of runs, slots left in the oldest run)
+__host__ __device__ constexpr int run_len(int lens, int j) { return 9 + ((lens >> (2 * j)) & 3); }
 
 enum : uint32_t { STREAM_RESET = 1, STREAM_CMD = 2, STREAM_DEPLOY = 3, STREAM_ROTOR = 4, STREAM_OBS = 5 };
 
@@ -108,6 +115,8 @@ TD float4 buf_ld4(rsrc_t r, uint32_t voff, uint32_t soff) {
 TD void buf_st4(rsrc_t r, float4 v, uint32_t voff, uint32_t soff) {
     llvm_amdgcn_raw_buffer_store_v4f32(f32x4_t{v.x, v.y, v.z, v.w}, r, (int)(voff + soff), 0, 0);
 }
+// per-component select (a ternary on the aggregate makes clang pick between two stack slots)
+TD float4 sel4(bool c, float4 a, float4 b) { return make_float4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w); }
 TD float as_f(int x) { return __builtin_bit_cast(float, x); }
 TD int as_i(float x) { return __builtin_bit_cast(int, x); }
 
@@ -411,8 +420,7 @@ TD void reset_env(const StepParams &P, rsrc_t rS, rsrc_t rR, uint32_t voff, uint
                                  ra ? 0.05f * (P.dr_sc * g0 + P.dr_lo) : ae0.z, ra ? -0.386f * (P.dr_sc * g1 + P.dr_lo) : ae0.w));
         CST(C_AERO1, make_float4(ra ? -0.53f * (P.dr_sc * g2 + P.dr_lo) : ae1.x, ra ? 0.009f * (P.dr_sc * g3 + P.dr_lo) : ae1.y, 0.0f, 0.0f));
     }
-    CST(C_ACT, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-    CST(C_ACT_OLD, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    CST(C_QUEUE, make_float4(0.0f, 0.0f, 0.0f, 0.0f));  // empty run queue: the pending line is Z implied zeros (FA:572-574)
     (void)rR;  // the ring is NOT zeroed (FA:574): the delay-line word marks every pending slot as an implied zero
 }
 
@@ -457,20 +465,20 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
     const bool is_reset = P.reset[i] != 0;
     const float4 a_in = reinterpret_cast<const float4 *>(P.act_in)[i];
     float4 c_pos = CLD(C_POS), c_quat = CLD(C_QUAT), c_lin = CLD(C_LINVEL), c_ang = CLD(C_ANGVEL);
-    float4 c_pp = CLD(C_PID_PREV), c_pi = CLD(C_PID_INT), c_om = CLD(C_OMEGA), c_act = CLD(C_ACT), c_misc = CLD(C_MISC);
+    float4 c_pp = CLD(C_PID_PREV), c_pi = CLD(C_PID_INT), c_om = CLD(C_OMEGA), c_que = CLD(C_QUEUE), c_misc = CLD(C_MISC);
     float4 c_tau = CLD(C_TAU), c_op = CLD(C_OPARA), c_a0 = CLD(C_AERO0), c_a1 = CLD(C_AERO1);
-    float4 ring_in[10];
+    const rsrc_t rH = make_rsrc(P.hist, P.hist_bytes);
+    // the four most recent history rows (wave-uniform addresses): they hold the two oldest queued runs whenever the
+    // queue is at most 4 runs deep, i.e. for delays up to ~40 ms; deeper queues fetch per lane further down
+    float4 hwin[4];
 #pragma unroll
-    for (int s = 0; s < 10; ++s) {
-        int ph = P.head + s; ph = ph >= TACO_RING_SLOTS ? ph - TACO_RING_SLOTS : ph;
-        ring_in[s] = buf_ld4(rR, voff, (uint32_t)ph * row_bytes);  // physical row is wave-uniform: coalesced
-    }
+    for (int k = 0; k < 4; ++k) hwin[k] = buf_ld4(rH, voff, (uint32_t)((P.hh - 1 - k) & (HIST_ROWS - 1)) * row_bytes);
     // reset_idx (FA:475-517) writes the fresh state straight to the env's chunks (none of its 37 random draws or
     // temporaries stay live); a wavefront that holds a reset lane then simply loads its chunks again.
     if (__builtin_amdgcn_ballot_w64(is_reset)) {
         if (is_reset) reset_env(P, rS, rR, voff, row_bytes, gid, grp, mix, active);
         c_pos = CLD(C_POS); c_quat = CLD(C_QUAT); c_lin = CLD(C_LINVEL); c_ang = CLD(C_ANGVEL);
-        c_pp = CLD(C_PID_PREV); c_pi = CLD(C_PID_INT); c_om = CLD(C_OMEGA); c_act = CLD(C_ACT); c_misc = CLD(C_MISC);
+        c_pp = CLD(C_PID_PREV); c_pi = CLD(C_PID_INT); c_om = CLD(C_OMEGA); c_que = CLD(C_QUEUE); c_misc = CLD(C_MISC);
         c_tau = CLD(C_TAU); c_op = CLD(C_OPARA); c_a0 = CLD(C_AERO0); c_a1 = CLD(C_AERO1);
     }
     V3 p{c_pos.x, c_pos.y, c_pos.z};
@@ -485,24 +493,32 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
     }
     float pid_prev[3] = {c_pp.x, c_pp.y, c_pp.z}, pid_int[3] = {c_pi.x, c_pi.y, c_pi.z};
     float omega[4] = {c_om.x, c_om.y, c_om.z, c_om.w};
-    float act[4] = {c_act.x, c_act.y, c_act.z, c_act.w}, act_old[4];
+    float act[4];
     const float tau[4] = {c_tau.x, c_tau.y, c_tau.z, c_tau.w};
     const float opara[5] = {c_op.x, c_op.y, c_op.z, c_op.w, c_a0.x};
     float bat_E = c_pp.w, bat_u1 = c_pi.w, bat_t = c_misc.x, bat_V = c_ang.w;
     float cmd0 = c_misc.y, cmd1 = c_misc.z, flip_radian = c_misc.w;
     const float cf = c_a0.y, ct = c_a0.z, dx = c_a0.w, dy = c_a1.x, kt = c_a1.y;
     int progress = as_i(c_pos.w);
-    // delay-line word: bits 0..15 L = actions_remained_length, bits 16..23 Z = leading logical slots that are still the
-    // zeros of the last reset, bit 31 DENSE.  While no write of an env has reached the tail slots [90,100) since its reset
-    // (L + T <= 90 always; with delay_time = 20 that is the whole episode), the reference's dense [4,100] buffer is exactly
-    // [Z zeros | written slots up to L | zeros]  -- so the ring needs neither zeroing at reset nor the per-step copy that
-    // preserves the stale tail [90,100) (FA:378).  The first write that touches the tail switches the env to DENSE: the
-    // implied zeros are materialised once and from then on the literal buffer semantics (tail copy, truncated writes,
-    // stale reads) are followed.  Exact in every regime (tests: overflow regime on GPU + dense numpy model of the oracle).
+    // ---- pending actions (actions_remained_buffer [4,100] + actions_remained_length, FA:189-193, :323-332, :366, :378-380).
+    // Every step appends its action T times at logical slots [L, L+T) and consumes slots 0..9, so the dense buffer is a
+    // queue of RUNS.  While no write of an env has reached the tail slots [90,100) since its reset (L + T <= 90 always; with
+    // delay_time = 20 that is the whole episode) the reference's buffer is exactly
+    //       [ Z zeros of the reset | run_0 (rem0 slots left) | run_1 | ... | run_{m-1} | zeros ],
+    // and it is kept as such: 2-bit length codes + (m, rem0) in C_QUEUE, Z and L in the delay word, the run VALUES in the
+    // action history hist[16][npad] (the action of the step j steps ago sits in row (hh - j) & 15: one coalesced 16-byte
+    // store per step instead of T slot stores, and the two oldest runs -- all that ten slots can span -- are read instead
+    // of ten slots).  The first write that touches the tail switches the env to DENSE: the queue is expanded once into the
+    // literal slot ring (logical slot s at physical (head + s) % 100, head advancing by 10 per step on the host), and from
+    // then on the reference's buffer semantics are followed to the letter (truncated mask write, the shift that leaves
+    // [90,100) stale, stale reads: SURVEY section 7 "overflow regime").  Exact in every regime.
     const int dl_word = as_i(c_lin.w);
-    int dlen = dl_word & 0xffff;
-    int zlead = (dl_word >> 16) & 0xff;
+    int dlen = dl_word & 0xffff;        // L
+    int zlead = (dl_word >> 16) & 0xff; // Z
     bool dense = dl_word < 0;
+    int q_lens = as_i(c_que.x);
+    int q_m = as_i(c_que.y) & 0xff;
+    int q_rem0 = (as_i(c_que.y) >> 8) & 0xff;
     const bool at_time = !is_reset && progress == 500;  // reset_command_condition FA:595-598 (a reset env has progress 0 here;
                                                         // its own progress==500 case is overwritten by the reset branch below)
     if (is_reset || at_time) {  // reset_command_idx: FA:758-759, :814-821, :886-917, :1058-1112
@@ -529,57 +545,87 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
             }
         }
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) act_old[k] = act[k];
-    act[0] = clampf(a_in.x, -P.clip_act, P.clip_act);  // VT:304
+    act[0] = clampf(a_in.x, -P.clip_act, P.clip_act);  // VT:304; actions_old <- actions <- a (FA:321-322) is implicit in hist
     act[1] = clampf(a_in.y, -P.clip_act, P.clip_act);
     act[2] = clampf(a_in.z, -P.clip_act, P.clip_act);
     act[3] = clampf(a_in.w, -P.clip_act, P.clip_act);
-    if (active) {
-        CST(C_ACT_OLD, make_float4(act_old[0], act_old[1], act_old[2], act_old[3]));
-        CST(C_ACT, make_float4(act[0], act[1], act[2], act[3]));
-    }
+    const float4 act4 = make_float4(act[0], act[1], act[2], act[3]);
+    const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (active) buf_st4(rH, act4, voff, (uint32_t)(P.hh & (HIST_ROWS - 1)) * row_bytes);  // this step's action, row hh
     int T = 10;
     if (fl & TACO_F_RANDOM_DEPLOY_TIME) {
         U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, P.step, STREAM_DEPLOY, 0u);
         T = 10 - rounded_normal(uniform(r.x), 1);
     }
-    if (!dense && dlen + T > TACO_RING_SLOTS - 10) {  // first write that reaches the tail [90,100): materialise the implied zeros
+    // value of queued run j (0 = oldest) BEFORE this step's push: the action of (m - j) steps ago
+    auto run_value = [&](int j) -> float4 {
+        const uint32_t row = (uint32_t)((P.hh - (q_m - j)) & (HIST_ROWS - 1));
+        return buf_ld4(rH, row * row_bytes + voff, 0u);
+    };
+    if (!dense && dlen + T > TACO_RING_SLOTS - 10) {
+        // first write that reaches the tail [90,100): expand the queue into the literal slot ring, once
         if (active) {
-            for (int s = 0; s < TACO_RING_SLOTS; ++s) {
-                if (s < zlead || s >= dlen) {
-                    int ph = P.head + s; ph = ph >= TACO_RING_SLOTS ? ph - TACO_RING_SLOTS : ph;
-                    buf_st4(rR, make_float4(0.0f, 0.0f, 0.0f, 0.0f), (uint32_t)ph * row_bytes + voff, 0u);
+            int pos = 0;
+            for (; pos < zlead; ++pos) {
+                int ph = P.head + pos; ph = ph >= TACO_RING_SLOTS ? ph - TACO_RING_SLOTS : ph;
+                buf_st4(rR, zero4, (uint32_t)ph * row_bytes + voff, 0u);
+            }
+            for (int j = 0; j < q_m; ++j) {
+                const float4 val = run_value(j);
+                const int len = (j == 0) ? q_rem0 : run_len(q_lens, j);
+                for (int t = 0; t < len; ++t, ++pos) {
+                    int ph = P.head + pos; ph = ph >= TACO_RING_SLOTS ? ph - TACO_RING_SLOTS : ph;
+                    buf_st4(rR, val, (uint32_t)ph * row_bytes + voff, 0u);
                 }
+            }
+            for (; pos < TACO_RING_SLOTS; ++pos) {
+                int ph = P.head + pos; ph = ph >= TACO_RING_SLOTS ? ph - TACO_RING_SLOTS : ph;
+                buf_st4(rR, zero4, (uint32_t)ph * row_bytes + voff, 0u);
             }
         }
         dense = true;
-        zlead = 0;
+        zlead = 0; q_m = 0; q_rem0 = 0; q_lens = 0;
     }
-    // The 10 slots this step consumes: logical 0..9, physical (head+s)%100 -- uniform across the wave, so coalesced.
-    // Slots the write below covers are overlaid from registers instead of being re-read; implied zeros are not read.
+    // ---- the ten slots this step consumes -> per-wave LDS table (substep k reads entry min(L-1, k), FA:366)
+    const bool wave_dense = __builtin_amdgcn_ballot_w64(dense) != 0;  // wave-uniform: normally no lane is DENSE
     {
+        // queue lanes: slots 0..9 of [Z zeros | run_0 | run_1 | ...] after the push span at most two runs
+        float4 v0 = act4, v1 = act4;  // the pushed run itself is run_0 (empty queue) or run_1 (one run queued)
+        v0 = sel4(q_m == 1, hwin[0], v0); v0 = sel4(q_m == 2, hwin[1], v0); v0 = sel4(q_m == 3, hwin[2], v0); v0 = sel4(q_m >= 4, hwin[3], v0);
+        v1 = sel4(q_m == 2, hwin[0], v1); v1 = sel4(q_m == 3, hwin[1], v1); v1 = sel4(q_m >= 4, hwin[2], v1);
+        if (__builtin_amdgcn_ballot_w64(!dense && q_m > 4)) {  // deep queue (delay > ~40 ms): fetch the two oldest runs per lane
+            const bool deep = !dense && q_m > 4;
+            const float4 g0 = run_value(0), g1 = run_value(1);
+            v0 = sel4(deep, g0, v0); v1 = sel4(deep, g1, v1);
+        }
+        const int n0 = (q_m >= 1) ? q_rem0 : T;  // slots of run_0 ahead of run_1
 #pragma unroll
         for (int s = 0; s < 10; ++s) {
-            const bool fresh = (s >= dlen) && (s < dlen + T);
-            const bool keep = !fresh && (dense || (s >= zlead && s < dlen));
-            float4 o = ring_in[s];
-            if (!keep) o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (fresh) o = make_float4(act[0], act[1], act[2], act[3]);
+            float4 o = sel4(s < zlead, zero4, sel4((s - zlead) < n0, v0, v1));
+            if (wave_dense) {
+                int ph = P.head + s; ph = ph >= TACO_RING_SLOTS ? ph - TACO_RING_SLOTS : ph;
+                const float4 r = buf_ld4(rR, voff, (uint32_t)ph * row_bytes);  // physical row is wave-uniform: coalesced
+                const bool fresh = (s >= dlen) && (s < dlen + T);             // covered by this step's write: from registers
+                o = sel4(dense, sel4(fresh, act4, r), o);
+            }
             slots[s * 64 + lane] = o;
         }
     }
-    if (active) {  // FA:327-330: write the action into logical slots [L, L+T) & [0,100)
-        for (int j = 0; j < 11; ++j) {
-            int sl = dlen + j;
-            if (j < T && sl < TACO_RING_SLOTS) {
-                int ph = P.head + sl; ph = ph >= TACO_RING_SLOTS ? ph - TACO_RING_SLOTS : ph;
-                buf_st4(rR, make_float4(act[0], act[1], act[2], act[3]), (uint32_t)ph * row_bytes + voff, 0u);
-            }
-        }
+    if (!dense) {  // push the run (T, this action)
+        q_lens |= (T - 9) << (2 * q_m);
+        if (q_m == 0) q_rem0 = T;
+        q_m += 1;
     }
-    if (__builtin_amdgcn_ballot_w64(dense && active)) {  // wave-uniform skip: normally no lane is DENSE
+    if (wave_dense) {
         if (dense && active) {
+            // FA:327-330: write the action into logical slots [L, L+T) & [0,100)
+            for (int j = 0; j < 11; ++j) {
+                int sl = dlen + j;
+                if (j < T && sl < TACO_RING_SLOTS) {
+                    int ph = P.head + sl; ph = ph >= TACO_RING_SLOTS ? ph - TACO_RING_SLOTS : ph;
+                    buf_st4(rR, act4, (uint32_t)ph * row_bytes + voff, 0u);
+                }
+            }
             const int dlen_after = dlen + T;
             // FA:378 leaves logical slots [90,100) untouched by the shift.  With the ring advancing by 10 (host side), the
             // new logical [90,100) are the physical slots just consumed, so they must be given the values of the old
@@ -592,7 +638,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
                 dst = dst >= TACO_RING_SLOTS ? dst - TACO_RING_SLOTS : dst;
                 const bool fresh = (90 + j >= dlen) && (90 + j < dlen_after);
                 float4 old = buf_ld4(rR, voff, (uint32_t)src * row_bytes);
-                if (fresh) old = make_float4(act[0], act[1], act[2], act[3]);
+                old = sel4(fresh, act4, old);
                 buf_st4(rR, old, voff, (uint32_t)dst * row_bytes);
             }
         }
@@ -722,8 +768,25 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
             CST(C_RPY_OLD, make_float4(rpy_old[0], rpy_old[1], rpy_old[2], 0.0f));
             CST(C_RPY_CONT, make_float4(rpy_cont[0], rpy_cont[1], rpy_cont[2], 0.0f));
         }
+        {   // consume ten slots: implied zeros first, then at most two runs (rem0 >= 1 and every full run >= 9 slots)
+            int c = 10;
+            const int zu = zlead < c ? zlead : c;
+            zlead -= zu; c -= zu;
+#pragma unroll
+            for (int rep = 0; rep < 2; ++rep) {
+                if (c > 0 && q_m > 0) {
+                    const int take = q_rem0 < c ? q_rem0 : c;
+                    q_rem0 -= take; c -= take;
+                    if (q_rem0 == 0) {
+                        q_lens = (int)((uint32_t)q_lens >> 2);
+                        q_m -= 1;
+                        q_rem0 = (q_m > 0) ? run_len(q_lens, 0) : 0;
+                    }
+                }
+            }
+        }
         dlen = dlen - 10 < 0 ? 0 : dlen - 10;
-        zlead = zlead - 10 < 0 ? 0 : zlead - 10;
+        CST(C_QUEUE, make_float4(as_f(q_lens), as_f(q_m | (q_rem0 << 8)), 0.0f, 0.0f));
         CST(C_LINVEL, make_float4(v.x, v.y, v.z, as_f((dlen & 0xffff) | (zlead << 16) | (dense ? (int)0x80000000 : 0))));
     }
     // relative quantities FA:354-360 (target velocities are identically zero); the target pose is only needed from here on
