@@ -1,0 +1,118 @@
+"""The VecTask surface of taco_amd.vec_env on a real GPU (what ppo_asymmetry.py / train_fpv_asymmetry_ppo.py touch),
+and full-size parity: at BASELINE.json's sizes the oracle re-simulates random SLICES of global env ids (envs are
+independent and keyed by global id) and must agree bit-for-bit with the same rows of the full-size GPU run."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from taco_amd import config
+from util import assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def test_vectask_surface_matches_the_reference_contract():
+    from taco_amd.vec_env import isaacgym_task_map
+    cfg = config.default_cfg("pos", 128, env_lenStates=5, env_clipObservations=0.75, env_maxEpisodeLength=50)
+    env = isaacgym_task_map["Fpv_pos"](cfg, "cuda:0", "cuda:0", -1, True, False, False)
+    assert (env.num_envs, env.num_obs, env.len_obs, env.num_states, env.len_states, env.num_acts) == (128, 26, 1, 26, 5, 4)
+    assert env.observation_space.shape == (1, 26) and env.state_space.shape == (5, 26) and env.action_space.shape == (4,)
+    assert (env.action_space.low == -1).all() and env.max_episode_length == 50 and cfg["env"]["numObservations"] == 26
+    d = env.reset()                                   # VT:352-361: zero buffers, nothing is reset yet
+    assert set(d) == {"obs", "states"} and not d["obs"].any() and d["obs"].shape == (128, 1, 26) and d["states"].shape == (128, 5, 26)
+    assert env.reset_buf.dtype == torch.long and env.reset_buf.all()
+    a = env.zero_actions()
+    obs, rew, done, info = env.step(a)
+    assert obs["obs"].dtype == torch.float32 and rew.shape == (128,) and done.dtype == torch.long and info["time_outs"].dtype == torch.bool
+    assert obs["obs"].abs().max() <= 0.75 and env.obs_buf.abs().max() > 0.75      # returned copy is clamped, obs_buf is not
+    assert obs["obs"].data_ptr() != env.obs_buf.data_ptr()
+    assert (env.progress_buf == 1).all() and not done.any()
+    # frame stack: newest frame last, older frames shift towards index 0
+    s1 = env.states_buf.clone()
+    env.step(a)
+    assert torch.equal(env.states_buf[:, 3], s1[:, 4]) and not torch.equal(env.states_buf[:, 4], s1[:, 4])
+    # done -> re-initialised at the START of the next step; time_outs only together with done
+    saw_timeout = False
+    for t in range(60):
+        obs, rew, done, info = env.step(a)
+        assert not (info["time_outs"] & (done == 0)).any()
+        saw_timeout |= bool(info["time_outs"].any())
+        prog = env.progress_buf
+        assert (prog[done != 0] >= 1).all() and (prog <= 50).all()
+    assert saw_timeout
+    # reset_idx marks envs; the reset happens inside the next step
+    env.reset_idx(torch.tensor([3, 5], device="cuda"))
+    obs, ids = env.reset_done()
+    assert {3, 5} <= set(ids.tolist())
+    env.step(a)
+    assert (env.progress_buf[[3, 5]] == 1).all()
+    # difficulty is writable and read back (ppo_asymmetry.py:173-175)
+    env.difficulty = 0.25
+    assert env.difficulty == 0.25 and cfg["difficulty"] == 0.25
+    with pytest.raises(ValueError):
+        env.step(torch.zeros(7, 4, device="cuda"))
+
+
+def test_step_is_stream_ordered_and_async():
+    """taco_step only enqueues: steps issued on a side stream interleave correctly with torch ops on that stream."""
+    from taco_amd.vec_env import FpvPos
+    cfg = config.baseline_config(1, num_envs=512)
+    ref = FpvPos(cfg, copy_outputs=False)
+    env = FpvPos(config.baseline_config(1, num_envs=512), copy_outputs=False)
+    acts = (0.3 * torch.randn(30, 512, 4, device="cuda")).clamp(-1, 1)
+    for t in range(30):
+        ref.step_raw(acts[t])
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for t in range(30):
+            a = acts[t] * 1.0            # a torch kernel on the same stream produces the action
+            env.step_raw(a)
+    s.synchronize()
+    assert torch.equal(ref.get_state().view(torch.int32), env.get_state().view(torch.int32))
+
+
+@pytest.mark.parametrize("idx,steps", [(2, 150), (3, 150), (4, 120)])
+def test_full_size_parity_on_random_slices(idx, steps):
+    """BASELINE configs[2..4] at FULL size (16 384 / 65 536 / 262 144 envs): four random slices of 192 global env ids are
+    re-simulated by the oracle (env_offset / num_envs_global) and compared bit-for-bit every 10 steps."""
+    from oracle import oracle as O
+    from taco_amd.vec_env import FpvBase
+    cfg = config.baseline_config(idx)
+    flat = config.flat_cfg(cfg)
+    n = flat["num_envs"]
+    env = FpvBase(cfg, copy_outputs=False)
+    rng = np.random.default_rng(100 + idx)
+    width = 192
+    n1, n2 = int(n / 3 * 1), int(n / 3 * 2)
+    starts = sorted({0, n - width, n1 - width // 2, n2 - width // 2} if idx == 4 else set(int(x) for x in rng.integers(0, n - width, 4)))
+    orcs = [O.OracleEnv(dict(flat, num_envs=width, env_offset=lo, num_envs_global=n), threads=8) for lo in starts]
+    g = torch.Generator().manual_seed(idx)
+    for t in range(steps):
+        a = (0.3 * torch.randn((n, 4), generator=g)).clamp(-1, 1)
+        a[:, 0] = (a[:, 0] - 0.2).clamp(-1, 1)
+        ad = a.cuda()
+        env.step_raw(ad)
+        an = a.numpy()
+        for lo, orc in zip(starts, orcs):
+            orc.step(an[lo:lo + width])
+        if t % 10 == 9 or t == steps - 1:
+            obs = env.obs_buf.cpu().numpy(); st = env.states_buf.cpu().numpy()
+            rew = env.rew_buf.cpu().numpy(); done = env.reset_buf.cpu().numpy(); tmo = env.timeout_buf.cpu().numpy().astype(np.uint8)
+            for lo, orc in zip(starts, orcs):
+                what = f"config {idx} step {t} slice {lo}"
+                assert_bits_equal(obs[lo:lo + width], orc.obs_buf, what + " obs")
+                assert_bits_equal(st[lo:lo + width], orc.states_buf, what + " states")
+                assert_bits_equal(rew[lo:lo + width], orc.rew_buf, what + " rew")
+                assert_bits_equal(done[lo:lo + width], orc.reset_buf, what + " done")
+                assert_bits_equal(tmo[lo:lo + width], orc.timeout_buf, what + " time_outs")
+    # size-independent invariants on the whole batch
+    blob = env.get_state()
+    q = blob[3:7]
+    fin = torch.isfinite(q).all(0)
+    assert fin.float().mean() > 0.999
+    assert ((q[:, fin] ** 2).sum(0) - 1).abs().max() < 1e-5
+    prog = blob[65].view(torch.int32)
+    assert (prog >= 1).all() and (prog <= flat["max_episode_length"]).all()
