@@ -116,3 +116,28 @@ def test_full_size_parity_on_random_slices(idx, steps):
     assert ((q[:, fin] ** 2).sum(0) - 1).abs().max() < 1e-5
     prog = blob[65].view(torch.int32)
     assert (prog >= 1).all() and (prog <= flat["max_episode_length"]).all()
+
+
+def test_checkpoint_file_roundtrip_and_recorder(tmp_path):
+    """N2: save -> load into a fresh env -> both continue bit-identically; the recorder pulls env 0 with the reference's keys"""
+    from taco_amd import checkpoint
+    from taco_amd.recorder import EpisodeRecorder
+    from taco_amd.vec_env import FpvFlip
+    mk = lambda: FpvFlip(config.default_cfg("flip", 300, observation_noise=True, rotor_noise=True, env_lenStates=3, env_maxEpisodeLength=40), copy_outputs=False)
+    a = mk()
+    rec = EpisodeRecorder(str(tmp_path / "rec"))
+    acts = (0.3 * torch.randn(70, 300, 4, device="cuda")).clamp(-1, 1)
+    for t in range(33):
+        a.step_raw(acts[t]); rec.record(a)
+    checkpoint.save(a, str(tmp_path / "ck.pt"))
+    b = mk()
+    checkpoint.load(b, str(tmp_path / "ck.pt"))
+    for t in range(33, 70):
+        a.step_raw(acts[t]); b.step_raw(acts[t]); rec.record(a)
+        assert torch.equal(a.obs_buf.view(torch.int32), b.obs_buf.view(torch.int32)) and torch.equal(a.reset_buf, b.reset_buf)
+    assert torch.equal(a.get_state().view(torch.int32), b.get_state().view(torch.int32))
+    with pytest.raises(ValueError):
+        checkpoint.load(FpvFlip(config.default_cfg("flip", 64), copy_outputs=False), str(tmp_path / "ck.pt"))
+    assert rec.dump_index >= 1 and {"copter_pos0.npy", "observations0.csv", "actions_old0.npy"} <= set(__import__("os").listdir(tmp_path / "rec"))
+    pos = np.load(tmp_path / "rec" / "copter_pos0.npy")
+    assert pos.ndim == 2 and pos.shape[1] == 3
