@@ -141,3 +141,16 @@ def test_checkpoint_file_roundtrip_and_recorder(tmp_path):
     assert rec.dump_index >= 1 and {"copter_pos0.npy", "observations0.csv", "actions_old0.npy"} <= set(__import__("os").listdir(tmp_path / "rec"))
     pos = np.load(tmp_path / "rec" / "copter_pos0.npy")
     assert pos.ndim == 2 and pos.shape[1] == 3
+
+
+def test_c_abi_consumer_without_torch():
+    """examples/c_api_demo.cpp (plain HIP runtime + include/taco_env.h, built by __graft_entry__.build()) steps the env
+    through the C ABI alone and checks the error path; it exits 0 when its own checks pass."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "c_api_demo")
+    if not os.path.exists(exe):
+        pytest.skip("examples/c_api_demo not built (run __graft_entry__.build())")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "bad rows 0" in out.stdout
