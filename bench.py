@@ -13,8 +13,8 @@ Inputs (the action stream a_t = clamp(0.3 N(0,1) + (-0.45,0,0,0), -1, 1)) are re
 
 Extra objects on the JSON line: "roofline" (step kernel vs HBM peak, 820 algorithmic bytes per env-step),
 "cpu_baseline" (the CPU oracle timed on this host's cores on a bounded sample; rank 0, N = 1 only), "parity"
-(HIP vs oracle on the first steps of this very workload), "large_n" (the same kernel at 262 144 envs, where the HBM
-roofline is the meaningful bound).
+(HIP vs oracle on the first steps of this very workload), "large_n" (the same kernel at 262 144 and 1 048 576 envs, where
+the HBM roofline is the meaningful bound).
 """
 import argparse
 import json
@@ -260,18 +260,21 @@ def main():
             out["with_allgather"] = with_gather
         if world == 1:
             if not args.no_large_n:
-                big_n = 262144
-                benv = FpvBase(config.baseline_config(1, num_envs=big_n), sim_device=str(dev), rl_device=str(dev), copy_outputs=False)
-                bacts = make_actions(big_n, 4, 7, dev)
-                for t in range(20):
-                    benv.step_raw(bacts[t % 4])
-                torch.cuda.synchronize()
-                b_avg, b_med = time_kernel_launches(benv, bacts, 100, torch)
-                bg, bb = benv.launch_geometry()
-                ach = ALGO_BYTES_PER_ENV_STEP * big_n / (b_avg * 1e-6) / 1e9
-                out["large_n"] = {"envs": big_n, "kernel_avg_us": b_avg, "env_steps_per_s": big_n / (b_avg * 1e-6), "achieved_GBps": ach,
-                                  "frac_of_hbm_peak": ach / HBM_PEAK_GBPS, "grid": bg, "block": bb}
-                del benv
+                out["large_n"] = []
+                for big_n in (262144, 1048576):   # one full residency round (BASELINE configs[4]'s env count) / four rounds (steady state)
+                    benv = FpvBase(config.baseline_config(1, num_envs=big_n), sim_device=str(dev), rl_device=str(dev), copy_outputs=False)
+                    bacts = make_actions(big_n, 4, 7, dev)
+                    for t in range(20):
+                        benv.step_raw(bacts[t % 4])
+                    torch.cuda.synchronize()
+                    b_avg, b_med = time_kernel_launches(benv, bacts, 100, torch)
+                    bg, bb = benv.launch_geometry()
+                    ach = ALGO_BYTES_PER_ENV_STEP * big_n / (b_avg * 1e-6) / 1e9
+                    tr, _ = pmc_traffic(big_n)
+                    out["large_n"].append({"envs": big_n, "kernel_avg_us": b_avg, "env_steps_per_s": big_n / (b_avg * 1e-6), "achieved_GBps": ach,
+                                           "frac_of_hbm_peak": ach / HBM_PEAK_GBPS, "traffic": tr, "grid": bg, "block": bb})
+                    del benv, bacts
+                    torch.cuda.empty_cache()
             out["parity"] = parity_check(config.baseline_config(1, num_envs=n_local))
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(config.baseline_config(1, num_envs=n_local))

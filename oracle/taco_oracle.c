@@ -444,7 +444,11 @@ static inline float reward_flip(const float rpb[3], const float relq[4], const f
  *     b += h J^-1 (tau - b x J b)          body rates b; start value = the body-frame angular velocity of row C
  *     v += h (R(q) F / m + g);  p += h v    R(q) F by the quaternion sandwich  F + w t + qv x t,  t = 2 qv x F
  *     q <- normalize(q (x) exp(h/2 b))      closed-form quaternion update; a body-frame rate multiplies on the right
- * and, after the last sub-iteration, the world-frame angular velocity of the root state is w = R(q) b.
+ * The body rates are CARRIED in the body frame from one simulate() to the next inside a step(): they are taken from the
+ * root state once, at the start of the step (row C's formula, quat_rotate(conj q, w), FA:350), feed the rate PID of every
+ * substep directly, and the root state's world-frame angular velocity is rebuilt once, after the 10th simulate():
+ * w = R(q) b.  (The reference re-derives the body rates from the world-frame root tensor before every PID call; going
+ * through the world frame and back 10 times per step costs ~50 instructions per substep and only adds rounding noise.)
  * exp(): Taylor polynomials in a2 = (h/2 |b|)^2 while a2 <= 0.25, sqrt/sincos beyond; normalisation: one Newton step
  * from 1 (error 3/8 (n2-1)^2, far below fp32 resolution) while |n2 - 1| <= 1e-3, else 1/sqrt(n2).
  * Every operation below is written out (fma where fused) -- the HIP kernel repeats it verbatim. */
@@ -461,7 +465,7 @@ static inline void quat_sandwich(const float q[4], const float u[3], float out[3
     out[2] = fmaf(q[0], ty, fmaf(-q[1], tx, fmaf(q[3], tz, u[2])));
 }
 
-static inline void integrate_substep(const integ_par *P, float p[3], float q[4], float v[3], float w[3], const float wb[3],
+static inline void integrate_substep(const integ_par *P, float p[3], float q[4], float v[3], float wb[3],
                                      const float F[3], const float tau[3]) {
     float b0 = wb[0], b1 = wb[1], b2 = wb[2];
     for (int it = 0; it < P->substeps; ++it) {
@@ -509,8 +513,7 @@ static inline void integrate_substep(const integ_par *P, float p[3], float q[4],
         if (!(fabsf(n2 - 1.0f) <= 1e-3f)) inv = 1.0f / sqrtf(n2);
         q[0] = nx * inv; q[1] = ny * inv; q[2] = nz * inv; q[3] = nw * inv;
     }
-    const float bb[3] = {b0, b1, b2};
-    quat_sandwich(q, bb, w);
+    wb[0] = b0; wb[1] = b1; wb[2] = b2;
 }
 
 /* ------------------------------------------------------------------------------------------------ environment */
@@ -792,9 +795,11 @@ static void step_env(const orc_env *e, int i, const float *actions, float *obs_b
     s->delay_len += T;
 
     /* ---- control_freq_inv x (mid_physics_step + simulate)  VT:309-313 */
+    float wb[3];
+    rotate_inv(s->q, s->w, wb); /* body-frame angular velocity of the root state (FA:350); carried by row I from here on */
     for (int ks = 0; ks < c->control_freq_inv; ++ks) {
         /* refresh_state, the part the inner loop consumes (FA:339-350) */
-        float rpy[3], vb[3], wb[3];
+        float rpy[3], vb[3];
         euler_xyz_v1(s->q, rpy);
         for (int k = 0; k < 3; ++k) {
             float dl = rpy[k] - s->rpy_old[k];
@@ -804,7 +809,6 @@ static void step_env(const orc_env *e, int i, const float *actions, float *obs_b
             s->rpy_old[k] = rpy[k];
         }
         rotate_inv(s->q, s->v, vb);
-        rotate_inv(s->q, s->w, wb);
         /* delayed action FA:366 */
         int idx = s->delay_len - 1 < ks ? s->delay_len - 1 : ks;
         if (idx < 0) idx += ORC_RING_SLOTS;
@@ -836,8 +840,10 @@ static void step_env(const orc_env *e, int i, const float *actions, float *obs_b
             tq[1] = -(float)c->arm_x * ((fs[0] - fs[1]) - (fs[2] - fs[3]));
             tq[2] = (ts[0] + ts[1]) + (ts[2] + ts[3]);
         }
-        integrate_substep(&e->ip, s->p, s->q, s->v, s->w, wb, F, tq); /* gym.simulate VT:313 */
+        integrate_substep(&e->ip, s->p, s->q, s->v, wb, F, tq); /* gym.simulate VT:313 */
     }
+
+    quat_sandwich(s->q, wb, s->w); /* root state: world-frame angular velocity */
 
     /* ---- post_physics_step FA:374-388 */
     s->progress += 1;
@@ -1033,6 +1039,7 @@ void orc_integrate(const orc_cfg *cfg, int n, float *root13, const float *wrench
         float *r = root13 + 13 * i;
         float wb[3];
         rotate_inv(r + 3, r + 10, wb); /* row C's body-frame angular velocity (FA:350) */
-        integrate_substep(&tmp.ip, r, r + 3, r + 7, r + 10, wb, wrench6 + 6 * i, wrench6 + 6 * i + 3);
+        integrate_substep(&tmp.ip, r, r + 3, r + 7, wb, wrench6 + 6 * i, wrench6 + 6 * i + 3);
+        quat_sandwich(r + 3, wb, r + 10);
     }
 }

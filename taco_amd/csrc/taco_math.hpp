@@ -31,6 +31,12 @@ TD float clampf(float x, float lo, float hi) {
     return (t > hi) ? hi : t;
 }
 
+// the same for CONSTANT bounds lo < hi: one v_med3_f32 plus the NaN pass-through (v_med3 alone returns lo for a NaN x)
+TD float clamp_const(float x, float lo, float hi) {
+    const float r = __builtin_amdgcn_fmed3f(x, lo, hi);
+    return (x != x) ? x : r;
+}
+
 // ---- x / c for a divisor known in advance, without a division: q = x * RN(1/c) plus one fma correction.  Bit-identical to
 // the IEEE quotient for every divisor it is used with (0.001, 0.75, 3, 3.3, 6, 100, 1000, 4500, 9000, pi: checked
 // exhaustively over all signed mantissas) for |x| up to ~1e34; 3 instructions instead of the ~10 of v_div_scale/.../v_div_fixup.

@@ -202,13 +202,13 @@ TD void unwrap(float rpy, float &old, float &cont) {
 }
 // CTRL/angvel_control.py:67-88, one axis
 TD float pid_axis(float dt, float rdt, float kp, float des, float cur, float &prev, float &integ) {
-    float e = clampf(des - cur, -400.0f, 400.0f);
+    float e = clamp_const(des - cur, -400.0f, 400.0f);
     float pv = (prev == 0.0f) ? e : prev;
     float P = kp * e;
-    float I = clampf(integ + e * dt, -500.0f, 500.0f);
+    float I = clamp_const(integ + e * dt, -500.0f, 500.0f);
     float I_term = 0.0f * I;
     float deriv = (rdt != 0.0f) ? div_const(e - pv, dt, rdt) : (e - pv) / dt;  // rdt is wave-uniform: a scalar branch
-    float D = clampf(0.5f * deriv, -150.0f, 150.0f);
+    float D = clamp_const(0.5f * deriv, -150.0f, 150.0f);
     float FF = 0.0f * des;
     integ = I;
     prev = e;
@@ -241,11 +241,12 @@ TD V3 quat_sandwich(Q4 q, V3 u) {
 
 // One gym.simulate(dt) for one free rigid body (replaces VT:313 + FA:633-635; spec in DESIGN.md "row I"): `substeps`
 // sub-iterations of semi-implicit Euler in the body frame (start value of the body rates: row C's body-frame angular
-// velocity wb), closed-form quaternion update q <- normalize(q (x) exp(h/2 b)), body-frame wrench held constant; the
-// world-frame angular velocity of the root state is rebuilt once at the end.  The rare forms (|b| h/2 > 0.5 rad per
+// velocity wb), closed-form quaternion update q <- normalize(q (x) exp(h/2 b)), body-frame wrench held constant.  The body
+// rates stay in the body frame from one simulate() to the next: taken from the root state once per step (row C's formula),
+// fed to the rate PID of every substep, turned back into the root state's world-frame angular velocity after the 10th.  The rare forms (|b| h/2 > 0.5 rad per
 // sub-iteration, |q|^2 off by > 1e-3, NaN) are evaluated only when some lane of the wavefront needs them (ballot), and
 // selected per lane, so the common case has no divergent control flow at all.
-TD void integrate(const StepParams &P, V3 &p, Q4 &q, V3 &v, V3 &w, V3 wb, V3 F, V3 tq) {
+TD void integrate(const StepParams &P, V3 &p, Q4 &q, V3 &v, V3 &wb, V3 F, V3 tq) {
     float b0 = wb.x, b1 = wb.y, b2 = wb.z;
     for (int it = 0; it < P.substeps; ++it) {
         float L0 = P.J0 * b0, L1 = P.J1 * b1, L2 = P.J2 * b2;
@@ -291,7 +292,7 @@ TD void integrate(const StepParams &P, V3 &p, Q4 &q, V3 &v, V3 &w, V3 wb, V3 F, 
         }
         q.x = nx * inv; q.y = ny * inv; q.z = nz * inv; q.w = nw * inv;
     }
-    w = quat_sandwich(q, V3{b0, b1, b2});
+    wb = V3{b0, b1, b2};
 }
 
 // reset_idx for one env (FA:475-517), in the reference's call order: reset_copter_idx -> reset_controller_idx ->
@@ -649,6 +650,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
     const bool bat_on = (fl & TACO_F_BATTERY_CONSUMPTION) != 0;
     // the target pose is consumed only after the loop; issuing the loads here hides their latency behind the substeps
     const float4 c_tp = CLD(C_TGT_POS), c_tq = CLD(C_TGT_QUAT);
+    V3 wb = quat_rotate(conj(q), w);  // body-frame angular velocity of the root state (FA:350); row I carries it from here on
 #pragma unroll 1
     for (int ks = 0; ks < 10; ++ks) {
         // refresh_state, the part the inner loop consumes FA:339-350
@@ -660,7 +662,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
         }
         Q4 cq = conj(q);
         V3 vb = quat_rotate(cq, v);
-        V3 wb = quat_rotate(cq, w);
         // delayed action FA:366: slot min(L-1, ks); L >= 9 here, so only ks == 9 can be clipped (to slot 8)
         const int idx = (dlen - 1 < ks) ? dlen - 1 : ks;
         const float4 dact = slots[idx * 64 + lane];
@@ -681,8 +682,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
         mx = (t2 > mx || t2 != t2) ? t2 : mx;
         mx = (t3 > mx || t3 != t3) ? t3 : mx;
         float ex = (mx < 0.0f) ? 0.0f : mx;
-        float thr[4] = {clampf(f0 - ex, 100.0f, 1000.0f), clampf(f1 - ex, 100.0f, 1000.0f), clampf(f2 - ex, 100.0f, 1000.0f),
-                        clampf(f3 - ex, 100.0f, 1000.0f)};
+        float thr[4] = {clamp_const(f0 - ex, 100.0f, 1000.0f), clamp_const(f1 - ex, 100.0f, 1000.0f), clamp_const(f2 - ex, 100.0f, 1000.0f),
+                        clamp_const(f3 - ex, 100.0f, 1000.0f)};
         // mechanical power FA:614
         float Pm;
         {
@@ -743,8 +744,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
             tq.z = (ts0 + ts1) + (ts2 + ts3);
         }
         if (is_reset) { F = V3{0.0f, 0.0f, 0.0f}; tq = V3{0.0f, 0.0f, 0.0f}; }  // FA:629-630: no force during the reset step
-        integrate(P, p, q, v, w, wb, F, tq);
+        integrate(P, p, q, v, wb, F, tq);
     }
+
+    w = quat_sandwich(q, wb);  // root state: world-frame angular velocity
 
     // ------------------------------------------------------------------ post_physics_step FA:374-388
     progress += 1;
