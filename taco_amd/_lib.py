@@ -48,6 +48,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(LIB_PATH) and "TACO_ENV_LIB" not in os.environ:
+        # a fresh checkout has no binary (it is git-ignored): compile the HIP library now if the toolchain is here
+        try:
+            from . import build as _build
+            _build.build()
+        except Exception as e:  # noqa: BLE001 -- report the build failure, never fall back to anything else
+            raise TacoError(f"{LIB_PATH} is missing and building it failed ({e}); run `python -m taco_amd.build` (hipcc, gfx950). "
+                            "There is no CPU fallback for the step path.") from e
     if not os.path.exists(LIB_PATH):
         raise TacoError(f"{LIB_PATH} is missing: build it with `python -m taco_amd.build` (hipcc, gfx950). "
                         "There is no CPU fallback for the step path.")

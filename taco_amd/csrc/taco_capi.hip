@@ -49,25 +49,6 @@ namespace {
 
 int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
-bool cfg_ok(const taco_cfg *c) {
-    if (!c) return fail(0, "cfg is null"), false;
-    if (c->num_envs <= 0) return fail(0, "num_envs must be > 0"), false;
-    if (c->num_envs > 2000000) return fail(0, "num_envs must be <= 2 000 000 per handle (32-bit buffer offsets); shard larger jobs"), false;
-    if (c->env_offset < 0 || c->num_envs_global < c->env_offset + c->num_envs)
-        return fail(0, "env_offset + num_envs exceeds num_envs_global"), false;
-    if (c->task_mode < TACO_TASK_POS || c->task_mode > TACO_TASK_MIX) return fail(0, "task_mode out of range"), false;
-    if (c->len_obs < 1 || c->len_states < 1) return fail(0, "len_obs / len_states must be >= 1"), false;
-    if ((size_t)c->num_envs * (size_t)(c->len_obs > c->len_states ? c->len_obs : c->len_states) * 104 >= 0xffffffffull)
-        return fail(0, "num_envs * len * 104 bytes must stay below 4 GiB (32-bit buffer offsets); shard the job"), false;
-    if (c->control_freq_inv != 10) return fail(0, "control_freq_inv must be 10 (the delay line holds 10 one-ms slots per action)"), false;
-    if (c->substeps < 1 || c->substeps > 8) return fail(0, "substeps must be in 1..8"), false;
-    if (c->delay_time < 0 || c->delay_time > 90) return fail(0, "delay_time must be in 0..90 ms"), false;
-    if (c->max_episode_length < 2) return fail(0, "max_episode_length must be >= 2"), false;
-    if (!(c->dt > 0) || !(c->mass > 0) || !(c->inertia[0] > 0) || !(c->inertia[1] > 0) || !(c->inertia[2] > 0))
-        return fail(0, "dt, mass and inertia must be positive"), false;
-    return true;
-}
-
 // x / c via q = x * RN(1/c) + one fma correction (taco_math.hpp div_const) is used for the run-time divisor dt only if it is
 // bit-identical to the IEEE quotient for this dt: checked exhaustively over one binade of x, both signs (the three
 // operations are scale-invariant, so this covers the normal range).  ~10 ms on the host, once per taco_create / difficulty change.
@@ -89,6 +70,27 @@ bool div_const_is_exact(float c) {
     return ok;
 }
 
+bool cfg_ok(const taco_cfg *c) {
+    if (!c) return fail(0, "cfg is null"), false;
+    if (c->num_envs <= 0) return fail(0, "num_envs must be > 0"), false;
+    if (c->num_envs > 2000000) return fail(0, "num_envs must be <= 2 000 000 per handle (32-bit buffer offsets); shard larger jobs"), false;
+    if (c->env_offset < 0 || c->num_envs_global < c->env_offset + c->num_envs)
+        return fail(0, "env_offset + num_envs exceeds num_envs_global"), false;
+    if (c->task_mode < TACO_TASK_POS || c->task_mode > TACO_TASK_MIX) return fail(0, "task_mode out of range"), false;
+    if (c->len_obs < 1 || c->len_states < 1) return fail(0, "len_obs / len_states must be >= 1"), false;
+    if ((size_t)c->num_envs * (size_t)(c->len_obs > c->len_states ? c->len_obs : c->len_states) * 104 >= 0xffffffffull)
+        return fail(0, "num_envs * len * 104 bytes must stay below 4 GiB (32-bit buffer offsets); shard the job"), false;
+    if (c->control_freq_inv != 10) return fail(0, "control_freq_inv must be 10 (the delay line holds 10 one-ms slots per action)"), false;
+    if (c->substeps < 1 || c->substeps > 8) return fail(0, "substeps must be in 1..8"), false;
+    if (c->delay_time < 0 || c->delay_time > 90) return fail(0, "delay_time must be in 0..90 ms"), false;
+    if (c->max_episode_length < 2) return fail(0, "max_episode_length must be >= 2"), false;
+    if (c->dt > 0 && !div_const_is_exact((float)c->dt))
+        return fail(0, "this dt is not supported: x / dt cannot be evaluated exactly as a multiply-and-correct (use dt = 0.001, the rotor model's fixed sample time)"), false;
+    if (!(c->dt > 0) || !(c->mass > 0) || !(c->inertia[0] > 0) || !(c->inertia[1] > 0) || !(c->inertia[2] > 0))
+        return fail(0, "dt, mass and inertia must be positive"), false;
+    return true;
+}
+
 // fp32 images of the Python-double expressions of the reference, computed in double exactly where Python would
 void derive(taco_env *e) {
     const taco_cfg &c = e->cfg;
@@ -108,7 +110,7 @@ void derive(taco_env *e) {
     P.hJi0 = (float)((c.dt / (double)c.substeps) / c.inertia[0]);
     P.hJi1 = (float)((c.dt / (double)c.substeps) / c.inertia[1]);
     P.hJi2 = (float)((c.dt / (double)c.substeps) / c.inertia[2]);
-    P.rdt = div_const_is_exact(P.dt) ? 1.0f / P.dt : 0.0f;
+    P.rdt = 1.0f / P.dt;
     P.arm_x = (float)c.arm_x; P.arm_y = (float)c.arm_y;
     // torch_rand_float(lower, upper): (upper - lower) * u + lower
     P.flip_xy_sc = (float)((0.5 + 1.5 * d) - (-0.5 - 1.5 * d)); P.flip_xy_lo = (float)(-0.5 - 1.5 * d);  // fpv_asymmetry.py:856

@@ -36,7 +36,7 @@ struct StepParams {
     int hh;              // history row this step writes (= number of steps taken so far, mod 16)
     uint32_t obs_bytes, states_bytes, gather_bytes, gather_row;  // gather_row = floats per env in the gather block (multiple of 32)
     // fp32 images of the Python doubles the reference feeds into tensor ops
-    float dt, rdt, clip_act, df;  // rdt = 1/dt when div_const is exact for this dt (checked on the host), else 0
+    float dt, rdt, clip_act, df;  // rdt = RN(1/dt); taco_create refuses a dt for which div_const(x, dt, rdt) != x / dt
     float h, half_h, inv_m, g, J0, J1, J2, hJi0, hJi1, hJi2, arm_x, arm_y;
     float flip_xy_sc, flip_xy_lo, flip_v_sc, flip_v_lo, dr_sc, dr_lo, tau_sc, tau_lo, tau_fixed, nq_sc, nq_lo;
 };
@@ -207,7 +207,7 @@ TD float pid_axis(float dt, float rdt, float kp, float des, float cur, float &pr
     float P = kp * e;
     float I = clamp_const(integ + e * dt, -500.0f, 500.0f);
     float I_term = 0.0f * I;
-    float deriv = (rdt != 0.0f) ? div_const(e - pv, dt, rdt) : (e - pv) / dt;  // rdt is wave-uniform: a scalar branch
+    float deriv = div_const(e - pv, dt, rdt);  // == (e - pv) / dt bit for bit: taco_create verified it for this dt
     float D = clamp_const(0.5f * deriv, -150.0f, 150.0f);
     float FF = 0.0f * des;
     integ = I;
