@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TACO_ABI_VERSION 1
+#define TACO_ABI_VERSION 2
 
 typedef enum taco_status {
     TACO_OK = 0,
@@ -148,6 +148,34 @@ void taco_destroy(taco_env *env);
  * One kernel launch, asynchronous on `stream`; no host synchronisation. */
 int taco_step(taco_env *env, const float *actions, float *obs_buf, float *states_buf, float *rew_buf, int64_t *reset_buf,
               uint8_t *timeout_buf, void *stream);
+
+/* ---- the replay buffer directly behind step() ------------------------------------------------
+ * The reference's rollout loop (ppo_asymmetry.py:96-131) copies every step's obs / states / reward / done into
+ * PPOReplayBuffer slots with nine torch copies (buffer_asymmetry.py:70-91 `store`).  taco_step_rollout lets the step kernel
+ * write those slots itself: the frame stacks are read from the PREVIOUS slot and written to the NEXT one, and the done
+ * flags are also emitted as the f32 image done_buf keeps.  NULL obs_prev / states_prev mean "in place" (= taco_step);
+ * done_f32 may be NULL.  The prev / next stacks of one call may be the same buffer but must not partially overlap. */
+typedef struct taco_rollout_io {
+    const float *actions;      /* [num_envs][4]                                                                   */
+    const float *obs_prev;     /* [num_envs][len_obs][26]     slot t   (read only when len_obs > 1), or NULL       */
+    float *obs_next;           /* [num_envs][len_obs][26]     slot t+1                                            */
+    const float *states_prev;  /* [num_envs][len_states][26]  slot t, or NULL                                     */
+    float *states_next;        /* [num_envs][len_states][26]  slot t+1                                            */
+    float *rew;                /* [num_envs]  rew_buf[t]                                                          */
+    int64_t *reset_buf;        /* [num_envs]  in/out, as taco_step                                                */
+    uint8_t *timeout_buf;      /* [num_envs]                                                                      */
+    float *done_f32;           /* [num_envs]  done_buf[t] (buffer_asymmetry.py:67, 82), or NULL                   */
+} taco_rollout_io;
+int taco_step_rollout(taco_env *env, const taco_rollout_io *io, void *stream);
+
+/* PPOReplayBuffer.compute_returns_and_advantage (buffer_asymmetry.py:93-132) on DEVICE arrays laid out [horizon][num_envs]
+ * (the reference's [H, N, 1]):  adv = GAE(gamma, lam), ret = adv + value, then (normalize != 0)
+ * adv = (adv - mean(adv)) / (std(adv) + 1e-8) with the unbiased std.  ret and the un-normalised adv are bit-identical
+ * to the reference's fp32 arithmetic; the two reductions are done in double (deterministic, fixed tree).
+ * `workspace` = taco_gae_workspace_bytes() bytes of device memory (only used when normalize != 0). */
+size_t taco_gae_workspace_bytes(void);
+int taco_gae(const float *rew, const float *done, const float *value, const float *last_value, int horizon, int num_envs,
+             double gamma, double lam, float *adv, float *ret, int normalize, void *workspace, void *stream);
 
 /* Multi-GPU (no counterpart in the reference, which is single-process): bind a DEVICE block
  * [num_envs][taco_gather_row_floats(len_obs)] f32, 128-byte aligned, that every following taco_step also fills with

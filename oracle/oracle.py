@@ -277,3 +277,19 @@ def vec(fn_name, *xs):
     """apply a scalar own-math function elementwise"""
     f = getattr(lib(), fn_name)
     return np.array([f(*[float(v) for v in t]) for t in zip(*xs)], np.float32)
+
+
+def gae(rew, done, value, last_value, gamma, lam):
+    rew, done, value, last_value = _f32(rew), _f32(done), _f32(value), _f32(last_value)
+    H, N = rew.shape
+    adv = np.empty_like(rew); ret = np.empty_like(rew)
+    fn = lib().orc_gae; fn.restype = None
+    fn(C.c_int(H), C.c_int(N), C.c_double(gamma), C.c_double(lam), _p(rew), _p(done), _p(value), _p(last_value), _p(adv), _p(ret))
+    return adv, ret
+
+
+def normalize_advantage(adv):
+    a = _f32(adv).copy()
+    fn = lib().orc_normalize_advantage; fn.restype = None
+    fn(C.c_size_t(a.size), _p(a))
+    return a

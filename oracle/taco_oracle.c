@@ -1029,6 +1029,36 @@ void orc_obs_frame(int n, int task, const float *p, const float *q, const float 
         pack_frame(&R, V[i], act + 4 * i, p[3 * i + 2], task, c2, frame26 + 26 * i);
     }
 }
+/* ------------------------------------------------------------------------------------------------ row N1 (next): replay buffer
+ * PPOReplayBuffer.compute_returns_and_advantage (IsaacGymEnvs/algorithms/buffer_asymmetry.py:93-132).  Arrays are [H][N]
+ * (the reference's [H, N, 1]); gamma / lam are Python floats that meet fp32 tensors.  adv_raw is the GAE before the
+ * normalisation of :132, ret = adv_raw + value (:130). */
+void orc_gae(int H, int N, double gamma, double lam, const float *rew, const float *done, const float *value, const float *last_value,
+             float *adv_raw, float *ret) {
+    const float g = (float)gamma, l = (float)lam;
+    for (int i = 0; i < N; ++i) {
+        float last = 0.0f;
+        for (int t = H - 1; t >= 0; --t) {
+            const float nv = (t == H - 1) ? last_value[i] : value[(size_t)(t + 1) * N + i];
+            const float nnt = 1.0f - done[(size_t)t * N + i];
+            const float td = rew[(size_t)t * N + i] + nnt * g * nv;
+            const float delta = td - value[(size_t)t * N + i];
+            last = delta + nnt * g * l * last;
+            adv_raw[(size_t)t * N + i] = last;
+            ret[(size_t)t * N + i] = last + value[(size_t)t * N + i];
+        }
+    }
+}
+/* (adv - mean) / (std + 1e-8), torch.std = unbiased (buffer_asymmetry.py:132); the reductions are done in double */
+void orc_normalize_advantage(size_t n, float *adv) {
+    double s = 0.0, ss = 0.0;
+    for (size_t k = 0; k < n; ++k) s += adv[k];
+    const double mean = s / (double)n;
+    for (size_t k = 0; k < n; ++k) ss += (adv[k] - mean) * (adv[k] - mean);
+    const float stdv = (float)sqrt(ss / (double)(n - 1)), m = (float)mean;
+    for (size_t k = 0; k < n; ++k) adv[k] = (adv[k] - m) / (stdv + 1e-8f);
+}
+
 void orc_rand_float(int n, double lower, double upper, const float *u, float *out) { for (int i = 0; i < n; ++i) out[i] = rand_float(lower, upper, u[i]); }
 void orc_integrate(const orc_cfg *cfg, int n, float *root13, const float *wrench6) {
     orc_env tmp;

@@ -20,6 +20,7 @@
  */
 #ifndef TACO_ORACLE_H
 #define TACO_ORACLE_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -130,6 +131,10 @@ void orc_obs_frame(int n, int task, const float *p, const float *q, const float 
                    const float *qt, const float *V, const float *act, const float *cmd, const float *flip_radian,
                    const float *roll_cont, float *frame26, float *flip_cmd_out);
 void orc_rand_float(int n, double lower, double upper, const float *u, float *out);
+/* replay buffer: GAE + advantage normalisation, arrays [H][N] */
+void orc_gae(int H, int N, double gamma, double lam, const float *rew, const float *done, const float *value, const float *last_value,
+             float *adv_raw, float *ret);
+void orc_normalize_advantage(size_t n, float *adv);
 /* row I alone: advance root state [n][13] by one simulate(dt) under a body-frame wrench [n][6] (F then tau) */
 void orc_integrate(const orc_cfg *cfg, int n, float *root13, const float *wrench6);
 

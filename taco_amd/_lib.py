@@ -6,7 +6,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TACO_ENV_LIB", os.path.join(HERE, "libtaco_env.so"))  # override = A/B builds of the same ABI
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 NUM_FIELDS = 67
 RING_SLOTS = 100
 BLOB_ROWS = NUM_FIELDS + 4 * RING_SLOTS
@@ -22,7 +22,7 @@ FLAG_BITS = {
 # every symbol include/taco_env.h declares
 EXPORTS = ["taco_abi_version", "taco_last_error", "taco_workspace_bytes", "taco_create", "taco_destroy", "taco_step",
            "taco_gather_row_floats", "taco_bind_gather_block", "taco_set_difficulty", "taco_get_step_count", "taco_set_step_count", "taco_get_state", "taco_set_state",
-           "taco_step_kernel_name", "taco_launch_geometry"]
+           "taco_step_kernel_name", "taco_launch_geometry", "taco_step_rollout", "taco_gae_workspace_bytes", "taco_gae"]
 
 
 class TacoCfg(C.Structure):
@@ -34,6 +34,13 @@ class TacoCfg(C.Structure):
         ("clip_actions", C.c_double), ("clip_obs", C.c_double), ("clip_states", C.c_double), ("mass", C.c_double),
         ("inertia", C.c_double * 3), ("arm_x", C.c_double), ("arm_y", C.c_double), ("gravity_z", C.c_double),
     ]
+
+
+class RolloutIO(C.Structure):
+    """struct taco_rollout_io (include/taco_env.h)"""
+    _fields_ = [("actions", C.c_void_p), ("obs_prev", C.c_void_p), ("obs_next", C.c_void_p), ("states_prev", C.c_void_p),
+                ("states_next", C.c_void_p), ("rew", C.c_void_p), ("reset_buf", C.c_void_p), ("timeout_buf", C.c_void_p),
+                ("done_f32", C.c_void_p)]
 
 
 class TacoError(RuntimeError):
@@ -87,6 +94,12 @@ def load():
     lib.taco_set_state.restype = C.c_int
     lib.taco_launch_geometry.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.taco_launch_geometry.restype = C.c_int
+    lib.taco_step_rollout.argtypes = [C.c_void_p, C.POINTER(RolloutIO), C.c_void_p]
+    lib.taco_step_rollout.restype = C.c_int
+    lib.taco_gae_workspace_bytes.argtypes = []
+    lib.taco_gae_workspace_bytes.restype = C.c_size_t
+    lib.taco_gae.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.taco_gae.restype = C.c_int
     if lib.taco_abi_version() != ABI_VERSION:
         raise TacoError(f"libtaco_env.so ABI {lib.taco_abi_version()} != binding ABI {ABI_VERSION}")
     _lib = lib

@@ -12,6 +12,7 @@
 #include <new>
 
 #include "taco_step.hpp"
+#include "taco_rollout.hpp"
 
 namespace {
 
@@ -271,17 +272,21 @@ int taco_create(const taco_cfg *cfg, int device, void *workspace, size_t workspa
 
 void taco_destroy(taco_env *env) { delete env; }
 
-int taco_step(taco_env *e, const float *actions, float *obs_buf, float *states_buf, float *rew_buf, int64_t *reset_buf,
-              uint8_t *timeout_buf, void *stream) {
-    if (!e) return fail(TACO_ERR_INVALID_ARG, "env is null");
-    if (!actions || !obs_buf || !states_buf || !rew_buf || !reset_buf || !timeout_buf)
+namespace {
+int launch_step(taco_env *e, const taco_rollout_io *io, void *stream) {
+    if (!io->actions || !io->obs_next || !io->states_next || !io->rew || !io->reset_buf || !io->timeout_buf)
         return fail(TACO_ERR_INVALID_ARG, "taco_step: null buffer pointer");
-    if (((uintptr_t)actions & 15u) != 0) return fail(TACO_ERR_INVALID_ARG, "actions must be 16-byte aligned");
+    if (((uintptr_t)io->actions & 15u) != 0) return fail(TACO_ERR_INVALID_ARG, "actions must be 16-byte aligned");
     const size_t n_envs = (size_t)e->cfg.num_envs;
     taco::StepParams P = e->P;
     P.S = e->S; P.ring = e->ring; P.hist = e->hist;
-    P.act_in = actions; P.obs = obs_buf; P.states = states_buf; P.rew = rew_buf;
-    P.reset = (long long *)reset_buf; P.timeout = timeout_buf;
+    P.act_in = io->actions; P.obs = io->obs_next; P.states = io->states_next; P.rew = io->rew;
+    P.obs_prev = io->obs_prev ? io->obs_prev : io->obs_next;
+    P.states_prev = io->states_prev ? io->states_prev : io->states_next;
+    if ((((uintptr_t)P.obs_prev | (uintptr_t)P.states_prev | (uintptr_t)P.obs | (uintptr_t)P.states) & 3u) != 0)
+        return fail(TACO_ERR_INVALID_ARG, "obs / states buffers must be 4-byte aligned");
+    P.done_f32 = io->done_f32;
+    P.reset = (long long *)io->reset_buf; P.timeout = io->timeout_buf;
     P.gather = e->gather;
     P.step = (uint32_t)e->step_count;
     P.s_bytes = (uint32_t)((size_t)taco::NUM_CHUNKS * e->npad * 4 * sizeof(float));
@@ -303,6 +308,47 @@ int taco_step(taco_env *e, const float *actions, float *obs_buf, float *states_b
     e->step_count += 1;
     e->head = (e->head + 10) % TACO_RING_SLOTS;
     e->hh = (e->hh + 1) % taco::HIST_ROWS;
+    return TACO_OK;
+}
+}  // namespace
+
+int taco_step(taco_env *e, const float *actions, float *obs_buf, float *states_buf, float *rew_buf, int64_t *reset_buf,
+              uint8_t *timeout_buf, void *stream) {
+    if (!e) return fail(TACO_ERR_INVALID_ARG, "env is null");
+    taco_rollout_io io{};
+    io.actions = actions; io.obs_next = obs_buf; io.states_next = states_buf; io.rew = rew_buf;
+    io.reset_buf = reset_buf; io.timeout_buf = timeout_buf;
+    return launch_step(e, &io, stream);
+}
+
+int taco_step_rollout(taco_env *e, const taco_rollout_io *io, void *stream) {
+    if (!e) return fail(TACO_ERR_INVALID_ARG, "env is null");
+    if (!io) return fail(TACO_ERR_INVALID_ARG, "taco_step_rollout: io is null");
+    return launch_step(e, io, stream);
+}
+
+size_t taco_gae_workspace_bytes(void) { return (size_t)2 * taco::kNormBlocks * sizeof(double); }
+
+int taco_gae(const float *rew, const float *done, const float *value, const float *last_value, int horizon, int num_envs,
+             double gamma, double lam, float *adv, float *ret, int normalize, void *workspace, void *stream) {
+    if (!rew || !done || !value || !last_value || !adv || !ret) return fail(TACO_ERR_INVALID_ARG, "taco_gae: null buffer pointer");
+    if (horizon < 1 || num_envs < 1) return fail(TACO_ERR_INVALID_ARG, "taco_gae: horizon and num_envs must be >= 1");
+    hipLaunchKernelGGL(taco::gae_kernel, dim3((num_envs + taco::kGaeBlock - 1) / taco::kGaeBlock), dim3(taco::kGaeBlock), 0, (hipStream_t)stream,
+                       rew, done, value, last_value, horizon, num_envs, (float)gamma, (float)lam, adv, ret);
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) return hip_fail(he, "gae_kernel launch");
+    if (normalize) {
+        if (!workspace || ((uintptr_t)workspace & 7u) != 0) return fail(TACO_ERR_INVALID_ARG, "taco_gae: normalize needs an 8-byte aligned workspace");
+        const size_t count = (size_t)horizon * (size_t)num_envs;
+        if (count < 2) return fail(TACO_ERR_INVALID_ARG, "taco_gae: normalize needs at least two samples");
+        double *part = (double *)workspace;
+        hipLaunchKernelGGL(taco::adv_partial_kernel, dim3(taco::kNormBlocks), dim3(taco::kNormThreads), 0, (hipStream_t)stream, adv, count, part);
+        size_t blocks = (count + taco::kNormThreads - 1) / taco::kNormThreads;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(taco::adv_apply_kernel, dim3((unsigned)blocks), dim3(taco::kNormThreads), 0, (hipStream_t)stream, adv, count, (const double *)part);
+        he = hipGetLastError();
+        if (he != hipSuccess) return hip_fail(he, "advantage normalisation launch");
+    }
     return TACO_OK;
 }
 

@@ -28,6 +28,9 @@ struct StepParams {
     float *rew;          // [n]
     long long *reset;    // [n] in/out
     uint8_t *timeout;    // [n]
+    const float *obs_prev;    // frame stacks the len>1 shift reads (== obs / states for the in-place step; the previous
+    const float *states_prev; //   replay-buffer slot for taco_step_rollout)
+    float *done_f32;     // optional [n] f32 image of the new reset flags (PPOReplayBuffer.done_buf, buffer_asymmetry.py:67)
     float *gather;       // optional [n][len_obs*26 + 3] f32: obs stack | reward | done | time-out (one all-gather block per rank)
     // geometry / cfg
     int n, npad, env_offset, task_mode, mix_n1, mix_n2, len_obs, len_states, substeps, max_len, delay_time, head;
@@ -828,7 +831,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
     //  len  > 1 : each lane shifts its own row by one frame (8-byte accesses, in place, ascending) and appends the frame.
     // Stores go through range-checked buffer descriptors, so ragged tails need no special casing.
     const uint32_t wave_env0 = (uint32_t)(blockIdx.x * BLOCK + wv * 64);
-    auto put_frame = [&](float *buf, uint32_t buf_bytes, int len, const float (&f)[26]) {
+    auto put_frame = [&](float *buf, const float *prev, uint32_t buf_bytes, int len, const float (&f)[26]) {
         const rsrc_t rB = make_rsrc(buf, buf_bytes);
         if (len == 1) {
             __syncthreads();  // previous users of the scratch (action slots / the other buffer's tile) are done
@@ -845,8 +848,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
         } else if (active) {
             const uint32_t row0 = (uint32_t)i * (uint32_t)len * 104u;
             const int pairs = (len - 1) * 13;
+            const rsrc_t rP = make_rsrc(prev, buf_bytes);  // == rB for the in-place step (ascending copy: safe)
             for (int j = 0; j < pairs; ++j) {
-                const f32x2_t o = llvm_amdgcn_raw_buffer_load_v2f32(rB, (int)(row0 + 104u + (uint32_t)j * 8u), 0, 0);
+                const f32x2_t o = llvm_amdgcn_raw_buffer_load_v2f32(rP, (int)(row0 + 104u + (uint32_t)j * 8u), 0, 0);
                 llvm_amdgcn_raw_buffer_store_v2f32(o, rB, (int)(row0 + (uint32_t)j * 8u), 0, 0);
             }
 #pragma unroll
@@ -855,7 +859,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
         }
     };
     // states first (noise-free frame), then obs (possibly noised)
-    put_frame(P.states, P.states_bytes, P.len_states, fr);
+    put_frame(P.states, P.states_prev, P.states_bytes, P.len_states, fr);
     if (fl & TACO_F_OBSERVATION_NOISE) {  // FA:402-410
         float nrm[12];
 #pragma unroll
@@ -885,7 +889,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
         fr[18] = fr[18] + P.df * (nrm[9] * (float)(0.06 / 3) + 0.0f);
         fr[23] = fr[23] + P.df * (nrm[10] * (float)(0.06 / 3 / 3) + 0.0f);
     }
-    put_frame(P.obs, P.obs_bytes, P.len_obs, fr);
+    put_frame(P.obs, P.obs_prev, P.obs_bytes, P.len_obs, fr);
 
     // ------------------------------------------------------------------ compute_reward CTRL/task_reward.py
     float rew, pos_dist;
@@ -938,6 +942,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
         P.rew[i] = rew;
         P.reset[i] = rs;
         P.timeout[i] = tmo ? 1 : 0;
+        if (P.done_f32) P.done_f32[i] = (float)rs;
         if (P.gather) {
             // one 128-byte-aligned row per env: [obs stack | reward | done | time-out | pad]; the obs stack is re-read from
             // this lane's own (just written) obs row when there is history, else taken from registers

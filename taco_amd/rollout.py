@@ -1,0 +1,138 @@
+"""Replay buffer directly behind step().
+
+Mirrors `PPOReplayBuffer` (IsaacGymEnvs/algorithms/buffer_asymmetry.py:9-139): same constructor, same attribute names
+and shapes (`obs_buf [H,N,L,D]`, `states_buf`, `act_buf`, `rew_buf [H,N,1]`, `done_buf`, `ret_buf`, `value_buf`,
+`adv_buf`, `mu_buf`, `sigma_buf`, `logp_buf`, `step`), same `store / reset / compute_returns_and_advantage /
+batch_idx_generator`, so `PPO.update()` (ppo_asymmetry.py:178-194) can index it unchanged.
+
+Two things are done the MI355X way:
+* `collect(env, actions)` lets the step kernel write slot t+1 of the obs / states storage, `rew_buf[t]` and `done_buf[t]`
+  itself (taco_step_rollout), replacing five of the nine per-step torch copies of `store` and the two `obs.copy_(next_obs)`
+  of the rollout loop (ppo_asymmetry.py:326-329).  The storage has H+1 slots; `obs_buf` / `states_buf` are views of the
+  first H, `next_obs` / `next_states` views of slot `step`.
+* `compute_returns_and_advantage` is three kernel launches (taco_gae) instead of ~9 H torch launches.
+PyTorch only owns the memory.  There is no torch fallback for the arithmetic.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+
+
+class RolloutBuffer:
+    def __init__(self, num_envs, obs_dim, obs_len, states_dim, states_len, act_dim, horizon_len, mini_batch_num, gamma, lam, device):
+        self.num_envs, self.obs_dim, self.obs_len = num_envs, obs_dim, obs_len
+        self.states_dim, self.states_len, self.act_dim = states_dim, states_len, act_dim
+        self.horizon_len, self.mini_batch_num = horizon_len, mini_batch_num
+        self.gamma, self.lam = gamma, lam
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.TacoError("RolloutBuffer lives in HBM next to the env: device must be a cuda:N (HIP) device")
+        self.lib = _lib.load()
+        H, N, dev = horizon_len, num_envs, self.device
+        self._obs_store = torch.zeros(H + 1, N, obs_len, obs_dim, dtype=torch.float32, device=dev)
+        self._states_store = torch.zeros(H + 1, N, states_len, states_dim, dtype=torch.float32, device=dev)
+        self.obs_buf = self._obs_store[:H]
+        self.states_buf = self._states_store[:H]
+        self._gae_ws = torch.empty(self.lib.taco_gae_workspace_bytes(), dtype=torch.uint8, device=dev)
+        self._alloc_small()
+        self.step = 0
+
+    def _alloc_small(self):
+        H, N, dev = self.horizon_len, self.num_envs, self.device
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)  # noqa: E731
+        self.act_buf = z(H, N, self.act_dim)
+        self.rew_buf, self.done_buf = z(H, N, 1), z(H, N, 1)
+        self.ret_buf, self.value_buf, self.adv_buf = z(H, N, 1), z(H, N, 1), z(H, N, 1)
+        self.mu_buf, self.sigma_buf, self.logp_buf = z(H, N, self.act_dim), z(H, N, self.act_dim), z(H, N, 1)
+
+    # ---- the reference's API -------------------------------------------------------------------------------------------
+    def store(self, obs, states, act, rew, log_prob, done, value, mu, sigma):
+        """buffer_asymmetry.py:49-68, the generic (copying) path; usable with any env."""
+        if self.step >= self.horizon_len:
+            raise AssertionError("Rollout buffer overflow")
+        t = self.step
+        self.obs_buf[t].copy_(obs)
+        self.states_buf[t].copy_(states)
+        self.rew_buf[t].copy_(rew.view(-1, 1))
+        self.done_buf[t].copy_(done.view(-1, 1))
+        self._store_policy(t, act, log_prob, value, mu, sigma)
+        self.step += 1
+
+    def reset(self):
+        """buffer_asymmetry.py:70-91.  The reference re-allocates zeroed tensors; here the frame-stack storage is kept and
+        the stacks the env last wrote (slot `step`) become slot 0 of the next rollout."""
+        if self.step > 0:
+            self._obs_store[0].copy_(self._obs_store[self.step])
+            self._states_store[0].copy_(self._states_store[self.step])
+        for t in (self.act_buf, self.rew_buf, self.done_buf, self.ret_buf, self.value_buf, self.adv_buf, self.mu_buf, self.sigma_buf, self.logp_buf):
+            t.zero_()  # in place: the pointers stay valid for captured graphs
+        self.step = 0
+
+    def compute_returns_and_advantage(self, last_values, normalize=True):
+        """buffer_asymmetry.py:93-132 in three launches."""
+        lv = last_values.to(device=self.device, dtype=torch.float32).contiguous()
+        if lv.numel() != self.num_envs:
+            raise ValueError("last_values must hold one value per env")
+        s = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(self.lib.taco_gae(self.rew_buf.data_ptr(), self.done_buf.data_ptr(), self.value_buf.data_ptr(), lv.data_ptr(),
+                                     self.horizon_len, self.num_envs, float(self.gamma), float(self.lam),
+                                     self.adv_buf.data_ptr(), self.ret_buf.data_ptr(), 1 if normalize else 0,
+                                     self._gae_ws.data_ptr(), s))
+
+    def batch_idx_generator(self):
+        """buffer_asymmetry.py:134-139 (host-side index lists, as the reference)."""
+        idx = torch.randperm(self.num_envs * self.horizon_len)
+        return idx.reshape(self.mini_batch_num, -1).tolist()
+
+    # ---- the fused rollout path ----------------------------------------------------------------------------------------
+    @property
+    def next_obs(self):
+        """The frame stacks the policy acts on at the current step (slot `step`): what the reference keeps in `obs`."""
+        return self._obs_store[self.step]
+
+    @property
+    def next_states(self):
+        return self._states_store[self.step]
+
+    def collect(self, env, actions, log_prob=None, value=None, mu=None, sigma=None):
+        """env.step(actions) + store(...) of ppo_asymmetry.py:311-329 with the env writing this step's slots in place.
+        Returns (rewards [N], dones [N] int64 = env.reset_buf, time_outs [N] bool = env.timeout_buf)."""
+        if self.step >= self.horizon_len:
+            raise AssertionError("Rollout buffer overflow")
+        if math.isfinite(env.clip_obs) or math.isfinite(env.clip_states):
+            raise _lib.TacoError("collect() stores the env's unclamped frame stacks; with finite clipObservations / clipStates use env.step() + store()")
+        if (env.num_envs, env.len_obs, env.num_obs, env.len_states, env.num_states) != (self.num_envs, self.obs_len, self.obs_dim, self.states_len, self.states_dim):
+            raise ValueError("env and buffer geometry differ")
+        t = self.step
+        env.step_into(actions, self._obs_store[t], self._obs_store[t + 1], self._states_store[t], self._states_store[t + 1],
+                      self.rew_buf[t], self.done_buf[t])
+        self._store_policy(t, actions, log_prob, value, mu, sigma)
+        self.step += 1
+        return self.rew_buf[t].view(-1), env.reset_buf, env.timeout_buf
+
+    def add_timeout_bootstrap(self, t, env_ids, time_out_value):
+        """rewards_augmented[truncated] += gamma * V(s_t)  (ppo_asymmetry.py:320-324) on the stored reward of step t."""
+        self.rew_buf[t].view(-1)[env_ids] += self.gamma * time_out_value.view(-1)
+
+    def seed_stacks(self, env):
+        """Adopt the env's current frame stacks as slot `step` (e.g. when attaching to an env that already stepped)."""
+        self._obs_store[self.step].copy_(env.obs_buf)
+        self._states_store[self.step].copy_(env.states_buf)
+
+    def _store_policy(self, t, act, log_prob, value, mu, sigma):
+        self.act_buf[t].copy_(act)
+        if value is not None:
+            self.value_buf[t].copy_(value.view(-1, 1))
+        if mu is not None:
+            self.mu_buf[t].copy_(mu)
+        if sigma is not None:
+            self.sigma_buf[t].copy_(sigma)
+        if log_prob is not None:
+            self.logp_buf[t].copy_(log_prob.view(-1, 1))
+
+
+# the reference's class name, so `from taco_amd.rollout import PPOReplayBuffer` is a drop-in (buffer_asymmetry.py:9)
+PPOReplayBuffer = RolloutBuffer

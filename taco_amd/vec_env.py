@@ -144,6 +144,28 @@ class FpvBase:
                                 self.reset_buf.data_ptr(), self.timeout_buf.data_ptr(), _stream_ptr(self.device).value)
         _lib.check(rc)
 
+    def step_into(self, actions, obs_prev, obs_next, states_prev, states_next, rew, done_f32=None):
+        """taco_step_rollout: like step_raw, but the frame stacks are read from `*_prev` and written to `*_next` (replay-buffer
+        slots, see taco_amd/rollout.py), the reward goes to `rew` and the new done flags also to `done_f32` (fp32).
+        reset_buf / timeout_buf stay the env's own.  Tensors must be contiguous fp32 on the env's device."""
+        if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.device != self.device:
+            actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
+        if actions.shape != (self.num_envs, self.num_acts):
+            raise ValueError(f"actions must be [{self.num_envs}, {self.num_acts}], got {tuple(actions.shape)}")
+        shapes = ((obs_prev, self.obs_buf.shape), (obs_next, self.obs_buf.shape), (states_prev, self.states_buf.shape),
+                  (states_next, self.states_buf.shape), (rew, None), (done_f32, None))
+        for t, shp in shapes:
+            if t is None:
+                continue
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device:
+                raise ValueError("step_into: buffers must be contiguous fp32 tensors on the env's device")
+            if (shp is not None and tuple(t.shape) != tuple(shp)) or (shp is None and t.numel() != self.num_envs):
+                raise ValueError(f"step_into: buffer of shape {tuple(t.shape)} does not match the env")
+        io = _lib.RolloutIO(actions.data_ptr(), obs_prev.data_ptr(), obs_next.data_ptr(), states_prev.data_ptr(), states_next.data_ptr(),
+                            rew.data_ptr(), self.reset_buf.data_ptr(), self.timeout_buf.data_ptr(),
+                            done_f32.data_ptr() if done_f32 is not None else None)
+        _lib.check(self.lib.taco_step_rollout(self._h, C.byref(io), _stream_ptr(self.device)))
+
     def step(self, actions):
         """vec_task_asymmetry.py:290-334."""
         self.step_raw(actions)

@@ -23,7 +23,7 @@ import sys, types, importlib.util, linecache, pathlib, math
 import numpy as np
 import torch
 
-REF = pathlib.Path(sys.argv[1] if len(sys.argv) > 1 else "/root/reference")
+REF = pathlib.Path(sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else "/root/reference")
 OUT = pathlib.Path(__file__).resolve().parent
 CTRL = REF / "IsaacGymEnvs/isaacgymenvs/tasks/control"
 
@@ -418,5 +418,31 @@ def gen_reset():
     save("reset", u=npy(u), e=npy(e), **outs)
 
 
+# --------------------------------------------------------------------------- (12) replay buffer: GAE + advantage normalisation
+def gen_gae():
+    """PPOReplayBuffer.store + compute_returns_and_advantage (algorithms/buffer_asymmetry.py:49-68, 93-132) run on CPU."""
+    _load("nets_asymmetry", REF / "IsaacGymEnvs/algorithms/nets_asymmetry.py")  # the buffer does `import nets_asymmetry as core`
+    BUF = _load("ref_buffer", REF / "IsaacGymEnvs/algorithms/buffer_asymmetry.py")
+    g = torch.Generator().manual_seed(1200)
+    H, N = 24, 96
+    gamma, lam = 0.99, 0.95
+    buf = BUF.PPOReplayBuffer(N, 26, 1, 26, 5, 4, H, 4, gamma, lam, "cpu")
+    rew = torch.rand(H, N, generator=g) * 0.02
+    done = (torch.rand(H, N, generator=g) < 0.08).long()
+    val = torch.randn(H, N, 1, generator=g) * 0.3
+    last = torch.randn(N, 1, generator=g) * 0.3
+    z4 = torch.zeros(N, 4)
+    for t in range(H):
+        buf.store(torch.zeros(N, 1, 26), torch.zeros(N, 5, 26), z4, rew[t], torch.zeros(N), done[t], val[t], z4, z4)
+    buf.compute_returns_and_advantage(last)
+    # un-normalised advantage = ret - value
+    save("gae", gamma=np.float64(gamma), lam=np.float64(lam), rew=npy(rew), done=npy(done), value=npy(val[:, :, 0]), last_value=npy(last[:, 0]),
+         ret=npy(buf.ret_buf[:, :, 0]), adv_norm=npy(buf.adv_buf[:, :, 0]), adv_raw=npy(buf.ret_buf[:, :, 0] - buf.value_buf[:, :, 0]),
+         done_f32=npy(buf.done_buf[:, :, 0]), rew_buf=npy(buf.rew_buf[:, :, 0]))
+
+
 if __name__ == "__main__":
+    gen_gae()
+    if "--only-gae" in sys.argv:
+        sys.exit(0)
     gen_quat(); gen_pid(); gen_alloc(); gen_battery(); gen_rotor(); gen_aero(); gen_reward(); gen_chain(); gen_obs(); gen_reset()

@@ -166,3 +166,25 @@ def test_composed_substep_chain(golden):
         np.testing.assert_allclose(ts, c["t_sim"][t], rtol=6e-7); assert_bits_equal(bf, c["body_f"][t], f"body force t={t}")
     assert np.abs(c["rpy_cont"][-1] - c["rpy"][-1]).max() > 3, "fixture must cross the +-pi euler wrap"
     np.testing.assert_allclose(E, c["E_end"], rtol=1e-7)
+
+
+def test_gae_returns_and_advantage_vs_reference_buffer(golden):
+    """orc_gae / orc_normalize_advantage vs PPOReplayBuffer.compute_returns_and_advantage run on CPU (gae.npz).
+    ret is bit-exact; the golden `adv_raw` is ret - value (one extra rounding), the normalised advantage depends on
+    torch's reduction order -> 1e-6 absolute on O(1) values."""
+    g = golden("gae")
+    assert np.array_equal(g["done_f32"], g["done"].astype(np.float32)) and np.array_equal(g["rew_buf"], g["rew"])
+    adv, ret = O.gae(g["rew"], g["done_f32"], g["value"], g["last_value"], float(g["gamma"]), float(g["lam"]))
+    assert_bits_equal(ret, g["ret"], "ret_buf")
+    np.testing.assert_allclose(adv, g["adv_raw"], rtol=0, atol=1.5e-7)
+    np.testing.assert_allclose(O.normalize_advantage(adv), g["adv_norm"], rtol=0, atol=1e-6)
+    # pure-numpy restatement of the recurrence (fp32, same association) as a second witness
+    H, N = g["rew"].shape
+    gm, lm = np.float32(g["gamma"]), np.float32(g["lam"])
+    last = np.zeros(N, np.float32)
+    for t in reversed(range(H)):
+        nv = g["last_value"] if t == H - 1 else g["value"][t + 1]
+        nnt = np.float32(1) - g["done_f32"][t]
+        delta = (g["rew"][t] + nnt * gm * nv) - g["value"][t]
+        last = delta + nnt * gm * lm * last
+        assert_bits_equal(last, adv[t], f"adv step {t}")

@@ -1,0 +1,106 @@
+"""SURVEY.md 8f row N1 on the GPU: taco_step_rollout (the step kernel writing replay-buffer slots) and taco_gae
+(PPOReplayBuffer.compute_returns_and_advantage, buffer_asymmetry.py:93-132) against the CPU oracle and the golden
+vectors generated from the reference's own PPOReplayBuffer (tests/golden/gae.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from taco_amd import config
+from util import assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _buffer(n, H, len_obs=1, len_states=1, gamma=0.99, lam=0.95):
+    from taco_amd.rollout import RolloutBuffer
+    return RolloutBuffer(n, 26, len_obs, 26, len_states, 4, H, 4, gamma, lam, "cuda:0")
+
+
+def test_gae_matches_reference_golden():
+    g = np.load(os.path.join(GOLD, "gae.npz"))
+    H, N = g["rew"].shape
+    buf = _buffer(N, H, gamma=float(g["gamma"]), lam=float(g["lam"]))
+    buf.rew_buf.copy_(torch.from_numpy(g["rew"]).view(H, N, 1))
+    buf.done_buf.copy_(torch.from_numpy(g["done_f32"]).view(H, N, 1))
+    buf.value_buf.copy_(torch.from_numpy(g["value"]).view(H, N, 1))
+    buf.compute_returns_and_advantage(torch.from_numpy(g["last_value"]).cuda().view(N, 1))
+    assert_bits_equal(buf.ret_buf.cpu().numpy()[:, :, 0], g["ret"], "ret_buf vs the reference")
+    # mean / std reductions: torch's summation order is not specified -> tolerance 1e-6 absolute (values are O(1))
+    np.testing.assert_allclose(buf.adv_buf.cpu().numpy()[:, :, 0], g["adv_norm"], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("H,N", [(1, 2), (7, 63), (32, 4096), (16, 70001)])
+def test_gae_matches_oracle_bitwise(H, N):
+    from oracle import oracle as O
+    rng = np.random.default_rng(H * 1000 + N)
+    rew = (rng.random((H, N)) * 0.02).astype(np.float32)
+    done = (rng.random((H, N)) < 0.05).astype(np.float32)
+    val = (rng.standard_normal((H, N)) * 0.3).astype(np.float32)
+    last = (rng.standard_normal(N) * 0.3).astype(np.float32)
+    adv_o, ret_o = O.gae(rew, done, val, last, 0.98, 0.9)
+    buf = _buffer(N, H, gamma=0.98, lam=0.9)
+    buf.rew_buf.copy_(torch.from_numpy(rew).view(H, N, 1))
+    buf.done_buf.copy_(torch.from_numpy(done).view(H, N, 1))
+    buf.value_buf.copy_(torch.from_numpy(val).view(H, N, 1))
+    lv = torch.from_numpy(last).cuda()
+    buf.compute_returns_and_advantage(lv, normalize=False)
+    assert_bits_equal(buf.adv_buf.cpu().numpy()[:, :, 0], adv_o, "raw advantage")
+    assert_bits_equal(buf.ret_buf.cpu().numpy()[:, :, 0], ret_o, "returns")
+    buf.compute_returns_and_advantage(lv, normalize=True)
+    a1 = buf.adv_buf.cpu().numpy()[:, :, 0].copy()
+    np.testing.assert_allclose(a1, O.normalize_advantage(adv_o), rtol=0, atol=2e-6)
+    assert abs(float(a1.astype(np.float64).mean())) < 1e-5 and abs(float(a1.astype(np.float64).std(ddof=1)) - 1) < 1e-5
+    buf.compute_returns_and_advantage(lv, normalize=True)   # fixed reduction tree: bit-reproducible
+    assert_bits_equal(buf.adv_buf.cpu().numpy()[:, :, 0], a1, "normalised advantage, second run")
+
+
+@pytest.mark.parametrize("n,len_obs,len_states,task", [(63, 5, 3, "mix"), (256, 1, 1, "pos"), (130, 1, 4, "flip")])
+def test_collect_equals_step_plus_store_and_oracle(n, len_obs, len_states, task):
+    """The fused path (kernel writes slot t+1 / rew_buf[t] / done_buf[t]) == env.step_raw + PPOReplayBuffer.store copies
+    == the oracle, bit for bit, across two rollouts (reset() carries the last stacks into slot 0).  n = 63 makes every
+    slot base only 8-byte aligned."""
+    from oracle import oracle as O
+    from taco_amd.vec_env import FpvBase
+    H = 6
+    cfg = config.default_cfg(task, n, env_lenObservations=len_obs, env_lenStates=len_states, env_maxEpisodeLength=9, seed=5)
+    fused, plain = FpvBase(cfg, copy_outputs=False), FpvBase(cfg, copy_outputs=False)
+    orc = O.OracleEnv(config.flat_cfg(cfg), threads=4)
+    bf, bp = _buffer(n, H, len_obs, len_states), _buffer(n, H, len_obs, len_states)
+    rng = np.random.default_rng(3)
+    for epoch in range(2):
+        bf.reset(); bp.reset()
+        for t in range(H):
+            a = torch.from_numpy(np.clip(0.3 * rng.standard_normal((n, 4)), -1, 1).astype(np.float32)).cuda()
+            obs_t, st_t = plain.obs_buf.clone(), plain.states_buf.clone()   # what the reference calls obs / states
+            assert torch.equal(bf.next_obs, obs_t) and torch.equal(bf.next_states, st_t)
+            rew, done, tmo = bf.collect(fused, a)
+            plain.step_raw(a)
+            bp.store(obs_t, st_t, a, plain.rew_buf, torch.zeros(n, device="cuda"), plain.reset_buf, torch.zeros(n, 1, device="cuda"), a, a)
+            orc.step(a.cpu().numpy())
+            assert_bits_equal(rew.cpu().numpy(), orc.rew_buf, f"epoch {epoch} step {t} reward")
+            assert_bits_equal(done.cpu().numpy(), orc.reset_buf, "done")
+            assert_bits_equal(tmo.cpu().numpy().astype(np.uint8), orc.timeout_buf, "time-outs")
+            assert_bits_equal(bf.next_obs.cpu().numpy(), orc.obs_buf, "slot t+1 obs vs oracle")
+            assert_bits_equal(bf.next_states.cpu().numpy(), orc.states_buf, "slot t+1 states vs oracle")
+        for name in ("obs_buf", "states_buf", "act_buf", "rew_buf", "done_buf"):
+            assert torch.equal(getattr(bf, name), getattr(bp, name)), name
+        assert bf.done_buf.sum() > 0 or epoch == 0
+        assert_bits_equal(fused.get_state().cpu().numpy().view(np.uint32), plain.get_state().cpu().numpy().view(np.uint32), "env state")
+    with pytest.raises(AssertionError):
+        bf.collect(fused, a)       # buffer_asymmetry.py:50-51 "Rollout buffer overflow"
+
+
+def test_collect_refuses_what_it_cannot_do_exactly():
+    from taco_amd._lib import TacoError
+    from taco_amd.vec_env import FpvPos
+    env = FpvPos(config.default_cfg("pos", 64, env_clipObservations=5.0))
+    buf = _buffer(64, 4)
+    with pytest.raises(TacoError):
+        buf.collect(env, env.zero_actions().cuda())
+    env2 = FpvPos(config.default_cfg("pos", 32))
+    with pytest.raises(ValueError):
+        buf.collect(env2, env2.zero_actions().cuda())
+    assert len(buf.batch_idx_generator()) == 4 and sorted(sum(buf.batch_idx_generator(), [])) == list(range(64 * 4))

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 outputs of tools/profile_all.sh into the two small files that are committed under profiles/:
+<tag>_pmc_summary.json (per-launch counter means of taco_step_kernel, HBM bytes per env-step with the gfx950 corrections of
+MI355X_MICROARCH.md) and <tag>_kernel_stats_bench_4096.csv (the --stats kernel table of the bench run)."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1]
+O = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+DROP = 3  # reset-all launch + warm-up
+
+
+def counters(d):
+    out = {}
+    for f in glob.glob(os.path.join(O, d, "*", "*counter_collection.csv")):
+        per = {}
+        for r in csv.DictReader(open(f)):
+            if "taco_step_kernel" not in r["Kernel_Name"]:
+                continue
+            per.setdefault(r["Counter_Name"], {}).setdefault(int(r["Dispatch_Id"]), 0.0)
+            per[r["Counter_Name"]][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
+        for name, by in per.items():
+            vals = [by[k] for k in sorted(by)][DROP:]
+            out[name] = {"launches_averaged": len(vals), "mean_per_launch": sum(vals) / max(len(vals), 1)}
+    return out
+
+
+S = {"sq_262144": counters(f"{tag}_pmc_sq_262144")}
+for n in (262144, 4096):
+    S[f"fetch_{n}"] = counters(f"{tag}_pmc_FETCH_SIZE_{n}")
+    S[f"write_{n}"] = counters(f"{tag}_pmc_WRITE_SIZE_{n}")
+der = {"note": "FETCH_SIZE/WRITE_SIZE are in KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of "
+               "16-B-per-lane coalesced reads); separate --pmc passes, first 3 launches (reset-all + warm-up) dropped"}
+for n in (262144, 4096):
+    try:
+        rd = S[f"fetch_{n}"]["FETCH_SIZE"]["mean_per_launch"] * 1024 * 2
+        wr = S[f"write_{n}"]["WRITE_SIZE"]["mean_per_launch"] * 1024
+        der[f"hbm_bytes_per_launch_{n}"] = rd + wr
+        der[f"hbm_bytes_per_env_step_{n}"] = (rd + wr) / n
+        der[f"read_B_per_env_step_{n}"] = rd / n
+        der[f"write_B_per_env_step_{n}"] = wr / n
+    except KeyError:
+        pass
+sq = S["sq_262144"]
+if "SQ_WAVES" in sq and sq["SQ_WAVES"]["mean_per_launch"]:
+    w = sq["SQ_WAVES"]["mean_per_launch"]
+    der["per_wave_262144"] = {k: v["mean_per_launch"] / w for k, v in sq.items() if k != "SQ_WAVES"}
+S["derived"] = der
+json.dump(S, open(os.path.join(O, f"{tag}_pmc_summary.json"), "w"), indent=1)
+for f in glob.glob(os.path.join(O, f"{tag}_stats", "*", "*kernel_stats.csv")):
+    shutil.copy(f, os.path.join(O, f"{tag}_kernel_stats_bench_4096.csv"))
+print(json.dumps(der, indent=1))

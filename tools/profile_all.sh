@@ -1,0 +1,23 @@
+#!/bin/bash
+# Reproduces everything under profiles/ for one build:  bash tools/profile_all.sh <tag>     (run ON the MI355X box, repo root)
+#   1. un-profiled bench line                          -> gpurun_out/<tag>_bench_4096.json
+#   2. rocprofv3 --kernel-trace --stats of the bench   -> gpurun_out/<tag>_stats/
+#   3. three separate --pmc passes (SQ set, FETCH_SIZE, WRITE_SIZE) at 262144 envs and FETCH/WRITE at 4096 envs
+#   4. tools/pmc_summary.py                            -> gpurun_out/<tag>_pmc_summary.json, <tag>_kernel_stats_bench_4096.csv
+# --pmc is never combined with any trace domain other than --kernel-trace; python3 is the program right after `--`.
+set -eo pipefail
+TAG=${1:-r01_x}
+R=$(pwd)
+O=$R/gpurun_out
+mkdir -p "$O"
+python3 bench.py --steps 2000 --warmup 200 > "$O/${TAG}_bench_4096.json" 2> "$O/${TAG}_bench.err"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${TAG}_stats" -- python3 "$R/bench.py" --steps 2000 --warmup 200 --no-cpu-baseline > "$O/${TAG}_bench_prof.json" 2> "$O/${TAG}_bench_prof.err"
+SQ="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_WAIT_ANY"
+rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d "$O/${TAG}_pmc_sq_262144" -- python3 "$R/tools/prof_step.py" --envs 262144 --steps 12 > "$O/${TAG}_pmc.log" 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/${TAG}_pmc_${c}_262144" -- python3 "$R/tools/prof_step.py" --envs 262144 --steps 12 >> "$O/${TAG}_pmc.log" 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/${TAG}_pmc_${c}_4096" -- python3 "$R/tools/prof_step.py" --envs 4096 --steps 40 >> "$O/${TAG}_pmc.log" 2>&1
+done
+cd "$R"
+python3 tools/pmc_summary.py "$TAG"
