@@ -199,6 +199,14 @@ int taco_set_state(taco_env *env, const uint32_t *blob, void *stream);
 /* Diagnostics for bench.py: name of the step kernel (as rocprofv3 reports it) and its launch geometry. */
 const char *taco_step_kernel_name(void);
 int taco_launch_geometry(const taco_env *env, int *grid, int *block);
+/* Introspection (profiling aid): bind a DEVICE array of 8 uint64; every following taco_step makes lane 0 of workgroup 0 record
+ * the shader clock (s_memtime) at: 0 kernel entry, 1 up-front loads landed, 2 pre-phase done (reset / delay line / slot table),
+ * 3 ten substeps done, 4 state stores + frame stacks done, 5 kernel end.  NULL unbinds.  Costs a scalar branch per phase. */
+int taco_bind_phase_stamps(taco_env *env, uint64_t *stamps);
+
+/* Introspection: workgroups of the step kernel the runtime can keep resident per CU, and the kernel's LDS bytes per
+ * workgroup (what bounds it). */
+int taco_occupancy(const taco_env *env, int *resident_blocks_per_cu, int *lds_bytes_per_block);
 
 #ifdef __cplusplus
 }

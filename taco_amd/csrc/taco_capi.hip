@@ -42,7 +42,10 @@ struct taco_env {
     int64_t step_count;
     int head;  // physical ring slot of logical slot 0; advances by 10 per step (mod 100)
     int hh;    // action-history row the next step writes; advances by 1 per step (mod 16)
+    int lpe;   // lanes per env of the step kernel this handle launches (1 or 4)
+    int block; // its workgroup size (64 or 256)
     float *gather;  // optional per-rank all-gather block, see taco_bind_gather_block
+    unsigned long long *stamps;  // optional phase stamps, see taco_bind_phase_stamps
     taco::StepParams P;
 };
 
@@ -214,12 +217,22 @@ __global__ void import_state_kernel(float *S, float *hist, float *ring, const ui
     }
 }
 
-int block_for(const taco_env *e) {
-    if (const char *f = std::getenv("TACO_FORCE_BLOCK")) {  // experiments only
-        const int b = std::atoi(f);
-        if (b == kBlockSmall || b == kBlockLarge) return b;
+// Launch geometry, fixed when the handle is created.  lanes per env: 4 (quad layout) while one lane per env would leave most
+// SIMDs without a wavefront (measured: 19.8 us vs 21.0 us at 16 384 envs, 24.6 us vs 22 us at 20 480); 256-thread workgroups from 65 536 envs.
+// TACO_FORCE_LPE / TACO_FORCE_BLOCK (read at taco_create) override the choice for experiments and for the LPE-equivalence test.
+constexpr int kQuadMaxEnvs = 16384;
+void choose_geometry(taco_env *e) {
+    e->lpe = e->cfg.num_envs <= kQuadMaxEnvs ? 4 : 1;
+    e->block = e->cfg.num_envs >= 65536 ? kBlockLarge : kBlockSmall;
+    if (const char *f = std::getenv("TACO_FORCE_LPE")) {
+        const int l = std::atoi(f);
+        if (l == 1 || l == 4) e->lpe = l;
     }
-    return e->cfg.num_envs >= 65536 ? kBlockLarge : kBlockSmall;
+    if (const char *f = std::getenv("TACO_FORCE_BLOCK")) {
+        const int b = std::atoi(f);
+        if (b == kBlockSmall || b == kBlockLarge) e->block = b;
+    }
+    if (e->lpe == 4) e->block = kBlockSmall;
 }
 
 }  // namespace
@@ -260,6 +273,8 @@ int taco_create(const taco_cfg *cfg, int device, void *workspace, size_t workspa
     e->head = 0;
     e->hh = 0;
     e->gather = nullptr;
+    e->stamps = nullptr;
+    choose_geometry(e);
     std::memset(&e->P, 0, sizeof(e->P));
     derive(e);
     hipLaunchKernelGGL(init_state_kernel, dim3((e->npad + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->S, e->hist, e->ring, e->npad,
@@ -288,6 +303,7 @@ int launch_step(taco_env *e, const taco_rollout_io *io, void *stream) {
     P.done_f32 = io->done_f32;
     P.reset = (long long *)io->reset_buf; P.timeout = io->timeout_buf;
     P.gather = e->gather;
+    P.stamps = e->stamps;
     P.step = (uint32_t)e->step_count;
     P.s_bytes = (uint32_t)((size_t)taco::NUM_CHUNKS * e->npad * 4 * sizeof(float));
     P.ring_bytes = (uint32_t)((size_t)TACO_RING_SLOTS * e->npad * 4 * sizeof(float));
@@ -299,10 +315,12 @@ int launch_step(taco_env *e, const taco_rollout_io *io, void *stream) {
     P.hh = e->hh;
     P.hist_bytes = (uint32_t)((size_t)taco::HIST_ROWS * e->npad * 4 * sizeof(float));
     const int n = e->cfg.num_envs;
-    if (block_for(e) == kBlockLarge)
-        hipLaunchKernelGGL(taco::taco_step_kernel<kBlockLarge>, dim3((n + kBlockLarge - 1) / kBlockLarge), dim3(kBlockLarge), 0, (hipStream_t)stream, P);
+    if (e->lpe == 4)
+        hipLaunchKernelGGL((taco::taco_step_kernel<kBlockSmall, 4>), dim3((n * 4 + kBlockSmall - 1) / kBlockSmall), dim3(kBlockSmall), 0, (hipStream_t)stream, P);
+    else if (e->block == kBlockLarge)
+        hipLaunchKernelGGL((taco::taco_step_kernel<kBlockLarge, 1>), dim3((n + kBlockLarge - 1) / kBlockLarge), dim3(kBlockLarge), 0, (hipStream_t)stream, P);
     else
-        hipLaunchKernelGGL(taco::taco_step_kernel<kBlockSmall>, dim3((n + kBlockSmall - 1) / kBlockSmall), dim3(kBlockSmall), 0, (hipStream_t)stream, P);
+        hipLaunchKernelGGL((taco::taco_step_kernel<kBlockSmall, 1>), dim3((n + kBlockSmall - 1) / kBlockSmall), dim3(kBlockSmall), 0, (hipStream_t)stream, P);
     hipError_t he = hipGetLastError();
     if (he != hipSuccess) return hip_fail(he, "taco_step_kernel launch");
     e->step_count += 1;
@@ -394,8 +412,32 @@ int taco_set_state(taco_env *e, const uint32_t *blob, void *stream) {
 
 int taco_launch_geometry(const taco_env *e, int *grid, int *block) {
     if (!e || !grid || !block) return fail(TACO_ERR_INVALID_ARG, "taco_launch_geometry: null argument");
-    *block = block_for(e);
-    *grid = (e->cfg.num_envs + *block - 1) / *block;
+    *block = e->block;
+    *grid = (e->cfg.num_envs * e->lpe + *block - 1) / *block;
+    return TACO_OK;
+}
+
+int taco_bind_phase_stamps(taco_env *e, uint64_t *stamps) {
+    if (!e) return fail(TACO_ERR_INVALID_ARG, "env is null");
+    if (stamps && ((uintptr_t)stamps & 7u) != 0) return fail(TACO_ERR_INVALID_ARG, "stamps must be 8-byte aligned");
+    e->stamps = (unsigned long long *)stamps;
+    return TACO_OK;
+}
+
+int taco_occupancy(const taco_env *e, int *resident_blocks_per_cu, int *lds_bytes_per_block) {
+    if (!e || !resident_blocks_per_cu || !lds_bytes_per_block) return fail(TACO_ERR_INVALID_ARG, "taco_occupancy: null argument");
+    const bool quad = e->lpe == 4;
+    const bool large = !quad && e->block == kBlockLarge;
+    const void *fn = quad ? (const void *)taco::taco_step_kernel<kBlockSmall, 4>
+                          : (large ? (const void *)taco::taco_step_kernel<kBlockLarge, 1> : (const void *)taco::taco_step_kernel<kBlockSmall, 1>);
+    hipFuncAttributes at;
+    hipError_t he = hipFuncGetAttributes(&at, fn);
+    if (he != hipSuccess) return hip_fail(he, "hipFuncGetAttributes");
+    *lds_bytes_per_block = (int)at.sharedSizeBytes;
+    if (quad) he = hipOccupancyMaxActiveBlocksPerMultiprocessor(resident_blocks_per_cu, taco::taco_step_kernel<kBlockSmall, 4>, kBlockSmall, 0);
+    else if (large) he = hipOccupancyMaxActiveBlocksPerMultiprocessor(resident_blocks_per_cu, taco::taco_step_kernel<kBlockLarge, 1>, kBlockLarge, 0);
+    else he = hipOccupancyMaxActiveBlocksPerMultiprocessor(resident_blocks_per_cu, taco::taco_step_kernel<kBlockSmall, 1>, kBlockSmall, 0);
+    if (he != hipSuccess) return hip_fail(he, "hipOccupancyMaxActiveBlocksPerMultiprocessor");
     return TACO_OK;
 }
 

@@ -31,6 +31,7 @@ struct StepParams {
     const float *obs_prev;    // frame stacks the len>1 shift reads (== obs / states for the in-place step; the previous
     const float *states_prev; //   replay-buffer slot for taco_step_rollout)
     float *done_f32;     // optional [n] f32 image of the new reset flags (PPOReplayBuffer.done_buf, buffer_asymmetry.py:67)
+    unsigned long long *stamps;  // optional [8]: shader-clock stamps of workgroup 0 at the phase boundaries (taco_bind_phase_stamps)
     float *gather;       // optional [n][len_obs*26 + 3] f32: obs stack | reward | done | time-out (one all-gather block per rank)
     // geometry / cfg
     int n, npad, env_offset, task_mode, mix_n1, mix_n2, len_obs, len_states, substeps, max_len, delay_time, head;
@@ -298,6 +299,83 @@ TD void integrate(const StepParams &P, V3 &p, Q4 &q, V3 &v, V3 &wb, V3 F, V3 tq)
     wb = V3{b0, b1, b2};
 }
 
+
+// ---- quad layout (LPE = 4 lanes per env, the latency regime): inside the substep loop lane j of an env's quad holds
+// component j of every vector (x y z [w], rotor j, PID axis j); cross-lane operands come from DPP quad_perm reads, which
+// ride on the consuming VALU instruction or cost one v_mov.  Every lane runs the scalar code's operation sequence for its
+// component, and every reduction adds in the scalar code's order, so the results are bit-identical to LPE = 1.
+constexpr int QP(int a, int b, int c, int d) { return a | (b << 2) | (c << 4) | (d << 6); }
+template <int CTRL> TD float dppf(float x) { return as_f(__builtin_amdgcn_update_dpp(0, as_i(x), CTRL, 0xf, 0xf, true)); }
+TD float bc0(float x) { return dppf<QP(0, 0, 0, 0)>(x); }
+TD float bc1(float x) { return dppf<QP(1, 1, 1, 1)>(x); }
+TD float bc2(float x) { return dppf<QP(2, 2, 2, 2)>(x); }
+TD float bc3(float x) { return dppf<QP(3, 3, 3, 3)>(x); }
+TD float rot1(float x) { return dppf<QP(1, 2, 0, 3)>(x); }  // lane j <- component (j + 1) mod 3
+TD float rot2(float x) { return dppf<QP(2, 0, 1, 3)>(x); }  // lane j <- component (j + 2) mod 3
+TD float swp(float x) { return dppf<QP(1, 0, 3, 2)>(x); }   // neighbour inside the pairs (0,1) (2,3)
+TD float xorf(float x, uint32_t m) { return from_bits(bits(x) ^ m); }
+TD float pick4(int sub, float a, float b, float c, float d) { return sub == 0 ? a : (sub == 1 ? b : (sub == 2 ? c : d)); }
+// select by a precomputed lane mask (all ones: take a): one v_bfi_b32, no VCC round trip, never a branch
+TD float selm(uint32_t m, float a, float b) { return from_bits((bits(a) & m) | (bits(b) & ~m)); }
+// component j of TU:58-68 quat_rotate((qv, w), v); qv / v hold components 0..2 in lanes 0..2
+TD float quad_rotate(float qv, float w, float v) {
+    const float s = 2.0f * (w * w) - 1.0f;
+    const float c = cross_term(rot1(qv), rot2(v), rot2(qv), rot1(v));
+    const float pr = qv * v;
+    const float dot = bc0(pr) + bc1(pr) + bc2(pr);
+    return v * s + c * w * 2.0f + qv * dot * 2.0f;
+}
+// row I (integrate above) in the quad layout.  qq = (x y z w) over the four lanes; pq vq bq Fq tqq components 0..2 in lanes 0..2.
+// Jq / hJiq: this lane's inertia terms; gzq = (-0, -0, g, -0) (fma(RF, 1/m, -0) == RF * (1/m) exactly); sm3 = sign bit in lane 3,
+// k3 = all ones in lane 3.
+TD void integrate_quad(const StepParams &P, uint32_t k3, float &pq, float &qq, float &vq, float &bq, float Fq, float tqq, float Jq, float hJiq,
+                       float gzq, uint32_t sm3) {
+    for (int it = 0; it < P.substeps; ++it) {
+        const float L = Jq * bq;
+        const float g = fma(rot1(bq), rot2(L), -(rot2(bq) * rot1(L)));
+        bq = fma(hJiq, tqq - g, bq);
+        const float ww = bc3(qq);
+        const float q1 = rot1(qq), q2 = rot2(qq);
+        float t = fma(q1, rot2(Fq), -(q2 * rot1(Fq)));
+        t = t + t;
+        const float RF = fma(q1, rot2(t), fma(-q2, rot1(t), fma(ww, t, Fq)));
+        vq = fma(P.h, fma(RF, P.inv_m, gzq), vq);
+        pq = fma(P.h, vq, pq);
+        const float sqb = bq * bq, b1 = bc1(bq), b2 = bc2(bq);
+        const float w2 = fma(b2, b2, fma(b1, b1, bc0(sqb)));
+        const float A2 = (P.half_h * P.half_h) * w2;
+        const float sp = fma(fma(fma(fma(2.7557319224e-6f, A2, -1.9841269841e-4f), A2, 8.3333333333e-3f), A2, -1.6666666667e-1f), A2, 1.0f);
+        float c = fma(fma(fma(fma(2.4801587302e-5f, A2, -1.3888888889e-3f), A2, 4.1666666667e-2f), A2, -0.5f), A2, 1.0f);
+        float k = P.half_h * sp;
+        const bool big = !(A2 <= 0.25f);
+        if (__builtin_amdgcn_ballot_w64(big)) {
+            const float wn = __builtin_sqrtf(w2);
+            float sn, cs;
+            sincos(P.half_h * wn, sn, cs);
+            float ks = sn / wn;
+            if (A2 != A2) { ks = nanf32(); cs = nanf32(); }
+            k = big ? ks : k;
+            c = big ? cs : c;
+        }
+        // n = q (x) (d, c): lanes 0..2  fma(w, d_j, fma(q_j, c, fma(q_j+1, d_j+2, -(q_j+2 * d_j+1))));
+        // lane 3  fma(w, c, -fma(x, dx, fma(y, dy, z * dz))) == fma(w, c, fma(-x, dx, fma(-y, dy, -(z * dz))))  (same shape)
+        const float d4 = selm(k3, c, bq * k);
+        const float Qn = xorf(dppf<QP(0, 1, 2, 0)>(qq), sm3), Cc = dppf<QP(3, 3, 3, 0)>(d4);
+        const float Qa = xorf(dppf<QP(1, 2, 0, 1)>(qq), sm3), Db = dppf<QP(2, 0, 1, 1)>(d4);
+        const float Qb = dppf<QP(2, 0, 1, 2)>(qq), Da = dppf<QP(1, 2, 0, 2)>(d4);
+        const float n = fma(ww, d4, fma(Qn, Cc, fma(Qa, Db, -(Qb * Da))));
+        const float nsq = n * n, n1 = bc1(n), n2_ = bc2(n), n3 = bc3(n);
+        const float n2 = fma(n3, n3, fma(n2_, n2_, fma(n1, n1, bc0(nsq))));
+        float inv = fma(-0.5f, n2, 1.5f);
+        const bool off = !(absf(n2 - 1.0f) <= 1e-3f);
+        if (__builtin_amdgcn_ballot_w64(off)) {
+            const float ie = 1.0f / __builtin_sqrtf(n2);
+            inv = off ? ie : inv;
+        }
+        qq = n * inv;
+    }
+}
+
 // reset_idx for one env (FA:475-517), in the reference's call order: reset_copter_idx -> reset_controller_idx ->
 // reset_env_idx -> reset_target_idx.  Every new value goes straight to the env's chunks; the 37 uniforms come from
 // 10 Philox blocks of STREAM_RESET, each generated where it is consumed.
@@ -432,22 +510,31 @@ TD void reset_env(const StepParams &P, rsrc_t rS, rsrc_t rR, uint32_t voff, uint
 // Two instantiations: BLOCK = 64 for the latency regime (few envs: one wavefront per workgroup, spread over as many CUs
 // as possible, registers unconstrained) and BLOCK = 256 for the throughput regime, where the register budget is capped
 // at 128 VGPRs so that 4 wavefronts per SIMD hide each other's dependent-issue latency.
-template <int BLOCK>
+// LPE (lanes per env) = 4: the third instantiation, for launches that cannot fill the chip with one lane per env (4 096 envs
+// = 64 wavefronts on 1 024 SIMDs).  A wavefront then carries 16 envs; everything outside the substep loop runs the scalar code
+// redundantly in the four lanes of an env (sub-lane 0 does the stores), the substep loop runs in the quad layout above.
+template <int BLOCK, int LPE>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 256 ? 4 : 1, BLOCK >= 256 ? 4 : 8))) void taco_step_kernel(const StepParams P) {
     // Per-wavefront LDS scratch, used for two things one after the other:
     //   substeps : the 10 pending-action slots this step consumes, slots[s][lane] as float4 (10 KiB) -- keeps 40 values
     //              out of the register file and lets substep k fetch its action with one ds_read_b128;
     //   post-step: the 64 x 26 frame tile that transposes lane-major registers into env-major bytes (6.5 KiB).
-    constexpr int WAVE_LDS_WORDS = 10 * 64 * 4;
-    static_assert(WAVE_LDS_WORDS >= 64 * 26, "tile must fit in the per-wave scratch");
+#define TACO_STAMP(k) do { if (P.stamps && blockIdx.x == 0 && threadIdx.x == 0) P.stamps[k] = __builtin_readcyclecounter(); } while (0)
+    TACO_STAMP(0);
+    constexpr int EPW = 64 / LPE;  // envs per wavefront
+    constexpr int WAVE_LDS_WORDS = 10 * EPW * 4;
+    static_assert(WAVE_LDS_WORDS >= EPW * 26, "tile must fit in the per-wave scratch");
     __shared__ __attribute__((aligned(16))) float lds_all[BLOCK / 64][WAVE_LDS_WORDS];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     float *tile = lds_all[wv];
     float4 *slots = reinterpret_cast<float4 *>(lds_all[wv]);
-    const int i_raw = blockIdx.x * BLOCK + threadIdx.x;
-    const bool active = i_raw < P.n;
-    const int i = active ? i_raw : P.n - 1;  // tail lanes shadow the last env and store nothing
+    const int sub = lane & (LPE - 1);  // lane inside the env's quad (0 when LPE == 1)
+    const int el = lane / LPE;         // env slot inside the wavefront
+    const int i_raw = (blockIdx.x * BLOCK + threadIdx.x) / LPE;
+    const bool in_range = i_raw < P.n;
+    const bool active = in_range && sub == 0;  // the lane that stores for its env
+    const int i = in_range ? i_raw : P.n - 1;  // tail lanes shadow the last env and store nothing
     const int gid = P.env_offset + i;
     const uint32_t voff = (uint32_t)i * 16u;            // this lane's byte offset inside every float4 row
     const uint32_t row_bytes = (uint32_t)P.npad * 16u;  // one float4 row (chunk or ring slot)
@@ -481,10 +568,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
     // temporaries stay live); a wavefront that holds a reset lane then simply loads its chunks again.
     if (__builtin_amdgcn_ballot_w64(is_reset)) {
         if (is_reset) reset_env(P, rS, rR, voff, row_bytes, gid, grp, mix, active);
+        if (LPE > 1) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // sub-lane 0 stored, the whole quad reloads
         c_pos = CLD(C_POS); c_quat = CLD(C_QUAT); c_lin = CLD(C_LINVEL); c_ang = CLD(C_ANGVEL);
         c_pp = CLD(C_PID_PREV); c_pi = CLD(C_PID_INT); c_om = CLD(C_OMEGA); c_que = CLD(C_QUEUE); c_misc = CLD(C_MISC);
         c_tau = CLD(C_TAU); c_op = CLD(C_OPARA); c_a0 = CLD(C_AERO0); c_a1 = CLD(C_AERO1);
     }
+    if (P.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TACO_STAMP(1); }  // all up-front loads have landed
     V3 p{c_pos.x, c_pos.y, c_pos.z};
     Q4 q{c_quat.x, c_quat.y, c_quat.z, c_quat.w};
     V3 v{c_lin.x, c_lin.y, c_lin.z};
@@ -612,7 +701,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
                 const bool fresh = (s >= dlen) && (s < dlen + T);             // covered by this step's write: from registers
                 o = sel4(dense, sel4(fresh, act4, r), o);
             }
-            slots[s * 64 + lane] = o;
+            slots[s * EPW + el] = o;
         }
     }
     if (!dense) {  // push the run (T, this action)
@@ -650,106 +739,228 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
     dlen += T;
 
     // ------------------------------------------------------------------ 10 x (mid_physics_step + simulate) VT:309-313
+    TACO_STAMP(2);  // pre-phase done
     const bool bat_on = (fl & TACO_F_BATTERY_CONSUMPTION) != 0;
     // the target pose is consumed only after the loop; issuing the loads here hides their latency behind the substeps
     const float4 c_tp = CLD(C_TGT_POS), c_tq = CLD(C_TGT_QUAT);
     V3 wb = quat_rotate(conj(q), w);  // body-frame angular velocity of the root state (FA:350); row I carries it from here on
-#pragma unroll 1
-    for (int ks = 0; ks < 10; ++ks) {
-        // refresh_state, the part the inner loop consumes FA:339-350
-        if (wave_tracks_rpy) {
-            V3 e = euler_xyz_v1(q);
-            unwrap(e.x, rpy_old[0], rpy_cont[0]);
-            unwrap(e.y, rpy_old[1], rpy_cont[1]);
-            unwrap(e.z, rpy_old[2], rpy_cont[2]);
-        }
-        Q4 cq = conj(q);
-        V3 vb = quat_rotate(cq, v);
-        // delayed action FA:366: slot min(L-1, ks); L >= 9 here, so only ks == 9 can be clipped (to slot 8)
-        const int idx = (dlen - 1 < ks) ? dlen - 1 : ks;
-        const float4 dact = slots[idx * 64 + lane];
-        const float d0 = dact.x, d1 = dact.y, d2 = dact.z, d3 = dact.w;
-        // angular_vel_control FA:637-650
-        float u0 = (d0 + 1.0f) / 2.0f * 1000.0f;
-        float u1 = pid_axis(P.dt, P.rdt, 27.5f, d1 * 20.0f, wb.x, pid_prev[0], pid_int[0]);
-        float u2 = pid_axis(P.dt, P.rdt, 50.0f, d2 * 20.0f, wb.y, pid_prev[1], pid_int[1]);
-        float u3 = pid_axis(P.dt, P.rdt, 200.0f, d3 * 20.0f, wb.z, pid_prev[2], pid_int[2]);
-        // control_allocator CTRL/fpv_dynamics.py:35-46
-        u3 = clampf(u3, -u0 / 2.0f, u0 / 2.0f);
-        float f0 = ((u0 * 1.0f + u1 * -1.0f) + u2 * 1.0f) + u3 * -1.0f;
-        float f1 = ((u0 * 1.0f + u1 * -1.0f) + u2 * -1.0f) + u3 * 1.0f;
-        float f2 = ((u0 * 1.0f + u1 * 1.0f) + u2 * -1.0f) + u3 * -1.0f;
-        float f3 = ((u0 * 1.0f + u1 * 1.0f) + u2 * 1.0f) + u3 * 1.0f;
-        float mx = f0 - 1000.0f, t1 = f1 - 1000.0f, t2 = f2 - 1000.0f, t3 = f3 - 1000.0f;
-        mx = (t1 > mx || t1 != t1) ? t1 : mx;
-        mx = (t2 > mx || t2 != t2) ? t2 : mx;
-        mx = (t3 > mx || t3 != t3) ? t3 : mx;
-        float ex = (mx < 0.0f) ? 0.0f : mx;
-        float thr[4] = {clamp_const(f0 - ex, 100.0f, 1000.0f), clamp_const(f1 - ex, 100.0f, 1000.0f), clamp_const(f2 - ex, 100.0f, 1000.0f),
-                        clamp_const(f3 - ex, 100.0f, 1000.0f)};
-        // mechanical power FA:614
-        float Pm;
-        {
-            float b = TACO_DIVC(omega[0] * 2.0f * kPi, 4500.0f); Pm = 400.0f * ((b * b) * b);
-            b = TACO_DIVC(omega[1] * 2.0f * kPi, 4500.0f); Pm = Pm + 400.0f * ((b * b) * b);
-            b = TACO_DIVC(omega[2] * 2.0f * kPi, 4500.0f); Pm = Pm + 400.0f * ((b * b) * b);
-            b = TACO_DIVC(omega[3] * 2.0f * kPi, 4500.0f); Pm = Pm + 400.0f * ((b * b) * b);
-        }
-        // Battery_Dynamics.sim_process CTRL/battery_dynamics.py:47-75
-        if (bat_on) {
-            bat_t = bat_t + P.dt;
-            float p_c = TACO_DIVC(TACO_DIVC(Pm, 0.75f), 9000.0f);
-            bat_E = bat_E + p_c * P.dt;
-            float P_avg = bat_E / bat_t;
-            float r0_ = 0.0015778f + -7.7608e-5f * P_avg + (float)(0.0069498 * 1500.0);
-            float r0 = (r0_ > 4.5f) ? r0_ : 4.5f;
-            float uo = 4.35f + -0.1102178f * bat_E + 0.0103368f * (bat_E * bat_E) + -4.3778e-4f * ((bat_E * bat_E) * bat_E);
-            float u1_dot = TACO_DIVC(0.00104846f * p_c - bat_u1, 3.3f);
-            bat_u1 = bat_u1 + u1_dot * P.dt;
-            float dd = uo - bat_u1;
-            float rad = dd * dd - 4.0f * r0 * p_c;
-            bat_V = 0.5f * (dd + __builtin_sqrtf(rad)) * 6.0f;
-        } else {
-            bat_V = 4.35f * 6.0f;
-        }
-        // RotorDynamics.sim_process CTRL/thrust_dynamics.py:98-104
-        {
-            float y = TACO_DIVC(bat_V - 23.0f, 3.0f);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float x = TACO_DIVC(thr[k], 1000.0f);
-                float target = (opara[0] * 1.0f + opara[1] * x + opara[2] * y + opara[3] * (x * x) + opara[4] * x * y) * 100.0f;
-                omega[k] = omega[k] + (1.0f / tau[k]) * 0.001f * (target - omega[k]);
+    if constexpr (LPE == 1) {
+    #pragma unroll 1
+        for (int ks = 0; ks < 10; ++ks) {
+            // refresh_state, the part the inner loop consumes FA:339-350
+            if (wave_tracks_rpy) {
+                V3 e = euler_xyz_v1(q);
+                unwrap(e.x, rpy_old[0], rpy_cont[0]);
+                unwrap(e.y, rpy_old[1], rpy_cont[1]);
+                unwrap(e.z, rpy_old[2], rpy_cont[2]);
             }
+            Q4 cq = conj(q);
+            V3 vb = quat_rotate(cq, v);
+            // delayed action FA:366: slot min(L-1, ks); L >= 9 here, so only ks == 9 can be clipped (to slot 8)
+            const int idx = (dlen - 1 < ks) ? dlen - 1 : ks;
+            const float4 dact = slots[idx * EPW + el];
+            const float d0 = dact.x, d1 = dact.y, d2 = dact.z, d3 = dact.w;
+            // angular_vel_control FA:637-650
+            float u0 = (d0 + 1.0f) / 2.0f * 1000.0f;
+            float u1 = pid_axis(P.dt, P.rdt, 27.5f, d1 * 20.0f, wb.x, pid_prev[0], pid_int[0]);
+            float u2 = pid_axis(P.dt, P.rdt, 50.0f, d2 * 20.0f, wb.y, pid_prev[1], pid_int[1]);
+            float u3 = pid_axis(P.dt, P.rdt, 200.0f, d3 * 20.0f, wb.z, pid_prev[2], pid_int[2]);
+            // control_allocator CTRL/fpv_dynamics.py:35-46
+            u3 = clampf(u3, -u0 / 2.0f, u0 / 2.0f);
+            float f0 = ((u0 * 1.0f + u1 * -1.0f) + u2 * 1.0f) + u3 * -1.0f;
+            float f1 = ((u0 * 1.0f + u1 * -1.0f) + u2 * -1.0f) + u3 * 1.0f;
+            float f2 = ((u0 * 1.0f + u1 * 1.0f) + u2 * -1.0f) + u3 * -1.0f;
+            float f3 = ((u0 * 1.0f + u1 * 1.0f) + u2 * 1.0f) + u3 * 1.0f;
+            float mx = f0 - 1000.0f, t1 = f1 - 1000.0f, t2 = f2 - 1000.0f, t3 = f3 - 1000.0f;
+            mx = (t1 > mx || t1 != t1) ? t1 : mx;
+            mx = (t2 > mx || t2 != t2) ? t2 : mx;
+            mx = (t3 > mx || t3 != t3) ? t3 : mx;
+            float ex = (mx < 0.0f) ? 0.0f : mx;
+            float thr[4] = {clamp_const(f0 - ex, 100.0f, 1000.0f), clamp_const(f1 - ex, 100.0f, 1000.0f), clamp_const(f2 - ex, 100.0f, 1000.0f),
+                            clamp_const(f3 - ex, 100.0f, 1000.0f)};
+            // mechanical power FA:614
+            float Pm;
+            {
+                float b = TACO_DIVC(omega[0] * 2.0f * kPi, 4500.0f); Pm = 400.0f * ((b * b) * b);
+                b = TACO_DIVC(omega[1] * 2.0f * kPi, 4500.0f); Pm = Pm + 400.0f * ((b * b) * b);
+                b = TACO_DIVC(omega[2] * 2.0f * kPi, 4500.0f); Pm = Pm + 400.0f * ((b * b) * b);
+                b = TACO_DIVC(omega[3] * 2.0f * kPi, 4500.0f); Pm = Pm + 400.0f * ((b * b) * b);
+            }
+            // Battery_Dynamics.sim_process CTRL/battery_dynamics.py:47-75
+            if (bat_on) {
+                bat_t = bat_t + P.dt;
+                float p_c = TACO_DIVC(TACO_DIVC(Pm, 0.75f), 9000.0f);
+                bat_E = bat_E + p_c * P.dt;
+                float P_avg = bat_E / bat_t;
+                float r0_ = 0.0015778f + -7.7608e-5f * P_avg + (float)(0.0069498 * 1500.0);
+                float r0 = (r0_ > 4.5f) ? r0_ : 4.5f;
+                float uo = 4.35f + -0.1102178f * bat_E + 0.0103368f * (bat_E * bat_E) + -4.3778e-4f * ((bat_E * bat_E) * bat_E);
+                float u1_dot = TACO_DIVC(0.00104846f * p_c - bat_u1, 3.3f);
+                bat_u1 = bat_u1 + u1_dot * P.dt;
+                float dd = uo - bat_u1;
+                float rad = dd * dd - 4.0f * r0 * p_c;
+                bat_V = 0.5f * (dd + __builtin_sqrtf(rad)) * 6.0f;
+            } else {
+                bat_V = 4.35f * 6.0f;
+            }
+            // RotorDynamics.sim_process CTRL/thrust_dynamics.py:98-104
+            {
+                float y = TACO_DIVC(bat_V - 23.0f, 3.0f);
+    #pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float x = TACO_DIVC(thr[k], 1000.0f);
+                    float target = (opara[0] * 1.0f + opara[1] * x + opara[2] * y + opara[3] * (x * x) + opara[4] * x * y) * 100.0f;
+                    omega[k] = omega[k] + (1.0f / tau[k]) * 0.001f * (target - omega[k]);
+                }
+            }
+            if (fl & TACO_F_ROTOR_NOISE) {  // CTRL/thrust_dynamics.py:68-78
+                U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, P.step, STREAM_ROTOR, (uint32_t)ks);
+                const float n_sc = (float)((1 + 10.0 / 700) - (1 - 10.0 / 700)), n_lo = (float)(1 - 10.0 / 700);
+                omega[0] = omega[0] * (n_sc * uniform(r.x) + n_lo);
+                omega[1] = omega[1] * (n_sc * uniform(r.y) + n_lo);
+                omega[2] = omega[2] * (n_sc * uniform(r.z) + n_lo);
+                omega[3] = omega[3] * (n_sc * uniform(r.w) + n_lo);
+            }
+            // AeroDynamics.sim_process CTRL/thrust_dynamics.py:173-199 + real->sim re-index CTRL/fpv_dynamics.py:48-56
+            float rf[4], rt[4];
+    #pragma unroll
+            for (int k = 0; k < 4; ++k) { rf[k] = cf * omega[k] * omega[k]; rt[k] = ct * rf[k]; }
+            float vxy = norm2(vb.x, vb.y);
+            V3 F, tq;
+            {
+                const float fs0 = rf[2], fs1 = rf[3], fs2 = rf[0], fs3 = rf[1];
+                const float ts0 = -rt[2], ts1 = rt[3], ts2 = -rt[0], ts3 = rt[1];
+                F.x = dx * vb.x;
+                F.y = dy * vb.y;
+                F.z = kt * vxy * vxy + ((fs0 + fs1) + (fs2 + fs3));
+                tq.x = P.arm_y * ((fs0 + fs1) - (fs2 + fs3));
+                tq.y = -P.arm_x * ((fs0 - fs1) - (fs2 - fs3));
+                tq.z = (ts0 + ts1) + (ts2 + ts3);
+            }
+            if (is_reset) { F = V3{0.0f, 0.0f, 0.0f}; tq = V3{0.0f, 0.0f, 0.0f}; }  // FA:629-630: no force during the reset step
+            integrate(P, p, q, v, wb, F, tq);
         }
-        if (fl & TACO_F_ROTOR_NOISE) {  // CTRL/thrust_dynamics.py:68-78
-            U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, P.step, STREAM_ROTOR, (uint32_t)ks);
-            const float n_sc = (float)((1 + 10.0 / 700) - (1 - 10.0 / 700)), n_lo = (float)(1 - 10.0 / 700);
-            omega[0] = omega[0] * (n_sc * uniform(r.x) + n_lo);
-            omega[1] = omega[1] * (n_sc * uniform(r.y) + n_lo);
-            omega[2] = omega[2] * (n_sc * uniform(r.z) + n_lo);
-            omega[3] = omega[3] * (n_sc * uniform(r.w) + n_lo);
+
+    } else {
+        // ---- quad layout: scatter (lane j keeps component j), run the ten substeps, gather back
+        float pq = pick4(sub, p.x, p.y, p.z, 0.0f), qq = pick4(sub, q.x, q.y, q.z, q.w), vq = pick4(sub, v.x, v.y, v.z, 0.0f);
+        float bq = pick4(sub, wb.x, wb.y, wb.z, 0.0f);
+        float ppq = pick4(sub, pid_prev[0], pid_prev[1], pid_prev[2], 0.0f), piq = pick4(sub, pid_int[0], pid_int[1], pid_int[2], 0.0f);
+        float omq = pick4(sub, omega[0], omega[1], omega[2], omega[3]);
+        float roq = pick4(sub, rpy_old[0], rpy_old[1], rpy_old[2], 0.0f), rcq = pick4(sub, rpy_cont[0], rpy_cont[1], rpy_cont[2], 0.0f);
+        const float itq = (1.0f / pick4(sub, tau[0], tau[1], tau[2], tau[3])) * 0.001f;
+        const float kpq = pick4(sub, 27.5f, 50.0f, 200.0f, 0.0f);
+        const float Jq = pick4(sub, P.J0, P.J1, P.J2, 0.0f), hJiq = pick4(sub, P.hJi0, P.hJi1, P.hJi2, 0.0f);
+        const float gzq = pick4(sub, -0.0f, -0.0f, P.g, -0.0f);
+        const float dragq = pick4(sub, dx, dy, 0.0f, 0.0f);
+        const uint32_t sgn = 0x80000000u;
+        const uint32_t m1 = (sub < 2) ? sgn : 0u;               // allocator column of u1: - - + +
+        const uint32_t m2 = (sub == 1 || sub == 2) ? sgn : 0u;  //                     u2: + - - +
+        const uint32_t m3 = (sub == 0 || sub == 2) ? sgn : 0u;  //                     u3: - + - +   (also the sign of ts: -rt0 rt1 -rt2 rt3)
+        const uint32_t sm3 = (sub == 3) ? sgn : 0u;
+        const uint32_t k2 = (sub == 2) ? ~0u : 0u, k3 = (sub == 3) ? ~0u : 0u, keven = (sub & 1) ? 0u : ~0u;
+        const uint32_t keep = is_reset ? 0u : ~0u;  // FA:629-630: no force during the reset step
+        const float Sq = pick4(sub, P.arm_y, -P.arm_x, 1.0f, 1.0f);
+        const float *slotsf = reinterpret_cast<const float *>(slots);
+#pragma unroll 1
+        for (int ks = 0; ks < 10; ++ks) {
+            if (wave_tracks_rpy) {  // refresh_state FA:339-347: every lane evaluates the three angles, lane j unwraps angle j
+                const V3 e = euler_xyz_v1(Q4{bc0(qq), bc1(qq), bc2(qq), bc3(qq)});
+                unwrap(pick4(sub, e.x, e.y, e.z, 0.0f), roq, rcq);
+            }
+            const float vbq = quad_rotate(-qq, bc3(qq), vq);  // FA:350 body-frame linear velocity
+            const int idx = (dlen - 1 < ks) ? dlen - 1 : ks;
+            const float dq = slotsf[(idx * EPW + el) * 4 + sub];
+            const float d0 = bc0(dq);
+            // angular_vel_control FA:637-650: lane j runs PID axis j on action component j + 1
+            const float u0 = (d0 + 1.0f) / 2.0f * 1000.0f;
+            const float upid = pid_axis(P.dt, P.rdt, kpq, dppf<QP(1, 2, 3, 3)>(dq) * 20.0f, bq, ppq, piq);
+            // control_allocator CTRL/fpv_dynamics.py:35-46: lane k computes motor k
+            const float u1 = bc0(upid), u2 = bc1(upid);
+            float u3 = bc2(upid);
+            u3 = clampf(u3, -u0 / 2.0f, u0 / 2.0f);
+            const float fq = ((u0 * 1.0f + xorf(u1, m1)) + xorf(u2, m2)) + xorf(u3, m3);
+            const float tm = fq - 1000.0f;
+            float mx = bc0(tm);
+            { const float t1 = bc1(tm); mx = (t1 > mx || t1 != t1) ? t1 : mx; }
+            { const float t2 = bc2(tm); mx = (t2 > mx || t2 != t2) ? t2 : mx; }
+            { const float t3 = bc3(tm); mx = (t3 > mx || t3 != t3) ? t3 : mx; }
+            const float ex = (mx < 0.0f) ? 0.0f : mx;
+            const float thrq = clamp_const(fq - ex, 100.0f, 1000.0f);
+            // mechanical power FA:614
+            float Pm;
+            {
+                const float b = TACO_DIVC(omq * 2.0f * kPi, 4500.0f);
+                const float c3 = 400.0f * ((b * b) * b);
+                Pm = bc0(c3);
+                Pm = Pm + bc1(c3);
+                Pm = Pm + bc2(c3);
+                Pm = Pm + bc3(c3);
+            }
+            // Battery_Dynamics.sim_process CTRL/battery_dynamics.py:47-75 (replicated in the quad)
+            if (bat_on) {
+                bat_t = bat_t + P.dt;
+                float p_c = TACO_DIVC(TACO_DIVC(Pm, 0.75f), 9000.0f);
+                bat_E = bat_E + p_c * P.dt;
+                float P_avg = bat_E / bat_t;
+                float r0_ = 0.0015778f + -7.7608e-5f * P_avg + (float)(0.0069498 * 1500.0);
+                float r0 = (r0_ > 4.5f) ? r0_ : 4.5f;
+                float uo = 4.35f + -0.1102178f * bat_E + 0.0103368f * (bat_E * bat_E) + -4.3778e-4f * ((bat_E * bat_E) * bat_E);
+                float u1_dot = TACO_DIVC(0.00104846f * p_c - bat_u1, 3.3f);
+                bat_u1 = bat_u1 + u1_dot * P.dt;
+                float dd = uo - bat_u1;
+                float rad = dd * dd - 4.0f * r0 * p_c;
+                bat_V = 0.5f * (dd + __builtin_sqrtf(rad)) * 6.0f;
+            } else {
+                bat_V = 4.35f * 6.0f;
+            }
+            // RotorDynamics.sim_process CTRL/thrust_dynamics.py:98-104: lane k = rotor k
+            {
+                const float y = TACO_DIVC(bat_V - 23.0f, 3.0f);
+                const float x = TACO_DIVC(thrq, 1000.0f);
+                const float target = (opara[0] * 1.0f + opara[1] * x + opara[2] * y + opara[3] * (x * x) + opara[4] * x * y) * 100.0f;
+                omq = omq + itq * (target - omq);
+            }
+            if (fl & TACO_F_ROTOR_NOISE) {  // CTRL/thrust_dynamics.py:68-78
+                U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, P.step, STREAM_ROTOR, (uint32_t)ks);
+                const float n_sc = (float)((1 + 10.0 / 700) - (1 - 10.0 / 700)), n_lo = (float)(1 - 10.0 / 700);
+                const uint32_t rk = sub == 0 ? r.x : (sub == 1 ? r.y : (sub == 2 ? r.z : r.w));
+                omq = omq * (n_sc * uniform(rk) + n_lo);
+            }
+            // AeroDynamics.sim_process CTRL/thrust_dynamics.py:173-199 + real->sim re-index CTRL/fpv_dynamics.py:48-56
+            // fs = (rf2 rf3 rf0 rf1), ts = (-rt2 rt3 -rt0 rt1): the pair sums live in lanes (2,3) and (0,1)
+            float Fq, tqq;
+            {
+                const float rf = cf * omq * omq;
+                const float rt = ct * rf;
+                const float vxy = norm2(bc0(vbq), bc1(vbq));
+                const float psum = rf + swp(rf);          // lanes 0,1: rf0 + rf1   lanes 2,3: rf2 + rf3
+                const float pdif = rf - swp(rf);          // lane 0: rf0 - rf1      lane 2: rf2 - rf3
+                const float srt = xorf(rt, m3);           // -rt0 rt1 -rt2 rt3
+                const float pz = srt + swp(srt);          // lanes 0,1: -rt0 + rt1  lanes 2,3: -rt2 + rt3
+                const float Fz = kt * vxy * vxy + (bc2(psum) + bc0(psum));
+                // tq.x = arm_y ((fs0+fs1) - (fs2+fs3)), tq.y = -arm_x ((fs0-fs1) - (fs2-fs3)): lane 0 / 1 read the pair terms of
+                // M = (pdif psum pdif psum) from lanes (3,1) / (2,0); tq.z = (ts0+ts1) + (ts2+ts3)
+                const float M = selm(keven, pdif, psum);
+                const float txy = Sq * (dppf<QP(3, 2, 2, 2)>(M) - dppf<QP(1, 0, 0, 0)>(M));
+                const float tz = bc2(pz) + bc0(pz);
+                Fq = from_bits(bits(selm(k2, Fz, dragq * vbq)) & keep);
+                tqq = from_bits(bits(selm(k2, tz, txy)) & keep);
+            }
+            integrate_quad(P, k3, pq, qq, vq, bq, Fq, tqq, Jq, hJiq, gzq, sm3);
         }
-        // AeroDynamics.sim_process CTRL/thrust_dynamics.py:173-199 + real->sim re-index CTRL/fpv_dynamics.py:48-56
-        float rf[4], rt[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { rf[k] = cf * omega[k] * omega[k]; rt[k] = ct * rf[k]; }
-        float vxy = norm2(vb.x, vb.y);
-        V3 F, tq;
-        {
-            const float fs0 = rf[2], fs1 = rf[3], fs2 = rf[0], fs3 = rf[1];
-            const float ts0 = -rt[2], ts1 = rt[3], ts2 = -rt[0], ts3 = rt[1];
-            F.x = dx * vb.x;
-            F.y = dy * vb.y;
-            F.z = kt * vxy * vxy + ((fs0 + fs1) + (fs2 + fs3));
-            tq.x = P.arm_y * ((fs0 + fs1) - (fs2 + fs3));
-            tq.y = -P.arm_x * ((fs0 - fs1) - (fs2 - fs3));
-            tq.z = (ts0 + ts1) + (ts2 + ts3);
-        }
-        if (is_reset) { F = V3{0.0f, 0.0f, 0.0f}; tq = V3{0.0f, 0.0f, 0.0f}; }  // FA:629-630: no force during the reset step
-        integrate(P, p, q, v, wb, F, tq);
+        p = V3{bc0(pq), bc1(pq), bc2(pq)};
+        q = Q4{bc0(qq), bc1(qq), bc2(qq), bc3(qq)};
+        v = V3{bc0(vq), bc1(vq), bc2(vq)};
+        wb = V3{bc0(bq), bc1(bq), bc2(bq)};
+        pid_prev[0] = bc0(ppq); pid_prev[1] = bc1(ppq); pid_prev[2] = bc2(ppq);
+        pid_int[0] = bc0(piq); pid_int[1] = bc1(piq); pid_int[2] = bc2(piq);
+        omega[0] = bc0(omq); omega[1] = bc1(omq); omega[2] = bc2(omq); omega[3] = bc3(omq);
+        rpy_old[0] = bc0(roq); rpy_old[1] = bc1(roq); rpy_old[2] = bc2(roq);
+        rpy_cont[0] = bc0(rcq); rpy_cont[1] = bc1(rcq); rpy_cont[2] = bc2(rcq);
     }
 
+    TACO_STAMP(3);  // substeps done
     w = quat_sandwich(q, wb);  // root state: world-frame angular velocity
 
     // ------------------------------------------------------------------ post_physics_step FA:374-388
@@ -830,20 +1041,23 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
     //             (lane-major registers -> env-major bytes) and leave as seven fully coalesced 16-byte-per-lane stores.
     //  len  > 1 : each lane shifts its own row by one frame (8-byte accesses, in place, ascending) and appends the frame.
     // Stores go through range-checked buffer descriptors, so ragged tails need no special casing.
-    const uint32_t wave_env0 = (uint32_t)(blockIdx.x * BLOCK + wv * 64);
+    const uint32_t wave_env0 = (uint32_t)((blockIdx.x * BLOCK + wv * 64) / LPE);
     auto put_frame = [&](float *buf, const float *prev, uint32_t buf_bytes, int len, const float (&f)[26]) {
         const rsrc_t rB = make_rsrc(buf, buf_bytes);
         if (len == 1) {
             __syncthreads();  // previous users of the scratch (action slots / the other buffer's tile) are done
-            f32x2_t *t2 = reinterpret_cast<f32x2_t *>(tile + lane * 26);  // 104-byte rows: 8-byte aligned
+            f32x2_t *t2 = reinterpret_cast<f32x2_t *>(tile + el * 26);  // 104-byte rows: 8-byte aligned
+            if (sub == 0) {
 #pragma unroll
-            for (int k = 0; k < 13; ++k) t2[k] = f32x2_t{f[2 * k], f[2 * k + 1]};
+                for (int k = 0; k < 13; ++k) t2[k] = f32x2_t{f[2 * k], f[2 * k + 1]};
+            }
             __syncthreads();
             const f32x4_t *t4 = reinterpret_cast<const f32x4_t *>(tile);
+            constexpr uint32_t TILE_W4 = (uint32_t)EPW * 26u / 4u;  // 16-byte words of the wave's contiguous range (416 or 104)
 #pragma unroll
-            for (int it = 0; it < 7; ++it) {
-                const uint32_t w4 = (uint32_t)(it * 64 + lane);  // 16-byte word inside the wave's 416-word range
-                if (w4 < 416u) llvm_amdgcn_raw_buffer_store_v4f32(t4[w4], rB, (int)(wave_env0 * 104u + w4 * 16u), 0, 0);
+            for (int it = 0; it < (int)((TILE_W4 + 63u) / 64u); ++it) {
+                const uint32_t w4 = (uint32_t)(it * 64 + lane);
+                if (w4 < TILE_W4) llvm_amdgcn_raw_buffer_store_v4f32(t4[w4], rB, (int)(wave_env0 * 104u + w4 * 16u), 0, 0);
             }
         } else if (active) {
             const uint32_t row0 = (uint32_t)i * (uint32_t)len * 104u;
@@ -891,6 +1105,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
     }
     put_frame(P.obs, P.obs_prev, P.obs_bytes, P.len_obs, fr);
 
+    TACO_STAMP(4);  // state stores + frames done
     // ------------------------------------------------------------------ compute_reward CTRL/task_reward.py
     float rew, pos_dist;
     if (grp == TACO_TASK_POS) {  // :20-47
@@ -964,6 +1179,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
         }
         CST(C_MISC, make_float4(bat_t, cmd0, cmd1, flip_radian));
     }
+    TACO_STAMP(5);
+#undef TACO_STAMP
 }
 
 }  // namespace taco

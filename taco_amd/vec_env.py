@@ -209,6 +209,28 @@ class FpvBase:
         return g.value, b.value
 
 
+    def phase_stamps(self, actions, steps=20):
+        """Profiling aid: run `steps` steps with the phase stamps bound and return the mean shader-clock ticks between the
+        phase boundaries of workgroup 0 (entry->loads, ->pre-phase, ->substeps, ->stores+frames, ->end)."""
+        st = torch.zeros(8, dtype=torch.int64, device=self.device)
+        _lib.check(self.lib.taco_bind_phase_stamps(self._h, st.data_ptr()))
+        acc = torch.zeros(5, dtype=torch.float64)
+        try:
+            for _ in range(steps):
+                self.step_raw(actions)
+                t = st.cpu()
+                acc += (t[1:6] - t[0:5]).double()
+        finally:
+            _lib.check(self.lib.taco_bind_phase_stamps(self._h, None))
+        return (acc / steps).tolist()
+
+    def occupancy(self):
+        """(resident workgroups per CU, LDS bytes per workgroup) of the step kernel this env launches"""
+        b, l = C.c_int(), C.c_int()
+        _lib.check(self.lib.taco_occupancy(self._h, C.byref(b), C.byref(l)))
+        return b.value, l.value
+
+
 class FpvPos(FpvBase):
     task_mode = "pos"
 

@@ -1,0 +1,14 @@
+"""Phase breakdown of one step launch (shader-clock ticks of workgroup 0, see taco_bind_phase_stamps)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from taco_amd import config
+from taco_amd.vec_env import FpvBase
+for n in [int(x) for x in sys.argv[1:]] or (4096,):
+    env = FpvBase(config.baseline_config(1, num_envs=n), copy_outputs=False)
+    a = (0.3 * torch.randn((n, 4)) + torch.tensor([-0.45, 0, 0, 0])).clamp(-1, 1).cuda()
+    for _ in range(30): env.step_raw(a)
+    ph = env.phase_stamps(a, 50)
+    # calibrate ticks: time a long run of steps with events and compare with the stamped total of the same launches
+    tot = sum(ph)
+    print(f"N={n} geometry={env.launch_geometry()} ticks: loads={ph[0]:.0f} pre={ph[1]:.0f} substeps={ph[2]:.0f} stores+frames={ph[3]:.0f} reward+out={ph[4]:.0f} total={tot:.0f}", flush=True)
