@@ -249,11 +249,12 @@ def main():
                        "envs_per_gpu": n_local, "envs_total": n_global, "parallelism": f"env-sharded x{world}",
                        "collective": ("1 RCCL all-gather of [obs|rew|done|timeout] per step" if (world > 1 and args.gather) else
                                       "none in the timed region: envs are independent, each rank steps its own slice"),
-                       "kernel": base.lib.taco_step_kernel_name().decode(), "grid": grid, "block": block},
+                       "kernel": base.lib.taco_step_kernel_name().decode(), "grid": grid, "block": block,
+                       "lanes_per_env": 4 if grid * block >= 4 * n_local else 1},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel_avg_us": k_avg_us, "kernel_bracketed_median_us": k_med_us,
                          "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
-                         "note": "4096 envs = 64 wavefronts on 256 CUs: latency-bound regime, see large_n for the bandwidth regime"},
+                         "note": "4096 envs = 256 wavefronts (4 lanes per env) on 1024 SIMDs, one lone wavefront per CU: instruction-latency regime, see large_n for the throughput regime"},
             "gpu_event_ms_per_step": ev0.elapsed_time(ev1) / args.steps,
         }
         if with_gather is not None:
