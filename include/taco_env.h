@@ -177,6 +177,27 @@ size_t taco_gae_workspace_bytes(void);
 int taco_gae(const float *rew, const float *done, const float *value, const float *last_value, int horizon, int num_envs,
              double gamma, double lam, float *adv, float *ret, int normalize, void *workspace, void *stream);
 
+/* PPO_ActorCritic.act (algorithms/nets_asymmetry.py:326-355) for the documented configuration (README.md:60-66): actor = MLP on
+ * the observation stack (ReLU hidden layers, tanh head), critic = 1-layer unidirectional LSTM over the state stack (lstm_hidden > 0;
+ * 0 = no encoder, the MLP takes the flattened stack) + MLP (ReLU, linear head).  One launch; f32 MFMA, f32 throughout.
+ *   blob    taco_policy_blob_floats(cfg) floats, 16-byte aligned: every matrix zero-padded to multiples of 16 ([OUTp][INp] row-major, bias
+ *           [OUTp]) in the order actor layers | log_std[16] | LSTM W_ih[4][Hp][Ip], W_hh[4][Hp][Hp], (b_ih + b_hh)[4][Hp] (gates i f g o) |
+ *           critic layers                                                     (taco_amd/policy.py::pack_state_dict builds it from a state_dict)
+ *   obs [n][obs_len][obs_dim], states [n][states_len][states_dim]             f32 in
+ *   action, mu, sigma [n][act_dim]; logp [n]; value [n]                       f32 out.  sigma = log_std repeated, as the reference returns it;
+ *           the distribution is MultivariateNormal(mean, scale_tril = diag(exp(log_std)^2)) (:334-335).
+ *   (seed, call) key the Philox action noise together with the row index; deterministic != 0: action = mean.
+ *   action_only != 0: only the actor runs (states / value may be NULL). */
+typedef struct taco_policy_cfg {
+    int32_t obs_len, obs_dim, states_len, states_dim, act_dim;
+    int32_t n_actor_hidden, actor_hidden[4];
+    int32_t lstm_hidden;
+    int32_t n_critic_hidden, critic_hidden[4];
+} taco_policy_cfg;
+size_t taco_policy_blob_floats(const taco_policy_cfg *cfg);   /* 0 (and taco_last_error) for an unsupported configuration */
+int taco_policy_act(const taco_policy_cfg *cfg, const float *blob, int n, const float *obs, const float *states, uint64_t seed, uint32_t call,
+                    int deterministic, int action_only, float *action, float *logp, float *value, float *mu, float *sigma, void *stream);
+
 /* Multi-GPU (no counterpart in the reference, which is single-process): bind a DEVICE block
  * [num_envs][taco_gather_row_floats(len_obs)] f32, 128-byte aligned, that every following taco_step also fills with
  * (obs stack [len_obs*26] | reward | done | time-out | zero padding) per env, so the host layer can publish a rank's

@@ -39,7 +39,8 @@ class OrcCfg(C.Structure):
 
 def build(force=False):
     """Compile oracle/libtaco_oracle.so with the committed Makefile (gcc only, no reference sources involved)."""
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "taco_oracle.c")):
+    srcs = [os.path.join(_HERE, f) for f in ("taco_oracle.c", "taco_policy_oracle.c", "taco_oracle.h")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "libtaco_oracle.so"])
     return _LIB_PATH
 
@@ -293,3 +294,65 @@ def normalize_advantage(adv):
     fn = lib().orc_normalize_advantage; fn.restype = None
     fn(C.c_size_t(a.size), _p(a))
     return a
+
+
+# ---- policy forward (row N1, second half)
+class OrcPolicyCfg(C.Structure):
+    _fields_ = [("obs_len", C.c_int32), ("obs_dim", C.c_int32), ("states_len", C.c_int32), ("states_dim", C.c_int32), ("act_dim", C.c_int32),
+                ("n_actor_hidden", C.c_int32), ("actor_hidden", C.c_int32 * 4), ("lstm_hidden", C.c_int32),
+                ("n_critic_hidden", C.c_int32), ("critic_hidden", C.c_int32 * 4)]
+
+
+def policy_cfg(obs_len, states_len, actor_hidden, lstm_hidden, critic_hidden, obs_dim=26, states_dim=26, act_dim=4):
+    c = OrcPolicyCfg(obs_len, obs_dim, states_len, states_dim, act_dim)
+    c.n_actor_hidden = len(actor_hidden)
+    for i, h in enumerate(actor_hidden):
+        c.actor_hidden[i] = h
+    c.lstm_hidden = lstm_hidden
+    c.n_critic_hidden = len(critic_hidden)
+    for i, h in enumerate(critic_hidden):
+        c.critic_hidden[i] = h
+    return c
+
+
+def policy_blob_floats(cfg):
+    fn = lib().orc_policy_blob_floats; fn.restype = C.c_size_t; fn.argtypes = [C.POINTER(OrcPolicyCfg)]
+    return fn(C.byref(cfg))
+
+
+def policy_act(cfg, blob, obs, states, eps=None, deterministic=False):
+    obs, states, blob = _f32(obs), _f32(states), _f32(blob)
+    n = obs.shape[0]
+    assert blob.size == policy_blob_floats(cfg)
+    a = cfg.act_dim
+    action, mu, sigma = np.empty((n, a), np.float32), np.empty((n, a), np.float32), np.empty((n, a), np.float32)
+    logp, value = np.empty(n, np.float32), np.empty(n, np.float32)
+    e = _f32(eps) if eps is not None else None
+    fn = lib().orc_policy_act; fn.restype = C.c_int
+    rc = fn(C.byref(cfg), _p(blob), C.c_int(n), _p(obs), _p(states), _p(e) if e is not None else None, C.c_int(1 if deterministic else 0),
+            _p(action), _p(logp), _p(value), _p(mu), _p(sigma))
+    if rc != 0:
+        raise ValueError("orc_policy_act rejected the configuration")
+    return action, logp, value, mu, sigma
+
+
+def expf(x):
+    fn = lib().orc_expf; fn.restype = C.c_float; fn.argtypes = [C.c_float]
+    return np.array([fn(float(v)) for v in np.asarray(x, np.float32).ravel()], np.float32)
+
+
+def tanhf(x):
+    fn = lib().orc_tanhf; fn.restype = C.c_float; fn.argtypes = [C.c_float]
+    return np.array([fn(float(v)) for v in np.asarray(x, np.float32).ravel()], np.float32)
+
+
+def sigmoidf(x):
+    fn = lib().orc_sigmoidf; fn.restype = C.c_float; fn.argtypes = [C.c_float]
+    return np.array([fn(float(v)) for v in np.asarray(x, np.float32).ravel()], np.float32)
+
+
+def policy_noise(seed, call, n, act_dim=4):
+    eps = np.empty((n, act_dim), np.float32)
+    fn = lib().orc_policy_noise; fn.restype = None
+    fn(C.c_uint64(seed), C.c_uint32(call), C.c_int(n), C.c_int(act_dim), _p(eps))
+    return eps

@@ -1029,6 +1029,22 @@ void orc_obs_frame(int n, int task, const float *p, const float *q, const float 
         pack_frame(&R, V[i], act + 4 * i, p[3 * i + 2], task, c2, frame26 + 26 * i);
     }
 }
+/* action noise of the policy forward (taco_policy.hpp: STREAM 7, counter (row, call, 7, a >> 2), two Box-Muller pairs per block) */
+void orc_policy_noise(uint64_t seed, uint32_t call, int n, int act_dim, float *eps) {
+    for (int i = 0; i < n; ++i) {
+        uint32_t r[4] = {0, 0, 0, 0};
+        for (int a = 0; a < act_dim; ++a) {
+            if ((a & 3) == 0) orc_philox(seed, (uint32_t)i, call, 7u, (uint32_t)(a >> 2), r);
+            const uint32_t ba = (a & 2) ? r[2] : r[0], bb = (a & 2) ? r[3] : r[1];
+            const float ua = 1.0f - orc_uniform(ba), ub = orc_uniform(bb);
+            const float rad = sqrtf(-2.0f * orc_logf(ua));
+            float sn, cs;
+            sincos_own(TWO_PI_F * ub, &sn, &cs);
+            eps[(size_t)i * act_dim + a] = (a & 1) ? rad * sn : rad * cs;
+        }
+    }
+}
+
 /* ------------------------------------------------------------------------------------------------ row N1 (next): replay buffer
  * PPOReplayBuffer.compute_returns_and_advantage (IsaacGymEnvs/algorithms/buffer_asymmetry.py:93-132).  Arrays are [H][N]
  * (the reference's [H, N, 1]); gamma / lam are Python floats that meet fp32 tensors.  adv_raw is the GAE before the

@@ -135,6 +135,22 @@ void orc_rand_float(int n, double lower, double upper, const float *u, float *ou
 void orc_gae(int H, int N, double gamma, double lam, const float *rew, const float *done, const float *value, const float *last_value,
              float *adv_raw, float *ret);
 void orc_normalize_advantage(size_t n, float *adv);
+
+/* policy forward (second half; oracle/taco_policy_oracle.c) */
+#define ORC_POLICY_MAXW 256
+typedef struct orc_policy_cfg {
+    int32_t obs_len, obs_dim, states_len, states_dim, act_dim;
+    int32_t n_actor_hidden, actor_hidden[4];
+    int32_t lstm_hidden;            /* 0: no critic encoder (the critic MLP takes the flattened state stack) */
+    int32_t n_critic_hidden, critic_hidden[4];
+} orc_policy_cfg;
+size_t orc_policy_blob_floats(const orc_policy_cfg *c);
+int orc_policy_act(const orc_policy_cfg *c, const float *blob, int n, const float *obs, const float *states, const float *eps, int deterministic,
+                   float *action, float *logp, float *value, float *mu, float *sigma);
+void orc_policy_noise(uint64_t seed, uint32_t call, int n, int act_dim, float *eps);
+float orc_expf(float x);
+float orc_tanhf(float x);
+float orc_sigmoidf(float x);
 /* row I alone: advance root state [n][13] by one simulate(dt) under a body-frame wrench [n][6] (F then tau) */
 void orc_integrate(const orc_cfg *cfg, int n, float *root13, const float *wrench6);
 

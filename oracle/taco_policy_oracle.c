@@ -1,0 +1,195 @@
+/* CPU ORACLE for SURVEY.md section 8f row N1, second half: PPO_ActorCritic.act (IsaacGymEnvs/algorithms/nets_asymmetry.py:326-355)
+ * for the documented training configuration (README.md:60-66: actor = MLP on obs, critic = 1-layer LSTM over the state stack
+ * + MLP).  TEST INFRASTRUCTURE ONLY (see oracle/taco_oracle.h).
+ *
+ * The arithmetic is DEFINED here and followed bit for bit by the HIP kernel (taco_amd/csrc/taco_policy.hpp):
+ *   linear:  acc = bias[o];  for s, t, g:  k = 16 s + 4 g + t;  acc = fmaf(x[k], W[o][k], acc)
+ *            (the order in which the 16x16x4 f32 MFMA consumes 16-byte operand fragments; an f32 MFMA is a k-ordered fmaf chain)
+ *   LSTM:    gates start from b_ih + b_hh, run the chain over x_t, then over h_{t-1}; i f o = sigmoid, g = tanh (own kernels
+ *            below); c = f * c + i * g; h = o * tanh(c)                                   (nets_asymmetry.py:128-136, torch.nn.LSTM)
+ *   actor head: tanh; log_std / scale_tril quirk of :334-335 (scale = exp(log_std) * exp(log_std)); MultivariateNormal log_prob.
+ * Parity with the reference (which uses the platform BLAS / vectorised transcendentals) is a tolerance, 1e-5, pinned by
+ * tests/golden/policy.npz generated from the reference module on CPU. */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#include "taco_oracle.h"
+
+static inline uint32_t pf2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float pu2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline float pow2i(int k) { return pu2f((uint32_t)(k + 127) << 23); }
+
+float orc_expf(float x) {
+    const float xc = fminf(fmaxf(x, -87.33654475055310898657f), 88.72283905206835f);
+    const float k = rintf(xc * 1.44269504088896341f);
+    float r = fmaf(-k, 0.693359375f, xc);
+    r = fmaf(-k, -2.12194440e-4f, r);
+    const float z = r * r;
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    p = fmaf(p, z, r) + 1.0f;
+    const int ki = (int)k, k1 = ki >> 1, k2 = ki - k1;
+    const float e = (p * pow2i(k1)) * pow2i(k2);
+    return (x != x) ? x : e;
+}
+float orc_sigmoidf(float x) { return 1.0f / (1.0f + orc_expf(-x)); }
+float orc_tanhf(float x) {
+    const float z = fabsf(x);
+    const float zc = fminf(z, 44.0f);
+    const float bigm = 1.0f - 2.0f / (orc_expf(zc + zc) + 1.0f);
+    const float big = pu2f((pf2u(bigm) & 0x7fffffffu) | (pf2u(x) & 0x80000000u));
+    const float z2 = x * x;
+    float p = -5.70498872745e-3f;
+    p = fmaf(p, z2, 2.06390887954e-2f);
+    p = fmaf(p, z2, -5.37397155531e-2f);
+    p = fmaf(p, z2, 1.33314422036e-1f);
+    p = fmaf(p, z2, -3.33332819422e-1f);
+    const float small = fmaf(p * z2, x, x);
+    const float t = (z >= 0.625f) ? big : small;
+    return (x != x) ? x : t;
+}
+
+static inline int pad16(int x) { return (x + 15) / 16 * 16; }
+
+/* Weight matrices are stored FRAGMENT-MAJOR: [out tile of 16][k block of 16][lane = 16 g + r][t], i.e. the 16 bytes lane (r, g) of
+ * a wavefront feeds to the four MFMAs of k block s sit at ((tile * S + s) * 64 + 16 g + r) * 4 -- one wavefront load = 1 KiB contiguous.
+ * chain(): acc over one padded operand row for output column o, in the MFMA's k order (k = 16 s + 4 g + t for s, t, g). */
+static inline float chain(const float *x, const float *Wf, int o, int kp, float acc) {
+    const int S = kp / 16, tile = o >> 4, r = o & 15;
+    for (int s = 0; s < S; ++s)
+        for (int t = 0; t < 4; ++t)
+            for (int g = 0; g < 4; ++g) {
+                const int k = 16 * s + 4 * g + t;
+                acc = fmaf(x[k], Wf[(((size_t)tile * S + s) * 64 + 16 * g + r) * 4 + t], acc);
+            }
+    return acc;
+}
+
+enum { ACT_RELU = 0, ACT_TANH = 1, ACT_NONE = 2 };
+/* y[outp] = act(W[outp][inp] x + b), all padded */
+static void linear(const float *x, const float *W, const float *b, int inp, int outp, int act, float *y) {
+    for (int o = 0; o < outp; ++o) {
+        float a = chain(x, W, o, inp, b[o]);
+        if (act == ACT_RELU) a = (a < 0.0f) ? 0.0f : a;   /* a NaN stays NaN, like torch.relu */
+        else if (act == ACT_TANH) a = orc_tanhf(a);
+        y[o] = a;
+    }
+}
+
+size_t orc_policy_blob_floats(const orc_policy_cfg *c) {
+    size_t n = 0;
+    int in = pad16(c->obs_len * c->obs_dim);
+    for (int l = 0; l <= c->n_actor_hidden; ++l) {
+        const int out = pad16(l < c->n_actor_hidden ? c->actor_hidden[l] : c->act_dim);
+        n += (size_t)out * in + out;
+        in = out;
+    }
+    n += 16; /* log_std */
+    if (c->lstm_hidden > 0) {
+        const int hp = pad16(c->lstm_hidden), ip = pad16(c->states_dim);
+        n += (size_t)4 * hp * ip + (size_t)4 * hp * hp + (size_t)4 * hp;
+        in = hp;
+    } else {
+        in = pad16(c->states_len * c->states_dim);
+    }
+    for (int l = 0; l <= c->n_critic_hidden; ++l) {
+        const int out = pad16(l < c->n_critic_hidden ? c->critic_hidden[l] : 1);
+        n += (size_t)out * in + out;
+        in = out;
+    }
+    return n;
+}
+
+/* One env.  obs [obs_len*obs_dim], states [states_len][states_dim]; eps [act_dim] = the standard-normal draw (ignored when
+ * deterministic).  Outputs: action, mu, sigma [act_dim]; logp, value scalars. */
+static void act_one(const orc_policy_cfg *c, const float *blob, const float *obs, const float *states, const float *eps, int deterministic,
+                    float *action, float *logp, float *value, float *mu, float *sigma) {
+    float bufa[ORC_POLICY_MAXW], bufb[ORC_POLICY_MAXW];
+    const float *w = blob;
+    /* ---- actor MLP */
+    int in = pad16(c->obs_len * c->obs_dim);
+    memset(bufa, 0, sizeof(bufa));
+    memcpy(bufa, obs, sizeof(float) * (size_t)(c->obs_len * c->obs_dim));
+    float *x = bufa, *y = bufb;
+    for (int l = 0; l <= c->n_actor_hidden; ++l) {
+        const int last = l == c->n_actor_hidden;
+        const int out = pad16(last ? c->act_dim : c->actor_hidden[l]);
+        linear(x, w, w + (size_t)out * in, in, out, last ? ACT_TANH : ACT_RELU, y);
+        w += (size_t)out * in + out;
+        in = out;
+        float *t = x; x = y; y = t;
+    }
+    const float *log_std = w;
+    w += 16;
+    /* distribution: covariance = diag(exp(log_std) * exp(log_std)) passed as scale_tril (nets_asymmetry.py:334-335) */
+    float lp = 0.0f, half_log_det = 0.0f;
+    for (int a = 0; a < c->act_dim; ++a) {
+        const float e = orc_expf(log_std[a]);
+        const float scale = e * e;
+        mu[a] = x[a];
+        sigma[a] = log_std[a];                       /* the reference returns log_std.repeat(N, 1) as "sigma" (:354) */
+        action[a] = deterministic ? x[a] : x[a] + scale * eps[a];
+        const float zz = (action[a] - x[a]) / scale; /* MultivariateNormal.log_prob: M = |L^-1 diff|^2, half_log_det = sum log diag(L) */
+        lp = lp + zz * zz;
+        half_log_det = half_log_det + orc_logf(scale);
+    }
+    *logp = -0.5f * ((float)c->act_dim * 1.8378770664093453f + lp) - half_log_det;
+    /* ---- critic */
+    if (c->lstm_hidden > 0) {
+        const int hp = pad16(c->lstm_hidden), ip = pad16(c->states_dim);
+        const float *Wih = w, *Whh = w + (size_t)4 * hp * ip, *bs = Whh + (size_t)4 * hp * hp;
+        w = bs + (size_t)4 * hp;
+        float h[ORC_POLICY_MAXW], hn[ORC_POLICY_MAXW], cst[ORC_POLICY_MAXW], xt[ORC_POLICY_MAXW];
+        memset(h, 0, sizeof(h)); memset(cst, 0, sizeof(cst));
+        for (int t = 0; t < c->states_len; ++t) {
+            memset(xt, 0, sizeof(float) * (size_t)ip);
+            memcpy(xt, states + (size_t)t * c->states_dim, sizeof(float) * (size_t)c->states_dim);
+            for (int j = 0; j < hp; ++j) {
+                float gate[4];
+                for (int q = 0; q < 4; ++q) {
+                    float a = bs[q * hp + j];
+                    a = chain(xt, Wih + (size_t)q * hp * ip, j, ip, a);
+                    a = chain(h, Whh + (size_t)q * hp * hp, j, hp, a);
+                    gate[q] = a;
+                }
+                const float ig = orc_sigmoidf(gate[0]), fg = orc_sigmoidf(gate[1]), gg = orc_tanhf(gate[2]), og = orc_sigmoidf(gate[3]);
+                cst[j] = fg * cst[j] + ig * gg;
+                hn[j] = og * orc_tanhf(cst[j]);
+            }
+            memcpy(h, hn, sizeof(float) * (size_t)hp);
+        }
+        memset(bufa, 0, sizeof(bufa));
+        memcpy(bufa, h, sizeof(float) * (size_t)hp);
+        in = hp;
+    } else {
+        in = pad16(c->states_len * c->states_dim);
+        memset(bufa, 0, sizeof(bufa));
+        memcpy(bufa, states, sizeof(float) * (size_t)(c->states_len * c->states_dim));
+    }
+    x = bufa; y = bufb;
+    for (int l = 0; l <= c->n_critic_hidden; ++l) {
+        const int last = l == c->n_critic_hidden;
+        const int out = pad16(last ? 1 : c->critic_hidden[l]);
+        linear(x, w, w + (size_t)out * in, in, out, last ? ACT_NONE : ACT_RELU, y);
+        w += (size_t)out * in + out;
+        in = out;
+        float *t = x; x = y; y = t;
+    }
+    *value = x[0];
+}
+
+int orc_policy_act(const orc_policy_cfg *c, const float *blob, int n, const float *obs, const float *states, const float *eps, int deterministic,
+                   float *action, float *logp, float *value, float *mu, float *sigma) {
+    if (c->act_dim < 1 || c->act_dim > 16 || c->n_actor_hidden < 0 || c->n_actor_hidden > 4 || c->n_critic_hidden < 0 || c->n_critic_hidden > 4) return -1;
+    const size_t od = (size_t)c->obs_len * c->obs_dim, sd = (size_t)c->states_len * c->states_dim;
+    if (pad16((int)od) > ORC_POLICY_MAXW || pad16((int)sd) > ORC_POLICY_MAXW || pad16(c->lstm_hidden) > ORC_POLICY_MAXW) return -1;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i)
+        act_one(c, blob, obs + i * od, states + i * sd, eps ? eps + (size_t)i * c->act_dim : NULL, deterministic || !eps,
+                action + (size_t)i * c->act_dim, logp + i, value + i, mu + (size_t)i * c->act_dim, sigma + (size_t)i * c->act_dim);
+    return 0;
+}

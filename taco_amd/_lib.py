@@ -22,7 +22,7 @@ FLAG_BITS = {
 # every symbol include/taco_env.h declares
 EXPORTS = ["taco_abi_version", "taco_last_error", "taco_workspace_bytes", "taco_create", "taco_destroy", "taco_step",
            "taco_gather_row_floats", "taco_bind_gather_block", "taco_set_difficulty", "taco_get_step_count", "taco_set_step_count", "taco_get_state", "taco_set_state",
-           "taco_step_kernel_name", "taco_launch_geometry", "taco_step_rollout", "taco_gae_workspace_bytes", "taco_gae", "taco_occupancy", "taco_bind_phase_stamps"]
+           "taco_step_kernel_name", "taco_launch_geometry", "taco_step_rollout", "taco_gae_workspace_bytes", "taco_gae", "taco_occupancy", "taco_bind_phase_stamps", "taco_policy_blob_floats", "taco_policy_act"]
 
 
 class TacoCfg(C.Structure):
@@ -94,6 +94,11 @@ def load():
     lib.taco_set_state.restype = C.c_int
     lib.taco_launch_geometry.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.taco_launch_geometry.restype = C.c_int
+    lib.taco_policy_blob_floats.argtypes = [C.c_void_p]
+    lib.taco_policy_blob_floats.restype = C.c_size_t
+    lib.taco_policy_act.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_int,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.taco_policy_act.restype = C.c_int
     lib.taco_bind_phase_stamps.argtypes = [C.c_void_p, C.c_void_p]
     lib.taco_bind_phase_stamps.restype = C.c_int
     lib.taco_occupancy.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]

@@ -13,6 +13,7 @@
 
 #include "taco_step.hpp"
 #include "taco_rollout.hpp"
+#include "taco_policy.hpp"
 
 namespace {
 
@@ -414,6 +415,69 @@ int taco_launch_geometry(const taco_env *e, int *grid, int *block) {
     if (!e || !grid || !block) return fail(TACO_ERR_INVALID_ARG, "taco_launch_geometry: null argument");
     *block = e->block;
     *grid = (e->cfg.num_envs * e->lpe + *block - 1) / *block;
+    return TACO_OK;
+}
+
+// ---- policy forward (second half)
+static int policy_cfg_ok(const taco_policy_cfg *c) {
+    auto p16 = [](int x) { return (x + 15) / 16 * 16; };
+    if (!c) return fail(TACO_ERR_INVALID_ARG, "policy cfg is null");
+    if (c->obs_len < 1 || c->obs_dim < 1 || p16(c->obs_len * c->obs_dim) > taco::POL_MAXW) return fail(TACO_ERR_INVALID_ARG, "policy: obs_len * obs_dim must be 1..256");
+    if (c->act_dim < 1 || c->act_dim > 16) return fail(TACO_ERR_INVALID_ARG, "policy: act_dim must be 1..16");
+    if (c->n_actor_hidden < 0 || c->n_actor_hidden > 4 || c->n_critic_hidden < 0 || c->n_critic_hidden > 4) return fail(TACO_ERR_INVALID_ARG, "policy: at most four hidden layers per MLP");
+    for (int l = 0; l < c->n_actor_hidden; ++l) if (c->actor_hidden[l] < 1 || c->actor_hidden[l] > taco::POL_MAXW) return fail(TACO_ERR_INVALID_ARG, "policy: hidden widths must be 1..256");
+    for (int l = 0; l < c->n_critic_hidden; ++l) if (c->critic_hidden[l] < 1 || c->critic_hidden[l] > taco::POL_MAXW) return fail(TACO_ERR_INVALID_ARG, "policy: hidden widths must be 1..256");
+    if (c->states_len < 1 || c->states_dim < 1) return fail(TACO_ERR_INVALID_ARG, "policy: states_len / states_dim must be >= 1");
+    if (c->lstm_hidden < 0 || c->lstm_hidden > taco::POL_MAXW) return fail(TACO_ERR_INVALID_ARG, "policy: lstm_hidden must be 0..256");
+    if (c->lstm_hidden > 0 && (c->states_len > taco::POL_MAXT || c->states_dim > 32)) return fail(TACO_ERR_INVALID_ARG, "policy: the LSTM critic takes at most 8 frames of at most 32 features");
+    if (c->lstm_hidden == 0 && p16(c->states_len * c->states_dim) > taco::POL_MAXW) return fail(TACO_ERR_INVALID_ARG, "policy: states_len * states_dim must be <= 256 without an encoder");
+    return TACO_OK;
+}
+
+size_t taco_policy_blob_floats(const taco_policy_cfg *c) {
+    if (policy_cfg_ok(c) != TACO_OK) return 0;
+    auto p16 = [](int x) { return (x + 15) / 16 * 16; };
+    size_t n = 0;
+    int in = p16(c->obs_len * c->obs_dim);
+    for (int l = 0; l <= c->n_actor_hidden; ++l) {
+        const int out = p16(l < c->n_actor_hidden ? c->actor_hidden[l] : c->act_dim);
+        n += (size_t)out * in + out;
+        in = out;
+    }
+    n += 16;
+    if (c->lstm_hidden > 0) {
+        const int hp = p16(c->lstm_hidden), ip = p16(c->states_dim);
+        n += (size_t)4 * hp * ip + (size_t)4 * hp * hp + (size_t)4 * hp;
+        in = hp;
+    } else {
+        in = p16(c->states_len * c->states_dim);
+    }
+    for (int l = 0; l <= c->n_critic_hidden; ++l) {
+        const int out = p16(l < c->n_critic_hidden ? c->critic_hidden[l] : 1);
+        n += (size_t)out * in + out;
+        in = out;
+    }
+    return n;
+}
+
+int taco_policy_act(const taco_policy_cfg *c, const float *blob, int n, const float *obs, const float *states, uint64_t seed, uint32_t call,
+                    int deterministic, int action_only, float *action, float *logp, float *value, float *mu, float *sigma, void *stream) {
+    const int rc = policy_cfg_ok(c);
+    if (rc != TACO_OK) return rc;
+    if (!blob || !obs || !action || !logp || !mu || !sigma) return fail(TACO_ERR_INVALID_ARG, "taco_policy_act: null buffer pointer");
+    if (!action_only && (!states || !value)) return fail(TACO_ERR_INVALID_ARG, "taco_policy_act: states / value are needed unless action_only");
+    if (n < 1) return fail(TACO_ERR_INVALID_ARG, "taco_policy_act: n must be >= 1");
+    if (((uintptr_t)blob & 15u) != 0) return fail(TACO_ERR_INVALID_ARG, "taco_policy_act: the weight blob must be 16-byte aligned");
+    taco::PolicyParams P{};
+    P.obs_len = c->obs_len; P.obs_dim = c->obs_dim; P.states_len = c->states_len; P.states_dim = c->states_dim; P.act_dim = c->act_dim;
+    P.n_actor_hidden = c->n_actor_hidden; P.lstm_hidden = c->lstm_hidden; P.n_critic_hidden = c->n_critic_hidden;
+    for (int l = 0; l < 4; ++l) { P.actor_hidden[l] = c->actor_hidden[l]; P.critic_hidden[l] = c->critic_hidden[l]; }
+    P.blob = blob; P.obs = obs; P.states = states; P.action = action; P.logp = logp; P.value = value; P.mu = mu; P.sigma = sigma;
+    P.n = n; P.deterministic = deterministic ? 1 : 0;
+    P.seed_lo = (uint32_t)seed; P.seed_hi = (uint32_t)(seed >> 32); P.call = call;
+    hipLaunchKernelGGL(taco::taco_policy_kernel, dim3((n + taco::POL_ROWS - 1) / taco::POL_ROWS, action_only ? 1 : 2), dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) return hip_fail(he, "taco_policy_kernel launch");
     return TACO_OK;
 }
 

@@ -131,6 +131,44 @@ TD float log(float x) {
     return fma(0.693359375f, fe, m + y);
 }
 
+// ---- exp / tanh / sigmoid for the policy forward (Cephes single-precision kernels, explicit fma, one division in sigmoid/tanh)
+TD float pow2i(int k) { return from_bits((uint32_t)(k + 127) << 23); }  // 2^k, k in [-126, 127]
+TD float expf_own(float x) {
+    // the argument is clamped to the range in which p * 2^k neither overflows nor goes subnormal: exp(x >= 88.72) = 3.4e38,
+    // exp(x <= -87.34) = 1.2e-38 (sigmoid / tanh saturate long before); straight-line code, a NaN comes back as NaN
+    const float xc = __builtin_fminf(__builtin_fmaxf(x, -87.33654475055310898657f), 88.72283905206835f);
+    const float k = __builtin_rintf(xc * 1.44269504088896341f);
+    float r = fma(-k, 0.693359375f, xc);
+    r = fma(-k, -2.12194440e-4f, r);
+    const float z = r * r;
+    float p = 1.9875691500e-4f;
+    p = fma(p, r, 1.3981999507e-3f);
+    p = fma(p, r, 8.3334519073e-3f);
+    p = fma(p, r, 4.1665795894e-2f);
+    p = fma(p, r, 1.6666665459e-1f);
+    p = fma(p, r, 5.0000001201e-1f);
+    p = fma(p, z, r) + 1.0f;
+    const int ki = (int)k, k1 = ki >> 1, k2 = ki - k1;
+    const float e = (p * pow2i(k1)) * pow2i(k2);
+    return (x != x) ? x : e;
+}
+TD float sigmoid_own(float x) { return 1.0f / (1.0f + expf_own(-x)); }
+// both forms are evaluated and one is selected (no divergent control flow in the LSTM epilogue)
+TD float tanh_own(float x) {
+    const float z = absf(x);
+    const float zc = __builtin_fminf(z, 44.0f);
+    const float big = with_sign_of(1.0f - 2.0f / (expf_own(zc + zc) + 1.0f), x);
+    const float z2 = x * x;
+    float p = -5.70498872745e-3f;
+    p = fma(p, z2, 2.06390887954e-2f);
+    p = fma(p, z2, -5.37397155531e-2f);
+    p = fma(p, z2, 1.33314422036e-1f);
+    p = fma(p, z2, -3.33332819422e-1f);
+    const float small = fma(p * z2, x, x);
+    const float t = (z >= 0.625f) ? big : small;
+    return (x != x) ? x : t;
+}
+
 // ---- Philox4x32-10 (Salmon et al., SC'11).  counter = (global env id, step index, stream, block), key = seed
 struct U4 { uint32_t x, y, z, w; };
 TD U4 philox(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {

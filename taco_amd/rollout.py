@@ -97,9 +97,10 @@ class RolloutBuffer:
     def next_states(self):
         return self._states_store[self.step]
 
-    def collect(self, env, actions, log_prob=None, value=None, mu=None, sigma=None):
+    def collect(self, env, actions, log_prob=None, value=None, mu=None, sigma=None, act=None):
         """env.step(actions) + store(...) of ppo_asymmetry.py:311-329 with the env writing this step's slots in place.
-        Returns (rewards [N], dones [N] int64 = env.reset_buf, time_outs [N] bool = env.timeout_buf)."""
+        `actions` is what the env executes (the reference clips first, :310), `act` what goes into act_buf (the un-clipped sample,
+        :326; defaults to `actions`).  Returns (rewards [N], dones [N] int64 = env.reset_buf, time_outs [N] bool = env.timeout_buf)."""
         if self.step >= self.horizon_len:
             raise AssertionError("Rollout buffer overflow")
         if math.isfinite(env.clip_obs) or math.isfinite(env.clip_states):
@@ -109,7 +110,7 @@ class RolloutBuffer:
         t = self.step
         env.step_into(actions, self._obs_store[t], self._obs_store[t + 1], self._states_store[t], self._states_store[t + 1],
                       self.rew_buf[t], self.done_buf[t])
-        self._store_policy(t, actions, log_prob, value, mu, sigma)
+        self._store_policy(t, actions if act is None else act, log_prob, value, mu, sigma)
         self.step += 1
         return self.rew_buf[t].view(-1), env.reset_buf, env.timeout_buf
 

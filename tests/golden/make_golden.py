@@ -441,8 +441,49 @@ def gen_gae():
          done_f32=npy(buf.done_buf[:, :, 0]), rew_buf=npy(buf.rew_buf[:, :, 0]))
 
 
+# --------------------------------------------------------------------------- (13) policy forward: PPO_ActorCritic.act / evaluate
+def gen_policy():
+    """PPO_ActorCritic (algorithms/nets_asymmetry.py:270-378) in the documented training configuration (README.md:60-66:
+    actor = MLP on obs, critic = 1-layer LSTM over the 5-frame state stack + MLP), run on CPU.  Small widths keep the fixture small;
+    the weights are whatever the reference's own initialisation produced under the seed below (they are data)."""
+    import torch.nn as nn
+    NETS = _load("nets_asymmetry", REF / "IsaacGymEnvs/algorithms/nets_asymmetry.py")
+    torch.manual_seed(1300)
+    para = {
+        "actor_critic_mlp_dict": {"actor_input_dim": 26, "actor_output_dim": 4, "critic_input_dim": 26 * 5, "critic_output_dim": 1,
+                                  "actor_hidden_sizes": [64, 40], "critic_hidden_sizes": [48], "activation": nn.ReLU},
+        "use_actor_encoder": False, "use_critic_encoder": True, "share_encoder": False, "critic_encoder_type": "LSTM",
+        "critic_encoder_dict": {"encoder_type": "LSTM", "input_size": 26, "output_size": 24, "num_layers": 1, "bidirectional": False},
+    }
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        agent = NETS.PPO_ActorCritic(para)
+    with torch.no_grad():
+        agent.log_std.copy_(torch.tensor([-0.5, -0.2, 0.1, 0.3]))
+        # the reference's para_init leaves the output layers tiny; scale the weights up so that every nonlinearity is exercised
+        for p_ in agent.parameters():
+            if p_.dim() >= 2:
+                p_.mul_(3.0)
+    g = torch.Generator().manual_seed(1301)
+    N = 96
+    obs = torch.randn(N, 1, 26, generator=g)
+    states = torch.randn(N, 5, 26, generator=g)
+    eps = torch.randn(N, 4, generator=g)
+    with torch.no_grad():
+        action, logp_det, value, mu, sigma = agent.act(obs, states, deterministic=True)
+        scale = agent.log_std.exp() * agent.log_std.exp()
+        action_s = mu + scale * eps
+        logp_s, entropy, value_e, mu_e, sigma_e = agent.evaluate(obs, states, action_s)
+        fwd = agent.forward(obs)
+    assert torch.equal(mu, mu_e) and torch.equal(value, value_e) and torch.equal(fwd, mu)
+    sd = {"sd." + k: npy(v) for k, v in agent.state_dict().items()}
+    save("policy", obs=npy(obs), states=npy(states), eps=npy(eps), mu=npy(mu), value=npy(value[:, 0]), sigma=npy(sigma), logp_det=npy(logp_det),
+         action_s=npy(action_s), logp_s=npy(logp_s), actor_hidden=np.array([64, 40]), critic_hidden=np.array([48]), lstm_hidden=np.array(24), **sd)
+
+
 if __name__ == "__main__":
     gen_gae()
-    if "--only-gae" in sys.argv:
+    gen_policy()
+    if "--only-gae" in sys.argv or "--only-next" in sys.argv:
         sys.exit(0)
     gen_quat(); gen_pid(); gen_alloc(); gen_battery(); gen_rotor(); gen_aero(); gen_reward(); gen_chain(); gen_obs(); gen_reset()

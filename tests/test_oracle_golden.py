@@ -188,3 +188,41 @@ def test_gae_returns_and_advantage_vs_reference_buffer(golden):
         delta = (g["rew"][t] + nnt * gm * nv) - g["value"][t]
         last = delta + nnt * gm * lm * last
         assert_bits_equal(last, adv[t], f"adv step {t}")
+
+
+def test_policy_forward_vs_reference_module(golden):
+    """orc_policy_act vs PPO_ActorCritic.act / evaluate run on CPU (policy.npz: widths 26-64-40-4, LSTM 26->24 over 5 frames,
+    24-48-1; weights from the reference's own initialisation).  Tolerance 1e-5: the reference goes through the platform BLAS and
+    vectorised tanh/sigmoid, the oracle through the kernel's fma chain order and its own exp/tanh."""
+    from taco_amd import policy as P
+    g = golden("policy")
+    sd = {k[3:]: g[k] for k in g if k.startswith("sd.")}
+    cfg = P.cfg_from_state_dict(sd, 1, 5)
+    assert (list(cfg.actor_hidden)[:cfg.n_actor_hidden], cfg.lstm_hidden, list(cfg.critic_hidden)[:cfg.n_critic_hidden]) == ([64, 40], 24, [48])
+    blob = P.pack_state_dict(cfg, sd)
+    oc = O.policy_cfg(1, 5, [64, 40], 24, [48])
+    assert blob.size == O.policy_blob_floats(oc)
+    a, lp, v, mu, sg = O.policy_act(oc, blob, g["obs"], g["states"], deterministic=True)
+    np.testing.assert_allclose(mu, g["mu"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(v, g["value"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(lp, g["logp_det"], rtol=0, atol=1e-5)
+    assert_bits_equal(a, mu, "deterministic action == mean") and None
+    assert_bits_equal(sg, g["sigma"], "sigma = log_std repeated")
+    a, lp, v, mu, sg = O.policy_act(oc, blob, g["obs"], g["states"], eps=g["eps"])
+    np.testing.assert_allclose(a, g["action_s"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(lp, g["logp_s"], rtol=1e-6, atol=1e-5)
+
+
+def test_policy_transcendentals_and_noise():
+    x = np.linspace(-30, 30, 6001).astype(np.float32)
+    xd = x.astype(np.float64)
+    assert np.max(np.abs(O.expf(x).astype(np.float64) - np.exp(xd)) / np.exp(xd)) < 2e-7
+    assert np.max(np.abs(O.tanhf(x).astype(np.float64) - np.tanh(xd))) < 1.5e-7
+    assert np.max(np.abs(O.sigmoidf(x).astype(np.float64) - 1 / (1 + np.exp(-xd)))) < 1.5e-7
+    e = O.expf([-200.0, 200.0, np.nan])         # the argument is clamped: straight-line code, saturating instead of 0 / inf
+    assert 0 < e[0] < 1.3e-38 and e[1] > 3.3e38 and np.isnan(e[2]) and np.isnan(O.tanhf([np.nan])[0]) and np.isnan(O.sigmoidf([np.nan])[0])
+    assert np.array_equal(O.tanhf([100.0, -100.0, 0.0]), np.array([1, -1, 0], np.float32)) and np.array_equal(O.sigmoidf([200.0]), np.array([1], np.float32))
+    assert O.sigmoidf([-200.0])[0] < 1e-38 and O.sigmoidf([-80.0])[0] > 0
+    e = O.policy_noise(3, 1, 100000)
+    assert abs(e.mean()) < 0.01 and abs(e.std() - 1) < 0.01 and abs(np.corrcoef(e[:, 0], e[:, 1])[0, 1]) < 0.01
+    assert not np.array_equal(e, O.policy_noise(3, 2, 100000)) and np.array_equal(e, O.policy_noise(3, 1, 100000))

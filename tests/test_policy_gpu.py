@@ -1,0 +1,113 @@
+"""SURVEY.md 8f row N1, second half, on the GPU: taco_policy_act (one MFMA launch for PPO_ActorCritic.act) against the CPU oracle
+(bit-exact: the f32 MFMA is a k-ordered fma chain and the oracle follows the kernel's fragment order) and against the golden
+vectors generated from the reference module (tolerance 1e-5, see tests/test_oracle_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from util import assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _golden_policy():
+    from taco_amd import policy as P
+    g = np.load(os.path.join(GOLD, "policy.npz"))
+    sd = {k[3:]: g[k] for k in g.files if k.startswith("sd.")}
+    return g, sd, P.ActorCritic(sd, 1, 5, seed=9)
+
+
+def test_act_matches_reference_golden():
+    g, sd, pol = _golden_policy()
+    obs, st = torch.from_numpy(g["obs"]).cuda(), torch.from_numpy(g["states"]).cuda()
+    action, logp, value, mu, sigma = pol.act(obs, st, deterministic=True)
+    assert action.shape == (96, 4) and logp.shape == (96,) and value.shape == (96, 1) and sigma.shape == (96, 4)
+    np.testing.assert_allclose(mu.cpu().numpy(), g["mu"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(value.cpu().numpy()[:, 0], g["value"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(logp.cpu().numpy(), g["logp_det"], rtol=0, atol=1e-5)
+    assert torch.equal(action, mu) and np.array_equal(sigma.cpu().numpy(), g["sigma"])
+    assert torch.equal(pol.forward(obs), mu) and torch.equal(pol.act(obs, None, deterministic=True, action_only=True), mu)
+
+
+def _random_policy(rng, obs_len, states_len, actor_hidden, lstm, critic_hidden):
+    sd = {"log_std": rng.uniform(-1, 0.5, 4).astype(np.float32)}
+    dims = [obs_len * 26] + actor_hidden + [4]
+    for i in range(len(dims) - 1):
+        sd[f"actor_mlp.layers.{2 * i}.weight"] = (rng.standard_normal((dims[i + 1], dims[i])) * (1.5 / np.sqrt(dims[i]))).astype(np.float32)
+        sd[f"actor_mlp.layers.{2 * i}.bias"] = (rng.standard_normal(dims[i + 1]) * 0.1).astype(np.float32)
+    if lstm:
+        sd["critic_encoder.layers.weight_ih_l0"] = (rng.standard_normal((4 * lstm, 26)) * 0.3).astype(np.float32)
+        sd["critic_encoder.layers.weight_hh_l0"] = (rng.standard_normal((4 * lstm, lstm)) * (1.0 / np.sqrt(lstm))).astype(np.float32)
+        sd["critic_encoder.layers.bias_ih_l0"] = (rng.standard_normal(4 * lstm) * 0.1).astype(np.float32)
+        sd["critic_encoder.layers.bias_hh_l0"] = (rng.standard_normal(4 * lstm) * 0.1).astype(np.float32)
+    dims = [lstm if lstm else states_len * 26] + critic_hidden + [1]
+    for i in range(len(dims) - 1):
+        sd[f"critic_mlp.layers.{2 * i}.weight"] = (rng.standard_normal((dims[i + 1], dims[i])) * (1.5 / np.sqrt(dims[i]))).astype(np.float32)
+        sd[f"critic_mlp.layers.{2 * i}.bias"] = (rng.standard_normal(dims[i + 1]) * 0.1).astype(np.float32)
+    return sd
+
+
+@pytest.mark.parametrize("n,obs_len,states_len,actor_hidden,lstm,critic_hidden", [
+    (96, 1, 5, [64, 40], 24, [48]),            # the golden shape (ragged widths: padding to 16)
+    (4096, 1, 5, [128, 128, 128], 128, [128, 128]),   # the default production shape
+    (1000, 3, 4, [256], 0, [256, 32]),         # frame-stacked actor, no critic encoder, ragged row count
+    (17, 1, 8, [], 256, []),                   # no hidden layers, widest LSTM, longest stack
+])
+def test_act_equals_oracle_bitwise(n, obs_len, states_len, actor_hidden, lstm, critic_hidden):
+    from oracle import oracle as O
+    from taco_amd import policy as P
+    rng = np.random.default_rng(n + lstm)
+    sd = _random_policy(rng, obs_len, states_len, actor_hidden, lstm, critic_hidden)
+    pol = P.ActorCritic(sd, obs_len, states_len, seed=77)
+    oc = O.policy_cfg(obs_len, states_len, actor_hidden, lstm, critic_hidden)
+    blob = P.pack_state_dict(pol.cfg, sd)
+    obs = rng.standard_normal((n, obs_len, 26)).astype(np.float32)
+    st = rng.standard_normal((n, states_len, 26)).astype(np.float32)
+    obs[0, 0, :3] = [1e4, -1e4, 0.0]           # saturate a few units
+    for call, det in ((0, True), (1, False), (2, False)):
+        assert pol.calls == call
+        got = pol.act(torch.from_numpy(obs).cuda(), torch.from_numpy(st).cuda(), deterministic=det)
+        eps = None if det else O.policy_noise(77, call, n)
+        exp = O.policy_act(oc, blob, obs, st, eps=eps, deterministic=det)
+        for name, gt, ex in zip(("action", "logp", "value", "mu", "sigma"), got, exp):
+            assert_bits_equal(gt.cpu().numpy().reshape(ex.shape), ex, f"call {call} {name}")
+    a1 = pol.act(torch.from_numpy(obs).cuda(), torch.from_numpy(st).cuda())[0]
+    a2 = pol.act(torch.from_numpy(obs).cuda(), torch.from_numpy(st).cuda())[0]
+    assert not torch.equal(a1, a2)             # a fresh noise draw per call
+
+
+def test_policy_drives_the_env_rollout():
+    """act -> collect for a short rollout: the pieces of ppo_asymmetry.py:308-342 on one stream, no host sync inside the loop."""
+    from taco_amd import config
+    from taco_amd.rollout import RolloutBuffer
+    from taco_amd.vec_env import FpvPos
+    g, sd, pol = _golden_policy()
+    n, H = 256, 8
+    env = FpvPos(config.default_cfg("pos", n, env_lenStates=5), copy_outputs=False)
+    buf = RolloutBuffer(n, 26, 1, 26, 5, 4, H, 4, 0.99, 0.95, "cuda:0")
+    for t in range(H):
+        action, logp, value, mu, sigma = pol.act(buf.next_obs, buf.next_states)
+        buf.collect(env, torch.clip(action, -1, 1), logp, value, mu, sigma, act=action)
+    buf.compute_returns_and_advantage(pol.act(buf.next_obs, buf.next_states)[2])
+    assert torch.isfinite(buf.adv_buf).all() and torch.isfinite(buf.ret_buf).all() and buf.value_buf.abs().sum() > 0
+    assert torch.equal(buf.obs_buf[1], buf._obs_store[1]) and buf.act_buf.abs().max() > 0
+
+
+def test_unsupported_configurations_fail_loudly():
+    from taco_amd import policy as P
+    from taco_amd._lib import TacoError
+    rng = np.random.default_rng(0)
+    sd = _random_policy(rng, 1, 5, [32], 16, [32])
+    sd["actor_encoder.layers.weight_ih_l0"] = np.zeros((4, 4), np.float32)
+    with pytest.raises(TacoError):
+        P.ActorCritic(sd, 1, 5)
+    sd = _random_policy(rng, 1, 9, [32], 16, [32])
+    with pytest.raises(TacoError):
+        P.ActorCritic(sd, 1, 9)                # LSTM stack longer than 8 frames
+    sd = _random_policy(rng, 1, 5, [32], 16, [32])
+    pol = P.ActorCritic(sd, 1, 5)
+    with pytest.raises(ValueError):
+        pol.act(torch.zeros(4, 2, 26).cuda(), torch.zeros(4, 5, 26).cuda())

@@ -8,22 +8,31 @@
 #define REP4(x) x x x x
 #define REP32(x) REP4(REP4(x)) REP4(REP4(x))
 
-enum { FMA, MUL2, ADD2, CHAIN, CNDMASK, CMPCND, MED3, RCP, SQRT, MULHI, MULLO, FMAAK, XOR, DIVSEQ, LDSRD, CVT, NPAT };
-static const char *names[NPAT] = {"v_fma_f32 (8 indep)", "v_mul_f32 e32 indep", "v_add_f32 e32 indep", "v_fma dependent chain", "v_cndmask vcc (static)",
+enum { PKMUL, PKFMA, FMA, MUL2, ADD2, CHAIN, CNDMASK, CMPCND, MED3, RCP, SQRT, MULHI, MULLO, FMAAK, XOR, DIVSEQ, LDSRD, CVT, NPAT };
+static const char *names[NPAT] = {"v_pk_mul_f32 (2 ops each)", "v_pk_fma_f32 (2 ops each)", "v_fma_f32 (8 indep)", "v_mul_f32 e32 indep", "v_add_f32 e32 indep", "v_fma dependent chain", "v_cndmask vcc (static)",
                                   "v_cmp+s_nop1+v_cndmask", "v_med3_f32", "v_rcp_f32", "v_sqrt_f32", "v_mul_hi_u32", "v_mul_lo_u32", "v_fmaak_f32 literal",
                                   "v_xor_b32", "full IEEE div sequence(10)", "ds_read_b128", "v_cvt_f32_u32"};
-static const int ninstr[NPAT] = {8, 8, 8, 8, 8, 8 * 2, 8, 8, 8, 8, 8, 8, 8, 10, 4, 8};
+static const int ninstr[NPAT] = {8, 8, 8, 8, 8, 8, 8, 8 * 2, 8, 8, 8, 8, 8, 8, 8, 10, 4, 8};
 
 template <int P>
 __global__ __launch_bounds__(256) void k(float *out, int iters, unsigned long long *cyc) {
     __shared__ float4 sh[256];
     float a0 = threadIdx.x * 1e-3f + 1.0f, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     const float m = 1.0000001f, c = 1e-9f;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7};
+    const f2 pm = {m, m}, pc = {c, c};
     sh[threadIdx.x] = float4{a0, a1, a2, a3};
     __syncthreads();
     uint32_t addr = threadIdx.x * 16;
     unsigned long long t0 = __builtin_readcyclecounter();
     for (int i = 0; i < iters; ++i) {
+        if (P == PKMUL) asm volatile(REP4("v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4\n"
+                             "v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4\n")
+                             : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pm));
+        if (P == PKFMA) asm volatile(REP4("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5\n"
+                             "v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5\n")
+                             : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pm), "v"(pc));
         if (P == FMA) asm volatile(REP4("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
                              "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n")
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
@@ -78,7 +87,7 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, unsigned long lo
         }
     }
     unsigned long long t1 = __builtin_readcyclecounter();
-    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p1.y + p2.x + p3.y;
     if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
 }
 
@@ -98,7 +107,7 @@ template <int P> void run(float *d, unsigned long long *dc, int k_per_cu) {
 template <int P> void all(float *d, unsigned long long *dc) { for (int kk : {1, 2, 4}) run<P>(d, dc, kk); }
 int main() {
     float *d; unsigned long long *dc; (void)hipMalloc(&d, 256 * 8 * 256 * sizeof(float)); (void)hipMalloc(&dc, 8);
-    all<FMA>(d, dc); all<MUL2>(d, dc); all<ADD2>(d, dc); all<CHAIN>(d, dc); all<CNDMASK>(d, dc); all<CMPCND>(d, dc); all<MED3>(d, dc);
+    all<PKMUL>(d, dc); all<PKFMA>(d, dc); all<FMA>(d, dc); all<MUL2>(d, dc); all<ADD2>(d, dc); all<CHAIN>(d, dc); all<CNDMASK>(d, dc); all<CMPCND>(d, dc); all<MED3>(d, dc);
     all<RCP>(d, dc); all<SQRT>(d, dc); all<MULHI>(d, dc); all<MULLO>(d, dc); all<FMAAK>(d, dc); all<XOR>(d, dc); all<DIVSEQ>(d, dc); all<LDSRD>(d, dc); all<CVT>(d, dc);
     return 0;
 }
