@@ -198,6 +198,34 @@ size_t taco_policy_blob_floats(const taco_policy_cfg *cfg);   /* 0 (and taco_las
 int taco_policy_act(const taco_policy_cfg *cfg, const float *blob, int n, const float *obs, const float *states, uint64_t seed, uint32_t call,
                     int deterministic, int action_only, float *action, float *logp, float *value, float *mu, float *sigma, void *stream);
 
+/* Profiling aid: DEVICE array of 16 uint64 (NULL unbinds); workgroup x = 0 of every following policy launch records the shader clock at
+ * [0..3] actor: entry, inputs staged, MLP done, end; [8..12] critic: entry, inputs staged, LSTM done, MLP done, end. */
+int taco_policy_bind_stamps(uint64_t *stamps);
+
+/* One PPO rollout (ppo_asymmetry.py:308-342) enqueued from C on `stream`: for t < horizon { act on replay slot t -> action / log-prob /
+ * value / mean / log-std of step t; the action clipped to [act_lo, act_hi] (:310) drives taco_step_rollout, which writes slot t + 1,
+ * rew_buf[t], done_buf[t], timeout_buf[t] }, then the value of the final state (:341) and the time-out bootstrap
+ * rew[t] += gamma * value[t] where an env was truncated (:314-324; the value of the pre-step state IS value_buf[t]).
+ * 2 * horizon + 2 launches, no host work between the steps; the policy's noise counter runs call0 .. call0 + horizon.
+ * All arrays are DEVICE memory in the replay-buffer layout (taco_amd/rollout.py::RolloutBuffer.run). */
+typedef struct taco_rollout_bufs {
+    float *obs_store;     /* [horizon + 1][num_envs][len_obs][26]    slot 0 = the stacks to start from */
+    float *states_store;  /* [horizon + 1][num_envs][len_states][26] */
+    float *act_buf;       /* [horizon][num_envs][4]   sampled (un-clipped) action, what store() keeps (:326) */
+    float *act_env;       /* [num_envs][4]            scratch: the clipped action of the current step */
+    float *rew_buf;       /* [horizon][num_envs] */
+    float *done_buf;      /* [horizon][num_envs]      f32 */
+    float *value_buf;     /* [horizon][num_envs] */
+    float *logp_buf;      /* [horizon][num_envs] */
+    float *mu_buf;        /* [horizon][num_envs][4] */
+    float *sigma_buf;     /* [horizon][num_envs][4] */
+    uint8_t *timeout_buf; /* [horizon][num_envs] */
+    float *last_value;    /* [num_envs] */
+    float *scratch;       /* [num_envs][13] */
+} taco_rollout_bufs;
+int taco_rollout_run(taco_env *env, const taco_policy_cfg *cfg, const float *blob, const taco_rollout_bufs *bufs, int horizon, uint64_t seed,
+                     uint32_t call0, double gamma, double act_lo, double act_hi, int64_t *reset_buf, void *stream);
+
 /* Multi-GPU (no counterpart in the reference, which is single-process): bind a DEVICE block
  * [num_envs][taco_gather_row_floats(len_obs)] f32, 128-byte aligned, that every following taco_step also fills with
  * (obs stack [len_obs*26] | reward | done | time-out | zero padding) per env, so the host layer can publish a rank's

@@ -22,7 +22,7 @@ FLAG_BITS = {
 # every symbol include/taco_env.h declares
 EXPORTS = ["taco_abi_version", "taco_last_error", "taco_workspace_bytes", "taco_create", "taco_destroy", "taco_step",
            "taco_gather_row_floats", "taco_bind_gather_block", "taco_set_difficulty", "taco_get_step_count", "taco_set_step_count", "taco_get_state", "taco_set_state",
-           "taco_step_kernel_name", "taco_launch_geometry", "taco_step_rollout", "taco_gae_workspace_bytes", "taco_gae", "taco_occupancy", "taco_bind_phase_stamps", "taco_policy_blob_floats", "taco_policy_act"]
+           "taco_step_kernel_name", "taco_launch_geometry", "taco_step_rollout", "taco_gae_workspace_bytes", "taco_gae", "taco_occupancy", "taco_bind_phase_stamps", "taco_policy_blob_floats", "taco_policy_act", "taco_rollout_run", "taco_policy_bind_stamps"]
 
 
 class TacoCfg(C.Structure):
@@ -41,6 +41,12 @@ class RolloutIO(C.Structure):
     _fields_ = [("actions", C.c_void_p), ("obs_prev", C.c_void_p), ("obs_next", C.c_void_p), ("states_prev", C.c_void_p),
                 ("states_next", C.c_void_p), ("rew", C.c_void_p), ("reset_buf", C.c_void_p), ("timeout_buf", C.c_void_p),
                 ("done_f32", C.c_void_p)]
+
+
+class RolloutBufs(C.Structure):
+    """struct taco_rollout_bufs (include/taco_env.h)"""
+    _fields_ = [(k, C.c_void_p) for k in ("obs_store", "states_store", "act_buf", "act_env", "rew_buf", "done_buf", "value_buf", "logp_buf",
+                                          "mu_buf", "sigma_buf", "timeout_buf", "last_value", "scratch")]
 
 
 class TacoError(RuntimeError):
@@ -99,6 +105,11 @@ def load():
     lib.taco_policy_act.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_int,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.taco_policy_act.restype = C.c_int
+    lib.taco_policy_bind_stamps.argtypes = [C.c_void_p]
+    lib.taco_policy_bind_stamps.restype = C.c_int
+    lib.taco_rollout_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(RolloutBufs), C.c_int, C.c_uint64, C.c_uint32, C.c_double,
+                                     C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+    lib.taco_rollout_run.restype = C.c_int
     lib.taco_bind_phase_stamps.argtypes = [C.c_void_p, C.c_void_p]
     lib.taco_bind_phase_stamps.restype = C.c_int
     lib.taco_occupancy.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]

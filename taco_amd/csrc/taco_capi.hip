@@ -460,6 +460,27 @@ size_t taco_policy_blob_floats(const taco_policy_cfg *c) {
     return n;
 }
 
+static unsigned long long *g_policy_stamps = nullptr;
+int taco_policy_bind_stamps(uint64_t *stamps) { g_policy_stamps = (unsigned long long *)stamps; return TACO_OK; }
+
+static int launch_policy(const taco_policy_cfg *c, const float *blob, int n, const float *obs, const float *states, uint64_t seed, uint32_t call,
+                         int deterministic, int action_only, float *action, float *logp, float *value, float *mu, float *sigma,
+                         float *action_env, float act_lo, float act_hi, void *stream) {
+    taco::PolicyParams P{};
+    P.obs_len = c->obs_len; P.obs_dim = c->obs_dim; P.states_len = c->states_len; P.states_dim = c->states_dim; P.act_dim = c->act_dim;
+    P.n_actor_hidden = c->n_actor_hidden; P.lstm_hidden = c->lstm_hidden; P.n_critic_hidden = c->n_critic_hidden;
+    for (int l = 0; l < 4; ++l) { P.actor_hidden[l] = c->actor_hidden[l]; P.critic_hidden[l] = c->critic_hidden[l]; }
+    P.blob = blob; P.obs = obs; P.states = states; P.action = action; P.logp = logp; P.value = value; P.mu = mu; P.sigma = sigma;
+    P.action_env = action_env; P.act_lo = act_lo; P.act_hi = act_hi;
+    P.stamps = g_policy_stamps;
+    P.n = n; P.deterministic = deterministic ? 1 : 0;
+    P.seed_lo = (uint32_t)seed; P.seed_hi = (uint32_t)(seed >> 32); P.call = call;
+    hipLaunchKernelGGL(taco::taco_policy_kernel, dim3((n + taco::POL_ROWS - 1) / taco::POL_ROWS, action_only ? 1 : 2), dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) return hip_fail(he, "taco_policy_kernel launch");
+    return TACO_OK;
+}
+
 int taco_policy_act(const taco_policy_cfg *c, const float *blob, int n, const float *obs, const float *states, uint64_t seed, uint32_t call,
                     int deterministic, int action_only, float *action, float *logp, float *value, float *mu, float *sigma, void *stream) {
     const int rc = policy_cfg_ok(c);
@@ -468,16 +489,50 @@ int taco_policy_act(const taco_policy_cfg *c, const float *blob, int n, const fl
     if (!action_only && (!states || !value)) return fail(TACO_ERR_INVALID_ARG, "taco_policy_act: states / value are needed unless action_only");
     if (n < 1) return fail(TACO_ERR_INVALID_ARG, "taco_policy_act: n must be >= 1");
     if (((uintptr_t)blob & 15u) != 0) return fail(TACO_ERR_INVALID_ARG, "taco_policy_act: the weight blob must be 16-byte aligned");
-    taco::PolicyParams P{};
-    P.obs_len = c->obs_len; P.obs_dim = c->obs_dim; P.states_len = c->states_len; P.states_dim = c->states_dim; P.act_dim = c->act_dim;
-    P.n_actor_hidden = c->n_actor_hidden; P.lstm_hidden = c->lstm_hidden; P.n_critic_hidden = c->n_critic_hidden;
-    for (int l = 0; l < 4; ++l) { P.actor_hidden[l] = c->actor_hidden[l]; P.critic_hidden[l] = c->critic_hidden[l]; }
-    P.blob = blob; P.obs = obs; P.states = states; P.action = action; P.logp = logp; P.value = value; P.mu = mu; P.sigma = sigma;
-    P.n = n; P.deterministic = deterministic ? 1 : 0;
-    P.seed_lo = (uint32_t)seed; P.seed_hi = (uint32_t)(seed >> 32); P.call = call;
-    hipLaunchKernelGGL(taco::taco_policy_kernel, dim3((n + taco::POL_ROWS - 1) / taco::POL_ROWS, action_only ? 1 : 2), dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
+    return launch_policy(c, blob, n, obs, states, seed, call, deterministic, action_only, action, logp, value, mu, sigma, nullptr, 0.0f, 0.0f, stream);
+}
+
+// ---- a whole PPO rollout (ppo_asymmetry.py:308-342) enqueued from C: 2 H + 2 launches, no host work between the steps
+int taco_rollout_run(taco_env *e, const taco_policy_cfg *c, const float *blob, const taco_rollout_bufs *b, int horizon, uint64_t seed, uint32_t call0,
+                     double gamma, double act_lo, double act_hi, int64_t *reset_buf, void *stream) {
+    if (!e) return fail(TACO_ERR_INVALID_ARG, "env is null");
+    int rc = policy_cfg_ok(c);
+    if (rc != TACO_OK) return rc;
+    if (!b || !blob || !reset_buf) return fail(TACO_ERR_INVALID_ARG, "taco_rollout_run: null argument");
+    if (!b->obs_store || !b->states_store || !b->act_buf || !b->act_env || !b->rew_buf || !b->done_buf || !b->value_buf || !b->logp_buf || !b->mu_buf ||
+        !b->sigma_buf || !b->timeout_buf || !b->last_value || !b->scratch)
+        return fail(TACO_ERR_INVALID_ARG, "taco_rollout_run: null buffer pointer");
+    if (horizon < 1) return fail(TACO_ERR_INVALID_ARG, "taco_rollout_run: horizon must be >= 1");
+    if (((uintptr_t)blob & 15u) != 0) return fail(TACO_ERR_INVALID_ARG, "taco_rollout_run: the weight blob must be 16-byte aligned");
+    const taco_cfg &ec = e->cfg;
+    if (c->obs_len != ec.len_obs || c->states_len != ec.len_states || c->obs_dim != 26 || c->states_dim != 26 || c->act_dim != 4)
+        return fail(TACO_ERR_INVALID_ARG, "taco_rollout_run: policy and env geometry differ");
+    const size_t n = (size_t)ec.num_envs;
+    const size_t obs_slot = n * ec.len_obs * 26, st_slot = n * ec.len_states * 26;
+    for (int t = 0; t < horizon; ++t) {
+        float *act_t = b->act_buf + (size_t)t * n * 4;
+        rc = launch_policy(c, blob, (int)n, b->obs_store + (size_t)t * obs_slot, b->states_store + (size_t)t * st_slot, seed, call0 + (uint32_t)t, 0, 0,
+                           act_t, b->logp_buf + (size_t)t * n, b->value_buf + (size_t)t * n, b->mu_buf + (size_t)t * n * 4, b->sigma_buf + (size_t)t * n * 4,
+                           b->act_env, (float)act_lo, (float)act_hi, stream);
+        if (rc != TACO_OK) return rc;
+        taco_rollout_io io{};
+        io.actions = b->act_env;
+        io.obs_prev = b->obs_store + (size_t)t * obs_slot; io.obs_next = b->obs_store + (size_t)(t + 1) * obs_slot;
+        io.states_prev = b->states_store + (size_t)t * st_slot; io.states_next = b->states_store + (size_t)(t + 1) * st_slot;
+        io.rew = b->rew_buf + (size_t)t * n; io.reset_buf = reset_buf; io.timeout_buf = b->timeout_buf + (size_t)t * n;
+        io.done_f32 = b->done_buf + (size_t)t * n;
+        rc = launch_step(e, &io, stream);
+        if (rc != TACO_OK) return rc;
+    }
+    // value of the final state (:341), deterministic: only the critic's output is kept
+    rc = launch_policy(c, blob, (int)n, b->obs_store + (size_t)horizon * obs_slot, b->states_store + (size_t)horizon * st_slot, seed, call0 + (uint32_t)horizon, 1, 0,
+                       b->scratch, b->scratch + n * 4, b->last_value, b->scratch + n * 5, b->scratch + n * 9, nullptr, 0.0f, 0.0f, stream);
+    if (rc != TACO_OK) return rc;
+    const size_t count = (size_t)horizon * n;
+    hipLaunchKernelGGL(taco::timeout_bootstrap_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, b->rew_buf, b->value_buf, b->done_buf,
+                       b->timeout_buf, count, (float)gamma);
     hipError_t he = hipGetLastError();
-    if (he != hipSuccess) return hip_fail(he, "taco_policy_kernel launch");
+    if (he != hipSuccess) return hip_fail(he, "timeout_bootstrap_kernel launch");
     return TACO_OK;
 }
 

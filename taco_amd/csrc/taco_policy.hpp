@@ -31,6 +31,9 @@ struct PolicyParams {
     int n_critic_hidden, critic_hidden[4];
     const float *blob, *obs, *states;
     float *action, *logp, *value, *mu, *sigma;
+    float *action_env;  // optional [n][act_dim]: the action clipped to [act_lo, act_hi], what the env executes (ppo_asymmetry.py:310)
+    float act_lo, act_hi;
+    unsigned long long *stamps;  // optional [16]: shader-clock stamps of workgroup x = 0 (actor: 0..3, critic: 8..13), taco_policy_bind_stamps
     int n, deterministic;
     uint32_t seed_lo, seed_hi, call;
 };
@@ -40,47 +43,121 @@ TD int pad16(int x) { return (x + 15) / 16 * 16; }
 
 enum { PACT_RELU = 0, PACT_TANH = 1, PACT_NONE = 2 };
 
-// out[16][outp] = act(in[16][inp] W^T + b); two output tiles per wavefront in flight (independent accumulators hide the 40-cycle
-// dependent-MFMA latency)
-TD void dense_layer(const float *in, float *out, const float *W, const float *b, int inp, int outp, int act, int wave, int lane) {
+// out[16][outp] = act(in[16][inp] W^T + b).  A wavefront owns output tiles tile = wave, wave + POL_NW, ...; ALL operand fragments of a
+// tile (KS = inp / 16 blocks, one float4 of weights from L2 and one of activations from LDS each) are requested up front, so the
+// latencies are paid once per tile, not once per k block (these layers are 16 x 128 x 128: latency-bound, not throughput-bound).
+// KS is a template parameter for the common widths so that the whole tile is straight-line code.
+template <int KS>
+TD void dense_tile(const float *in, float *out, const float *W, const float *b, int outp, int act, int wave, int lane, int ks_rt) {
     const int r = lane & 15, g = lane >> 4;
     const int ntiles = outp >> 4;
-    for (int tile = wave; tile < ntiles; tile += 2 * POL_NW) {
-        const int tile2 = tile + POL_NW;
-        const bool two = tile2 < ntiles;  // wave-uniform
-        const int col0 = tile * 16 + r, col1 = (two ? tile2 : tile) * 16 + r;
-        const float b0 = b[col0], b1 = b[col1];
-        pf32x4 acc0 = {b0, b0, b0, b0}, acc1 = {b1, b1, b1, b1};
-        // fragment-major weights: block s of tile T starts at ((T * ks + s) * 64 + lane) * 4 floats
-        const float *w0 = W + ((size_t)tile * (inp >> 4) * 64 + lane) * 4, *w1 = W + ((size_t)(two ? tile2 : tile) * (inp >> 4) * 64 + lane) * 4;
+    const int ks = KS > 0 ? KS : ks_rt;
+    constexpr int MAXKS = KS > 0 ? KS : POL_MAXW / 16;
+    for (int tile = wave; tile < ntiles; tile += POL_NW) {
+        const int col = tile * 16 + r;
+        const float *wt = W + ((size_t)tile * ks * 64 + lane) * 4;  // fragment-major: block s of this tile at +256 s floats
         const float *arow = in + r * POL_LD + 4 * g;
-        const int ks = inp >> 4;
-        float4 a4 = *reinterpret_cast<const float4 *>(arow), x0 = *reinterpret_cast<const float4 *>(w0), x1 = *reinterpret_cast<const float4 *>(w1);
-        for (int s = 0; s < ks; ++s) {
-            float4 an = a4, y0 = x0, y1 = x1;
-            if (s + 1 < ks) {  // next block's fragments are in flight while this block's MFMAs run
-                an = *reinterpret_cast<const float4 *>(arow + 16 * (s + 1));
-                y0 = *reinterpret_cast<const float4 *>(w0 + 256 * (s + 1));
-                if (two) y1 = *reinterpret_cast<const float4 *>(w1 + 256 * (s + 1));
+        float4 wreg[MAXKS], areg[MAXKS];
+#pragma unroll
+        for (int s = 0; s < MAXKS; ++s)
+            if (KS > 0 || s < ks) wreg[s] = *reinterpret_cast<const float4 *>(wt + 256 * s);
+#pragma unroll
+        for (int s = 0; s < MAXKS; ++s)
+            if (KS > 0 || s < ks) areg[s] = *reinterpret_cast<const float4 *>(arow + 16 * s);
+        const float b0 = b[col];
+        pf32x4 acc = {b0, b0, b0, b0};
+#pragma unroll
+        for (int s = 0; s < MAXKS; ++s) {
+            if (KS > 0 || s < ks) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[s].x, wreg[s].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[s].y, wreg[s].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[s].z, wreg[s].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[s].w, wreg[s].w, acc, 0, 0, 0);
             }
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, x0.x, acc0, 0, 0, 0);
-            if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, x1.x, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, x0.y, acc0, 0, 0, 0);
-            if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, x1.y, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, x0.z, acc0, 0, 0, 0);
-            if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, x1.z, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, x0.w, acc0, 0, 0, 0);
-            if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, x1.w, acc1, 0, 0, 0);
-            a4 = an; x0 = y0; x1 = y1;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {  // C/D layout: col = lane & 15, row = 4 (lane >> 4) + i
-            float v0 = acc0[i], v1 = acc1[i];
-            if (act == PACT_RELU) { v0 = (v0 < 0.0f) ? 0.0f : v0; v1 = (v1 < 0.0f) ? 0.0f : v1; }
-            else if (act == PACT_TANH) { v0 = tanh_own(v0); v1 = tanh_own(v1); }
-            out[(4 * g + i) * POL_LD + col0] = v0;
-            if (two) out[(4 * g + i) * POL_LD + col1] = v1;
+            float v = acc[i];
+            if (act == PACT_RELU) v = (v < 0.0f) ? 0.0f : v;
+            else if (act == PACT_TANH) v = tanh_own(v);
+            out[(4 * g + i) * POL_LD + col] = v;
         }
+    }
+}
+TD void dense_layer(const float *in, float *out, const float *W, const float *b, int inp, int outp, int act, int wave, int lane) {
+    switch (inp >> 4) {
+        case 2: dense_tile<2>(in, out, W, b, outp, act, wave, lane, 2); break;
+        case 4: dense_tile<4>(in, out, W, b, outp, act, wave, lane, 4); break;
+        case 8: dense_tile<8>(in, out, W, b, outp, act, wave, lane, 8); break;
+        default: dense_tile<0>(in, out, W, b, outp, act, wave, lane, inp >> 4); break;
+    }
+}
+
+// LSTM with the wavefront's weight fragments RESIDENT in registers (one hidden tile per wavefront: hp <= 16 POL_NW): the operand
+// stream out of L2 -- the limit of the streaming form below, every workgroup pulling the same 1.7 MB per call -- happens once per
+// launch instead of once per timestep, and the MFMA loop touches only LDS.  Same MFMA order, same results.  KSX / KSH = k blocks of
+// the input / hidden operand.  160 of the 256 registers a wavefront may hold at two wavefronts per SIMD carry weights.
+template <int KSX, int KSH>
+TD void lstm_resident(const float *Wih, const float *Whh, const float *bs, int hp, int T, const float *xs, float *&x, float *&y, int wave, int lane) {
+    const int r = lane & 15, g = lane >> 4;
+    const int tile = wave;
+    const bool has = tile < (hp >> 4);  // wave-uniform
+    const int col = tile * 16 + r;
+    constexpr int ip = KSX * 16;
+    float4 wx[4][KSX], wh[4][KSH];
+    float bq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (has) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bq[q] = bs[q * hp + col];
+#pragma unroll
+            for (int s = 0; s < KSX; ++s) wx[q][s] = *reinterpret_cast<const float4 *>(Wih + (size_t)q * hp * ip + ((size_t)(tile * KSX + s) * 64 + lane) * 4);
+#pragma unroll
+            for (int s = 0; s < KSH; ++s) wh[q][s] = *reinterpret_cast<const float4 *>(Whh + (size_t)q * hp * hp + ((size_t)(tile * KSH + s) * 64 + lane) * 4);
+        }
+    }
+    float cst[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int t = 0; t < T; ++t) {
+        if (has) {
+            const float *xt = xs + (size_t)t * POL_ROWS * POL_XLD + r * POL_XLD + 4 * g;
+            const float *hrow = x + r * POL_LD + 4 * g;
+            pf32x4 acc[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = pf32x4{bq[q], bq[q], bq[q], bq[q]};
+#pragma unroll
+            for (int s = 0; s < KSX; ++s) {
+                const float4 a4 = *reinterpret_cast<const float4 *>(xt + 16 * s);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, wx[q][s].x, acc[q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, wx[q][s].y, acc[q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, wx[q][s].z, acc[q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wx[q][s].w, acc[q], 0, 0, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < KSH; ++s) {
+                const float4 a4 = *reinterpret_cast<const float4 *>(hrow + 16 * s);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, wh[q][s].x, acc[q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, wh[q][s].y, acc[q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, wh[q][s].z, acc[q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wh[q][s].w, acc[q], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float ig = sigmoid_own(acc[0][i]), fg = sigmoid_own(acc[1][i]), gg = tanh_own(acc[2][i]), og = sigmoid_own(acc[3][i]);
+                const float c = fg * cst[i] + ig * gg;
+                cst[i] = c;
+                y[(4 * g + i) * POL_LD + col] = og * tanh_own(c);
+            }
+        }
+        __syncthreads();  // h_t complete in y; every wavefront is done reading h_{t-1} from x
+        float *tt = x; x = y; y = tt;
     }
 }
 
@@ -89,6 +166,8 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_policy_kernel(const PolicyPa
     __shared__ __attribute__((aligned(16))) float bufB[POL_ROWS * POL_LD];
     __shared__ __attribute__((aligned(16))) float xs[POL_MAXT * POL_ROWS * POL_XLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#define POL_STAMP(k) do { if (P.stamps && blockIdx.x == 0 && tid == 0) P.stamps[(k) + 8 * blockIdx.y] = __builtin_readcyclecounter(); } while (0)
+    POL_STAMP(0);
     const int row0 = blockIdx.x * POL_ROWS;
     const float *w = P.blob;
     float *x = bufA, *y = bufB;
@@ -104,6 +183,7 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_policy_kernel(const PolicyPa
             x[r * POL_LD + k] = (env < P.n && k < kin) ? P.obs[(size_t)env * kin + k] : 0.0f;
         }
         __syncthreads();
+        POL_STAMP(1);
         int in = in_a;
         for (int l = 0; l <= P.n_actor_hidden; ++l) {
             const bool last = l == P.n_actor_hidden;
@@ -114,9 +194,48 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_policy_kernel(const PolicyPa
             in = out;
             float *t = x; x = y; y = t;
         }
+        POL_STAMP(2);
         const float *log_std = w;
-        // ---- distribution (:333-345): scale_tril = diag(exp(log_std) * exp(log_std)); one thread per env
-        if (tid < POL_ROWS && row0 + tid < P.n) {
+        // ---- distribution (:333-345): scale_tril = diag(exp(log_std) * exp(log_std)).  One thread per (env, action component) when
+        // act_dim == 4 (the log-prob's two sums run over the quad by DPP, in component order); one thread per env otherwise.
+        if (P.act_dim == 4) {
+            if (tid < 4 * POL_ROWS) {
+                const int er = tid >> 2, a = tid & 3;
+                const int env = row0 + er;
+                const bool live = env < P.n;
+                const float mean = x[er * POL_LD + a];
+                const float e = expf_own(log_std[a]);
+                const float scale = e * e;
+                float act = mean;
+                if (!P.deterministic) {
+                    const U4 rnd = philox(P.seed_lo, P.seed_hi, (uint32_t)env, P.call, STREAM_POLICY, 0u);
+                    const uint32_t ba = (a & 2) ? rnd.z : rnd.x, bb = (a & 2) ? rnd.w : rnd.y;
+                    const float ua = 1.0f - uniform(ba), ub = uniform(bb);
+                    const float rad = __builtin_sqrtf(-2.0f * log(ua));
+                    float sn, cs;
+                    sincos(kTwoPi * ub, sn, cs);
+                    const float eps = (a & 1) ? rad * sn : rad * cs;
+                    act = mean + scale * eps;
+                }
+                const float zz = (act - mean) / scale;
+                const float z2 = zz * zz, ls = log(scale);
+                auto bcq = [](float v, int k) {
+                    const int iv = __builtin_bit_cast(int, v);
+                    const int o = k == 0 ? __builtin_amdgcn_update_dpp(0, iv, 0x00, 0xf, 0xf, true) : k == 1 ? __builtin_amdgcn_update_dpp(0, iv, 0x55, 0xf, 0xf, true)
+                                : k == 2 ? __builtin_amdgcn_update_dpp(0, iv, 0xaa, 0xf, 0xf, true) : __builtin_amdgcn_update_dpp(0, iv, 0xff, 0xf, 0xf, true);
+                    return __builtin_bit_cast(float, o);
+                };
+                float lp = 0.0f + bcq(z2, 0); lp = lp + bcq(z2, 1); lp = lp + bcq(z2, 2); lp = lp + bcq(z2, 3);
+                float hld = 0.0f + bcq(ls, 0); hld = hld + bcq(ls, 1); hld = hld + bcq(ls, 2); hld = hld + bcq(ls, 3);
+                if (live) {
+                    P.action[(size_t)env * 4 + a] = act;
+                    if (P.action_env) P.action_env[(size_t)env * 4 + a] = clampf(act, P.act_lo, P.act_hi);
+                    P.mu[(size_t)env * 4 + a] = mean;
+                    P.sigma[(size_t)env * 4 + a] = log_std[a];
+                    if (a == 0) P.logp[env] = -0.5f * (4.0f * 1.8378770664093453f + lp) - hld;
+                }
+            }
+        } else if (tid < POL_ROWS && row0 + tid < P.n) {
             const int env = row0 + tid;
             float lp = 0.0f, half_log_det = 0.0f;
             U4 rnd{0u, 0u, 0u, 0u};
@@ -140,11 +259,13 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_policy_kernel(const PolicyPa
                 lp = lp + zz * zz;
                 half_log_det = half_log_det + log(scale);
                 P.action[(size_t)env * P.act_dim + a] = act;
+                if (P.action_env) P.action_env[(size_t)env * P.act_dim + a] = clampf(act, P.act_lo, P.act_hi);
                 P.mu[(size_t)env * P.act_dim + a] = mean;
                 P.sigma[(size_t)env * P.act_dim + a] = log_std[a];
             }
             P.logp[env] = -0.5f * ((float)P.act_dim * 1.8378770664093453f + lp) - half_log_det;
         }
+        POL_STAMP(3);
         return;
     }
 
@@ -168,8 +289,14 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_policy_kernel(const PolicyPa
         }
         for (int e = tid; e < POL_ROWS * hp; e += 64 * POL_NW) x[(e / hp) * POL_LD + (e % hp)] = 0.0f;
         __syncthreads();
-        const int r = lane & 15, g = lane >> 4;
+        POL_STAMP(1);
         const int ntiles = hp >> 4;
+        if (ip == 32 && ntiles == 8) {
+            lstm_resident<2, 8>(Wih, Whh, bs, hp, T, xs, x, y, wave, lane);
+        } else if (ip == 32 && ntiles == 4) {
+            lstm_resident<2, 4>(Wih, Whh, bs, hp, T, xs, x, y, wave, lane);
+        } else {
+        const int r = lane & 15, g = lane >> 4;
         constexpr int TPW = (POL_MAXW / 16 + POL_NW - 1) / POL_NW;  // hidden tiles per wavefront at the widest LSTM
         float cst[TPW][4];  // cell state of this wavefront's hidden tiles (tile = wave + POL_NW j), rows 4 g + i
 #pragma unroll
@@ -227,6 +354,8 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_policy_kernel(const PolicyPa
             __syncthreads();  // h_t complete in y; every wavefront is done reading h_{t-1} from x
             float *tt = x; x = y; y = tt;
         }
+        }
+        POL_STAMP(2);
         in = hp;
     } else {
         const int kin = P.states_len * P.states_dim;
@@ -247,7 +376,10 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_policy_kernel(const PolicyPa
         in = out;
         float *t = x; x = y; y = t;
     }
+    POL_STAMP(3);
     if (tid < POL_ROWS && row0 + tid < P.n) P.value[row0 + tid] = x[tid * POL_LD];
+    POL_STAMP(4);
+#undef POL_STAMP
 }
 
 }  // namespace taco

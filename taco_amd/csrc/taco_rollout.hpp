@@ -34,6 +34,13 @@ __global__ __launch_bounds__(kGaeBlock) void gae_kernel(const float *__restrict_
     }
 }
 
+// rewards_augmented[truncated] += gamma * V(s_t)  (ppo_asymmetry.py:314-324): the value of the pre-step state is value_buf[t] itself
+__global__ __launch_bounds__(256) void timeout_bootstrap_kernel(float *__restrict__ rew, const float *__restrict__ value, const float *__restrict__ done,
+                                                                const uint8_t *__restrict__ timeout, size_t count, float g) {
+    const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (k < count && timeout[k] != 0 && done[k] != 0.0f) rew[k] = rew[k] + g * value[k];
+}
+
 __device__ __forceinline__ double wave_sum(double x) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);

@@ -114,6 +114,40 @@ class RolloutBuffer:
         self.step += 1
         return self.rew_buf[t].view(-1), env.reset_buf, env.timeout_buf
 
+    def run(self, env, policy, act_low=-1.0, act_high=1.0):
+        """The whole rollout of ppo_asymmetry.py:308-342 as ONE C call (taco_rollout_run): horizon x (policy.act on slot t, clipped
+        action -> env step writing slot t + 1) + the value of the final state + the time-out bootstrap, 2 H + 2 launches enqueued
+        back to back with no host work in between.  Fills every buffer `store` fills; returns last_values [N, 1] for
+        compute_returns_and_advantage.  Equivalent, bit for bit, to the act()/collect() loop (tests/test_rollout_gpu.py)."""
+        if self.step != 0:
+            raise AssertionError("run() fills a whole rollout: call reset() first")
+        if math.isfinite(env.clip_obs) or math.isfinite(env.clip_states):
+            raise _lib.TacoError("run() stores the env's unclamped frame stacks; with finite clipObservations / clipStates use env.step() + store()")
+        if (env.num_envs, env.len_obs, env.num_obs, env.len_states, env.num_states) != (self.num_envs, self.obs_len, self.obs_dim, self.states_len, self.states_dim):
+            raise ValueError("env and buffer geometry differ")
+        H, N, dev = self.horizon_len, self.num_envs, self.device
+        if not hasattr(self, "_run_scratch"):
+            self._act_env = torch.empty(N, self.act_dim, device=dev)
+            self._timeouts = torch.zeros(H, N, dtype=torch.uint8, device=dev)
+            self._last_value = torch.empty(N, 1, device=dev)
+            self._run_scratch = torch.empty(N, 13, device=dev)
+        b = _lib.RolloutBufs(self._obs_store.data_ptr(), self._states_store.data_ptr(), self.act_buf.data_ptr(), self._act_env.data_ptr(),
+                             self.rew_buf.data_ptr(), self.done_buf.data_ptr(), self.value_buf.data_ptr(), self.logp_buf.data_ptr(),
+                             self.mu_buf.data_ptr(), self.sigma_buf.data_ptr(), self._timeouts.data_ptr(), self._last_value.data_ptr(),
+                             self._run_scratch.data_ptr())
+        s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(self.lib.taco_rollout_run(env._h, C.byref(policy.cfg), policy._blob.data_ptr(), C.byref(b), H, C.c_uint64(policy.seed),
+                                             C.c_uint32(policy.calls), float(self.gamma), float(act_low), float(act_high),
+                                             env.reset_buf.data_ptr(), s))
+        policy.calls += H + 1
+        self.step = H
+        return self._last_value
+
+    @property
+    def time_outs(self):
+        """[H, N] uint8: extras["time_outs"] of every step of the last run()"""
+        return self._timeouts
+
     def add_timeout_bootstrap(self, t, env_ids, time_out_value):
         """rewards_augmented[truncated] += gamma * V(s_t)  (ppo_asymmetry.py:320-324) on the stored reward of step t."""
         self.rew_buf[t].view(-1)[env_ids] += self.gamma * time_out_value.view(-1)

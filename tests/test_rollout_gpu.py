@@ -104,3 +104,46 @@ def test_collect_refuses_what_it_cannot_do_exactly():
     with pytest.raises(ValueError):
         buf.collect(env2, env2.zero_actions().cuda())
     assert len(buf.batch_idx_generator()) == 4 and sorted(sum(buf.batch_idx_generator(), [])) == list(range(64 * 4))
+
+
+@pytest.mark.parametrize("n,task,len_states", [(300, "pos", 5), (96, "mix", 3)])
+def test_rollout_run_equals_the_python_loop(n, task, len_states):
+    """taco_rollout_run (one C call, 2 H + 2 launches) == the act() / collect() / bootstrap loop of ppo_asymmetry.py:308-342, bit for bit."""
+    from taco_amd import policy as P
+    from taco_amd.vec_env import FpvBase
+    import test_policy_gpu as TP
+    H = 12
+    rng = np.random.default_rng(5)
+    sd = TP._random_policy(rng, 1, len_states, [48, 32], 32, [40])
+    cfg = config.default_cfg(task, n, env_lenStates=len_states, env_maxEpisodeLength=7, seed=3)
+    outs = []
+    for mode in ("run", "loop"):
+        env = FpvBase(cfg, copy_outputs=False)
+        pol = P.ActorCritic(sd, 1, len_states, seed=21)
+        buf = _buffer(n, H, 1, len_states)
+        for epoch in range(2):
+            buf.reset()
+            if mode == "run":
+                last = buf.run(env, pol)
+                tmo = buf.time_outs.clone()
+            else:
+                tmo = torch.zeros(H, n, dtype=torch.uint8, device="cuda")
+                for t in range(H):
+                    action, logp, value, mu, sigma = pol.act(buf.next_obs, buf.next_states)
+                    rew, dones, time_outs = buf.collect(env, torch.clip(action, -1, 1), logp, value, mu, sigma, act=action)
+                    tmo[t] = time_outs.to(torch.uint8)
+                    ids = (time_outs & (dones != 0)).nonzero().squeeze(-1)
+                    if ids.numel():
+                        buf.add_timeout_bootstrap(t, ids, value[ids])
+                last = pol.act(buf.next_obs, buf.next_states, deterministic=True)[2]
+            buf.compute_returns_and_advantage(last)
+        assert tmo.sum() > 0 and buf.done_buf.sum() > tmo.sum() * 0   # short episodes: time-outs happened, the bootstrap path ran
+        outs.append({k: getattr(buf, k).clone() for k in ("obs_buf", "states_buf", "act_buf", "rew_buf", "done_buf", "value_buf", "logp_buf",
+                                                            "mu_buf", "sigma_buf", "ret_buf", "adv_buf")} | {"last": last.clone(), "tmo": tmo,
+                                                                                                             "state": env.get_state().view(torch.int32)})
+    for k in outs[0]:
+        a, b = outs[0][k], outs[1][k]
+        if a.dtype == torch.float32:
+            assert_bits_equal(a.cpu().numpy(), b.cpu().numpy(), k)
+        else:
+            assert torch.equal(a, b), k

@@ -73,7 +73,45 @@ buf.value_buf.normal_(); lastv = torch.randn(N, 1, device="cuda"); adv = torch.z
 t_copy, t_fused = timed(loop_copy), timed(loop_fused)
 buf.step = H
 t_gt, t_gh = timed(gae_torch), timed(lambda: buf.compute_returns_and_advantage(lastv))
+# d) the whole rollout incl. policy inference: Python loop (act + collect) vs one taco_rollout_run call
+from taco_amd import policy as P  # noqa: E402
+import numpy as np  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+rng = np.random.default_rng(0)
+Hd = 128
+sd = {"log_std": np.zeros(4, np.float32)}
+dims = [26, Hd, Hd, Hd, 4]
+for i in range(4):
+    sd[f"actor_mlp.layers.{2 * i}.weight"] = (rng.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32)
+    sd[f"actor_mlp.layers.{2 * i}.bias"] = np.zeros(dims[i + 1], np.float32)
+sd["critic_encoder.layers.weight_ih_l0"] = (rng.standard_normal((4 * Hd, 26)) * 0.2).astype(np.float32)
+sd["critic_encoder.layers.weight_hh_l0"] = (rng.standard_normal((4 * Hd, Hd)) / np.sqrt(Hd)).astype(np.float32)
+sd["critic_encoder.layers.bias_ih_l0"] = np.zeros(4 * Hd, np.float32)
+sd["critic_encoder.layers.bias_hh_l0"] = np.zeros(4 * Hd, np.float32)
+dims = [Hd, Hd, Hd, 1]
+for i in range(3):
+    sd[f"critic_mlp.layers.{2 * i}.weight"] = (rng.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32)
+    sd[f"critic_mlp.layers.{2 * i}.bias"] = np.zeros(dims[i + 1], np.float32)
+pol = P.ActorCritic(sd, 1, a.len_states)
+
+
+def loop_policy():
+    buf.reset()
+    for t in range(H):
+        action, logp, value, mu, sigma = pol.act(buf.next_obs, buf.next_states)
+        buf.collect(env, torch.clip(action, -1, 1), logp, value, mu, sigma, act=action)
+    pol.act(buf.next_obs, buf.next_states, deterministic=True)
+
+
+def run_policy():
+    buf.reset()
+    buf.run(env, pol)
+
+
+t_loop, t_run = timed(loop_policy), timed(run_policy)
 print(json.dumps({"envs": N, "horizon": H, "len_states": a.len_states,
+                  "rollout_with_policy_python_loop_ms": t_loop * 1e3, "rollout_with_policy_one_call_ms": t_run * 1e3,
+                  "rollout_with_policy_env_steps_per_s": N * H / t_run,
                   "rollout_copy_ms": t_copy * 1e3, "rollout_fused_ms": t_fused * 1e3,
                   "rollout_copy_env_steps_per_s": N * H / t_copy, "rollout_fused_env_steps_per_s": N * H / t_fused,
                   "gae_torch_ms": t_gt * 1e3, "gae_hip_ms": t_gh * 1e3}))
