@@ -111,3 +111,14 @@ def test_unsupported_configurations_fail_loudly():
     pol = P.ActorCritic(sd, 1, 5)
     with pytest.raises(ValueError):
         pol.act(torch.zeros(4, 2, 26).cuda(), torch.zeros(4, 5, 26).cuda())
+
+
+def test_torchscript_export_agrees_with_the_hip_forward(tmp_path):
+    """Row N3: the TorchScript actor written by save_actor_as_pt (the on-board deployment format, ppo_asymmetry.py:458-468) and the HIP
+    policy kernel are the same function (1e-6: torch's GEMM order vs the kernel's fma chain)."""
+    from taco_amd.train_utils import save_actor_as_pt
+    g, sd, pol = _golden_policy()
+    save_actor_as_pt(sd, str(tmp_path / "actor_1.pt"), 1)
+    ts = torch.jit.load(str(tmp_path / "actor_1.pt"))
+    obs = torch.from_numpy(g["obs"])
+    np.testing.assert_allclose(pol.forward(obs.cuda()).cpu().numpy(), ts(obs).detach().numpy(), rtol=0, atol=1e-6)
