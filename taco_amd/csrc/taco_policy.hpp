@@ -47,13 +47,13 @@ enum { PACT_RELU = 0, PACT_TANH = 1, PACT_NONE = 2 };
 // tile (KS = inp / 16 blocks, one float4 of weights from L2 and one of activations from LDS each) are requested up front, so the
 // latencies are paid once per tile, not once per k block (these layers are 16 x 128 x 128: latency-bound, not throughput-bound).
 // KS is a template parameter for the common widths so that the whole tile is straight-line code.
-template <int KS>
+template <int KS, int NW>
 TD void dense_tile(const float *in, float *out, const float *W, const float *b, int outp, int act, int wave, int lane, int ks_rt) {
     const int r = lane & 15, g = lane >> 4;
     const int ntiles = outp >> 4;
     const int ks = KS > 0 ? KS : ks_rt;
     constexpr int MAXKS = KS > 0 ? KS : POL_MAXW / 16;
-    for (int tile = wave; tile < ntiles; tile += POL_NW) {
+    for (int tile = wave; tile < ntiles; tile += NW) {
         const int col = tile * 16 + r;
         const float *wt = W + ((size_t)tile * ks * 64 + lane) * 4;  // fragment-major: block s of this tile at +256 s floats
         const float *arow = in + r * POL_LD + 4 * g;
@@ -84,12 +84,13 @@ TD void dense_tile(const float *in, float *out, const float *W, const float *b, 
         }
     }
 }
+template <int NW>
 TD void dense_layer(const float *in, float *out, const float *W, const float *b, int inp, int outp, int act, int wave, int lane) {
     switch (inp >> 4) {
-        case 2: dense_tile<2>(in, out, W, b, outp, act, wave, lane, 2); break;
-        case 4: dense_tile<4>(in, out, W, b, outp, act, wave, lane, 4); break;
-        case 8: dense_tile<8>(in, out, W, b, outp, act, wave, lane, 8); break;
-        default: dense_tile<0>(in, out, W, b, outp, act, wave, lane, inp >> 4); break;
+        case 2: dense_tile<2, NW>(in, out, W, b, outp, act, wave, lane, 2); break;
+        case 4: dense_tile<4, NW>(in, out, W, b, outp, act, wave, lane, 4); break;
+        case 8: dense_tile<8, NW>(in, out, W, b, outp, act, wave, lane, 8); break;
+        default: dense_tile<0, NW>(in, out, W, b, outp, act, wave, lane, inp >> 4); break;
     }
 }
 
@@ -97,21 +98,22 @@ TD void dense_layer(const float *in, float *out, const float *W, const float *b,
 // stream out of L2 -- the limit of the streaming form below, every workgroup pulling the same 1.7 MB per call -- happens once per
 // launch instead of once per timestep, and the MFMA loop touches only LDS.  Same MFMA order, same results.  KSX / KSH = k blocks of
 // the input / hidden operand.  160 of the 256 registers a wavefront may hold at two wavefronts per SIMD carry weights.
-template <int KSX, int KSH>
+template <int KSX, int KSH, bool WIH_RES>
 TD void lstm_resident(const float *Wih, const float *Whh, const float *bs, int hp, int T, const float *xs, float *&x, float *&y, int wave, int lane) {
     const int r = lane & 15, g = lane >> 4;
     const int tile = wave;
     const bool has = tile < (hp >> 4);  // wave-uniform
     const int col = tile * 16 + r;
     constexpr int ip = KSX * 16;
-    float4 wx[4][KSX], wh[4][KSH];
+    float4 wx[4][WIH_RES ? KSX : 1], wh[4][KSH];
     float bq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (has) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             bq[q] = bs[q * hp + col];
+            if (WIH_RES)
 #pragma unroll
-            for (int s = 0; s < KSX; ++s) wx[q][s] = *reinterpret_cast<const float4 *>(Wih + (size_t)q * hp * ip + ((size_t)(tile * KSX + s) * 64 + lane) * 4);
+                for (int s = 0; s < KSX; ++s) wx[q][s] = *reinterpret_cast<const float4 *>(Wih + (size_t)q * hp * ip + ((size_t)(tile * KSX + s) * 64 + lane) * 4);
 #pragma unroll
             for (int s = 0; s < KSH; ++s) wh[q][s] = *reinterpret_cast<const float4 *>(Whh + (size_t)q * hp * hp + ((size_t)(tile * KSH + s) * 64 + lane) * 4);
         }
@@ -127,14 +129,18 @@ TD void lstm_resident(const float *Wih, const float *Whh, const float *bs, int h
 #pragma unroll
             for (int s = 0; s < KSX; ++s) {
                 const float4 a4 = *reinterpret_cast<const float4 *>(xt + 16 * s);
+                float4 wv[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, wx[q][s].x, acc[q], 0, 0, 0);
+                for (int q = 0; q < 4; ++q)
+                    wv[q] = WIH_RES ? wx[q][WIH_RES ? s : 0] : *reinterpret_cast<const float4 *>(Wih + (size_t)q * hp * ip + ((size_t)(tile * KSX + s) * 64 + lane) * 4);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, wx[q][s].y, acc[q], 0, 0, 0);
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, wv[q].x, acc[q], 0, 0, 0);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, wx[q][s].z, acc[q], 0, 0, 0);
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, wv[q].y, acc[q], 0, 0, 0);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wx[q][s].w, acc[q], 0, 0, 0);
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, wv[q].z, acc[q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wv[q].w, acc[q], 0, 0, 0);
             }
 #pragma unroll
             for (int s = 0; s < KSH; ++s) {
@@ -161,23 +167,23 @@ TD void lstm_resident(const float *Wih, const float *Whh, const float *bs, int h
     }
 }
 
-__global__ __launch_bounds__(64 * POL_NW) void taco_policy_kernel(const PolicyParams P) {
-    __shared__ __attribute__((aligned(16))) float bufA[POL_ROWS * POL_LD];
-    __shared__ __attribute__((aligned(16))) float bufB[POL_ROWS * POL_LD];
-    __shared__ __attribute__((aligned(16))) float xs[POL_MAXT * POL_ROWS * POL_XLD];
+#define POL_STAMP(k) do { if (P.stamps && blockIdx.x == 0 && tid == 0) P.stamps[(k) + 8 * ROLE] = __builtin_readcyclecounter(); } while (0)
+
+// ---- the actor: MLP + tanh head + action sampling / log-prob (nets_asymmetry.py:331-345) for the 16 envs of workgroup blockIdx.x
+template <int NW>
+TD void actor_body(const PolicyParams &P, float *bufA, float *bufB) {
+    constexpr int ROLE = 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#define POL_STAMP(k) do { if (P.stamps && blockIdx.x == 0 && tid == 0) P.stamps[(k) + 8 * blockIdx.y] = __builtin_readcyclecounter(); } while (0)
     POL_STAMP(0);
     const int row0 = blockIdx.x * POL_ROWS;
     const float *w = P.blob;
     float *x = bufA, *y = bufB;
-
     // ---- where the actor's parameters end (both roles walk the same blob)
     int in_a = pad16(P.obs_len * P.obs_dim);
-    if (blockIdx.y == 0) {
+    {
         // ------------------------------------------------------------------ actor: MLP + tanh head (nets_asymmetry.py:331-332)
         const int kin = P.obs_len * P.obs_dim;
-        for (int e = tid; e < POL_ROWS * in_a; e += 64 * POL_NW) {
+        for (int e = tid; e < POL_ROWS * in_a; e += 64 * NW) {
             const int r = e / in_a, k = e - r * in_a;
             const int env = row0 + r;
             x[r * POL_LD + k] = (env < P.n && k < kin) ? P.obs[(size_t)env * kin + k] : 0.0f;
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_policy_kernel(const PolicyPa
         for (int l = 0; l <= P.n_actor_hidden; ++l) {
             const bool last = l == P.n_actor_hidden;
             const int out = pad16(last ? P.act_dim : P.actor_hidden[l]);
-            dense_layer(x, y, w, w + (size_t)out * in, in, out, last ? PACT_TANH : PACT_RELU, wave, lane);
+            dense_layer<NW>(x, y, w, w + (size_t)out * in, in, out, last ? PACT_TANH : PACT_RELU, wave, lane);
             __syncthreads();
             w += (size_t)out * in + out;
             in = out;
@@ -266,8 +272,19 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_policy_kernel(const PolicyPa
             P.logp[env] = -0.5f * ((float)P.act_dim * 1.8378770664093453f + lp) - half_log_det;
         }
         POL_STAMP(3);
-        return;
     }
+}
+
+// ---- the critic: LSTM over the state stack (or the flattened stack) + MLP (:348-352)
+template <int NW, bool WIH_RES>
+TD void critic_body(const PolicyParams &P, float *bufA, float *bufB, float *xs) {
+    constexpr int ROLE = 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    POL_STAMP(0);
+    const int row0 = blockIdx.x * POL_ROWS;
+    const float *w = P.blob;
+    float *x = bufA, *y = bufB;
+    int in_a = pad16(P.obs_len * P.obs_dim);
 
     // ------------------------------------------------------------------ critic (:348-352): skip the actor's parameters
     for (int l = 0; l <= P.n_actor_hidden; ++l) {
@@ -282,23 +299,23 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_policy_kernel(const PolicyPa
         const int hp = pad16(P.lstm_hidden), ip = pad16(P.states_dim), T = P.states_len;
         const float *Wih = w, *Whh = w + (size_t)4 * hp * ip, *bs = Whh + (size_t)4 * hp * hp;
         w = bs + (size_t)4 * hp;
-        for (int e = tid; e < T * POL_ROWS * ip; e += 64 * POL_NW) {
+        for (int e = tid; e < T * POL_ROWS * ip; e += 64 * NW) {
             const int t = e / (POL_ROWS * ip), rem = e - t * POL_ROWS * ip, r = rem / ip, k = rem - r * ip;
             const int env = row0 + r;
             xs[(t * POL_ROWS + r) * POL_XLD + k] = (env < P.n && k < P.states_dim) ? P.states[((size_t)env * T + t) * P.states_dim + k] : 0.0f;
         }
-        for (int e = tid; e < POL_ROWS * hp; e += 64 * POL_NW) x[(e / hp) * POL_LD + (e % hp)] = 0.0f;
+        for (int e = tid; e < POL_ROWS * hp; e += 64 * NW) x[(e / hp) * POL_LD + (e % hp)] = 0.0f;
         __syncthreads();
         POL_STAMP(1);
         const int ntiles = hp >> 4;
         if (ip == 32 && ntiles == 8) {
-            lstm_resident<2, 8>(Wih, Whh, bs, hp, T, xs, x, y, wave, lane);
+            lstm_resident<2, 8, WIH_RES>(Wih, Whh, bs, hp, T, xs, x, y, wave, lane);
         } else if (ip == 32 && ntiles == 4) {
-            lstm_resident<2, 4>(Wih, Whh, bs, hp, T, xs, x, y, wave, lane);
+            lstm_resident<2, 4, WIH_RES>(Wih, Whh, bs, hp, T, xs, x, y, wave, lane);
         } else {
         const int r = lane & 15, g = lane >> 4;
-        constexpr int TPW = (POL_MAXW / 16 + POL_NW - 1) / POL_NW;  // hidden tiles per wavefront at the widest LSTM
-        float cst[TPW][4];  // cell state of this wavefront's hidden tiles (tile = wave + POL_NW j), rows 4 g + i
+        constexpr int TPW = (POL_MAXW / 16 + NW - 1) / NW;  // hidden tiles per wavefront at the widest LSTM
+        float cst[TPW][4];  // cell state of this wavefront's hidden tiles (tile = wave + NW j), rows 4 g + i
 #pragma unroll
         for (int j = 0; j < TPW; ++j)
 #pragma unroll
@@ -334,7 +351,7 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_policy_kernel(const PolicyPa
             const float *hrow = x + r * POL_LD + 4 * g;
 #pragma unroll
             for (int j = 0; j < TPW; ++j) {
-                const int tile = wave + POL_NW * j;
+                const int tile = wave + NW * j;
                 if (tile < ntiles) {  // wave-uniform
                     const int col = tile * 16 + r;
                     pf32x4 acc[4];
@@ -360,7 +377,7 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_policy_kernel(const PolicyPa
     } else {
         const int kin = P.states_len * P.states_dim;
         in = pad16(kin);
-        for (int e = tid; e < POL_ROWS * in; e += 64 * POL_NW) {
+        for (int e = tid; e < POL_ROWS * in; e += 64 * NW) {
             const int r = e / in, k = e - r * in;
             const int env = row0 + r;
             x[r * POL_LD + k] = (env < P.n && k < kin) ? P.states[(size_t)env * kin + k] : 0.0f;
@@ -370,7 +387,7 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_policy_kernel(const PolicyPa
     for (int l = 0; l <= P.n_critic_hidden; ++l) {
         const bool last = l == P.n_critic_hidden;
         const int out = pad16(last ? 1 : P.critic_hidden[l]);
-        dense_layer(x, y, w, w + (size_t)out * in, in, out, last ? PACT_NONE : PACT_RELU, wave, lane);
+        dense_layer<NW>(x, y, w, w + (size_t)out * in, in, out, last ? PACT_NONE : PACT_RELU, wave, lane);
         __syncthreads();
         w += (size_t)out * in + out;
         in = out;
@@ -379,7 +396,16 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_policy_kernel(const PolicyPa
     POL_STAMP(3);
     if (tid < POL_ROWS && row0 + tid < P.n) P.value[row0 + tid] = x[tid * POL_LD];
     POL_STAMP(4);
+}
 #undef POL_STAMP
+
+// One launch for both roles (taco_policy_act): grid.y = 0 actor, 1 critic
+__global__ __launch_bounds__(64 * POL_NW) void taco_policy_kernel(const PolicyParams P) {
+    __shared__ __attribute__((aligned(16))) float bufA[POL_ROWS * POL_LD];
+    __shared__ __attribute__((aligned(16))) float bufB[POL_ROWS * POL_LD];
+    __shared__ __attribute__((aligned(16))) float xs[POL_MAXT * POL_ROWS * POL_XLD];
+    if (blockIdx.y == 0) actor_body<POL_NW>(P, bufA, bufB);
+    else critic_body<POL_NW, true>(P, bufA, bufB, xs);
 }
 
 }  // namespace taco
