@@ -276,6 +276,24 @@ def main():
                                            "frac_of_hbm_peak": ach / HBM_PEAK_GBPS, "traffic": tr, "grid": bg, "block": bb})
                     del benv, bacts
                     torch.cuda.empty_cache()
+                # the documented training configuration stacks 5 state frames for the LSTM critic (README.md:60-66 of the reference):
+                # + (len - 1) * 104 B read and len * 104 B written per env-step for the stack (936 B at len 5)
+                out["stacked_states"] = []
+                for sn in (n_local, 262144):
+                    scfg = config.baseline_config(1, num_envs=sn)
+                    scfg["env"]["lenStates"] = 5
+                    senv = FpvBase(scfg, sim_device=str(dev), rl_device=str(dev), copy_outputs=False)
+                    sacts = make_actions(sn, 4, 7, dev)
+                    for t in range(20):
+                        senv.step_raw(sacts[t % 4])
+                    torch.cuda.synchronize()
+                    s_avg, _ = time_kernel_launches(senv, sacts, 100, torch)
+                    sbytes = ALGO_BYTES_PER_ENV_STEP + 4 * 104 + 5 * 104 - 104   # the len-1 state frame is already in the 820 B
+                    out["stacked_states"].append({"envs": sn, "len_states": 5, "kernel_avg_us": s_avg, "env_steps_per_s": sn / (s_avg * 1e-6),
+                                                  "algorithmic_bytes_per_env_step": sbytes, "achieved_GBps": sbytes * sn / (s_avg * 1e-6) / 1e9,
+                                                  "frac_of_hbm_peak": sbytes * sn / (s_avg * 1e-6) / 1e9 / HBM_PEAK_GBPS})
+                    del senv, sacts
+                    torch.cuda.empty_cache()
             out["parity"] = parity_check(config.baseline_config(1, num_envs=n_local))
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(config.baseline_config(1, num_envs=n_local))
