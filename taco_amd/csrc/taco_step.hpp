@@ -1042,15 +1042,18 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
     //  len  > 1 : each lane shifts its own row by one frame (8-byte accesses, in place, ascending) and appends the frame.
     // Stores go through range-checked buffer descriptors, so ragged tails need no special casing.
     const uint32_t wave_env0 = (uint32_t)((blockIdx.x * BLOCK + wv * 64) / LPE);
-    auto put_frame = [&](float *buf, const float *prev, uint32_t buf_bytes, int len, const float (&f)[26]) {
+    // fill_tile = false: the tile already holds this frame (the obs frame equals the states frame when there is no observation noise)
+    auto put_frame = [&](float *buf, const float *prev, uint32_t buf_bytes, int len, const float (&f)[26], bool fill_tile) {
         const rsrc_t rB = make_rsrc(buf, buf_bytes);
-        __syncthreads();  // previous users of the scratch (action slots / the other buffer's tile) are done
-        f32x2_t *t2 = reinterpret_cast<f32x2_t *>(tile + el * 26);  // 104-byte rows: 8-byte aligned
-        if (sub == 0) {
+        if (fill_tile) {
+            __syncthreads();  // previous users of the scratch (action slots / the other buffer's tile) are done
+            f32x2_t *t2 = reinterpret_cast<f32x2_t *>(tile + el * 26);  // 104-byte rows: 8-byte aligned
+            if (sub == 0) {
 #pragma unroll
-            for (int k = 0; k < 13; ++k) t2[k] = f32x2_t{f[2 * k], f[2 * k + 1]};
+                for (int k = 0; k < 13; ++k) t2[k] = f32x2_t{f[2 * k], f[2 * k + 1]};
+            }
+            __syncthreads();
         }
-        __syncthreads();
         if (len == 1) {
             const f32x4_t *t4 = reinterpret_cast<const f32x4_t *>(tile);
             constexpr uint32_t TILE_W4 = (uint32_t)EPW * 26u / 4u;  // 16-byte words of the wave's contiguous range (416 or 104)
@@ -1090,7 +1093,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
         }
     };
     // states first (noise-free frame), then obs (possibly noised)
-    put_frame(P.states, P.states_prev, P.states_bytes, P.len_states, fr);
+    put_frame(P.states, P.states_prev, P.states_bytes, P.len_states, fr, true);
     if (fl & TACO_F_OBSERVATION_NOISE) {  // FA:402-410
         float nrm[12];
 #pragma unroll
@@ -1120,7 +1123,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
         fr[18] = fr[18] + P.df * (nrm[9] * (float)(0.06 / 3) + 0.0f);
         fr[23] = fr[23] + P.df * (nrm[10] * (float)(0.06 / 3 / 3) + 0.0f);
     }
-    put_frame(P.obs, P.obs_prev, P.obs_bytes, P.len_obs, fr);
+    put_frame(P.obs, P.obs_prev, P.obs_bytes, P.len_obs, fr, (fl & TACO_F_OBSERVATION_NOISE) != 0);
 
     TACO_STAMP(4);  // state stores + frames done
     // ------------------------------------------------------------------ compute_reward CTRL/task_reward.py
