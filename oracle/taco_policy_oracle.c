@@ -5,8 +5,8 @@
  * The arithmetic is DEFINED here and followed bit for bit by the HIP kernel (taco_amd/csrc/taco_policy.hpp):
  *   linear:  acc = bias[o];  for s, t, g:  k = 16 s + 4 g + t;  acc = fmaf(x[k], W[o][k], acc)
  *            (the order in which the 16x16x4 f32 MFMA consumes 16-byte operand fragments; an f32 MFMA is a k-ordered fmaf chain)
- *   LSTM:    gates start from b_ih + b_hh, run the chain over x_t, then over h_{t-1}; i f o = sigmoid, g = tanh (own kernels
- *            below); c = f * c + i * g; h = o * tanh(c)                                   (nets_asymmetry.py:128-136, torch.nn.LSTM)
+ *   LSTM:    gates start from b_ih + b_hh, run the chain over x_t, then over h_{t-1}; then the fused cell lstm_cell() below
+ *            (c = f * c + i * g, h = o * tanh(c) with three divisions for the five activations)   (nets_asymmetry.py:128-136, torch.nn.LSTM)
  *   actor head: tanh; log_std / scale_tril quirk of :334-335 (scale = exp(log_std) * exp(log_std)); MultivariateNormal log_prob.
  * Parity with the reference (which uses the platform BLAS / vectorised transcendentals) is a tolerance, 1e-5, pinned by
  * tests/golden/policy.npz generated from the reference module on CPU. */
@@ -51,6 +51,21 @@ float orc_tanhf(float x) {
     const float small = fmaf(p * z2, x, x);
     const float t = (z >= 0.625f) ? big : small;
     return (x != x) ? x : t;
+}
+
+/* the fused LSTM cell of taco_math.hpp::lstm_cell, operation for operation */
+static inline void lstm_cell(float ai, float af, float ag, float ao, float c_old, float *c_new, float *h) {
+    const float ei = orc_expf(-ai), ef = orc_expf(-af), eo = orc_expf(-ao);
+    const float zg = fabsf(ag);
+    const float tg = orc_expf(-(zg + zg));
+    const float ng = pu2f((pf2u(1.0f - tg) & 0x7fffffffu) | (pf2u(ag) & 0x80000000u));
+    const float ig = ng / ((1.0f + ei) * (1.0f + tg));
+    const float c = c_old / (1.0f + ef) + ig;
+    const float zc = fabsf(c);
+    const float tc = orc_expf(-(zc + zc));
+    const float nc = pu2f((pf2u(1.0f - tc) & 0x7fffffffu) | (pf2u(c) & 0x80000000u));
+    *c_new = c;
+    *h = nc / ((1.0f + eo) * (1.0f + tc));
 }
 
 static inline int pad16(int x) { return (x + 15) / 16 * 16; }
@@ -156,9 +171,7 @@ static void act_one(const orc_policy_cfg *c, const float *blob, const float *obs
                     a = chain(h, Whh + (size_t)q * hp * hp, j, hp, a);
                     gate[q] = a;
                 }
-                const float ig = orc_sigmoidf(gate[0]), fg = orc_sigmoidf(gate[1]), gg = orc_tanhf(gate[2]), og = orc_sigmoidf(gate[3]);
-                cst[j] = fg * cst[j] + ig * gg;
-                hn[j] = og * orc_tanhf(cst[j]);
+                lstm_cell(gate[0], gate[1], gate[2], gate[3], cst[j], &cst[j], &hn[j]);
             }
             memcpy(h, hn, sizeof(float) * (size_t)hp);
         }

@@ -169,6 +169,21 @@ TD float tanh_own(float x) {
     return (x != x) ? x : t;
 }
 
+// One LSTM cell update (torch.nn.LSTM gate order i f g o) with the activations FUSED so that three divisions serve five activations:
+//   sigmoid(a) = 1 / (1 + e^-a),  tanh(x) = sign(x) (1 - t) / (1 + t) with t = e^(-2|x|)   (absolute error <= 1e-7 everywhere)
+//   i * g = sign(ag) (1 - tg) / ((1 + ei)(1 + tg)),   f * c = c / (1 + ef),   h = o * tanh(c') = sign(c') (1 - tc) / ((1 + eo)(1 + tc))
+TD void lstm_cell(float ai, float af, float ag, float ao, float c_old, float &c_new, float &h) {
+    const float ei = expf_own(-ai), ef = expf_own(-af), eo = expf_own(-ao);
+    const float zg = absf(ag);
+    const float tg = expf_own(-(zg + zg));
+    const float ig = with_sign_of(1.0f - tg, ag) / ((1.0f + ei) * (1.0f + tg));
+    const float c = c_old / (1.0f + ef) + ig;
+    const float zc = absf(c);
+    const float tc = expf_own(-(zc + zc));
+    c_new = c;
+    h = with_sign_of(1.0f - tc, c) / ((1.0f + eo) * (1.0f + tc));
+}
+
 // ---- Philox4x32-10 (Salmon et al., SC'11).  counter = (global env id, step index, stream, block), key = seed
 struct U4 { uint32_t x, y, z, w; };
 TD U4 philox(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {

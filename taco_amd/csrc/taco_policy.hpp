@@ -154,12 +154,14 @@ TD void lstm_resident(const float *Wih, const float *Whh, const float *bs, int h
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wh[q][s].w, acc[q], 0, 0, 0);
             }
+            // (issuing the next step's W_ih x_{t+1} MFMAs between the VALU instructions of this epilogue was tried: no gain, the other
+            // wavefront of the SIMD already keeps the matrix pipe busy there)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float ig = sigmoid_own(acc[0][i]), fg = sigmoid_own(acc[1][i]), gg = tanh_own(acc[2][i]), og = sigmoid_own(acc[3][i]);
-                const float c = fg * cst[i] + ig * gg;
+                float c, hv;
+                lstm_cell(acc[0][i], acc[1][i], acc[2][i], acc[3][i], cst[i], c, hv);
                 cst[i] = c;
-                y[(4 * g + i) * POL_LD + col] = og * tanh_own(c);
+                y[(4 * g + i) * POL_LD + col] = hv;
             }
         }
         __syncthreads();  // h_t complete in y; every wavefront is done reading h_{t-1} from x
@@ -361,10 +363,10 @@ TD void critic_body(const PolicyParams &P, float *bufA, float *bufB, float *xs) 
                     gate_chain(acc, hrow, Whh + ((size_t)tile * (hp >> 4) * 64 + lane) * 4, (size_t)hp * hp, hp >> 4);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const float ig = sigmoid_own(acc[0][i]), fg = sigmoid_own(acc[1][i]), gg = tanh_own(acc[2][i]), og = sigmoid_own(acc[3][i]);
-                        const float c = fg * cst[j][i] + ig * gg;
+                        float c, hv;
+                        lstm_cell(acc[0][i], acc[1][i], acc[2][i], acc[3][i], cst[j][i], c, hv);
                         cst[j][i] = c;
-                        y[(4 * g + i) * POL_LD + col] = og * tanh_own(c);
+                        y[(4 * g + i) * POL_LD + col] = hv;
                     }
                 }
             }
