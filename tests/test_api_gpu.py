@@ -119,6 +119,37 @@ def test_full_size_parity_on_random_slices(idx, steps):
     assert (prog >= 1).all() and (prog <= flat["max_episode_length"]).all()
 
 
+def test_maximum_size_two_million_envs_with_stacked_states():
+    """The largest launch taco_create accepts (2 000 000 envs), with the documented 5-frame state stack: slices at the first, a middle
+    and the last envs are re-simulated by the oracle and compared bit for bit; the stack of every env shifts by one frame."""
+    from oracle import oracle as O
+    from taco_amd._lib import TacoError
+    from taco_amd.vec_env import FpvBase
+    n, width, steps = 2_000_000, 64, 7
+    cfg = config.default_cfg("mix", n, env_lenStates=5, seed=2)
+    flat = config.flat_cfg(cfg)
+    env = FpvBase(cfg, copy_outputs=False)
+    starts = [0, 1_333_300, n - width]
+    orcs = [O.OracleEnv(dict(flat, num_envs=width, env_offset=lo, num_envs_global=n), threads=4) for lo in starts]
+    g = torch.Generator().manual_seed(9)
+    prev = None
+    for t in range(steps):
+        a = (0.3 * torch.randn((n, 4), generator=g)).clamp(-1, 1)
+        env.step_raw(a.cuda())
+        for lo, orc in zip(starts, orcs):
+            orc.step(a[lo:lo + width].numpy())
+            assert_bits_equal(env.states_buf[lo:lo + width].cpu().numpy(), orc.states_buf, f"step {t} slice {lo} states")
+            assert_bits_equal(env.obs_buf[lo:lo + width].cpu().numpy(), orc.obs_buf, f"step {t} slice {lo} obs")
+            assert_bits_equal(env.rew_buf[lo:lo + width].cpu().numpy(), orc.rew_buf, f"step {t} slice {lo} rew")
+        if prev is not None:   # size-independent property over ALL envs: frames 1..4 of the old stack are frames 0..3 of the new one
+            assert torch.equal(env.states_buf[:, :4].view(torch.int32), prev[:, 1:].view(torch.int32))
+        prev = env.states_buf.clone()
+    del env, prev
+    torch.cuda.empty_cache()
+    with pytest.raises(TacoError):
+        FpvBase(config.default_cfg("pos", 2_000_001), copy_outputs=False)
+
+
 def test_checkpoint_file_roundtrip_and_recorder(tmp_path):
     """N2: save -> load into a fresh env -> both continue bit-identically; the recorder pulls env 0 with the reference's keys"""
     from taco_amd import checkpoint
