@@ -250,11 +250,12 @@ def main():
                        "collective": ("1 RCCL all-gather of [obs|rew|done|timeout] per step" if (world > 1 and args.gather) else
                                       "none in the timed region: envs are independent, each rank steps its own slice"),
                        "kernel": base.lib.taco_step_kernel_name().decode(), "grid": grid, "block": block,
-                       "lanes_per_env": 4 if grid * block >= 4 * n_local else 1},
+                       "lanes_per_env": 4 if grid * block >= 4 * n_local else 1,
+                       "role_wavefronts": bool(block == 256 and grid * 64 >= 4 * n_local and n_local <= 8192)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel_avg_us": k_avg_us, "kernel_bracketed_median_us": k_med_us,
                          "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
-                         "note": "4096 envs = 256 wavefronts (4 lanes per env) on 1024 SIMDs, one lone wavefront per CU: instruction-latency regime, see large_n for the throughput regime"},
+                         "note": "4096 envs = 256 step wavefronts (4 lanes per env, one per CU) + 3 post-phase role wavefronts each: instruction-latency regime, see large_n for the throughput regime"},
             "gpu_event_ms_per_step": ev0.elapsed_time(ev1) / args.steps,
         }
         if with_gather is not None:

@@ -45,6 +45,7 @@ struct taco_env {
     int hh;    // action-history row the next step writes; advances by 1 per step (mod 16)
     int lpe;   // lanes per env of the step kernel this handle launches (1 or 4)
     int block; // its workgroup size (64 or 256)
+    int split; // 1: the four-role form of the quad kernel (<= 4 096 envs; used while no gather block is bound)
     float *gather;  // optional per-rank all-gather block, see taco_bind_gather_block
     unsigned long long *stamps;  // optional phase stamps, see taco_bind_phase_stamps
     taco::StepParams P;
@@ -222,6 +223,7 @@ __global__ void import_state_kernel(float *S, float *hist, float *ring, const ui
 // SIMDs without a wavefront (measured: 19.8 us vs 21.0 us at 16 384 envs, 24.6 us vs 22 us at 20 480); 256-thread workgroups from 65 536 envs.
 // TACO_FORCE_LPE / TACO_FORCE_BLOCK (read at taco_create) override the choice for experiments and for the LPE-equivalence test.
 constexpr int kQuadMaxEnvs = 16384;
+constexpr int kSplitMaxEnvs = 8192;  // measured: 16.8 vs 17.6 us at 4 096 envs, 18.4 vs 18.8 at 8 192, no gain at 16 384
 void choose_geometry(taco_env *e) {
     e->lpe = e->cfg.num_envs <= kQuadMaxEnvs ? 4 : 1;
     e->block = e->cfg.num_envs >= 65536 ? kBlockLarge : kBlockSmall;
@@ -234,7 +236,11 @@ void choose_geometry(taco_env *e) {
         if (b == kBlockSmall || b == kBlockLarge) e->block = b;
     }
     if (e->lpe == 4) e->block = kBlockSmall;
+    // three helper wavefronts per 16 envs take over the post-phase: pays while every wavefront still has a SIMD to itself
+    e->split = (e->lpe == 4 && e->cfg.num_envs <= kSplitMaxEnvs) ? 1 : 0;
+    if (const char *f = std::getenv("TACO_FORCE_SPLIT")) e->split = (e->lpe == 4 && std::atoi(f) != 0) ? 1 : 0;
 }
+bool use_split(const taco_env *e) { return e->split && e->gather == nullptr; }
 
 }  // namespace
 
@@ -316,7 +322,9 @@ int launch_step(taco_env *e, const taco_rollout_io *io, void *stream) {
     P.hh = e->hh;
     P.hist_bytes = (uint32_t)((size_t)taco::HIST_ROWS * e->npad * 4 * sizeof(float));
     const int n = e->cfg.num_envs;
-    if (e->lpe == 4)
+    if (use_split(e))
+        hipLaunchKernelGGL((taco::taco_step_kernel<kBlockLarge, 4, true>), dim3((n * 4 + 63) / 64), dim3(kBlockLarge), 0, (hipStream_t)stream, P);
+    else if (e->lpe == 4)
         hipLaunchKernelGGL((taco::taco_step_kernel<kBlockSmall, 4>), dim3((n * 4 + kBlockSmall - 1) / kBlockSmall), dim3(kBlockSmall), 0, (hipStream_t)stream, P);
     else if (e->block == kBlockLarge)
         hipLaunchKernelGGL((taco::taco_step_kernel<kBlockLarge, 1>), dim3((n + kBlockLarge - 1) / kBlockLarge), dim3(kBlockLarge), 0, (hipStream_t)stream, P);
@@ -413,6 +421,7 @@ int taco_set_state(taco_env *e, const uint32_t *blob, void *stream) {
 
 int taco_launch_geometry(const taco_env *e, int *grid, int *block) {
     if (!e || !grid || !block) return fail(TACO_ERR_INVALID_ARG, "taco_launch_geometry: null argument");
+    if (use_split(e)) { *block = kBlockLarge; *grid = (e->cfg.num_envs * 4 + 63) / 64; return TACO_OK; }
     *block = e->block;
     *grid = (e->cfg.num_envs * e->lpe + *block - 1) / *block;
     return TACO_OK;
@@ -545,6 +554,15 @@ int taco_bind_phase_stamps(taco_env *e, uint64_t *stamps) {
 
 int taco_occupancy(const taco_env *e, int *resident_blocks_per_cu, int *lds_bytes_per_block) {
     if (!e || !resident_blocks_per_cu || !lds_bytes_per_block) return fail(TACO_ERR_INVALID_ARG, "taco_occupancy: null argument");
+    if (use_split(e)) {
+        hipFuncAttributes at;
+        hipError_t he = hipFuncGetAttributes(&at, (const void *)taco::taco_step_kernel<kBlockLarge, 4, true>);
+        if (he != hipSuccess) return hip_fail(he, "hipFuncGetAttributes");
+        *lds_bytes_per_block = (int)at.sharedSizeBytes;
+        he = hipOccupancyMaxActiveBlocksPerMultiprocessor(resident_blocks_per_cu, taco::taco_step_kernel<kBlockLarge, 4, true>, kBlockLarge, 0);
+        if (he != hipSuccess) return hip_fail(he, "hipOccupancyMaxActiveBlocksPerMultiprocessor");
+        return TACO_OK;
+    }
     const bool quad = e->lpe == 4;
     const bool large = !quad && e->block == kBlockLarge;
     const void *fn = quad ? (const void *)taco::taco_step_kernel<kBlockSmall, 4>

@@ -513,8 +513,23 @@ TD void reset_env(const StepParams &P, rsrc_t rS, rsrc_t rR, uint32_t voff, uint
 // LPE (lanes per env) = 4: the third instantiation, for launches that cannot fill the chip with one lane per env (4 096 envs
 // = 64 wavefronts on 1 024 SIMDs).  A wavefront then carries 16 envs; everything outside the substep loop runs the scalar code
 // redundantly in the four lanes of an env (sub-lane 0 does the stores), the substep loop runs in the quad layout above.
-template <int BLOCK, int LPE>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 256 ? 4 : 1, BLOCK >= 256 ? 4 : 8))) void taco_step_kernel(const StepParams P) {
+// What the post-phase (frame stacks, reward / done) needs from the rest of the step.
+struct Carry {
+    V3 p, v, w;
+    Q4 q;
+    float bat_V, act[4], cmd0, cmd1, flip_radian;
+    int progress;
+    float4 c_tp, c_tq;
+};
+constexpr int CARRY_WORDS = 32;  // 30 used
+
+// SPLIT (BLOCK = 256, LPE = 4; launches of at most 4 096 envs = 1 024 wavefronts, one per SIMD): wave 0 of the workgroup runs the step
+// as the <64, 4> instantiation does; the other three wavefronts sleep at a barrier until the substeps are done, take the Carry out of
+// LDS and run one post-phase role each (states frame stack / obs frame stack / reward + done) on their own SIMDs while wave 0 stores
+// the state.  The post-phase critical path drops from the sum of the four parts to the longest one.
+template <int BLOCK, int LPE, bool SPLIT = false>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >= 256 && !SPLIT) ? 4 : 1, (BLOCK >= 256 && !SPLIT) ? 4 : 8))) void taco_step_kernel(const StepParams P) {
+    static_assert(!SPLIT || (BLOCK == 256 && LPE == 4), "SPLIT is the four-role form of the quad kernel");
     // Per-wavefront LDS scratch, used for two things one after the other:
     //   substeps : the 10 pending-action slots this step consumes, slots[s][lane] as float4 (10 KiB) -- keeps 40 values
     //              out of the register file and lets substep k fetch its action with one ds_read_b128;
@@ -531,9 +546,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
     float4 *slots = reinterpret_cast<float4 *>(lds_all[wv]);
     const int sub = lane & (LPE - 1);  // lane inside the env's quad (0 when LPE == 1)
     const int el = lane / LPE;         // env slot inside the wavefront
-    const int i_raw = (blockIdx.x * BLOCK + threadIdx.x) / LPE;
+    const int i_raw = SPLIT ? (blockIdx.x * 64 + lane) / LPE : (blockIdx.x * BLOCK + threadIdx.x) / LPE;
     const bool in_range = i_raw < P.n;
     const bool active = in_range && sub == 0;  // the lane that stores for its env
+    const bool roleS = !SPLIT || wv == 1, roleO = !SPLIT || wv == 2, roleR = !SPLIT || wv == 3;  // post-phase roles (SPLIT: wave 0 = the step itself)
+    __shared__ __attribute__((aligned(16))) float hand[SPLIT ? (64 / LPE) * CARRY_WORDS : 4];
+    Carry K;
     const int i = in_range ? i_raw : P.n - 1;  // tail lanes shadow the last env and store nothing
     const int gid = P.env_offset + i;
     const uint32_t voff = (uint32_t)i * 16u;            // this lane's byte offset inside every float4 row
@@ -550,6 +568,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
     // other tasks then compute values nobody reads), which keeps the substep loop free of divergent control flow
     const bool wave_tracks_rpy = __builtin_amdgcn_ballot_w64(track_rpy) != 0;
 
+    if (!SPLIT || wv == 0) {
     // ------------------------------------------------------------------ pre_physics_step FA:317-332
     // Every load the step needs is issued up front, before the reset flag is known: the flag, the action, the 13 state
     // chunks and the 10 ring slots of this step are independent, so they share ONE memory round trip.
@@ -972,6 +991,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
         unwrap(e.z, rpy_old[2], rpy_cont[2]);
     }
     const float roll_cont = rpy_cont[0];
+    if (grp == TACO_TASK_FLIP) cmd1 = clampf(flip_radian - roll_cont, -kTwoPi, kTwoPi);  // FA:831-832 / :930-931
+    K.p = p; K.v = v; K.w = w; K.q = q; K.bat_V = bat_V; K.cmd0 = cmd0; K.cmd1 = cmd1; K.flip_radian = flip_radian; K.progress = progress;
+    K.act[0] = act[0]; K.act[1] = act[1]; K.act[2] = act[2]; K.act[3] = act[3]; K.c_tp = c_tp; K.c_tq = c_tq;
+    if (SPLIT && sub == 0) {  // hand the Carry to the three role wavefronts
+        float4 *h4 = reinterpret_cast<float4 *>(hand + el * CARRY_WORDS);
+        h4[0] = make_float4(p.x, p.y, p.z, bat_V); h4[1] = make_float4(v.x, v.y, v.z, cmd0); h4[2] = make_float4(w.x, w.y, w.z, cmd1);
+        h4[3] = make_float4(q.x, q.y, q.z, q.w); h4[4] = make_float4(act[0], act[1], act[2], act[3]);
+        h4[5] = make_float4(flip_radian, as_f(progress), 0.0f, 0.0f); h4[6] = c_tp; h4[7] = c_tq;
+    }
+    if (SPLIT) __syncthreads();  // the only workgroup barrier of the kernel: every wavefront executes exactly this one
     if (active) {
         // Everything the substep loop evolved goes back to its SoA row NOW, so the registers are free for the
         // observation / reward code below.
@@ -1005,7 +1034,24 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
         dlen = dlen - 10 < 0 ? 0 : dlen - 10;
         CST(C_QUEUE, make_float4(as_f(q_lens), as_f(q_m | (q_rem0 << 8)), 0.0f, 0.0f));
         CST(C_LINVEL, make_float4(v.x, v.y, v.z, as_f((dlen & 0xffff) | (zlead << 16) | (dense ? (int)0x80000000 : 0))));
+        CST(C_MISC, make_float4(bat_t, cmd0, cmd1, flip_radian));
     }
+    if (SPLIT) { TACO_STAMP(4); TACO_STAMP(5); return; }  // wave 0 is done; the roles below belong to the other three wavefronts
+    } else {
+        __syncthreads();
+        const float4 *h4 = reinterpret_cast<const float4 *>(hand + el * CARRY_WORDS);
+        const float4 a0 = h4[0], a1 = h4[1], a2 = h4[2], a3 = h4[3], a4 = h4[4], a5 = h4[5];
+        K.p = V3{a0.x, a0.y, a0.z}; K.bat_V = a0.w; K.v = V3{a1.x, a1.y, a1.z}; K.cmd0 = a1.w; K.w = V3{a2.x, a2.y, a2.z}; K.cmd1 = a2.w;
+        K.q = Q4{a3.x, a3.y, a3.z, a3.w}; K.act[0] = a4.x; K.act[1] = a4.y; K.act[2] = a4.z; K.act[3] = a4.w;
+        K.flip_radian = a5.x; K.progress = as_i(a5.y); K.c_tp = h4[6]; K.c_tq = h4[7];
+    }
+    // ------------------------------------------------------------------ post-phase: works on the Carry only
+    const V3 &p = K.p, &v = K.v, &w = K.w;
+    const Q4 &q = K.q;
+    const float bat_V = K.bat_V, cmd0 = K.cmd0, cmd1 = K.cmd1;
+    const float (&act)[4] = K.act;
+    const int progress = K.progress;
+    const float4 c_tp = K.c_tp, c_tq = K.c_tq;
     // relative quantities FA:354-360 (target velocities are identically zero); the target pose is only needed from here on
     const V3 pt{c_tp.x, c_tp.y, c_tp.z};
     const Q4 qt{c_tq.x, c_tq.y, c_tq.z, c_tq.w};
@@ -1014,45 +1060,51 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
     const V3 rel_v{0.0f - v.x, 0.0f - v.y, 0.0f - v.z};
     const V3 rel_w{0.0f - w.x, 0.0f - w.y, 0.0f - w.z};
     const V3 rel_pos_b = quat_rotate(cq, rel_pos);
-    const Q4 rel_q_b = quat_mul(cq, qt);
-    const V3 rel_v_b = quat_rotate(cq, rel_v);
-    const V3 rel_w_b = quat_rotate(cq, rel_w);
-    if (grp == TACO_TASK_FLIP) cmd1 = clampf(flip_radian - roll_cont, -kTwoPi, kTwoPi);  // FA:831-832 / :930-931
-
-    // 26-D frame FA:415-421 + task tails
+    const bool frames = roleS || roleO;  // (SPLIT: the reward wavefront needs only R00, and only for flip envs)
+    Q4 rel_q_b{0.0f, 0.0f, 0.0f, 1.0f};
     float fr[26];
     float m[9];
-    quat_to_matrix(rel_q_b, m);
-    const float tilt00 = m[0];  // R00 of the noise-free relative attitude: the flip reward's x_tiltage
-    fr[0] = TACO_DIVC(rel_pos_b.x, 3.0f); fr[1] = TACO_DIVC(rel_pos_b.y, 3.0f); fr[2] = TACO_DIVC(rel_pos_b.z, 3.0f);
+    float tilt00 = 1.0f;  // R00 of the noise-free relative attitude: the flip reward's x_tiltage
+    if (frames || wave_tracks_rpy) {
+        rel_q_b = quat_mul(cq, qt);
+        quat_to_matrix(rel_q_b, m);
+        tilt00 = m[0];
+    }
+    if (frames) {
+        const V3 rel_v_b = quat_rotate(cq, rel_v);
+        const V3 rel_w_b = quat_rotate(cq, rel_w);
+        // 26-D frame FA:415-421 + task tails
+        fr[0] = TACO_DIVC(rel_pos_b.x, 3.0f); fr[1] = TACO_DIVC(rel_pos_b.y, 3.0f); fr[2] = TACO_DIVC(rel_pos_b.z, 3.0f);
 #pragma unroll
-    for (int k = 0; k < 9; ++k) fr[3 + k] = m[k];
-    fr[12] = rel_v_b.x / 2.0f; fr[13] = rel_v_b.y / 2.0f; fr[14] = rel_v_b.z / 2.0f;
-    fr[15] = TACO_DIVC(rel_w_b.x, kPi); fr[16] = TACO_DIVC(rel_w_b.y, kPi); fr[17] = TACO_DIVC(rel_w_b.z, kPi);
-    fr[18] = TACO_DIVC(bat_V - 23.0f, 3.0f);
+        for (int k = 0; k < 9; ++k) fr[3 + k] = m[k];
+        fr[12] = rel_v_b.x / 2.0f; fr[13] = rel_v_b.y / 2.0f; fr[14] = rel_v_b.z / 2.0f;
+        fr[15] = TACO_DIVC(rel_w_b.x, kPi); fr[16] = TACO_DIVC(rel_w_b.y, kPi); fr[17] = TACO_DIVC(rel_w_b.z, kPi);
+        fr[18] = TACO_DIVC(bat_V - 23.0f, 3.0f);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) fr[19 + k] = act[k];
-    fr[23] = 4.0f * clampf(p.z, 0.0f, 0.5f) - 1.0f;
-    fr[24] = cmd0;
-    fr[25] = (grp == TACO_TASK_POS) ? cmd1 : (grp == TACO_TASK_ROTATE ? TACO_DIVC(cmd1, 6.0f) : TACO_DIVC(cmd1 / 2.0f, kPi));
+        for (int k = 0; k < 4; ++k) fr[19 + k] = act[k];
+        fr[23] = 4.0f * clampf(p.z, 0.0f, 0.5f) - 1.0f;
+        fr[24] = cmd0;
+        fr[25] = (grp == TACO_TASK_POS) ? cmd1 : (grp == TACO_TASK_ROTATE ? TACO_DIVC(cmd1, 6.0f) : TACO_DIVC(cmd1 / 2.0f, kPi));
+    }
 
     // ---- frame stacks [env][len][26] (newest frame last).  Two store paths:
     //  len == 1 : the wavefront's 64 rows are one contiguous 6 656-byte range.  The frames go through a per-wave LDS tile
     //             (lane-major registers -> env-major bytes) and leave as seven fully coalesced 16-byte-per-lane stores.
     //  len  > 1 : each lane shifts its own row by one frame (8-byte accesses, in place, ascending) and appends the frame.
     // Stores go through range-checked buffer descriptors, so ragged tails need no special casing.
-    const uint32_t wave_env0 = (uint32_t)((blockIdx.x * BLOCK + wv * 64) / LPE);
+    const uint32_t wave_env0 = SPLIT ? (uint32_t)(blockIdx.x * 64 / LPE) : (uint32_t)((blockIdx.x * BLOCK + wv * 64) / LPE);
     // fill_tile = false: the tile already holds this frame (the obs frame equals the states frame when there is no observation noise)
     auto put_frame = [&](float *buf, const float *prev, uint32_t buf_bytes, int len, const float (&f)[26], bool fill_tile) {
         const rsrc_t rB = make_rsrc(buf, buf_bytes);
         if (fill_tile) {
-            __syncthreads();  // previous users of the scratch (action slots / the other buffer's tile) are done
+            // the scratch is private to the wavefront and its LDS operations execute in order: only the compiler needs the fence
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             f32x2_t *t2 = reinterpret_cast<f32x2_t *>(tile + el * 26);  // 104-byte rows: 8-byte aligned
             if (sub == 0) {
 #pragma unroll
                 for (int k = 0; k < 13; ++k) t2[k] = f32x2_t{f[2 * k], f[2 * k + 1]};
             }
-            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         }
         if (len == 1) {
             const f32x4_t *t4 = reinterpret_cast<const f32x4_t *>(tile);
@@ -1093,8 +1145,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
         }
     };
     // states first (noise-free frame), then obs (possibly noised)
-    put_frame(P.states, P.states_prev, P.states_bytes, P.len_states, fr, true);
-    if (fl & TACO_F_OBSERVATION_NOISE) {  // FA:402-410
+    if (roleS) put_frame(P.states, P.states_prev, P.states_bytes, P.len_states, fr, true);
+    if (roleO && (fl & TACO_F_OBSERVATION_NOISE)) {  // FA:402-410
         float nrm[12];
 #pragma unroll
         for (int pr = 0; pr < 3; ++pr) {  // uniforms 4..15 of STREAM_OBS = blocks 1..3, two Box-Muller pairs per block
@@ -1123,9 +1175,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
         fr[18] = fr[18] + P.df * (nrm[9] * (float)(0.06 / 3) + 0.0f);
         fr[23] = fr[23] + P.df * (nrm[10] * (float)(0.06 / 3 / 3) + 0.0f);
     }
-    put_frame(P.obs, P.obs_prev, P.obs_bytes, P.len_obs, fr, (fl & TACO_F_OBSERVATION_NOISE) != 0);
+    if (roleO) put_frame(P.obs, P.obs_prev, P.obs_bytes, P.len_obs, fr, SPLIT || (fl & TACO_F_OBSERVATION_NOISE) != 0);
 
     TACO_STAMP(4);  // state stores + frames done
+    if (roleR) {
     // ------------------------------------------------------------------ compute_reward CTRL/task_reward.py
     float rew, pos_dist;
     if (grp == TACO_TASK_POS) {  // :20-47
@@ -1178,7 +1231,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
         P.reset[i] = rs;
         P.timeout[i] = tmo ? 1 : 0;
         if (P.done_f32) P.done_f32[i] = (float)rs;
-        if (P.gather) {
+        if (!SPLIT && P.gather) {  // (the host launches a non-SPLIT instantiation while a gather block is bound)
             // one 128-byte-aligned row per env: [obs stack | reward | done | time-out | pad]; the obs stack is re-read from
             // this lane's own (just written) obs row when there is history, else taken from registers
             const rsrc_t rG = make_rsrc(P.gather, P.gather_bytes);
@@ -1198,7 +1251,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
             llvm_amdgcn_raw_buffer_store_f32((float)rs, rG, (int)(tail + 4u), 0, 0);
             llvm_amdgcn_raw_buffer_store_f32(tmo ? 1.0f : 0.0f, rG, (int)(tail + 8u), 0, 0);
         }
-        CST(C_MISC, make_float4(bat_t, cmd0, cmd1, flip_radian));
+    }
     }
     TACO_STAMP(5);
 #undef TACO_STAMP

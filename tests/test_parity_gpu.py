@@ -176,28 +176,29 @@ def test_state_blob_roundtrip_and_restore():
 
 @pytest.mark.parametrize("task,n", [("pos", 1000), ("mix", 333), ("flip", 257), ("rotate", 4096)])
 def test_quad_layout_equals_one_lane_per_env(task, n, monkeypatch):
-    """The three instantiations of the step kernel (4 lanes per env / 1 lane per env with 64- and 256-thread workgroups)
-    are the same function: every output and every state word bit-identical, all randomisation on, stacked frames."""
+    """The four instantiations of the step kernel (4 lanes per env with and without the role wavefronts / 1 lane per env with 64- and
+    256-thread workgroups) are the same function: every output and every state word bit-identical, all randomisation on, stacked frames."""
     from taco_amd.vec_env import FpvBase
     kw = dict(env_lenObservations=2, env_lenStates=3, env_maxEpisodeLength=40, seed=11)
     if task == "mix":
         kw.update(rotor_noise=True, observation_noise=True, ramdom_deploy_time=True, ramdom_delay_time=True)
     envs = []
-    for lpe, block in (("4", "64"), ("1", "64"), ("1", "256")):
+    for lpe, block, split in (("4", "64", "0"), ("1", "64", "0"), ("1", "256", "0"), ("4", "64", "1")):
         monkeypatch.setenv("TACO_FORCE_LPE", lpe)
         monkeypatch.setenv("TACO_FORCE_BLOCK", block)
+        monkeypatch.setenv("TACO_FORCE_SPLIT", split)
         e = FpvBase(config.default_cfg(task, n, **kw), copy_outputs=False)
-        assert e.launch_geometry() == ((n * int(lpe) + int(block) - 1) // int(block), int(block))
+        assert e.launch_geometry() == (((n * 4 + 63) // 64, 256) if split == "1" else ((n * int(lpe) + int(block) - 1) // int(block), int(block)))
         envs.append(e)
     acts = torch.from_numpy(action_stream(n, 90, 4)).cuda()
     for t in range(90):
         for e in envs:
             e.step_raw(acts[t])
         ref = envs[1]
-        for e in (envs[0], envs[2]):
+        for e in (envs[0], envs[2], envs[3]):
             for name in ("obs_buf", "states_buf", "rew_buf", "reset_buf", "timeout_buf"):
                 assert_bits_equal(getattr(e, name).cpu().numpy(), getattr(ref, name).cpu().numpy(), f"step {t} {name}")
         if t % 10 == 9:
             b = [e.get_state().view(torch.int32) for e in envs]
-            assert torch.equal(b[0], b[1]) and torch.equal(b[2], b[1]), f"step {t} state blob"
+            assert torch.equal(b[0], b[1]) and torch.equal(b[2], b[1]) and torch.equal(b[3], b[1]), f"step {t} state blob"
     assert int(envs[1].reset_buf.sum()) >= 0
