@@ -129,6 +129,8 @@ class ActorCritic:
         self.cfg = cfg_from_state_dict(state_dict, obs_len, states_len, obs_dim, states_dim)
         self.seed = int(seed)
         self.calls = 0  # Philox counter of the action noise: (seed, env index, call number)
+        self.reuse_outputs = False  # True: act() returns the same five tensors every call (no allocations on the hot loop)
+        self._out = None
         n = self.lib.taco_policy_blob_floats(C.byref(self.cfg))
         if n == 0:
             raise _lib.TacoError(f"unsupported policy configuration: {self.lib.taco_last_error().decode()}")
@@ -155,8 +157,12 @@ class ActorCritic:
         obs = prep(actor_input, self.cfg.obs_len, self.cfg.obs_dim)
         st = prep(critic_input, self.cfg.states_len, self.cfg.states_dim) if critic_input is not None else None
         dev = self.device
-        action, mu, sigma = (torch.empty(n, a, device=dev) for _ in range(3))
-        logp, value = torch.empty(n, device=dev), torch.empty(n, 1, device=dev)
+        if self.reuse_outputs and self._out is not None and self._out[0].shape[0] == n:
+            action, logp, value, mu, sigma = self._out      # the previous call's tensors are overwritten
+        else:
+            action, mu, sigma = (torch.empty(n, a, device=dev) for _ in range(3))
+            logp, value = torch.empty(n, device=dev), torch.empty(n, 1, device=dev)
+            self._out = (action, logp, value, mu, sigma)
         s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(self.lib.taco_policy_act(C.byref(self.cfg), self._blob.data_ptr(), n, obs.data_ptr(), st.data_ptr() if st is not None else None,
                                             C.c_uint64(self.seed), C.c_uint32(self.calls), 1 if deterministic else 0, 1 if action_only else 0,
