@@ -513,6 +513,21 @@ TD void reset_env(const StepParams &P, rsrc_t rS, rsrc_t rR, uint32_t voff, uint
 // LPE (lanes per env) = 4: the third instantiation, for launches that cannot fill the chip with one lane per env (4 096 envs
 // = 64 wavefronts on 1 024 SIMDs).  A wavefront then carries 16 envs; everything outside the substep loop runs the scalar code
 // redundantly in the four lanes of an env (sub-lane 0 does the stores), the substep loop runs in the quad layout above.
+// Battery_Dynamics.sim_process CTRL/battery_dynamics.py:47-75 for one substep (Pm = mechanical power FA:614)
+TD float battery_step(float dt, float Pm, float &bat_E, float &bat_u1, float &bat_t) {
+    bat_t = bat_t + dt;
+    float p_c = TACO_DIVC(TACO_DIVC(Pm, 0.75f), 9000.0f);
+    bat_E = bat_E + p_c * dt;
+    float P_avg = bat_E / bat_t;
+    float r0_ = 0.0015778f + -7.7608e-5f * P_avg + (float)(0.0069498 * 1500.0);
+    float r0 = (r0_ > 4.5f) ? r0_ : 4.5f;
+    float uo = 4.35f + -0.1102178f * bat_E + 0.0103368f * (bat_E * bat_E) + -4.3778e-4f * ((bat_E * bat_E) * bat_E);
+    float u1_dot = TACO_DIVC(0.00104846f * p_c - bat_u1, 3.3f);
+    bat_u1 = bat_u1 + u1_dot * dt;
+    float dd = uo - bat_u1;
+    float rad = dd * dd - 4.0f * r0 * p_c;
+    return 0.5f * (dd + __builtin_sqrtf(rad)) * 6.0f;
+}
 // What the post-phase (frame stacks, reward / done) needs from the rest of the step.
 struct Carry {
     V3 p, v, w;
@@ -551,6 +566,23 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
     const bool active = in_range && sub == 0;  // the lane that stores for its env
     const bool roleS = !SPLIT || wv == 1, roleO = !SPLIT || wv == 2, roleR = !SPLIT || wv == 3;  // post-phase roles (SPLIT: wave 0 = the step itself)
     __shared__ __attribute__((aligned(16))) float hand[SPLIT ? (64 / LPE) * CARRY_WORDS : 4];
+    // SPLIT: while wavefront 0 runs the substeps, wavefront 1 serves the battery model one substep AHEAD: the voltage of substep k
+    // depends only on the rotor speeds left by substep k - 1, which are known ~2 000 clocks before the voltage is needed.
+    // mb_om: rotor speeds (wave 0 -> 1), mb_v: voltage (1 -> 0), mb_bs: battery state E u1 t (0 -> 1 before, 1 -> 0 after), mb_seq: counters
+    __shared__ float mb_om[SPLIT ? 64 : 4], mb_v[SPLIT ? 16 : 4], mb_bs[SPLIT ? 64 : 4];
+    __shared__ int mb_seq[4];
+    // The arrays are named directly at every use (macros, not lambdas or pointer parameters) so that the accesses stay LDS instructions;
+    // through a generic pointer they become flat loads.  MB_WAIT is bounded: a protocol bug shows up as a parity failure, never as a hung GPU.
+    // The LDS executes one wavefront's operations in order (data before counter on the writer's side, counter before data on the
+    // reader's), so the fences only have to stop the compiler: wavefront scope, no s_waitcnt on the critical path.
+#define MB_SEQ(idx) __hip_atomic_load(&mb_seq[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define MB_WAIT(idx, want) do { int spins_ = 0; while (MB_SEQ(idx) < (want) && ++spins_ < (1 << 20)) __builtin_amdgcn_s_sleep(1); \
+                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#define MB_POST(idx, value) do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+                                 __hip_atomic_store(&mb_seq[idx], (value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
+    // (only while every wavefront of the launch has a SIMD to itself -- 1 024 on the MI355X -- or the server would take issue slots
+    // from another workgroup's wavefront 0: 19.0 vs 18.4 us at 8 192 envs)
+    const bool bat_served = SPLIT && (P.flags & TACO_F_BATTERY_CONSUMPTION) != 0 && gridDim.x * 4u <= 1024u;
     Carry K;
     const int i = in_range ? i_raw : P.n - 1;  // tail lanes shadow the last env and store nothing
     const int gid = P.env_offset + i;
@@ -609,6 +641,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
     const float tau[4] = {c_tau.x, c_tau.y, c_tau.z, c_tau.w};
     const float opara[5] = {c_op.x, c_op.y, c_op.z, c_op.w, c_a0.x};
     float bat_E = c_pp.w, bat_u1 = c_pi.w, bat_t = c_misc.x, bat_V = c_ang.w;
+    if constexpr (SPLIT) {
+        __syncthreads();  // barrier 1 of 2: wavefront 1 has zeroed the mailbox counters (the helpers have been waiting here since their
+                          // launch and wavefront 0 arrives a load round trip later, so it does not wait)
+        if (bat_served) {  // the battery server can start on the first substep's voltage while wavefront 0 finishes its pre-phase
+            mb_om[lane] = pick4(sub, omega[0], omega[1], omega[2], omega[3]);
+            mb_bs[lane] = pick4(sub, bat_E, bat_u1, bat_t, 0.0f);
+            MB_POST(0, 1);
+        }
+    }
     float cmd0 = c_misc.y, cmd1 = c_misc.z, flip_radian = c_misc.w;
     const float cf = c_a0.y, ct = c_a0.z, dx = c_a0.w, dy = c_a1.x, kt = c_a1.y;
     int progress = as_i(c_pos.w);
@@ -894,6 +935,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
             // angular_vel_control FA:637-650: lane j runs PID axis j on action component j + 1
             const float u0 = (d0 + 1.0f) / 2.0f * 1000.0f;
             const float upid = pid_axis(P.dt, P.rdt, kpq, dppf<QP(1, 2, 3, 3)>(dq) * 20.0f, bq, ppq, piq);
+            // the voltage of this substep is being computed by wavefront 1 since the previous substep's rotor update: read counter and
+            // value here, ~40 instructions ahead of their use (LDS executes a wavefront's reads in order, so a value read after a
+            // sufficient counter is the right one)
+            int seq_early = 0;
+            float v_early = 0.0f;
+            if (bat_served) {
+                asm volatile("" ::"v"(upid) : "memory");  // not before the PID is done: gives wavefront 1 the time it needs
+                seq_early = MB_SEQ(1);
+                v_early = __hip_atomic_load(&mb_v[el], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             // control_allocator CTRL/fpv_dynamics.py:35-46: lane k computes motor k
             const float u1 = bc0(upid), u2 = bc1(upid);
             float u3 = bc2(upid);
@@ -906,32 +957,27 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
             { const float t3 = bc3(tm); mx = (t3 > mx || t3 != t3) ? t3 : mx; }
             const float ex = (mx < 0.0f) ? 0.0f : mx;
             const float thrq = clamp_const(fq - ex, 100.0f, 1000.0f);
-            // mechanical power FA:614
-            float Pm;
-            {
-                const float b = TACO_DIVC(omq * 2.0f * kPi, 4500.0f);
-                const float c3 = 400.0f * ((b * b) * b);
-                Pm = bc0(c3);
-                Pm = Pm + bc1(c3);
-                Pm = Pm + bc2(c3);
-                Pm = Pm + bc3(c3);
-            }
-            // Battery_Dynamics.sim_process CTRL/battery_dynamics.py:47-75 (replicated in the quad)
-            if (bat_on) {
-                bat_t = bat_t + P.dt;
-                float p_c = TACO_DIVC(TACO_DIVC(Pm, 0.75f), 9000.0f);
-                bat_E = bat_E + p_c * P.dt;
-                float P_avg = bat_E / bat_t;
-                float r0_ = 0.0015778f + -7.7608e-5f * P_avg + (float)(0.0069498 * 1500.0);
-                float r0 = (r0_ > 4.5f) ? r0_ : 4.5f;
-                float uo = 4.35f + -0.1102178f * bat_E + 0.0103368f * (bat_E * bat_E) + -4.3778e-4f * ((bat_E * bat_E) * bat_E);
-                float u1_dot = TACO_DIVC(0.00104846f * p_c - bat_u1, 3.3f);
-                bat_u1 = bat_u1 + u1_dot * P.dt;
-                float dd = uo - bat_u1;
-                float rad = dd * dd - 4.0f * r0 * p_c;
-                bat_V = 0.5f * (dd + __builtin_sqrtf(rad)) * 6.0f;
+            if (bat_served) {
+                asm volatile("" : "+v"(seq_early), "+v"(v_early));  // keeps the compiler from waiting for the early reads before this point
+                if (__builtin_amdgcn_ballot_w64(seq_early < ks + 1) != 0) {  // (not posted yet at the early read: rare)
+                    MB_WAIT(1, ks + 1);
+                    v_early = mb_v[el];
+                }
+                bat_V = v_early;
             } else {
-                bat_V = 4.35f * 6.0f;
+                // mechanical power FA:614
+                float Pm;
+                {
+                    const float b = TACO_DIVC(omq * 2.0f * kPi, 4500.0f);
+                    const float c3 = 400.0f * ((b * b) * b);
+                    Pm = bc0(c3);
+                    Pm = Pm + bc1(c3);
+                    Pm = Pm + bc2(c3);
+                    Pm = Pm + bc3(c3);
+                }
+                // Battery_Dynamics.sim_process CTRL/battery_dynamics.py:47-75 (replicated in the quad)
+                if (bat_on) bat_V = battery_step(P.dt, Pm, bat_E, bat_u1, bat_t);
+                else bat_V = 4.35f * 6.0f;
             }
             // RotorDynamics.sim_process CTRL/thrust_dynamics.py:98-104: lane k = rotor k
             {
@@ -945,6 +991,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
                 const float n_sc = (float)((1 + 10.0 / 700) - (1 - 10.0 / 700)), n_lo = (float)(1 - 10.0 / 700);
                 const uint32_t rk = sub == 0 ? r.x : (sub == 1 ? r.y : (sub == 2 ? r.z : r.w));
                 omq = omq * (n_sc * uniform(rk) + n_lo);
+            }
+            if (bat_served) {  // the rotor speeds the NEXT substep's battery step starts from
+                mb_om[lane] = omq;
+                MB_POST(0, ks + 2);
             }
             // AeroDynamics.sim_process CTRL/thrust_dynamics.py:173-199 + real->sim re-index CTRL/fpv_dynamics.py:48-56
             // fs = (rf2 rf3 rf0 rf1), ts = (-rt2 rt3 -rt0 rt1): the pair sums live in lanes (2,3) and (0,1)
@@ -967,6 +1017,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
                 tqq = from_bits(bits(selm(k2, tz, txy)) & keep);
             }
             integrate_quad(P, k3, pq, qq, vq, bq, Fq, tqq, Jq, hJiq, gzq, sm3);
+        }
+        if (bat_served) {
+            MB_WAIT(1, 11);
+            bat_E = mb_bs[el * 4]; bat_u1 = mb_bs[el * 4 + 1]; bat_t = mb_bs[el * 4 + 2];
         }
         p = V3{bc0(pq), bc1(pq), bc2(pq)};
         q = Q4{bc0(qq), bc1(qq), bc2(qq), bc3(qq)};
@@ -1000,7 +1054,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
         h4[3] = make_float4(q.x, q.y, q.z, q.w); h4[4] = make_float4(act[0], act[1], act[2], act[3]);
         h4[5] = make_float4(flip_radian, as_f(progress), 0.0f, 0.0f); h4[6] = c_tp; h4[7] = c_tq;
     }
-    if (SPLIT) __syncthreads();  // the only workgroup barrier of the kernel: every wavefront executes exactly this one
+    if (SPLIT) __syncthreads();  // barrier 2 of 2 (every wavefront executes exactly the same two)
     if (active) {
         // Everything the substep loop evolved goes back to its SoA row NOW, so the registers are free for the
         // observation / reward code below.
@@ -1038,7 +1092,27 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
     }
     if (SPLIT) { TACO_STAMP(4); TACO_STAMP(5); return; }  // wave 0 is done; the roles below belong to the other three wavefronts
     } else {
-        __syncthreads();
+        if (wv == 1 && lane < 4) mb_seq[lane] = 0;
+        __syncthreads();  // barrier 1 of 2
+        if (bat_served && wv == 1) {  // battery server: ten voltages, each one substep ahead of wavefront 0
+            MB_WAIT(0, 1);
+            float bE = mb_bs[el * 4], bu1 = mb_bs[el * 4 + 1], bt = mb_bs[el * 4 + 2];
+            for (int ks = 0; ks < 10; ++ks) {
+                MB_WAIT(0, ks + 1);
+                float Pm;
+                {   // mechanical power FA:614, summed in rotor order as the quad form does
+                    float b = TACO_DIVC(mb_om[el * 4] * 2.0f * kPi, 4500.0f); Pm = 400.0f * ((b * b) * b);
+                    b = TACO_DIVC(mb_om[el * 4 + 1] * 2.0f * kPi, 4500.0f); Pm = Pm + 400.0f * ((b * b) * b);
+                    b = TACO_DIVC(mb_om[el * 4 + 2] * 2.0f * kPi, 4500.0f); Pm = Pm + 400.0f * ((b * b) * b);
+                    b = TACO_DIVC(mb_om[el * 4 + 3] * 2.0f * kPi, 4500.0f); Pm = Pm + 400.0f * ((b * b) * b);
+                }
+                const float V = battery_step(P.dt, Pm, bE, bu1, bt);
+                if (sub == 0) mb_v[el] = V;
+                if (ks == 9 && sub == 0) { mb_bs[el * 4] = bE; mb_bs[el * 4 + 1] = bu1; mb_bs[el * 4 + 2] = bt; }
+                MB_POST(1, ks == 9 ? 11 : ks + 1);
+            }
+        }
+        __syncthreads();  // barrier 2 of 2
         const float4 *h4 = reinterpret_cast<const float4 *>(hand + el * CARRY_WORDS);
         const float4 a0 = h4[0], a1 = h4[1], a2 = h4[2], a3 = h4[3], a4 = h4[4], a5 = h4[5];
         K.p = V3{a0.x, a0.y, a0.z}; K.bat_V = a0.w; K.v = V3{a1.x, a1.y, a1.z}; K.cmd0 = a1.w; K.w = V3{a2.x, a2.y, a2.z}; K.cmd1 = a2.w;
@@ -1255,6 +1329,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
     }
     TACO_STAMP(5);
 #undef TACO_STAMP
+#undef MB_WAIT
+#undef MB_POST
+#undef MB_SEQ
 }
 
 }  // namespace taco
