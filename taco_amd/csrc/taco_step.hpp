@@ -741,7 +741,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
     }
     // ---- the ten slots this step consumes -> per-wave LDS table (substep k reads entry min(L-1, k), FA:366)
     const bool wave_dense = __builtin_amdgcn_ballot_w64(dense) != 0;  // wave-uniform: normally no lane is DENSE
-    {
+    if constexpr (LPE == 1) {
         // queue lanes: slots 0..9 of [Z zeros | run_0 | run_1 | ...] after the push span at most two runs
         float4 v0 = act4, v1 = act4;  // the pushed run itself is run_0 (empty queue) or run_1 (one run queued)
         v0 = sel4(q_m == 1, hwin[0], v0); v0 = sel4(q_m == 2, hwin[1], v0); v0 = sel4(q_m == 3, hwin[2], v0); v0 = sel4(q_m >= 4, hwin[3], v0);
@@ -762,6 +762,33 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
                 o = sel4(dense, sel4(fresh, act4, r), o);
             }
             slots[s * EPW + el] = o;
+        }
+    } else {
+        // the same table in the quad layout: lane j of an env only ever reads component j of a slot, so it selects and stores that one
+        float *slotsw = reinterpret_cast<float *>(slots);
+        const float ac = pick4(sub, act[0], act[1], act[2], act[3]);
+        const float h0 = pick4(sub, hwin[0].x, hwin[0].y, hwin[0].z, hwin[0].w), h1 = pick4(sub, hwin[1].x, hwin[1].y, hwin[1].z, hwin[1].w);
+        const float h2 = pick4(sub, hwin[2].x, hwin[2].y, hwin[2].z, hwin[2].w), h3 = pick4(sub, hwin[3].x, hwin[3].y, hwin[3].z, hwin[3].w);
+        float v0 = ac, v1 = ac;
+        v0 = (q_m == 1) ? h0 : v0; v0 = (q_m == 2) ? h1 : v0; v0 = (q_m == 3) ? h2 : v0; v0 = (q_m >= 4) ? h3 : v0;
+        v1 = (q_m == 2) ? h0 : v1; v1 = (q_m == 3) ? h1 : v1; v1 = (q_m >= 4) ? h2 : v1;
+        if (__builtin_amdgcn_ballot_w64(!dense && q_m > 4)) {  // deep queue (delay > ~40 ms): fetch the two oldest runs per lane
+            const bool deep = !dense && q_m > 4;
+            const float4 g0 = run_value(0), g1 = run_value(1);
+            v0 = deep ? pick4(sub, g0.x, g0.y, g0.z, g0.w) : v0;
+            v1 = deep ? pick4(sub, g1.x, g1.y, g1.z, g1.w) : v1;
+        }
+        const int n0 = (q_m >= 1) ? q_rem0 : T;  // slots of run_0 ahead of run_1
+#pragma unroll
+        for (int s = 0; s < 10; ++s) {
+            float o = (s < zlead) ? 0.0f : (((s - zlead) < n0) ? v0 : v1);
+            if (wave_dense) {
+                int ph = P.head + s; ph = ph >= TACO_RING_SLOTS ? ph - TACO_RING_SLOTS : ph;
+                const float4 r = buf_ld4(rR, voff, (uint32_t)ph * row_bytes);  // physical row is wave-uniform: coalesced
+                const bool fresh = (s >= dlen) && (s < dlen + T);             // covered by this step's write: from registers
+                o = dense ? (fresh ? ac : pick4(sub, r.x, r.y, r.z, r.w)) : o;
+            }
+            slotsw[(s * EPW + el) * 4 + sub] = o;
         }
     }
     if (!dense) {  // push the run (T, this action)
