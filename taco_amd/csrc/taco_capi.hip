@@ -107,6 +107,8 @@ void derive(taco_env *e) {
     P.mix_n2 = (int)((double)c.num_envs_global / 3 * 2);  // fpv_asymmetry.py:925
     P.len_obs = c.len_obs; P.len_states = c.len_states; P.substeps = c.substeps; P.max_len = c.max_episode_length;
     P.delay_time = c.delay_time; P.flags = c.flags;
+    // test hook: make the battery-server wavefront late on purpose, so that the wait path of the LDS mailbox is exercised (tests only)
+    if (const char *f = std::getenv("TACO_DEBUG_SLOW_SERVER")) { if (std::atoi(f) != 0) P.flags |= taco::kDebugSlowServer; }
     P.seed_lo = (uint32_t)c.seed; P.seed_hi = (uint32_t)(c.seed >> 32);
     P.dt = (float)c.dt; P.clip_act = (float)c.clip_actions; P.df = (float)d;
     P.h = (float)(c.dt / (double)c.substeps);

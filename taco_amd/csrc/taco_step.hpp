@@ -87,6 +87,7 @@ __host__ __device__ constexpr int field_slot(int f) {
 // two bits per run, oldest run in bits 1:0) and  m | rem0 << 8  (number of runs, slots left in the oldest run)
 __host__ __device__ constexpr int run_len(int lens, int j) { return 9 + ((lens >> (2 * j)) & 3); }
 
+constexpr uint32_t kDebugSlowServer = 1u << 31;  // StepParams.flags: test hook, see taco_capi.hip derive()
 enum : uint32_t { STREAM_RESET = 1, STREAM_CMD = 2, STREAM_DEPLOY = 3, STREAM_ROTOR = 4, STREAM_OBS = 5 };
 
 
@@ -1134,6 +1135,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
                     b = TACO_DIVC(mb_om[el * 4 + 3] * 2.0f * kPi, 4500.0f); Pm = Pm + 400.0f * ((b * b) * b);
                 }
                 const float V = battery_step(P.dt, Pm, bE, bu1, bt);
+                if (P.flags & kDebugSlowServer) { for (int z = 0; z < 40; ++z) __builtin_amdgcn_s_sleep(100); }  // test hook: arrive late
                 if (sub == 0) mb_v[el] = V;
                 if (ks == 9 && sub == 0) { mb_bs[el * 4] = bE; mb_bs[el * 4 + 1] = bu1; mb_bs[el * 4 + 2] = bt; }
                 MB_POST(1, ks == 9 ? 11 : ks + 1);

@@ -202,3 +202,10 @@ def test_quad_layout_equals_one_lane_per_env(task, n, monkeypatch):
             b = [e.get_state().view(torch.int32) for e in envs]
             assert torch.equal(b[0], b[1]) and torch.equal(b[2], b[1]) and torch.equal(b[3], b[1]), f"step {t} state blob"
     assert int(envs[1].reset_buf.sum()) >= 0
+
+
+def test_battery_mailbox_wait_path(monkeypatch):
+    """The role-wavefront battery server normally posts each voltage long before wavefront 0 needs it; with the server delayed on purpose
+    (test hook) wavefront 0 has to take the mailbox's wait path every substep -- the results must not change."""
+    monkeypatch.setenv("TACO_DEBUG_SLOW_SERVER", "1")
+    run_pair(config.baseline_config(1, num_envs=512), steps=40)
