@@ -79,3 +79,47 @@ def test_missing_library_is_an_error_not_a_fallback(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libtaco_env.so")
     with pytest.raises(_lib.TacoError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_rollout_and_policy_refuse_to_run_without_the_gpu():
+    """The N1 host classes are thin shells over HIP kernels: on a CPU device they fail loudly instead of falling back to torch."""
+    import numpy as np
+    from taco_amd._lib import TacoError
+    from taco_amd.policy import ActorCritic
+    from taco_amd.rollout import RolloutBuffer
+    with pytest.raises(TacoError):
+        RolloutBuffer(8, 26, 1, 26, 5, 4, 4, 2, 0.99, 0.95, "cpu")
+    sd = {"log_std": np.zeros(4, np.float32), "actor_mlp.layers.0.weight": np.zeros((4, 26), np.float32), "actor_mlp.layers.0.bias": np.zeros(4, np.float32),
+          "critic_mlp.layers.0.weight": np.zeros((1, 130), np.float32), "critic_mlp.layers.0.bias": np.zeros(1, np.float32)}
+    with pytest.raises(TacoError):
+        ActorCritic(sd, 1, 5, device="cpu")
+
+
+def test_policy_packing_matches_the_layout_both_sides_read():
+    """pack_state_dict: blob size == what the C ABI and the oracle expect for the same widths; fragment-major round trip of one matrix."""
+    import numpy as np
+    from oracle import oracle as O
+    from taco_amd import policy as P
+    rng = np.random.default_rng(1)
+    for actor_h, lstm, critic_h, lo, ls in (([64, 40], 24, [48], 1, 5), ([], 0, [], 2, 3), ([256, 16, 16, 100], 200, [7], 1, 8)):
+        sd = {"log_std": np.zeros(4, np.float32)}
+        dims = [lo * 26] + actor_h + [4]
+        for i in range(len(dims) - 1):
+            sd[f"actor_mlp.layers.{2 * i}.weight"] = rng.standard_normal((dims[i + 1], dims[i])).astype(np.float32)
+            sd[f"actor_mlp.layers.{2 * i}.bias"] = rng.standard_normal(dims[i + 1]).astype(np.float32)
+        if lstm:
+            sd["critic_encoder.layers.weight_ih_l0"] = rng.standard_normal((4 * lstm, 26)).astype(np.float32)
+            sd["critic_encoder.layers.weight_hh_l0"] = rng.standard_normal((4 * lstm, lstm)).astype(np.float32)
+            sd["critic_encoder.layers.bias_ih_l0"] = rng.standard_normal(4 * lstm).astype(np.float32)
+            sd["critic_encoder.layers.bias_hh_l0"] = rng.standard_normal(4 * lstm).astype(np.float32)
+        dims = [lstm if lstm else ls * 26] + critic_h + [1]
+        for i in range(len(dims) - 1):
+            sd[f"critic_mlp.layers.{2 * i}.weight"] = rng.standard_normal((dims[i + 1], dims[i])).astype(np.float32)
+            sd[f"critic_mlp.layers.{2 * i}.bias"] = rng.standard_normal(dims[i + 1]).astype(np.float32)
+        cfg = P.cfg_from_state_dict(sd, lo, ls)
+        blob = P.pack_state_dict(cfg, sd)
+        assert blob.size == O.policy_blob_floats(O.policy_cfg(lo, ls, actor_h, lstm, critic_h))
+    W = np.arange(32 * 48, dtype=np.float32).reshape(32, 48)
+    F = P._frag(W).reshape(2, 3, 64, 4)                      # [tile][k block][lane = 16 g + r][t]
+    for tile, s, g, r, t in ((0, 0, 0, 0, 0), (1, 2, 3, 15, 3), (0, 1, 2, 5, 1)):
+        assert F[tile, s, 16 * g + r, t] == W[16 * tile + r, 16 * s + 4 * g + t]
