@@ -209,17 +209,22 @@ class FpvBase:
         return g.value, b.value
 
 
-    def phase_stamps(self, actions, steps=20):
+    def phase_stamps(self, actions, steps=20, back_to_back=False):
         """Profiling aid: run `steps` steps with the phase stamps bound and return the mean shader-clock ticks between the
-        phase boundaries of workgroup 0 (entry->loads, ->pre-phase, ->substeps, ->stores+frames, ->end)."""
+        phase boundaries of workgroup 0 (entry->loads, ->pre-phase, ->substeps, ->stores+frames, ->end).  back_to_back: launch the steps
+        without host synchronisation in between and read the LAST launch's stamps (warm instruction cache, as in a rollout)."""
         st = torch.zeros(8, dtype=torch.int64, device=self.device)
         _lib.check(self.lib.taco_bind_phase_stamps(self._h, st.data_ptr()))
         acc = torch.zeros(5, dtype=torch.float64)
         try:
             for _ in range(steps):
                 self.step_raw(actions)
+                if not back_to_back:
+                    t = st.cpu()
+                    acc += (t[1:6] - t[0:5]).double()
+            if back_to_back:
                 t = st.cpu()
-                acc += (t[1:6] - t[0:5]).double()
+                acc = (t[1:6] - t[0:5]).double() * steps
         finally:
             _lib.check(self.lib.taco_bind_phase_stamps(self._h, None))
         return (acc / steps).tolist()

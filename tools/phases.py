@@ -12,3 +12,5 @@ for n in [int(x) for x in sys.argv[1:]] or (4096,):
     # calibrate ticks: time a long run of steps with events and compare with the stamped total of the same launches
     tot = sum(ph)
     print(f"N={n} geometry={env.launch_geometry()} ticks: loads={ph[0]:.0f} pre={ph[1]:.0f} substeps={ph[2]:.0f} stores+frames={ph[3]:.0f} reward+out={ph[4]:.0f} total={tot:.0f}", flush=True)
+    pb = env.phase_stamps(a, 200, back_to_back=True)
+    print(f"   back to back (last of 200 launches): loads={pb[0]:.0f} pre={pb[1]:.0f} substeps={pb[2]:.0f} stores+frames={pb[3]:.0f} reward+out={pb[4]:.0f} total={sum(pb):.0f}", flush=True)
