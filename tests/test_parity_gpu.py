@@ -209,3 +209,19 @@ def test_battery_mailbox_wait_path(monkeypatch):
     (test hook) wavefront 0 has to take the mailbox's wait path every substep -- the results must not change."""
     monkeypatch.setenv("TACO_DEBUG_SLOW_SERVER", "1")
     run_pair(config.baseline_config(1, num_envs=512), steps=40)
+
+
+def test_random_configurations():
+    """a bounded slice of tools/fuzz.py: random task / size / flag / stack-length / clip / substep combinations, every word bit-exact
+    (the full generator ran 1 500 cases clean on the GPU box; see profiles/README.md)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz
+    rng = np.random.default_rng(2024)
+    for i in range(40):
+        cfg, steps = fuzz.draw_case(rng)
+        try:
+            run_pair(cfg, steps, seed=i, check_every=1 if steps > 8 else 2, hover_bias=bool(i & 1))
+        except AssertionError as e:
+            raise AssertionError(f"case {i}: {fuzz.describe(cfg)}: {e}") from e

@@ -1,0 +1,84 @@
+"""Configuration fuzz: random flag / task / size / stack-length combinations, HIP (through the C ABI) vs the CPU oracle, bit for bit.
+
+    python tools/fuzz.py [--cases 60] [--seed 0]
+
+Every case draws a task, an env count (ragged sizes on purpose, one in six above the 8 192 / 16 384 / 65 536 geometry thresholds), all 19
+boolean flags, delay_time, rotor_response_time, difficulty, clip limits, PhysX substeps, episode length and the two stack lengths, then
+steps both sides on the same action stream.  tests/test_parity_gpu.py::test_random_configurations runs a bounded slice of the same generator.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FLAGS = ("random_copter_pos", "random_copter_quat", "random_copter_vel", "random_target_pos", "random_target_yaw", "battery_consumption",
+         "random_voltage", "rotor_noise", "rotor_delay", "rotor_response", "random_rotordynamic_coe", "random_rotor_delay",
+         "random_rotor_response", "random_rotor_speed", "random_aerodynamic_coe", "ramdom_delay_time", "ramdom_deploy_time", "random_command",
+         "observation_noise")
+
+
+def draw_case(rng):
+    from taco_amd import config
+    task = str(rng.choice(["pos", "rotate", "flip", "mix"]))
+    r = rng.random()
+    if r < 0.55:
+        n = int(rng.integers(1, 700))
+    elif r < 0.85:
+        n = int(rng.integers(700, 6000))
+    else:
+        n = int(rng.choice([8192 + 5, 16384 + 33, 65536 + 129])) + int(rng.integers(0, 50))
+    cfg = config.default_cfg(task, n)
+    for k in FLAGS:
+        cfg[k] = bool(rng.random() < 0.5)
+    cfg["delay_time"] = int(rng.choice([0, 1, 9, 10, 20, 35, 60]))
+    cfg["rotor_response_time"] = float(rng.choice([0.016, 0.017, 0.018, 0.03]))
+    cfg["difficulty"] = float(rng.choice([0.0, 0.3, 1.0]))
+    env = cfg["env"]
+    env["lenObservations"] = int(rng.choice([1, 1, 2, 4]))
+    env["lenStates"] = int(rng.choice([1, 1, 3, 5]))
+    env["maxEpisodeLength"] = int(rng.choice([25, 60, 1000]))
+    if rng.random() < 0.3:
+        env["clipActions"] = float(rng.choice([0.4, 0.8]))
+    if rng.random() < 0.3:
+        env["clipObservations"] = float(rng.choice([0.5, 2.0]))
+        env["clipStates"] = float(rng.choice([0.7, 5.0]))
+    cfg["sim"]["substeps"] = int(rng.choice([1, 2, 2, 3]))
+    steps = 70 if n < 6000 else 8
+    return cfg, steps
+
+
+def describe(cfg):
+    on = [k for k in FLAGS if cfg[k]]
+    env = cfg["env"]
+    return (f"{cfg['task_mode'] if 'task_mode' in cfg else '?'} n={env['numEnvs']} delay={cfg['delay_time']} tau={cfg['rotor_response_time']} "
+            f"df={cfg['difficulty']} lo={env['lenObservations']} ls={env['lenStates']} T={env['maxEpisodeLength']} sub={cfg['sim']['substeps']} "
+            f"clipA={env.get('clipActions')} clipO={env.get('clipObservations')} on={','.join(on)}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=60)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    from test_parity_gpu import run_pair
+    rng = np.random.default_rng(args.seed)
+    t0 = time.time()
+    for i in range(args.cases):
+        cfg, steps = draw_case(rng)
+        try:
+            done = run_pair(cfg, steps, seed=i, check_every=1 if steps > 8 else 2, hover_bias=bool(i & 1))
+        except Exception:
+            print(f"case {i} FAILED: {describe(cfg)}", flush=True)
+            raise
+        print(f"case {i:3d} ok ({done} episode ends, {time.time() - t0:.0f} s): {describe(cfg)}", flush=True)
+    print("fuzz ok:", args.cases, "cases")
+
+
+if __name__ == "__main__":
+    main()
