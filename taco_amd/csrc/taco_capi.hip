@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 #include "taco_step.hpp"
@@ -59,8 +60,10 @@ int round_up(int x, int m) { return (x + m - 1) / m * m; }
 // bit-identical to the IEEE quotient for this dt: checked exhaustively over one binade of x, both signs (the three
 // operations are scale-invariant, so this covers the normal range).  ~10 ms on the host, once per taco_create / difficulty change.
 bool div_const_is_exact(float c) {
+    static std::mutex mu;  // handles may be created from several host threads (one per device)
     static float cached_c = 0.0f;
     static bool cached_ok = false;
+    std::lock_guard<std::mutex> lock(mu);
     if (c == cached_c) return cached_ok;
     const float rc = 1.0f / c;
     bool ok = true;
@@ -392,6 +395,9 @@ int taco_gather_row_floats(int len_obs) { return (len_obs * 26 + 3 + 31) / 32 * 
 
 int taco_bind_gather_block(taco_env *e, float *block) {
     if (!e) return fail(TACO_ERR_INVALID_ARG, "env is null");
+    if (block && (size_t)e->cfg.num_envs * (size_t)taco_gather_row_floats(e->cfg.len_obs) * sizeof(float) >= 0xffffffffull)
+        return fail(TACO_ERR_INVALID_ARG, "gather block of num_envs rows must stay below 4 GiB (32-bit buffer offsets); shard the job");
+    if (((uintptr_t)block & 7u) != 0) return fail(TACO_ERR_INVALID_ARG, "gather block must be 8-byte aligned");
     e->gather = block;
     return TACO_OK;
 }
