@@ -37,6 +37,12 @@ TD float clamp_const(float x, float lo, float hi) {
     return (x != x) ? x : r;
 }
 
+// FIN = the caller has established (wave-uniformly) that x cannot be a NaN: the pass-through select is dead
+template <bool FIN> TD float clamp_const_t(float x, float lo, float hi) {
+    if constexpr (FIN) return __builtin_amdgcn_fmed3f(x, lo, hi);
+    else return clamp_const(x, lo, hi);
+}
+
 // ---- x / c for a divisor known in advance, without a division: q = x * RN(1/c) plus one fma correction.  Bit-identical to
 // the IEEE quotient for every divisor it is used with (0.001, 0.75, 3, 3.3, 6, 100, 1000, 4500, 9000, pi: checked
 // exhaustively over all signed mantissas) for |x| up to ~1e34; 3 instructions instead of the ~10 of v_div_scale/.../v_div_fixup.

@@ -12,6 +12,7 @@
 // VT = tasks/base/vec_task_asymmetry.py, CTRL = tasks/control/, TU = python/isaacgym/torch_utils.py,
 // TJ = isaacgymenvs/utils/torch_jit_utils.py).
 #pragma once
+#include <type_traits>
 #include "taco_math.hpp"
 #include "../../include/taco_env.h"
 
@@ -206,14 +207,15 @@ TD void unwrap(float rpy, float &old, float &cont) {
     old = rpy;
 }
 // CTRL/angvel_control.py:67-88, one axis
-TD float pid_axis(float dt, float rdt, float kp, float des, float cur, float &prev, float &integ) {
-    float e = clamp_const(des - cur, -400.0f, 400.0f);
+// FIN: des, cur, prev and integ are known to be finite (see `fin` in the kernel), so the clamps need no NaN pass-through
+template <bool FIN = false> TD float pid_axis(float dt, float rdt, float kp, float des, float cur, float &prev, float &integ) {
+    float e = clamp_const_t<FIN>(des - cur, -400.0f, 400.0f);
     float pv = (prev == 0.0f) ? e : prev;
     float P = kp * e;
-    float I = clamp_const(integ + e * dt, -500.0f, 500.0f);
+    float I = clamp_const_t<FIN>(integ + e * dt, -500.0f, 500.0f);
     float I_term = 0.0f * I;
     float deriv = div_const(e - pv, dt, rdt);  // == (e - pv) / dt bit for bit: taco_create verified it for this dt
-    float D = clamp_const(0.5f * deriv, -150.0f, 150.0f);
+    float D = clamp_const_t<FIN>(0.5f * deriv, -150.0f, 150.0f);
     float FF = 0.0f * des;
     integ = I;
     prev = e;
@@ -251,9 +253,12 @@ TD V3 quat_sandwich(Q4 q, V3 u) {
 // fed to the rate PID of every substep, turned back into the root state's world-frame angular velocity after the 10th.  The rare forms (|b| h/2 > 0.5 rad per
 // sub-iteration, |q|^2 off by > 1e-3, NaN) are evaluated only when some lane of the wavefront needs them (ballot), and
 // selected per lane, so the common case has no divergent control flow at all.
-TD void integrate(const StepParams &P, V3 &p, Q4 &q, V3 &v, V3 &wb, V3 F, V3 tq) {
+// Returns (wave-uniformly) whether some lane took a rare form, i.e. whether the new body rates may be large, infinite or NaN.
+// SUBS: the sub-iteration count when it is known at compile time (the PLAIN loop form: 2, unrolled), 0 = P.substeps.
+template <int SUBS = 0> TD bool integrate(const StepParams &P, V3 &p, Q4 &q, V3 &v, V3 &wb, V3 F, V3 tq) {
     float b0 = wb.x, b1 = wb.y, b2 = wb.z;
-    for (int it = 0; it < P.substeps; ++it) {
+    bool any_big = false;
+    auto iteration = [&]() {
         float L0 = P.J0 * b0, L1 = P.J1 * b1, L2 = P.J2 * b2;
         float g0 = fma(b1, L2, -(b2 * L1));
         float g1 = fma(b2, L0, -(b0 * L2));
@@ -274,7 +279,8 @@ TD void integrate(const StepParams &P, V3 &p, Q4 &q, V3 &v, V3 &wb, V3 F, V3 tq)
         float c = fma(fma(fma(fma(2.4801587302e-5f, A2, -1.3888888889e-3f), A2, 4.1666666667e-2f), A2, -0.5f), A2, 1.0f);
         float k = P.half_h * sp;
         const bool big = !(A2 <= 0.25f);
-        if (__builtin_amdgcn_ballot_w64(big)) {
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(big) != 0, 0)) {
+            any_big = true;
             const float wn = __builtin_sqrtf(w2);
             float sn, cs;
             sincos(P.half_h * wn, sn, cs);
@@ -291,13 +297,16 @@ TD void integrate(const StepParams &P, V3 &p, Q4 &q, V3 &v, V3 &wb, V3 F, V3 tq)
         const float n2 = fma(nw, nw, fma(nz, nz, fma(ny, ny, nx * nx)));
         float inv = fma(-0.5f, n2, 1.5f);
         const bool off = !(absf(n2 - 1.0f) <= 1e-3f);
-        if (__builtin_amdgcn_ballot_w64(off)) {
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(off) != 0, 0)) {
             const float ie = 1.0f / __builtin_sqrtf(n2);
             inv = off ? ie : inv;
         }
         q.x = nx * inv; q.y = ny * inv; q.z = nz * inv; q.w = nw * inv;
-    }
+    };
+    if constexpr (SUBS == 2) { iteration(); iteration(); }
+    else for (int it = 0; it < P.substeps; ++it) iteration();
     wb = V3{b0, b1, b2};
+    return any_big;
 }
 
 
@@ -329,9 +338,11 @@ TD float quad_rotate(float qv, float w, float v) {
 // row I (integrate above) in the quad layout.  qq = (x y z w) over the four lanes; pq vq bq Fq tqq components 0..2 in lanes 0..2.
 // Jq / hJiq: this lane's inertia terms; gzq = (-0, -0, g, -0) (fma(RF, 1/m, -0) == RF * (1/m) exactly); sm3 = sign bit in lane 3,
 // k3 = all ones in lane 3.
-TD void integrate_quad(const StepParams &P, uint32_t k3, float &pq, float &qq, float &vq, float &bq, float Fq, float tqq, float Jq, float hJiq,
+template <int SUBS = 0>
+TD bool integrate_quad(const StepParams &P, uint32_t k3, float &pq, float &qq, float &vq, float &bq, float Fq, float tqq, float Jq, float hJiq,
                        float gzq, uint32_t sm3) {
-    for (int it = 0; it < P.substeps; ++it) {
+    bool any_big = false;
+    auto iteration = [&]() {
         const float L = Jq * bq;
         const float g = fma(rot1(bq), rot2(L), -(rot2(bq) * rot1(L)));
         bq = fma(hJiq, tqq - g, bq);
@@ -349,7 +360,8 @@ TD void integrate_quad(const StepParams &P, uint32_t k3, float &pq, float &qq, f
         float c = fma(fma(fma(fma(2.4801587302e-5f, A2, -1.3888888889e-3f), A2, 4.1666666667e-2f), A2, -0.5f), A2, 1.0f);
         float k = P.half_h * sp;
         const bool big = !(A2 <= 0.25f);
-        if (__builtin_amdgcn_ballot_w64(big)) {
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(big) != 0, 0)) {
+            any_big = true;
             const float wn = __builtin_sqrtf(w2);
             float sn, cs;
             sincos(P.half_h * wn, sn, cs);
@@ -369,12 +381,15 @@ TD void integrate_quad(const StepParams &P, uint32_t k3, float &pq, float &qq, f
         const float n2 = fma(n3, n3, fma(n2_, n2_, fma(n1, n1, bc0(nsq))));
         float inv = fma(-0.5f, n2, 1.5f);
         const bool off = !(absf(n2 - 1.0f) <= 1e-3f);
-        if (__builtin_amdgcn_ballot_w64(off)) {
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(off) != 0, 0)) {
             const float ie = 1.0f / __builtin_sqrtf(n2);
             inv = off ? ie : inv;
         }
         qq = n * inv;
-    }
+    };
+    if constexpr (SUBS == 2) { iteration(); iteration(); }
+    else for (int it = 0; it < P.substeps; ++it) iteration();
+    return any_big;
 }
 
 // reset_idx for one env (FA:475-517), in the reference's call order: reset_copter_idx -> reset_controller_idx ->
@@ -742,6 +757,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
     }
     // ---- the ten slots this step consumes -> per-wave LDS table (substep k reads entry min(L-1, k), FA:366)
     const bool wave_dense = __builtin_amdgcn_ballot_w64(dense) != 0;  // wave-uniform: normally no lane is DENSE
+    float in_mag;  // sum of the magnitudes of everything the PID / allocator of this step consume (see `fin` below)
     if constexpr (LPE == 1) {
         // queue lanes: slots 0..9 of [Z zeros | run_0 | run_1 | ...] after the push span at most two runs
         float4 v0 = act4, v1 = act4;  // the pushed run itself is run_0 (empty queue) or run_1 (one run queued)
@@ -753,6 +769,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
             v0 = sel4(deep, g0, v0); v1 = sel4(deep, g1, v1);
         }
         const int n0 = (q_m >= 1) ? q_rem0 : T;  // slots of run_0 ahead of run_1
+        in_mag = ((absf(v0.x) + absf(v0.y)) + (absf(v0.z) + absf(v0.w))) + ((absf(v1.x) + absf(v1.y)) + (absf(v1.z) + absf(v1.w)));
 #pragma unroll
         for (int s = 0; s < 10; ++s) {
             float4 o = sel4(s < zlead, zero4, sel4((s - zlead) < n0, v0, v1));
@@ -780,6 +797,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
             v1 = deep ? pick4(sub, g1.x, g1.y, g1.z, g1.w) : v1;
         }
         const int n0 = (q_m >= 1) ? q_rem0 : T;  // slots of run_0 ahead of run_1
+        in_mag = absf(v0) + absf(v1);  // this lane's component; the ballot below covers the quad
 #pragma unroll
         for (int s = 0; s < 10; ++s) {
             float o = (s < zlead) ? 0.0f : (((s - zlead) < n0) ? v0 : v1);
@@ -832,11 +850,25 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
     // the target pose is consumed only after the loop; issuing the loads here hides their latency behind the substeps
     const float4 c_tp = CLD(C_TGT_POS), c_tq = CLD(C_TGT_QUAT);
     V3 wb = quat_rotate(conj(q), w);  // body-frame angular velocity of the root state (FA:350); row I carries it from here on
+    // `fin` (wave-uniform): every value the rate PID and the allocator of the next substep consume -- the pending actions of this step,
+    // the body rates, the PID memory -- is finite and below 1e30 in every lane.  Then no intermediate of that block can be a NaN or
+    // overflow, and the selects that carry torch's NaN semantics (clamp pass-through, the NaN-propagating max) are dead: the block runs
+    // its FIN form (v_med3 / v_max alone), which is the same function on such inputs.  The PID memory stays clamped, the body rates stay
+    // bounded as long as the integrator takes its common form (|b| h/2 <= 0.5), so `fin` survives a substep unless integrate() reports
+    // a rare form; DENSE wavefronts (slot values straight from the ring) never take the FIN form.
+    in_mag = in_mag + ((absf(wb.x) + absf(wb.y)) + absf(wb.z)) + ((absf(pid_prev[0]) + absf(pid_prev[1])) + absf(pid_prev[2])) +
+             ((absf(pid_int[0]) + absf(pid_int[1])) + absf(pid_int[2]));
+    const bool fin = !wave_dense && __builtin_amdgcn_ballot_w64(!(in_mag < 1e30f)) == 0;
+    // `plain` (wave-uniform): the loop needs no euler/unwrap, no rotor noise, the battery model is on and PhysX runs its default two
+    // sub-iterations -- the PLAIN form of the loop has these decided at compile time (no branches over the unused blocks, integrator
+    // unrolled; a lone wavefront pays ~10 issue slots for every taken branch)
+    const bool plain = !wave_tracks_rpy && !(fl & TACO_F_ROTOR_NOISE) && P.substeps == 2 && (fl & TACO_F_BATTERY_CONSUMPTION) != 0;
     if constexpr (LPE == 1) {
-    #pragma unroll 1
-        for (int ks = 0; ks < 10; ++ks) {
+        // one substep; FIN: see `fin` above.  Returns whether the integrator took a rare form in some lane (wave-uniform).
+        auto substep = [&](auto fin_c, const int ks) -> bool {
+            constexpr bool FIN = decltype(fin_c)::value >= 1, PLAIN = decltype(fin_c)::value >= 2;  // loop forms: 0 exact, 1 FIN, 2 FIN + PLAIN
             // refresh_state, the part the inner loop consumes FA:339-350
-            if (wave_tracks_rpy) {
+            if (!PLAIN && wave_tracks_rpy) {
                 V3 e = euler_xyz_v1(q);
                 unwrap(e.x, rpy_old[0], rpy_cont[0]);
                 unwrap(e.y, rpy_old[1], rpy_cont[1]);
@@ -848,24 +880,33 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
             const int idx = (dlen - 1 < ks) ? dlen - 1 : ks;
             const float4 dact = slots[idx * EPW + el];
             const float d0 = dact.x, d1 = dact.y, d2 = dact.z, d3 = dact.w;
-            // angular_vel_control FA:637-650
-            float u0 = (d0 + 1.0f) / 2.0f * 1000.0f;
-            float u1 = pid_axis(P.dt, P.rdt, 27.5f, d1 * 20.0f, wb.x, pid_prev[0], pid_int[0]);
-            float u2 = pid_axis(P.dt, P.rdt, 50.0f, d2 * 20.0f, wb.y, pid_prev[1], pid_int[1]);
-            float u3 = pid_axis(P.dt, P.rdt, 200.0f, d3 * 20.0f, wb.z, pid_prev[2], pid_int[2]);
-            // control_allocator CTRL/fpv_dynamics.py:35-46
-            u3 = clampf(u3, -u0 / 2.0f, u0 / 2.0f);
-            float f0 = ((u0 * 1.0f + u1 * -1.0f) + u2 * 1.0f) + u3 * -1.0f;
-            float f1 = ((u0 * 1.0f + u1 * -1.0f) + u2 * -1.0f) + u3 * 1.0f;
-            float f2 = ((u0 * 1.0f + u1 * 1.0f) + u2 * -1.0f) + u3 * -1.0f;
-            float f3 = ((u0 * 1.0f + u1 * 1.0f) + u2 * 1.0f) + u3 * 1.0f;
-            float mx = f0 - 1000.0f, t1 = f1 - 1000.0f, t2 = f2 - 1000.0f, t3 = f3 - 1000.0f;
-            mx = (t1 > mx || t1 != t1) ? t1 : mx;
-            mx = (t2 > mx || t2 != t2) ? t2 : mx;
-            mx = (t3 > mx || t3 != t3) ? t3 : mx;
-            float ex = (mx < 0.0f) ? 0.0f : mx;
-            float thr[4] = {clamp_const(f0 - ex, 100.0f, 1000.0f), clamp_const(f1 - ex, 100.0f, 1000.0f), clamp_const(f2 - ex, 100.0f, 1000.0f),
-                            clamp_const(f3 - ex, 100.0f, 1000.0f)};
+            float thr[4];
+            {
+                // angular_vel_control FA:637-650
+                float u0 = (d0 + 1.0f) / 2.0f * 1000.0f;
+                float u1 = pid_axis<FIN>(P.dt, P.rdt, 27.5f, d1 * 20.0f, wb.x, pid_prev[0], pid_int[0]);
+                float u2 = pid_axis<FIN>(P.dt, P.rdt, 50.0f, d2 * 20.0f, wb.y, pid_prev[1], pid_int[1]);
+                float u3 = pid_axis<FIN>(P.dt, P.rdt, 200.0f, d3 * 20.0f, wb.z, pid_prev[2], pid_int[2]);
+                // control_allocator CTRL/fpv_dynamics.py:35-46
+                u3 = clampf(u3, -u0 / 2.0f, u0 / 2.0f);
+                float f0 = ((u0 * 1.0f + u1 * -1.0f) + u2 * 1.0f) + u3 * -1.0f;
+                float f1 = ((u0 * 1.0f + u1 * -1.0f) + u2 * -1.0f) + u3 * 1.0f;
+                float f2 = ((u0 * 1.0f + u1 * 1.0f) + u2 * -1.0f) + u3 * -1.0f;
+                float f3 = ((u0 * 1.0f + u1 * 1.0f) + u2 * 1.0f) + u3 * 1.0f;
+                float mx = f0 - 1000.0f, t1 = f1 - 1000.0f, t2 = f2 - 1000.0f, t3 = f3 - 1000.0f;
+                float ex;
+                if constexpr (FIN) {  // no NaN, and x - 1000 is never -0: plain maxima are the same function
+                    mx = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(mx, t1), t2), t3);
+                    ex = __builtin_fmaxf(mx, 0.0f);
+                } else {
+                    mx = (t1 > mx || t1 != t1) ? t1 : mx;
+                    mx = (t2 > mx || t2 != t2) ? t2 : mx;
+                    mx = (t3 > mx || t3 != t3) ? t3 : mx;
+                    ex = (mx < 0.0f) ? 0.0f : mx;
+                }
+                thr[0] = clamp_const_t<FIN>(f0 - ex, 100.0f, 1000.0f); thr[1] = clamp_const_t<FIN>(f1 - ex, 100.0f, 1000.0f);
+                thr[2] = clamp_const_t<FIN>(f2 - ex, 100.0f, 1000.0f); thr[3] = clamp_const_t<FIN>(f3 - ex, 100.0f, 1000.0f);
+            }
             // mechanical power FA:614
             float Pm;
             {
@@ -875,7 +916,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
                 b = TACO_DIVC(omega[3] * 2.0f * kPi, 4500.0f); Pm = Pm + 400.0f * ((b * b) * b);
             }
             // Battery_Dynamics.sim_process CTRL/battery_dynamics.py:47-75
-            if (bat_on) {
+            if (PLAIN || bat_on) {
                 bat_t = bat_t + P.dt;
                 float p_c = TACO_DIVC(TACO_DIVC(Pm, 0.75f), 9000.0f);
                 bat_E = bat_E + p_c * P.dt;
@@ -901,7 +942,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
                     omega[k] = omega[k] + (1.0f / tau[k]) * 0.001f * (target - omega[k]);
                 }
             }
-            if (fl & TACO_F_ROTOR_NOISE) {  // CTRL/thrust_dynamics.py:68-78
+            if (!PLAIN && (fl & TACO_F_ROTOR_NOISE)) {  // CTRL/thrust_dynamics.py:68-78
                 U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, P.step, STREAM_ROTOR, (uint32_t)ks);
                 const float n_sc = (float)((1 + 10.0 / 700) - (1 - 10.0 / 700)), n_lo = (float)(1 - 10.0 / 700);
                 omega[0] = omega[0] * (n_sc * uniform(r.x) + n_lo);
@@ -926,8 +967,27 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
                 tq.z = (ts0 + ts1) + (ts2 + ts3);
             }
             if (is_reset) { F = V3{0.0f, 0.0f, 0.0f}; tq = V3{0.0f, 0.0f, 0.0f}; }  // FA:629-630: no force during the reset step
-            integrate(P, p, q, v, wb, F, tq);
+            return integrate<PLAIN ? 2 : 0>(P, p, q, v, wb, F, tq);
+        };
+        // the FIN form of the loop runs while `fin` holds (normally all ten substeps), the exact form takes over at the first rare form
+        int ks = 0;
+        if (fin && plain) {
+    #pragma unroll 1
+            while (ks < 10) {
+                const bool rare = substep(std::integral_constant<int, 2>{}, ks);
+                ++ks;
+                if (rare) break;
+            }
+        } else if (fin) {
+    #pragma unroll 1
+            while (ks < 10) {
+                const bool rare = substep(std::integral_constant<int, 1>{}, ks);
+                ++ks;
+                if (rare) break;
+            }
         }
+    #pragma unroll 1
+        for (; ks < 10; ++ks) substep(std::integral_constant<int, 0>{}, ks);
 
     } else {
         // ---- quad layout: scatter (lane j keeps component j), run the ten substeps, gather back
@@ -950,9 +1010,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
         const uint32_t keep = is_reset ? 0u : ~0u;  // FA:629-630: no force during the reset step
         const float Sq = pick4(sub, P.arm_y, -P.arm_x, 1.0f, 1.0f);
         const float *slotsf = reinterpret_cast<const float *>(slots);
-#pragma unroll 1
-        for (int ks = 0; ks < 10; ++ks) {
-            if (wave_tracks_rpy) {  // refresh_state FA:339-347: every lane evaluates the three angles, lane j unwraps angle j
+        auto substep = [&](auto fin_c, const int ks) -> bool {
+            // loop forms: 0 exact, 1 FIN, 2 FIN + PLAIN (battery computed here), 6 FIN + PLAIN + battery served by wavefront 1
+            constexpr int MODE = decltype(fin_c)::value;
+            constexpr bool FIN = (MODE & 1) != 0 || MODE >= 2, PLAIN = (MODE & 2) != 0;
+            const bool served = PLAIN ? (MODE & 4) != 0 : bat_served;
+            if (!PLAIN && wave_tracks_rpy) {  // refresh_state FA:339-347: every lane evaluates the three angles, lane j unwraps angle j
                 const V3 e = euler_xyz_v1(Q4{bc0(qq), bc1(qq), bc2(qq), bc3(qq)});
                 unwrap(pick4(sub, e.x, e.y, e.z, 0.0f), roq, rcq);
             }
@@ -962,13 +1025,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
             const float d0 = bc0(dq);
             // angular_vel_control FA:637-650: lane j runs PID axis j on action component j + 1
             const float u0 = (d0 + 1.0f) / 2.0f * 1000.0f;
-            const float upid = pid_axis(P.dt, P.rdt, kpq, dppf<QP(1, 2, 3, 3)>(dq) * 20.0f, bq, ppq, piq);
+            const float upid = pid_axis<FIN>(P.dt, P.rdt, kpq, dppf<QP(1, 2, 3, 3)>(dq) * 20.0f, bq, ppq, piq);
             // the voltage of this substep is being computed by wavefront 1 since the previous substep's rotor update: read counter and
             // value here, ~40 instructions ahead of their use (LDS executes a wavefront's reads in order, so a value read after a
             // sufficient counter is the right one)
             int seq_early = 0;
             float v_early = 0.0f;
-            if (bat_served) {
+            if (served) {
                 asm volatile("" ::"v"(upid) : "memory");  // not before the PID is done: gives wavefront 1 the time it needs
                 seq_early = MB_SEQ(1);
                 v_early = __hip_atomic_load(&mb_v[el], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -979,13 +1042,19 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
             u3 = clampf(u3, -u0 / 2.0f, u0 / 2.0f);
             const float fq = ((u0 * 1.0f + xorf(u1, m1)) + xorf(u2, m2)) + xorf(u3, m3);
             const float tm = fq - 1000.0f;
-            float mx = bc0(tm);
-            { const float t1 = bc1(tm); mx = (t1 > mx || t1 != t1) ? t1 : mx; }
-            { const float t2 = bc2(tm); mx = (t2 > mx || t2 != t2) ? t2 : mx; }
-            { const float t3 = bc3(tm); mx = (t3 > mx || t3 != t3) ? t3 : mx; }
-            const float ex = (mx < 0.0f) ? 0.0f : mx;
-            const float thrq = clamp_const(fq - ex, 100.0f, 1000.0f);
-            if (bat_served) {
+            float thrq;
+            if constexpr (FIN) {  // no NaN, and x - 1000 is never -0: plain maxima are the same function
+                const float mx = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(bc0(tm), bc1(tm)), bc2(tm)), bc3(tm));
+                thrq = __builtin_amdgcn_fmed3f(fq - __builtin_fmaxf(mx, 0.0f), 100.0f, 1000.0f);
+            } else {
+                float mx = bc0(tm);
+                { const float t1 = bc1(tm); mx = (t1 > mx || t1 != t1) ? t1 : mx; }
+                { const float t2 = bc2(tm); mx = (t2 > mx || t2 != t2) ? t2 : mx; }
+                { const float t3 = bc3(tm); mx = (t3 > mx || t3 != t3) ? t3 : mx; }
+                const float ex = (mx < 0.0f) ? 0.0f : mx;
+                thrq = clamp_const(fq - ex, 100.0f, 1000.0f);
+            }
+            if (served) {
                 asm volatile("" : "+v"(seq_early), "+v"(v_early));  // keeps the compiler from waiting for the early reads before this point
                 if (__builtin_amdgcn_ballot_w64(seq_early < ks + 1) != 0) {  // (not posted yet at the early read: rare)
                     MB_WAIT(1, ks + 1);
@@ -1004,7 +1073,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
                     Pm = Pm + bc3(c3);
                 }
                 // Battery_Dynamics.sim_process CTRL/battery_dynamics.py:47-75 (replicated in the quad)
-                if (bat_on) bat_V = battery_step(P.dt, Pm, bat_E, bat_u1, bat_t);
+                if (PLAIN || bat_on) bat_V = battery_step(P.dt, Pm, bat_E, bat_u1, bat_t);
                 else bat_V = 4.35f * 6.0f;
             }
             // RotorDynamics.sim_process CTRL/thrust_dynamics.py:98-104: lane k = rotor k
@@ -1014,13 +1083,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
                 const float target = (opara[0] * 1.0f + opara[1] * x + opara[2] * y + opara[3] * (x * x) + opara[4] * x * y) * 100.0f;
                 omq = omq + itq * (target - omq);
             }
-            if (fl & TACO_F_ROTOR_NOISE) {  // CTRL/thrust_dynamics.py:68-78
+            if (!PLAIN && (fl & TACO_F_ROTOR_NOISE)) {  // CTRL/thrust_dynamics.py:68-78
                 U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, P.step, STREAM_ROTOR, (uint32_t)ks);
                 const float n_sc = (float)((1 + 10.0 / 700) - (1 - 10.0 / 700)), n_lo = (float)(1 - 10.0 / 700);
                 const uint32_t rk = sub == 0 ? r.x : (sub == 1 ? r.y : (sub == 2 ? r.z : r.w));
                 omq = omq * (n_sc * uniform(rk) + n_lo);
             }
-            if (bat_served) {  // the rotor speeds the NEXT substep's battery step starts from
+            if (served) {  // the rotor speeds the NEXT substep's battery step starts from
                 mb_om[lane] = omq;
                 MB_POST(0, ks + 2);
             }
@@ -1044,8 +1113,33 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
                 Fq = from_bits(bits(selm(k2, Fz, dragq * vbq)) & keep);
                 tqq = from_bits(bits(selm(k2, tz, txy)) & keep);
             }
-            integrate_quad(P, k3, pq, qq, vq, bq, Fq, tqq, Jq, hJiq, gzq, sm3);
+            return integrate_quad<PLAIN ? 2 : 0>(P, k3, pq, qq, vq, bq, Fq, tqq, Jq, hJiq, gzq, sm3);
+        };
+        int ks = 0;
+        if (SPLIT && fin && plain && bat_served) {
+#pragma unroll 1
+            while (ks < 10) {
+                const bool rare = substep(std::integral_constant<int, 6>{}, ks);
+                ++ks;
+                if (rare) break;
+            }
+        } else if (fin && plain) {
+#pragma unroll 1
+            while (ks < 10) {
+                const bool rare = substep(std::integral_constant<int, 2>{}, ks);
+                ++ks;
+                if (rare) break;
+            }
+        } else if (fin) {
+#pragma unroll 1
+            while (ks < 10) {
+                const bool rare = substep(std::integral_constant<int, 1>{}, ks);
+                ++ks;
+                if (rare) break;
+            }
         }
+#pragma unroll 1
+        for (; ks < 10; ++ks) substep(std::integral_constant<int, 0>{}, ks);
         if (bat_served) {
             MB_WAIT(1, 11);
             bat_E = mb_bs[el * 4]; bat_u1 = mb_bs[el * 4 + 1]; bat_t = mb_bs[el * 4 + 2];

@@ -60,7 +60,8 @@ def run_pair(cfg, steps, seed=0, check_every=1, hover_bias=False):
             assert_bits_equal(gb[20:26][:, flip_envs], ob[20:26][:, flip_envs], what + " rpy_old / rpy_continuous of the flip envs")
             assert_bits_equal(gb[67:], ob[67:], what + " delay line")
             fin = np.isfinite(ob[:13]) & np.isfinite(gb[:13])
-            max_err = max(max_err, float(np.abs(gb[:13] - ob[:13])[fin].max()))
+            if fin.any():
+                max_err = max(max_err, float(np.abs(gb[:13] - ob[:13])[fin].max()))
         n_done += int(orc.reset_buf.sum())
     assert max_err <= 1e-5, "north-star bar: root-state trajectory L-inf <= 1e-5"
     return n_done
@@ -225,3 +226,49 @@ def test_random_configurations():
             run_pair(cfg, steps, seed=i, check_every=1 if steps > 8 else 2, hover_bias=bool(i & 1))
         except AssertionError as e:
             raise AssertionError(f"case {i}: {fuzz.describe(cfg)}: {e}") from e
+
+
+@pytest.mark.parametrize("geom", [None, ("4", "64", "0"), ("1", "64", "0"), ("1", "256", "0")])
+def test_loop_forms_hand_over_on_rare_forms_and_nonfinite_inputs(geom, monkeypatch):
+    """The substep loop runs a FIN form (no NaN-carrying selects) and a PLAIN form (compile-time flags, unrolled integrator) while a
+    wave-uniform predicate says they are the same function as the exact form.  Two stress cases against the oracle, in every
+    instantiation: (1) an airframe with 1/3000 of the inertia -- body rates shoot past the integrator's common form within a few
+    substeps, at different substeps in different envs (hand-over in mid-step), and run on to inf / NaN; (2) NaN, inf and huge
+    actions (the predicate is false from the first substep for the wavefronts that consume them, `delay_time` ms later)."""
+    if geom:
+        monkeypatch.setenv("TACO_FORCE_LPE", geom[0])
+        monkeypatch.setenv("TACO_FORCE_BLOCK", geom[1])
+        monkeypatch.setenv("TACO_FORCE_SPLIT", geom[2])
+    from oracle import oracle as O
+    from taco_amd.vec_env import FpvBase
+    n = 300
+    # (1) tiny inertia
+    for scale in (1 / 300.0, 1 / 3000.0, 1 / 100000.0):
+        cfg = config.baseline_config(1, num_envs=n)
+        _, J = config.composite_body()
+        cfg["inertia"] = tuple(j * scale for j in J)
+        cfg["env"]["maxEpisodeLength"] = 40
+        run_pair(cfg, steps=60, seed=3, hover_bias=True)
+    # (2) non-finite / huge actions in some envs, some steps
+    cfg = config.baseline_config(1, num_envs=n)
+    cfg["env"]["maxEpisodeLength"] = 50
+    flat = config.flat_cfg(cfg)
+    env = FpvBase(cfg, copy_outputs=False)
+    orc = O.OracleEnv(flat, threads=8)
+    acts = action_stream(n, 70, 5)
+    rng = np.random.default_rng(9)
+    bad = np.array([np.nan, np.inf, -np.inf, 1e35, -3e37, 1e30, 5e29], np.float32)
+    for t in range(5, 70, 3):
+        rows = rng.integers(0, n, 12)
+        acts[t, rows, rng.integers(0, 4, 12)] = bad[rng.integers(0, len(bad), 12)]
+    acts_d = torch.from_numpy(acts).cuda()
+    for t in range(70):
+        env.step_raw(acts_d[t])
+        orc.step(acts[t])
+        what = f"non-finite actions, step {t}"
+        assert_bits_equal(env.obs_buf.cpu().numpy(), orc.obs_buf, what + " obs")
+        assert_bits_equal(env.rew_buf.cpu().numpy(), orc.rew_buf, what + " rew")
+        assert_bits_equal(env.reset_buf.cpu().numpy(), orc.reset_buf, what + " reset")
+        gb, ob = env.get_state().cpu().numpy(), orc.get_state().view(np.float32)
+        assert_bits_equal(gb[:20], ob[:20], what + " state 0..19")
+        assert_bits_equal(gb[26:65], ob[26:65], what + " state 26..64")
