@@ -771,15 +771,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
         const int n0 = (q_m >= 1) ? q_rem0 : T;  // slots of run_0 ahead of run_1
         in_mag = ((absf(v0.x) + absf(v0.y)) + (absf(v0.z) + absf(v0.w))) + ((absf(v1.x) + absf(v1.y)) + (absf(v1.z) + absf(v1.w)));
 #pragma unroll
-        for (int s = 0; s < 10; ++s) {
-            float4 o = sel4(s < zlead, zero4, sel4((s - zlead) < n0, v0, v1));
-            if (wave_dense) {
+        for (int s = 0; s < 10; ++s) slots[s * EPW + el] = sel4(s < zlead, zero4, sel4((s - zlead) < n0, v0, v1));
+        if (__builtin_expect(wave_dense, 0)) {  // DENSE lanes overwrite their entries from the ring (kept out of the common path)
+#pragma unroll 1
+            for (int s = 0; s < 10; ++s) {
                 int ph = P.head + s; ph = ph >= TACO_RING_SLOTS ? ph - TACO_RING_SLOTS : ph;
                 const float4 r = buf_ld4(rR, voff, (uint32_t)ph * row_bytes);  // physical row is wave-uniform: coalesced
                 const bool fresh = (s >= dlen) && (s < dlen + T);             // covered by this step's write: from registers
-                o = sel4(dense, sel4(fresh, act4, r), o);
+                if (dense) slots[s * EPW + el] = sel4(fresh, act4, r);
             }
-            slots[s * EPW + el] = o;
         }
     } else {
         // the same table in the quad layout: lane j of an env only ever reads component j of a slot, so it selects and stores that one
@@ -799,15 +799,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
         const int n0 = (q_m >= 1) ? q_rem0 : T;  // slots of run_0 ahead of run_1
         in_mag = absf(v0) + absf(v1);  // this lane's component; the ballot below covers the quad
 #pragma unroll
-        for (int s = 0; s < 10; ++s) {
-            float o = (s < zlead) ? 0.0f : (((s - zlead) < n0) ? v0 : v1);
-            if (wave_dense) {
+        for (int s = 0; s < 10; ++s) slotsw[(s * EPW + el) * 4 + sub] = (s < zlead) ? 0.0f : (((s - zlead) < n0) ? v0 : v1);
+        if (__builtin_expect(wave_dense, 0)) {  // DENSE lanes overwrite their entries from the ring (kept out of the common path)
+#pragma unroll 1
+            for (int s = 0; s < 10; ++s) {
                 int ph = P.head + s; ph = ph >= TACO_RING_SLOTS ? ph - TACO_RING_SLOTS : ph;
                 const float4 r = buf_ld4(rR, voff, (uint32_t)ph * row_bytes);  // physical row is wave-uniform: coalesced
                 const bool fresh = (s >= dlen) && (s < dlen + T);             // covered by this step's write: from registers
-                o = dense ? (fresh ? ac : pick4(sub, r.x, r.y, r.z, r.w)) : o;
+                if (dense) slotsw[(s * EPW + el) * 4 + sub] = fresh ? ac : pick4(sub, r.x, r.y, r.z, r.w);
             }
-            slotsw[(s * EPW + el) * 4 + sub] = o;
         }
     }
     if (!dense) {  // push the run (T, this action)
@@ -1010,6 +1010,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
         const uint32_t keep = is_reset ? 0u : ~0u;  // FA:629-630: no force during the reset step
         const float Sq = pick4(sub, P.arm_y, -P.arm_x, 1.0f, 1.0f);
         const float *slotsf = reinterpret_cast<const float *>(slots);
+        // the delayed action of substep k + 1 is fetched during substep k: its LDS latency would otherwise sit at the head of every substep
+        auto slot_of = [&](int k) { int r = (dlen - 1 < k) ? dlen - 1 : k; return r > 9 ? 9 : r; };
+        float dq_next = slotsf[(slot_of(0) * EPW + el) * 4 + sub];
         auto substep = [&](auto fin_c, const int ks) -> bool {
             // loop forms: 0 exact, 1 FIN, 2 FIN + PLAIN (battery computed here), 6 FIN + PLAIN + battery served by wavefront 1
             constexpr int MODE = decltype(fin_c)::value;
@@ -1020,8 +1023,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
                 unwrap(pick4(sub, e.x, e.y, e.z, 0.0f), roq, rcq);
             }
             const float vbq = quad_rotate(-qq, bc3(qq), vq);  // FA:350 body-frame linear velocity
-            const int idx = (dlen - 1 < ks) ? dlen - 1 : ks;
-            const float dq = slotsf[(idx * EPW + el) * 4 + sub];
+            const float dq = dq_next;  // slot min(L - 1, ks), FA:366
+            dq_next = slotsf[(slot_of(ks + 1) * EPW + el) * 4 + sub];
             const float d0 = bc0(dq);
             // angular_vel_control FA:637-650: lane j runs PID axis j on action component j + 1
             const float u0 = (d0 + 1.0f) / 2.0f * 1000.0f;
@@ -1056,7 +1059,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
             }
             if (served) {
                 asm volatile("" : "+v"(seq_early), "+v"(v_early));  // keeps the compiler from waiting for the early reads before this point
-                if (__builtin_amdgcn_ballot_w64(seq_early < ks + 1) != 0) {  // (not posted yet at the early read: rare)
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(seq_early < ks + 1) != 0, 0)) {  // (not posted yet at the early read: rare)
                     MB_WAIT(1, ks + 1);
                     v_early = mb_v[el];
                 }
