@@ -72,6 +72,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise TacoError(f"{LIB_PATH} is missing: build it with `python -m taco_amd.build` (hipcc, gfx950). "
                         "There is no CPU fallback for the step path.")
+    # PyTorch-ROCm ships its own HIP runtime (libamdhip64, same SONAME as /opt/rocm's).  The process must hold ONE runtime, and it has to be
+    # the one torch's other bundled libraries were built against: load torch first, so that libtaco_env.so binds to the runtime already
+    # in the process.  (The other order leaves torch on /opt/rocm's runtime and HIP reports "no ROCm-capable device".)
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     lib.taco_abi_version.restype = C.c_int
     lib.taco_last_error.restype = C.c_char_p
