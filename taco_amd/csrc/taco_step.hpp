@@ -580,7 +580,38 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
     const int i_raw = SPLIT ? (blockIdx.x * 64 + lane) / LPE : (blockIdx.x * BLOCK + threadIdx.x) / LPE;
     const bool in_range = i_raw < P.n;
     const bool active = in_range && sub == 0;  // the lane that stores for its env
-    const bool roleS = !SPLIT || wv == 1, roleO = !SPLIT || wv == 2, roleR = !SPLIT || wv == 3;  // post-phase roles (SPLIT: wave 0 = the step itself)
+    // post-phase roles (SPLIT: wave 0 = the step itself; wave 1 = battery server, then reward + done; wave 2 = obs stack; wave 3 = states stack)
+    const bool roleS = !SPLIT || wv == 3, roleO = !SPLIT || wv == 2, roleR = !SPLIT || wv == 1;
+    const uint32_t wave_env0 = SPLIT ? (uint32_t)(blockIdx.x * 64 / LPE) : (uint32_t)((blockIdx.x * BLOCK + wv * 64) / LPE);  // first env of this wavefront
+    // Frame stacks with len > 1: the wavefront's EPW rows are one contiguous range of EPW * len * 13 eight-byte words.  Word w of the new
+    // stack is word w + 13 of the previous one (one frame further) inside the first len - 1 frames of its row (the HISTORY words), and
+    // comes from this step's frame in the last frame of the row: the whole wavefront copies 512 contiguous bytes per instruction instead of
+    // 64 rows 104 * len bytes apart.  In place (prev == buf) the reads run 13 words ahead of the writes; loads are issued in batches of eight
+    // ahead of their stores.  shift_history moves the history words only -- they do not depend on this step, so the role wavefronts of the
+    // SPLIT form do it while wavefront 0 runs the substeps and only the newest frame is left for the post-phase.
+    auto shift_history = [&](float *buf, const float *prev, uint32_t buf_bytes, int len) {
+        const rsrc_t rB = make_rsrc(buf, buf_bytes), rP = make_rsrc(prev, buf_bytes);
+        const uint32_t L13 = (uint32_t)len * 13u, hist = L13 - 13u, tot = (uint32_t)EPW * L13;
+        const uint32_t magic = 0xFFFFFFFFu / L13 + 1u;  // row = (w * magic) >> 32 for w < 2^16
+        const uint32_t base = wave_env0 * L13;          // first word of the wavefront's range
+        for (uint32_t w0 = 0; w0 < tot; w0 += 8u * 64u) {
+            f32x2_t v[8];
+            bool mine[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t w = w0 + (uint32_t)k * 64u + (uint32_t)lane;
+                const uint32_t row = __umulhi(w, magic), wl = w - row * L13;
+                mine[k] = w < tot && wl < hist;
+                v[k] = f32x2_t{0.0f, 0.0f};
+                if (mine[k]) v[k] = llvm_amdgcn_raw_buffer_load_v2f32(rP, (int)((base + w + 13u) * 8u), 0, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t w = w0 + (uint32_t)k * 64u + (uint32_t)lane;
+                if (mine[k]) llvm_amdgcn_raw_buffer_store_v2f32(v[k], rB, (int)((base + w) * 8u), 0, 0);
+            }
+        }
+    };
     __shared__ __attribute__((aligned(16))) float hand[SPLIT ? (64 / LPE) * CARRY_WORDS : 4];
     // SPLIT: while wavefront 0 runs the substeps, wavefront 1 serves the battery model one substep AHEAD: the voltage of substep k
     // depends only on the rotor speeds left by substep k - 1, which are known ~2 000 clocks before the voltage is needed.
@@ -1219,7 +1250,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
     } else {
         if (wv == 1 && lane < 4) mb_seq[lane] = 0;
         __syncthreads();  // barrier 1 of 2
-        if (bat_served && wv == 1) {  // battery server: ten voltages, each one substep ahead of wavefront 0
+        if (wv == 3 && P.len_states > 1) shift_history(P.states, P.states_prev, P.states_bytes, P.len_states);
+        if (wv == 2 && P.len_obs > 1) shift_history(P.obs, P.obs_prev, P.obs_bytes, P.len_obs);
+        if (bat_served && wv == 1) {  // battery server (the reward wavefront, idle until the post-phase): ten voltages, each one substep ahead of wavefront 0
             MB_WAIT(0, 1);
             float bE = mb_bs[el * 4], bu1 = mb_bs[el * 4 + 1], bt = mb_bs[el * 4 + 2];
             for (int ks = 0; ks < 10; ++ks) {
@@ -1292,7 +1325,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
     //             (lane-major registers -> env-major bytes) and leave as seven fully coalesced 16-byte-per-lane stores.
     //  len  > 1 : each lane shifts its own row by one frame (8-byte accesses, in place, ascending) and appends the frame.
     // Stores go through range-checked buffer descriptors, so ragged tails need no special casing.
-    const uint32_t wave_env0 = SPLIT ? (uint32_t)(blockIdx.x * 64 / LPE) : (uint32_t)((blockIdx.x * BLOCK + wv * 64) / LPE);
     // fill_tile = false: the tile already holds this frame (the obs frame equals the states frame when there is no observation noise)
     auto put_frame = [&](float *buf, const float *prev, uint32_t buf_bytes, int len, const float (&f)[26], bool fill_tile) {
         const rsrc_t rB = make_rsrc(buf, buf_bytes);
@@ -1314,11 +1346,19 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
                 const uint32_t w4 = (uint32_t)(it * 64 + lane);
                 if (w4 < TILE_W4) llvm_amdgcn_raw_buffer_store_v4f32(t4[w4], rB, (int)(wave_env0 * 104u + w4 * 16u), 0, 0);
             }
+        } else if (SPLIT) {
+            // the history words were moved by shift_history while the substeps ran: only the newest frame of every row is left
+            const f32x2_t *tp = reinterpret_cast<const f32x2_t *>(tile);
+            const uint32_t L13 = (uint32_t)len * 13u, hist = L13 - 13u;
+            const uint32_t base = wave_env0 * L13;
+#pragma unroll
+            for (int it = 0; it < (EPW * 13 + 63) / 64; ++it) {
+                const uint32_t t = (uint32_t)(it * 64 + lane);  // word t of the tile = word (t % 13) of row t / 13
+                const uint32_t row = t / 13u;
+                if (t < (uint32_t)EPW * 13u) llvm_amdgcn_raw_buffer_store_v2f32(tp[t], rB, (int)((base + row * L13 + hist + (t - row * 13u)) * 8u), 0, 0);
+            }
         } else {
-            // The wavefront's EPW rows are one contiguous range of EPW * len * 13 eight-byte words.  Word w of the new stack is word
-            // w + 13 of the previous one (one frame further) inside the first len - 1 frames of its row, and comes from the LDS tile in
-            // the last frame: the whole wavefront copies 512 contiguous bytes per instruction instead of 64 rows 104 * len bytes apart.
-            // In place (prev == buf) the reads run 13 words ahead of the writes; loads are issued in batches of eight ahead of their stores.
+            // one wavefront does everything: history words from the previous stack, the newest frame from the LDS tile, in one pass
             const rsrc_t rP = make_rsrc(prev, buf_bytes);
             const f32x2_t *tp = reinterpret_cast<const f32x2_t *>(tile);
             const uint32_t L13 = (uint32_t)len * 13u, hist = L13 - 13u, tot = (uint32_t)EPW * L13;
