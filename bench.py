@@ -62,6 +62,18 @@ def time_kernel_launches(env, acts, steps, torch):
     return back_to_back, d[len(d) // 2]
 
 
+def time_kernel_settled(env, acts, steps, torch, tries=3):
+    """time_kernel_launches, repeated (at most `tries` times) while the back-to-back average sits more than 30 % above the median of
+    the bracketed launches: on a shared host a multi-millisecond stall of the GPU now and then lands inside a 100-launch window and
+    doubles its average.  Returns (average, bracketed median, windows measured).  Only the informational large-N / stacked entries
+    use it; the headline window is never re-measured."""
+    for k in range(tries):
+        avg, med = time_kernel_launches(env, acts, steps, torch)
+        if avg <= 1.3 * med:
+            break
+    return avg, med, k + 1
+
+
 def pmc_traffic(n_envs):
     """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC summary (FETCH_SIZE x2 per the gfx950 note in
     MI355X_MICROARCH.md + WRITE_SIZE, separate passes; profiles/README.md).  bench.py cannot run rocprofv3 on itself, so the
@@ -251,7 +263,7 @@ def main():
                                       "none in the timed region: envs are independent, each rank steps its own slice"),
                        "kernel": base.lib.taco_step_kernel_name().decode(), "grid": grid, "block": block,
                        "lanes_per_env": 4 if grid * block >= 4 * n_local else 1,
-                       "role_wavefronts": bool(block == 256 and grid * 64 >= 4 * n_local and n_local <= 8192)},
+                       "role_wavefronts": bool(block == 256 and grid * 64 >= 4 * n_local)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel_avg_us": k_avg_us, "kernel_bracketed_median_us": k_med_us,
                          "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
@@ -269,12 +281,13 @@ def main():
                     for t in range(20):
                         benv.step_raw(bacts[t % 4])
                     torch.cuda.synchronize()
-                    b_avg, b_med = time_kernel_launches(benv, bacts, 100, torch)
+                    b_avg, b_med, b_win = time_kernel_settled(benv, bacts, 100, torch)
                     bg, bb = benv.launch_geometry()
                     ach = ALGO_BYTES_PER_ENV_STEP * big_n / (b_avg * 1e-6) / 1e9
                     tr, _ = pmc_traffic(big_n)
                     out["large_n"].append({"envs": big_n, "kernel_avg_us": b_avg, "env_steps_per_s": big_n / (b_avg * 1e-6), "achieved_GBps": ach,
-                                           "frac_of_hbm_peak": ach / HBM_PEAK_GBPS, "traffic": tr, "grid": bg, "block": bb})
+                                           "frac_of_hbm_peak": ach / HBM_PEAK_GBPS, "traffic": tr, "grid": bg, "block": bb,
+                                           "kernel_bracketed_median_us": b_med, "windows_measured": b_win})
                     del benv, bacts
                     torch.cuda.empty_cache()
                 # the documented training configuration stacks 5 state frames for the LSTM critic (README.md:60-66 of the reference):
@@ -288,11 +301,12 @@ def main():
                     for t in range(20):
                         senv.step_raw(sacts[t % 4])
                     torch.cuda.synchronize()
-                    s_avg, _ = time_kernel_launches(senv, sacts, 100, torch)
+                    s_avg, s_med, s_win = time_kernel_settled(senv, sacts, 100, torch)
                     sbytes = ALGO_BYTES_PER_ENV_STEP + 4 * 104 + 5 * 104 - 104   # the len-1 state frame is already in the 820 B
                     out["stacked_states"].append({"envs": sn, "len_states": 5, "kernel_avg_us": s_avg, "env_steps_per_s": sn / (s_avg * 1e-6),
                                                   "algorithmic_bytes_per_env_step": sbytes, "achieved_GBps": sbytes * sn / (s_avg * 1e-6) / 1e9,
-                                                  "frac_of_hbm_peak": sbytes * sn / (s_avg * 1e-6) / 1e9 / HBM_PEAK_GBPS})
+                                                  "frac_of_hbm_peak": sbytes * sn / (s_avg * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                                                  "kernel_bracketed_median_us": s_med, "windows_measured": s_win})
                     del senv, sacts
                     torch.cuda.empty_cache()
             out["parity"] = parity_check(config.baseline_config(1, num_envs=n_local))

@@ -1009,7 +1009,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
                 ++ks;
                 if (rare) break;
             }
-        } else if (fin) {
+        } else if (BLOCK != 256 && fin) {  // (the throughput instantiation keeps two forms: a third costs it spills at 128 VGPRs)
     #pragma unroll 1
             while (ks < 10) {
                 const bool rare = substep(std::integral_constant<int, 1>{}, ks);
