@@ -46,7 +46,7 @@ struct taco_env {
     int hh;    // action-history row the next step writes; advances by 1 per step (mod 16)
     int lpe;   // lanes per env of the step kernel this handle launches (1 or 4)
     int block; // its workgroup size (64 or 256)
-    int split; // 1: the four-role form of the quad kernel (<= 4 096 envs; used while no gather block is bound)
+    int split; // 1: the four-role form of the quad kernel (<= 8 192 envs, <= 16 384 with frame stacks)
     float *gather;  // optional per-rank all-gather block, see taco_bind_gather_block
     unsigned long long *stamps;  // optional phase stamps, see taco_bind_phase_stamps
     taco::StepParams P;
@@ -248,7 +248,7 @@ void choose_geometry(taco_env *e) {
     e->split = (e->lpe == 4 && e->cfg.num_envs <= (stacks ? kQuadMaxEnvs : kSplitMaxEnvs)) ? 1 : 0;
     if (const char *f = std::getenv("TACO_FORCE_SPLIT")) e->split = (e->lpe == 4 && std::atoi(f) != 0) ? 1 : 0;
 }
-bool use_split(const taco_env *e) { return e->split && e->gather == nullptr; }
+bool use_split(const taco_env *e) { return e->split != 0; }
 
 }  // namespace
 

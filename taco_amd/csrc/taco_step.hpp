@@ -1416,6 +1416,23 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
         fr[23] = fr[23] + P.df * (nrm[10] * (float)(0.06 / 3 / 3) + 0.0f);
     }
     if (roleO) put_frame(P.obs, P.obs_prev, P.obs_bytes, P.len_obs, fr, SPLIT || (fl & TACO_F_OBSERVATION_NOISE) != 0);
+    // Optional all-gather block, one 128-byte-aligned row per env: [obs stack | reward | done | time-out | pad].  The obs part is written by
+    // the wavefront that holds the obs frame (the newest frame from registers, older frames re-read from this env's just-written obs row),
+    // the three tail words by the reward wavefront below.
+    if (roleO && P.gather && active) {
+        const rsrc_t rG = make_rsrc(P.gather, P.gather_bytes);
+        const rsrc_t rO = make_rsrc(P.obs, P.obs_bytes);
+        if (P.len_obs > 1) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the obs rows were stored by other lanes of this wavefront
+        const uint32_t g0 = (uint32_t)i * P.gather_row * 4u;
+        const uint32_t hist_pairs = (uint32_t)(P.len_obs - 1) * 13u;
+        for (uint32_t j = 0; j < hist_pairs; ++j) {
+            const f32x2_t o = llvm_amdgcn_raw_buffer_load_v2f32(rO, (int)((uint32_t)i * (uint32_t)P.len_obs * 104u + j * 8u), 0, 0);
+            llvm_amdgcn_raw_buffer_store_v2f32(o, rG, (int)(g0 + j * 8u), 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 13; ++k)
+            llvm_amdgcn_raw_buffer_store_v2f32(f32x2_t{fr[2 * k], fr[2 * k + 1]}, rG, (int)(g0 + (hist_pairs + (uint32_t)k) * 8u), 0, 0);
+    }
 
     TACO_STAMP(4);  // state stores + frames done
     if (roleR) {
@@ -1471,22 +1488,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
         P.reset[i] = rs;
         P.timeout[i] = tmo ? 1 : 0;
         if (P.done_f32) P.done_f32[i] = (float)rs;
-        if (!SPLIT && P.gather) {  // (the host launches a non-SPLIT instantiation while a gather block is bound)
-            // one 128-byte-aligned row per env: [obs stack | reward | done | time-out | pad]; the obs stack is re-read from
-            // this lane's own (just written) obs row when there is history, else taken from registers
+        if (P.gather) {  // tail of this env's all-gather row (the obs part is written above)
             const rsrc_t rG = make_rsrc(P.gather, P.gather_bytes);
-            const rsrc_t rO = make_rsrc(P.obs, P.obs_bytes);
-            if (P.len_obs > 1) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the obs rows were stored by other lanes of this wavefront
-            const uint32_t g0 = (uint32_t)i * P.gather_row * 4u;
-            const uint32_t hist_pairs = (uint32_t)(P.len_obs - 1) * 13u;
-            for (uint32_t j = 0; j < hist_pairs; ++j) {
-                const f32x2_t o = llvm_amdgcn_raw_buffer_load_v2f32(rO, (int)((uint32_t)i * (uint32_t)P.len_obs * 104u + j * 8u), 0, 0);
-                llvm_amdgcn_raw_buffer_store_v2f32(o, rG, (int)(g0 + j * 8u), 0, 0);
-            }
-#pragma unroll
-            for (int k = 0; k < 13; ++k)
-                llvm_amdgcn_raw_buffer_store_v2f32(f32x2_t{fr[2 * k], fr[2 * k + 1]}, rG, (int)(g0 + (hist_pairs + (uint32_t)k) * 8u), 0, 0);
-            const uint32_t tail = g0 + (uint32_t)P.len_obs * 104u;
+            const uint32_t tail = (uint32_t)i * P.gather_row * 4u + (uint32_t)P.len_obs * 104u;
             llvm_amdgcn_raw_buffer_store_f32(rew, rG, (int)tail, 0, 0);
             llvm_amdgcn_raw_buffer_store_f32((float)rs, rG, (int)(tail + 4u), 0, 0);
             llvm_amdgcn_raw_buffer_store_f32(tmo ? 1.0f : 0.0f, rG, (int)(tail + 8u), 0, 0);

@@ -125,10 +125,16 @@ def test_delay_line_overflow_regime():
     run_pair(cfg, steps=500, check_every=5, hover_bias=True)
 
 
+@pytest.mark.parametrize("geom", [None, ("4", "64", "0"), ("1", "64", "0"), ("1", "256", "0")])
 @pytest.mark.parametrize("len_obs", [1, 3])
-def test_gather_block_matches_outputs(len_obs):
-    """the packed per-rank block the kernel fills for the all-gather == pack_block(obs, rew, done, time_outs)"""
+def test_gather_block_matches_outputs(len_obs, geom, monkeypatch):
+    """the packed per-rank block the kernel fills for the all-gather == pack_block(obs, rew, done, time_outs), in every instantiation
+    (role wavefronts: the obs wavefront writes the obs part of a row, the reward wavefront its three tail words)"""
     import ctypes as C
+    if geom:
+        monkeypatch.setenv("TACO_FORCE_LPE", geom[0])
+        monkeypatch.setenv("TACO_FORCE_BLOCK", geom[1])
+        monkeypatch.setenv("TACO_FORCE_SPLIT", geom[2])
     from taco_amd import dist, _lib
     from taco_amd.vec_env import FpvBase
     n = 300
