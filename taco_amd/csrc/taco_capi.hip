@@ -228,6 +228,7 @@ __global__ void import_state_kernel(float *S, float *hist, float *ring, const ui
 // SIMDs without a wavefront (measured: 19.8 us vs 21.0 us at 16 384 envs, 24.6 us vs 22 us at 20 480); 256-thread workgroups from 65 536 envs.
 // TACO_FORCE_LPE / TACO_FORCE_BLOCK (read at taco_create) override the choice for experiments and for the LPE-equivalence test.
 constexpr int kQuadMaxEnvs = 16384;
+constexpr int kSplitLaneMaxEnvs = 49152;  // 768 workgroups of 48 KB LDS: three resident per CU
 constexpr int kSplitMaxEnvs = 8192;  // measured: 16.8 vs 17.6 us at 4 096 envs, 18.4 vs 18.8 at 8 192, no gain at 16 384
 void choose_geometry(taco_env *e) {
     e->lpe = e->cfg.num_envs <= kQuadMaxEnvs ? 4 : 1;
@@ -246,7 +247,11 @@ void choose_geometry(taco_env *e) {
     // (16 384 envs, 5 state frames: 19.2 us vs 22.1 us; 5 + 5 frames: 19.9 us vs 26.0 us; without stacks 18.0 us vs 17.5 us).
     const bool stacks = e->cfg.len_obs > 1 || e->cfg.len_states > 1;
     e->split = (e->lpe == 4 && e->cfg.num_envs <= (stacks ? kQuadMaxEnvs : kSplitMaxEnvs)) ? 1 : 0;
-    if (const char *f = std::getenv("TACO_FORCE_SPLIT")) e->split = (e->lpe == 4 && std::atoi(f) != 0) ? 1 : 0;
+    // One lane per env, 16 385 ... 49 152 envs with frame stacks: the same four-role form (64 envs per workgroup) hides the stack history,
+    // which a lone wavefront moves at only ~5 GB/s (tools/ubench/shift), under the substeps.
+    if (e->lpe == 1 && stacks && e->cfg.num_envs <= kSplitLaneMaxEnvs) e->split = 1;
+    if (const char *f = std::getenv("TACO_FORCE_SPLIT")) e->split = std::atoi(f) != 0 ? 1 : 0;
+    if (e->split) e->block = kBlockLarge;
 }
 bool use_split(const taco_env *e) { return e->split != 0; }
 
@@ -330,8 +335,10 @@ int launch_step(taco_env *e, const taco_rollout_io *io, void *stream) {
     P.hh = e->hh;
     P.hist_bytes = (uint32_t)((size_t)taco::HIST_ROWS * e->npad * 4 * sizeof(float));
     const int n = e->cfg.num_envs;
-    if (use_split(e))
+    if (use_split(e) && e->lpe == 4)
         hipLaunchKernelGGL((taco::taco_step_kernel<kBlockLarge, 4, true>), dim3((n * 4 + 63) / 64), dim3(kBlockLarge), 0, (hipStream_t)stream, P);
+    else if (use_split(e))
+        hipLaunchKernelGGL((taco::taco_step_kernel<kBlockLarge, 1, true>), dim3((n + 63) / 64), dim3(kBlockLarge), 0, (hipStream_t)stream, P);
     else if (e->lpe == 4)
         hipLaunchKernelGGL((taco::taco_step_kernel<kBlockSmall, 4>), dim3((n * 4 + kBlockSmall - 1) / kBlockSmall), dim3(kBlockSmall), 0, (hipStream_t)stream, P);
     else if (e->block == kBlockLarge)
@@ -432,7 +439,7 @@ int taco_set_state(taco_env *e, const uint32_t *blob, void *stream) {
 
 int taco_launch_geometry(const taco_env *e, int *grid, int *block) {
     if (!e || !grid || !block) return fail(TACO_ERR_INVALID_ARG, "taco_launch_geometry: null argument");
-    if (use_split(e)) { *block = kBlockLarge; *grid = (e->cfg.num_envs * 4 + 63) / 64; return TACO_OK; }
+    if (use_split(e)) { *block = kBlockLarge; *grid = (e->cfg.num_envs * e->lpe + 63) / 64; return TACO_OK; }
     *block = e->block;
     *grid = (e->cfg.num_envs * e->lpe + *block - 1) / *block;
     return TACO_OK;
@@ -567,10 +574,12 @@ int taco_occupancy(const taco_env *e, int *resident_blocks_per_cu, int *lds_byte
     if (!e || !resident_blocks_per_cu || !lds_bytes_per_block) return fail(TACO_ERR_INVALID_ARG, "taco_occupancy: null argument");
     if (use_split(e)) {
         hipFuncAttributes at;
-        hipError_t he = hipFuncGetAttributes(&at, (const void *)taco::taco_step_kernel<kBlockLarge, 4, true>);
+        const bool q = e->lpe == 4;
+        hipError_t he = hipFuncGetAttributes(&at, q ? (const void *)taco::taco_step_kernel<kBlockLarge, 4, true> : (const void *)taco::taco_step_kernel<kBlockLarge, 1, true>);
         if (he != hipSuccess) return hip_fail(he, "hipFuncGetAttributes");
         *lds_bytes_per_block = (int)at.sharedSizeBytes;
-        he = hipOccupancyMaxActiveBlocksPerMultiprocessor(resident_blocks_per_cu, taco::taco_step_kernel<kBlockLarge, 4, true>, kBlockLarge, 0);
+        he = q ? hipOccupancyMaxActiveBlocksPerMultiprocessor(resident_blocks_per_cu, taco::taco_step_kernel<kBlockLarge, 4, true>, kBlockLarge, 0)
+               : hipOccupancyMaxActiveBlocksPerMultiprocessor(resident_blocks_per_cu, taco::taco_step_kernel<kBlockLarge, 1, true>, kBlockLarge, 0);
         if (he != hipSuccess) return hip_fail(he, "hipOccupancyMaxActiveBlocksPerMultiprocessor");
         return TACO_OK;
     }

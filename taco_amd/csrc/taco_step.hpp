@@ -560,7 +560,7 @@ constexpr int CARRY_WORDS = 32;  // 30 used
 // the state.  The post-phase critical path drops from the sum of the four parts to the longest one.
 template <int BLOCK, int LPE, bool SPLIT = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >= 256 && !SPLIT) ? 4 : 1, (BLOCK >= 256 && !SPLIT) ? 4 : 8))) void taco_step_kernel(const StepParams P) {
-    static_assert(!SPLIT || (BLOCK == 256 && LPE == 4), "SPLIT is the four-role form of the quad kernel");
+    static_assert(!SPLIT || BLOCK == 256, "SPLIT is the four-role form: one step wavefront + three role wavefronts per workgroup");
     // Per-wavefront LDS scratch, used for two things one after the other:
     //   substeps : the 10 pending-action slots this step consumes, slots[s][lane] as float4 (10 KiB) -- keeps 40 values
     //              out of the register file and lets substep k fetch its action with one ds_read_b128;
@@ -629,7 +629,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
                                  __hip_atomic_store(&mb_seq[idx], (value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
     // (only while every wavefront of the launch has a SIMD to itself -- 1 024 on the MI355X -- or the server would take issue slots
     // from another workgroup's wavefront 0: 19.0 vs 18.4 us at 8 192 envs)
-    const bool bat_served = SPLIT && (P.flags & TACO_F_BATTERY_CONSUMPTION) != 0 && gridDim.x * 4u <= 1024u;
+    const bool bat_served = SPLIT && LPE == 4 && (P.flags & TACO_F_BATTERY_CONSUMPTION) != 0 && gridDim.x * 4u <= 1024u;
     Carry K;
     const int i = in_range ? i_raw : P.n - 1;  // tail lanes shadow the last env and store nothing
     const int gid = P.env_offset + i;

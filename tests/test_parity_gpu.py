@@ -125,7 +125,7 @@ def test_delay_line_overflow_regime():
     run_pair(cfg, steps=500, check_every=5, hover_bias=True)
 
 
-@pytest.mark.parametrize("geom", [None, ("4", "64", "0"), ("1", "64", "0"), ("1", "256", "0")])
+@pytest.mark.parametrize("geom", [None, ("4", "64", "0"), ("1", "64", "0"), ("1", "256", "0"), ("1", "64", "1")])
 @pytest.mark.parametrize("len_obs", [1, 3])
 def test_gather_block_matches_outputs(len_obs, geom, monkeypatch):
     """the packed per-rank block the kernel fills for the all-gather == pack_block(obs, rew, done, time_outs), in every instantiation
@@ -183,19 +183,19 @@ def test_state_blob_roundtrip_and_restore():
 
 @pytest.mark.parametrize("task,n", [("pos", 1000), ("mix", 333), ("flip", 257), ("rotate", 4096)])
 def test_quad_layout_equals_one_lane_per_env(task, n, monkeypatch):
-    """The four instantiations of the step kernel (4 lanes per env with and without the role wavefronts / 1 lane per env with 64- and
-    256-thread workgroups) are the same function: every output and every state word bit-identical, all randomisation on, stacked frames."""
+    """The five instantiations of the step kernel (4 lanes per env with and without the role wavefronts / 1 lane per env with 64- and
+    256-thread workgroups and with role wavefronts) are the same function: every output and every state word bit-identical, all randomisation on, stacked frames."""
     from taco_amd.vec_env import FpvBase
     kw = dict(env_lenObservations=2, env_lenStates=3, env_maxEpisodeLength=40, seed=11)
     if task == "mix":
         kw.update(rotor_noise=True, observation_noise=True, ramdom_deploy_time=True, ramdom_delay_time=True)
     envs = []
-    for lpe, block, split in (("4", "64", "0"), ("1", "64", "0"), ("1", "256", "0"), ("4", "64", "1")):
+    for lpe, block, split in (("4", "64", "0"), ("1", "64", "0"), ("1", "256", "0"), ("4", "64", "1"), ("1", "64", "1")):
         monkeypatch.setenv("TACO_FORCE_LPE", lpe)
         monkeypatch.setenv("TACO_FORCE_BLOCK", block)
         monkeypatch.setenv("TACO_FORCE_SPLIT", split)
         e = FpvBase(config.default_cfg(task, n, **kw), copy_outputs=False)
-        assert e.launch_geometry() == (((n * 4 + 63) // 64, 256) if split == "1" else ((n * int(lpe) + int(block) - 1) // int(block), int(block)))
+        assert e.launch_geometry() == (((n * int(lpe) + 63) // 64, 256) if split == "1" else ((n * int(lpe) + int(block) - 1) // int(block), int(block)))
         envs.append(e)
     acts = torch.from_numpy(action_stream(n, 90, 4)).cuda()
     for t in range(90):
@@ -234,7 +234,7 @@ def test_random_configurations():
             raise AssertionError(f"case {i}: {fuzz.describe(cfg)}: {e}") from e
 
 
-@pytest.mark.parametrize("geom", [None, ("4", "64", "0"), ("1", "64", "0"), ("1", "256", "0")])
+@pytest.mark.parametrize("geom", [None, ("4", "64", "0"), ("1", "64", "0"), ("1", "256", "0"), ("1", "64", "1")])
 def test_loop_forms_hand_over_on_rare_forms_and_nonfinite_inputs(geom, monkeypatch):
     """The substep loop runs a FIN form (no NaN-carrying selects) and a PLAIN form (compile-time flags, unrolled integrator) while a
     wave-uniform predicate says they are the same function as the exact form.  Two stress cases against the oracle, in every
