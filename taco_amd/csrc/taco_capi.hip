@@ -228,7 +228,7 @@ __global__ void import_state_kernel(float *S, float *hist, float *ring, const ui
 // SIMDs without a wavefront (measured: 19.8 us vs 21.0 us at 16 384 envs, 24.6 us vs 22 us at 20 480); 256-thread workgroups from 65 536 envs.
 // TACO_FORCE_LPE / TACO_FORCE_BLOCK (read at taco_create) override the choice for experiments and for the LPE-equivalence test.
 constexpr int kQuadMaxEnvs = 16384;
-constexpr int kSplitLaneMaxEnvs = 49152;  // 768 workgroups of 48 KB LDS: three resident per CU
+constexpr int kSplitLaneMaxEnvs = 65536;  // 1 024 workgroups (31 KB of LDS, 111 VGPRs): four resident per CU
 constexpr int kSplitMaxEnvs = 8192;  // measured: 16.8 vs 17.6 us at 4 096 envs, 18.4 vs 18.8 at 8 192, no gain at 16 384
 void choose_geometry(taco_env *e) {
     e->lpe = e->cfg.num_envs <= kQuadMaxEnvs ? 4 : 1;
@@ -247,7 +247,7 @@ void choose_geometry(taco_env *e) {
     // (16 384 envs, 5 state frames: 19.2 us vs 22.1 us; 5 + 5 frames: 19.9 us vs 26.0 us; without stacks 18.0 us vs 17.5 us).
     const bool stacks = e->cfg.len_obs > 1 || e->cfg.len_states > 1;
     e->split = (e->lpe == 4 && e->cfg.num_envs <= (stacks ? kQuadMaxEnvs : kSplitMaxEnvs)) ? 1 : 0;
-    // One lane per env, 16 385 ... 49 152 envs with frame stacks: the same four-role form (64 envs per workgroup) hides the stack history,
+    // One lane per env, 16 385 ... 65 536 envs with frame stacks: the same four-role form (64 envs per workgroup) hides the stack history,
     // which a lone wavefront moves at only ~5 GB/s (tools/ubench/shift), under the substeps.
     if (e->lpe == 1 && stacks && e->cfg.num_envs <= kSplitLaneMaxEnvs) e->split = 1;
     if (const char *f = std::getenv("TACO_FORCE_SPLIT")) e->split = std::atoi(f) != 0 ? 1 : 0;

@@ -570,11 +570,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
     constexpr int EPW = 64 / LPE;  // envs per wavefront
     constexpr int WAVE_LDS_WORDS = 10 * EPW * 4;
     static_assert(WAVE_LDS_WORDS >= EPW * 26, "tile must fit in the per-wave scratch");
-    __shared__ __attribute__((aligned(16))) float lds_all[BLOCK / 64][WAVE_LDS_WORDS];
+    // SPLIT: only wavefront 0 needs the slot table; the obs / states role wavefronts need a frame tile each, the reward wavefront nothing
+    constexpr int TILE_WORDS = EPW * 26;
+    static_assert(TILE_WORDS % 4 == 0, "tiles stay 16-byte aligned");
+    constexpr int LDS_WORDS = SPLIT ? WAVE_LDS_WORDS + 2 * TILE_WORDS : (BLOCK / 64) * WAVE_LDS_WORDS;
+    __shared__ __attribute__((aligned(16))) float lds_all[LDS_WORDS];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
-    float *tile = lds_all[wv];
-    float4 *slots = reinterpret_cast<float4 *>(lds_all[wv]);
+    float *tile = SPLIT ? lds_all + (wv == 0 ? 0 : WAVE_LDS_WORDS + (wv == 3 ? TILE_WORDS : 0)) : lds_all + wv * WAVE_LDS_WORDS;
+    float4 *slots = reinterpret_cast<float4 *>(tile);  // (wavefront 0 / non-SPLIT only)
     const int sub = lane & (LPE - 1);  // lane inside the env's quad (0 when LPE == 1)
     const int el = lane / LPE;         // env slot inside the wavefront
     const int i_raw = SPLIT ? (blockIdx.x * 64 + lane) / LPE : (blockIdx.x * BLOCK + threadIdx.x) / LPE;
