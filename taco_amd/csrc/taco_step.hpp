@@ -523,12 +523,12 @@ TD void reset_env(const StepParams &P, rsrc_t rS, rsrc_t rR, uint32_t voff, uint
 }
 
 
-// Two instantiations: BLOCK = 64 for the latency regime (few envs: one wavefront per workgroup, spread over as many CUs
-// as possible, registers unconstrained) and BLOCK = 256 for the throughput regime, where the register budget is capped
-// at 128 VGPRs so that 4 wavefronts per SIMD hide each other's dependent-issue latency.
-// LPE (lanes per env) = 4: the third instantiation, for launches that cannot fill the chip with one lane per env (4 096 envs
-// = 64 wavefronts on 1 024 SIMDs).  A wavefront then carries 16 envs; everything outside the substep loop runs the scalar code
-// redundantly in the four lanes of an env (sub-lane 0 does the stores), the substep loop runs in the quad layout above.
+// Instantiations (host side: choose_geometry in taco_capi.hip): BLOCK = 64 for the latency regime (few envs: one wavefront per
+// workgroup, spread over as many CUs as possible, registers unconstrained) and BLOCK = 256 for the throughput regime, where the
+// register budget is capped at 128 VGPRs so that 4 wavefronts per SIMD hide each other's dependent-issue latency.
+// LPE (lanes per env) = 4 for launches that cannot fill the chip with one lane per env (4 096 envs = 64 wavefronts on 1 024 SIMDs):
+// a wavefront then carries 16 envs; everything outside the substep loop runs the scalar code redundantly in the four lanes of an env
+// (sub-lane 0 does the stores), the substep loop runs in the quad layout above.  SPLIT: the four-role form, see the kernel.
 // Battery_Dynamics.sim_process CTRL/battery_dynamics.py:47-75 for one substep (Pm = mechanical power FA:614)
 TD float battery_step(float dt, float Pm, float &bat_E, float &bat_u1, float &bat_t) {
     bat_t = bat_t + dt;
@@ -554,10 +554,12 @@ struct Carry {
 };
 constexpr int CARRY_WORDS = 32;  // 30 used
 
-// SPLIT (BLOCK = 256, LPE = 4; launches of at most 4 096 envs = 1 024 wavefronts, one per SIMD): wave 0 of the workgroup runs the step
-// as the <64, 4> instantiation does; the other three wavefronts sleep at a barrier until the substeps are done, take the Carry out of
-// LDS and run one post-phase role each (states frame stack / obs frame stack / reward + done) on their own SIMDs while wave 0 stores
-// the state.  The post-phase critical path drops from the sum of the four parts to the longest one.
+// SPLIT (BLOCK = 256; LPE = 4 up to 8 192 envs -- 16 384 with frame stacks --, LPE = 1 for 16 385 ... 65 536 envs with frame stacks):
+// wave 0 of the workgroup runs the step as the one-wavefront instantiation does; the other three wavefronts wait at a barrier until the
+// substeps are done, take the Carry out of LDS and run one post-phase role each (1: reward + done, 2: obs frame stack, 3: states frame
+// stack) on their own SIMDs while wave 0 stores the state, so the post-phase critical path is the longest part instead of the sum.  While
+// they wait, waves 2 and 3 move the history of the frame stacks (which does not depend on this step) and wave 1 serves the battery model
+// (launches of at most 4 096 envs, where every wavefront has a SIMD to itself).
 template <int BLOCK, int LPE, bool SPLIT = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >= 256 && !SPLIT) ? 4 : 1, (BLOCK >= 256 && !SPLIT) ? 4 : 8))) void taco_step_kernel(const StepParams P) {
     static_assert(!SPLIT || BLOCK == 256, "SPLIT is the four-role form: one step wavefront + three role wavefronts per workgroup");
