@@ -117,8 +117,18 @@ def cpu_baseline(cfg, budget_s=12.0):
                     break
     except OSError:
         pass
+    # the same oracle on ONE thread (SURVEY 8d asks for both ends), a 3 s sample
+    orc1 = O.OracleEnv(flat, threads=1)
+    orc1.step(acts[0])
+    t1 = time.perf_counter()
+    steps1 = 0
+    while time.perf_counter() - t1 < 3.0:
+        orc1.step(acts[steps1 % 64])
+        steps1 += 1
+    dt1 = time.perf_counter() - t1
     return {"value": n * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
-            "sample": f"{steps} steps x {n} envs of the same workload through the CPU oracle (OpenMP over envs), {dt:.1f} s on {model or 'host CPU'}"}
+            "sample": f"{steps} steps x {n} envs of the same workload through the CPU oracle (OpenMP over envs), {dt:.1f} s on {model or 'host CPU'}",
+            "single_thread": {"value": n * steps1 / dt1, "unit": "env-steps/s", "cores": 1, "sample": f"{steps1} steps x {n} envs, {dt1:.1f} s"}}
 
 
 def parity_check(cfg, steps=60):
