@@ -146,6 +146,9 @@ void taco_destroy(taco_env *env);
  *   reset_buf   [num_envs]               i64 in/out  non-zero on entry = reset this env first (ones before step 1)
  *   timeout_buf [num_envs]               u8  out     extras["time_outs"]
  * One kernel launch, asynchronous on `stream`; no host synchronisation. */
+/* Not capturable into a HIP graph: the step index, ring head and history row are kernel arguments that advance on the host with every
+ * call (a replayed launch would repeat one step index); taco_step returns TACO_ERR_INVALID_ARG on a capturing stream.  For launch-bound
+ * loops enqueue the whole rollout with taco_rollout_run. */
 int taco_step(taco_env *env, const float *actions, float *obs_buf, float *states_buf, float *rew_buf, int64_t *reset_buf,
               uint8_t *timeout_buf, void *stream);
 

@@ -312,6 +312,13 @@ int launch_step(taco_env *e, const taco_rollout_io *io, void *stream) {
     if (!io->actions || !io->obs_next || !io->states_next || !io->rew || !io->reset_buf || !io->timeout_buf)
         return fail(TACO_ERR_INVALID_ARG, "taco_step: null buffer pointer");
     if (((uintptr_t)io->actions & 15u) != 0) return fail(TACO_ERR_INVALID_ARG, "actions must be 16-byte aligned");
+    {   // The step counter, the ring head and the history row travel in the kernel arguments and advance on the host with every call: a
+        // captured launch would replay ONE step index for ever (same Philox stream, same ring slots).  Refuse instead of going wrong quietly.
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (stream != nullptr && hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+            return fail(TACO_ERR_INVALID_ARG, "taco_step cannot be captured into a HIP graph (the step index lives in the kernel arguments); "
+                                              "enqueue a whole rollout with taco_rollout_run instead");
+    }
     const size_t n_envs = (size_t)e->cfg.num_envs;
     taco::StepParams P = e->P;
     P.S = e->S; P.ring = e->ring; P.hist = e->hist;

@@ -200,3 +200,29 @@ def test_training_example_runs_and_learns_something(tmp_path):
     rewards = [float(l.split("reward/step")[1].split()[0]) for l in out.stdout.splitlines() if "reward/step" in l]
     assert len(rewards) == 6 and all(math.isfinite(r) and r > 0 for r in rewards)
     assert torch.jit.load(str(tmp_path / "actor.pt"))(torch.zeros(1, 1, 26)).shape == (1, 4)
+
+
+def test_step_refuses_graph_capture():
+    """taco_step carries the step index in its kernel arguments, so a captured launch would replay one step for ever: the library refuses
+    to be captured (the supported launch-bound path is taco_rollout_run) and keeps working afterwards."""
+    import torch
+    from taco_amd import config, _lib
+    from taco_amd.vec_env import FpvBase
+    env = FpvBase(config.baseline_config(1, num_envs=256), copy_outputs=False)
+    a = torch.zeros((256, 4), device="cuda")
+    env.step_raw(a)
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with pytest.raises(_lib.TacoError, match="cannot be captured"):
+        with torch.cuda.stream(s):
+            g.capture_begin()
+            try:
+                env.step_raw(a)
+            finally:
+                g.capture_end()
+    torch.cuda.synchronize()
+    n0 = env.step_count
+    env.step_raw(a)
+    torch.cuda.synchronize()
+    assert env.step_count == n0 + 1
