@@ -561,7 +561,7 @@ constexpr int CARRY_WORDS = 32;  // 30 used
 // they wait, waves 2 and 3 move the history of the frame stacks (which does not depend on this step) and wave 1 serves the battery model
 // (launches of at most 4 096 envs, where every wavefront has a SIMD to itself).
 template <int BLOCK, int LPE, bool SPLIT = false>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >= 256 && !SPLIT) ? 4 : 1, (BLOCK >= 256 && !SPLIT) ? 4 : 8))) void taco_step_kernel(const StepParams P) {
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 256 ? 4 : 1, (BLOCK >= 256 && !SPLIT) ? 4 : 8))) void taco_step_kernel(const StepParams P) {
     static_assert(!SPLIT || BLOCK == 256, "SPLIT is the four-role form: one step wavefront + three role wavefronts per workgroup");
     // Per-wavefront LDS scratch, used for two things one after the other:
     //   substeps : the 10 pending-action slots this step consumes, slots[s][lane] as float4 (10 KiB) -- keeps 40 values
@@ -896,16 +896,18 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
     in_mag = in_mag + ((absf(wb.x) + absf(wb.y)) + absf(wb.z)) + ((absf(pid_prev[0]) + absf(pid_prev[1])) + absf(pid_prev[2])) +
              ((absf(pid_int[0]) + absf(pid_int[1])) + absf(pid_int[2]));
     const bool fin = !wave_dense && __builtin_amdgcn_ballot_w64(!(in_mag < 1e30f)) == 0;
-    // `plain` (wave-uniform): the loop needs no euler/unwrap, no rotor noise, the battery model is on and PhysX runs its default two
-    // sub-iterations -- the PLAIN form of the loop has these decided at compile time (no branches over the unused blocks, integrator
+    // `plain` (launch-uniform): no rotor noise, the battery model is on and PhysX runs its default two sub-iterations; together with the
+    // wave-uniform euler/unwrap switch (flip envs) the PLAIN forms of the loop have these decided at compile time (no branches over the unused blocks, integrator
     // unrolled; a lone wavefront pays ~10 issue slots for every taken branch)
-    const bool plain = !wave_tracks_rpy && !(fl & TACO_F_ROTOR_NOISE) && P.substeps == 2 && (fl & TACO_F_BATTERY_CONSUMPTION) != 0;
+    const bool plain = !(fl & TACO_F_ROTOR_NOISE) && P.substeps == 2 && (fl & TACO_F_BATTERY_CONSUMPTION) != 0;  // (+ bit 3 of the form: euler/unwrap on or off)
     if constexpr (LPE == 1) {
         // one substep; FIN: see `fin` above.  Returns whether the integrator took a rare form in some lane (wave-uniform).
         auto substep = [&](auto fin_c, const int ks) -> bool {
-            constexpr bool FIN = decltype(fin_c)::value >= 1, PLAIN = decltype(fin_c)::value >= 2;  // loop forms: 0 exact, 1 FIN, 2 FIN + PLAIN
+            // loop forms: 0 exact, 1 FIN, 2 FIN + PLAIN, 10 FIN + PLAIN with euler/unwrap (wavefronts that hold flip envs)
+            constexpr int MODE = decltype(fin_c)::value;
+            constexpr bool FIN = MODE >= 1, PLAIN = (MODE & 2) != 0;
             // refresh_state, the part the inner loop consumes FA:339-350
-            if (!PLAIN && wave_tracks_rpy) {
+            if (PLAIN ? (MODE & 8) != 0 : wave_tracks_rpy) {
                 V3 e = euler_xyz_v1(q);
                 unwrap(e.x, rpy_old[0], rpy_cont[0]);
                 unwrap(e.y, rpy_old[1], rpy_cont[1]);
@@ -1008,10 +1010,17 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
         };
         // the FIN form of the loop runs while `fin` holds (normally all ten substeps), the exact form takes over at the first rare form
         int ks = 0;
-        if (fin && plain) {
+        if (fin && plain && !wave_tracks_rpy) {
     #pragma unroll 1
             while (ks < 10) {
                 const bool rare = substep(std::integral_constant<int, 2>{}, ks);
+                ++ks;
+                if (rare) break;
+            }
+        } else if (BLOCK != 256 && fin && plain) {  // (the 256-thread instantiations keep two forms: more cost them spills at 128 VGPRs)
+    #pragma unroll 1
+            while (ks < 10) {
+                const bool rare = substep(std::integral_constant<int, 10>{}, ks);
                 ++ks;
                 if (rare) break;
             }
@@ -1043,6 +1052,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
         const uint32_t m2 = (sub == 1 || sub == 2) ? sgn : 0u;  //                     u2: + - - +
         const uint32_t m3 = (sub == 0 || sub == 2) ? sgn : 0u;  //                     u3: - + - +   (also the sign of ts: -rt0 rt1 -rt2 rt3)
         const uint32_t sm3 = (sub == 3) ? sgn : 0u;
+        const uint32_t m2_lane1 = (sub == 1) ? sgn : 0u, sgn_lane0 = (sub == 0) ? sgn : 0u, sgn_lane2 = (sub == 2) ? sgn : 0u;  // euler, see the loop
         const uint32_t k2 = (sub == 2) ? ~0u : 0u, k3 = (sub == 3) ? ~0u : 0u, keven = (sub & 1) ? 0u : ~0u;
         const uint32_t keep = is_reset ? 0u : ~0u;  // FA:629-630: no force during the reset step
         const float Sq = pick4(sub, P.arm_y, -P.arm_x, 1.0f, 1.0f);
@@ -1051,13 +1061,24 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
         auto slot_of = [&](int k) { int r = (dlen - 1 < k) ? dlen - 1 : k; return r > 9 ? 9 : r; };
         float dq_next = slotsf[(slot_of(0) * EPW + el) * 4 + sub];
         auto substep = [&](auto fin_c, const int ks) -> bool {
-            // loop forms: 0 exact, 1 FIN, 2 FIN + PLAIN (battery computed here), 6 FIN + PLAIN + battery served by wavefront 1
+            // loop forms: 0 exact, 1 FIN, 2 FIN + PLAIN (battery computed here), 6 FIN + PLAIN + battery served by wavefront 1; + 8: with
+            // euler/unwrap (wavefronts that hold flip envs)
             constexpr int MODE = decltype(fin_c)::value;
             constexpr bool FIN = (MODE & 1) != 0 || MODE >= 2, PLAIN = (MODE & 2) != 0;
             const bool served = PLAIN ? (MODE & 4) != 0 : bat_served;
-            if (!PLAIN && wave_tracks_rpy) {  // refresh_state FA:339-347: every lane evaluates the three angles, lane j unwraps angle j
-                const V3 e = euler_xyz_v1(Q4{bc0(qq), bc1(qq), bc2(qq), bc3(qq)});
-                unwrap(pick4(sub, e.x, e.y, e.z, 0.0f), roq, rcq);
+            if (PLAIN ? (MODE & 8) != 0 : wave_tracks_rpy) {
+                // refresh_state FA:339-347, get_euler_xyz_v1 TU:175-196 with lane j evaluating angle j: roll and yaw are the same atan2 on
+                // different operands (lanes 0 and 2), pitch the asin form (lane 1) -- one atan2 and one asin per substep instead of two and
+                // one.  With c = this lane's quaternion component: numerator 2 (w c +- c' c'') (c', c'' the next two components; minus in
+                // lane 1: a - b == a + (-b)), denominator ((ww -+ xx) - yy) +- zz; operation order as in the scalar euler_xyz_v1.
+                const float wq = bc3(qq), sq = qq * qq;
+                const float num = 2.0f * (wq * qq + xorf(rot1(qq) * rot2(qq), m2_lane1));
+                const float den = ((bc3(sq) + xorf(bc0(sq), sgn_lane0)) - bc1(sq)) + xorf(bc2(sq), sgn_lane2);
+                const float at = atan2(num, den);
+                float pit;
+                if (absf(num) >= 1.0f) pit = kHalfPi * (num > 0.0f ? 1.0f : (num < 0.0f ? -1.0f : 0.0f));
+                else pit = asin(num);
+                unwrap(sub == 1 ? pit : at, roq, rcq);
             }
             const float vbq = quad_rotate(-qq, bc3(qq), vq);  // FA:350 body-frame linear velocity
             const float dq = dq_next;  // slot min(L - 1, ks), FA:366
@@ -1156,20 +1177,20 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK >=
             return integrate_quad<PLAIN ? 2 : 0>(P, k3, pq, qq, vq, bq, Fq, tqq, Jq, hJiq, gzq, sm3);
         };
         int ks = 0;
+        auto run_form = [&](auto form) {
+#pragma unroll 1
+            while (ks < 10) {
+                const bool rare = substep(form, ks);
+                ++ks;
+                if (rare) break;
+            }
+        };
         if (SPLIT && fin && plain && bat_served) {
-#pragma unroll 1
-            while (ks < 10) {
-                const bool rare = substep(std::integral_constant<int, 6>{}, ks);
-                ++ks;
-                if (rare) break;
-            }
+            if (!wave_tracks_rpy) run_form(std::integral_constant<int, 6>{});
+            else run_form(std::integral_constant<int, 14>{});
         } else if (fin && plain) {
-#pragma unroll 1
-            while (ks < 10) {
-                const bool rare = substep(std::integral_constant<int, 2>{}, ks);
-                ++ks;
-                if (rare) break;
-            }
+            if (!wave_tracks_rpy) run_form(std::integral_constant<int, 2>{});
+            else run_form(std::integral_constant<int, 10>{});
         } else if (fin) {
 #pragma unroll 1
             while (ks < 10) {
