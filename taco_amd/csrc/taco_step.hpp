@@ -653,6 +653,28 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
     // other tasks then compute values nobody reads), which keeps the substep loop free of divergent control flow
     const bool wave_tracks_rpy = __builtin_amdgcn_ballot_w64(track_rpy) != 0;
 
+    // Observation noise FA:402-410: 12 normals (Box-Muller on uniforms 4..15 of STREAM_OBS) and the small random rotation.  None of it
+    // depends on the state, so the obs role wavefront of the SPLIT form draws it while the substeps run.
+    float nrm[12];
+    Q4 nq{0.0f, 0.0f, 0.0f, 1.0f};
+    bool noise_ready = false;
+    auto gen_obs_noise = [&]() {
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr) {  // uniforms 4..15 of STREAM_OBS = blocks 1..3, two Box-Muller pairs per block
+            U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, P.step, STREAM_OBS, (uint32_t)(1 + pr));
+            float ua = 1.0f - uniform(r.x), ub = uniform(r.y);
+            float rad = __builtin_sqrtf(-2.0f * log(ua));
+            float sn, cs;
+            sincos(kTwoPi * ub, sn, cs);
+            nrm[4 * pr] = rad * cs; nrm[4 * pr + 1] = rad * sn;
+            ua = 1.0f - uniform(r.z); ub = uniform(r.w);
+            rad = __builtin_sqrtf(-2.0f * log(ua));
+            sincos(kTwoPi * ub, sn, cs);
+            nrm[4 * pr + 2] = rad * cs; nrm[4 * pr + 3] = rad * sn;
+        }
+        U4 r0 = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, P.step, STREAM_OBS, 0u);
+        nq = quat_from_euler(P.nq_sc * uniform(r0.x) + P.nq_lo, P.nq_sc * uniform(r0.y) + P.nq_lo, P.nq_sc * uniform(r0.z) + P.nq_lo);
+    };
     if (!SPLIT || wv == 0) {
     // ------------------------------------------------------------------ pre_physics_step FA:317-332
     // Every load the step needs is issued up front, before the reset flag is known: the flag, the action, the 13 state
@@ -1279,6 +1301,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
         __syncthreads();  // barrier 1 of 2
         if (wv == 3 && P.len_states > 1) shift_history(P.states, P.states_prev, P.states_bytes, P.len_states);
         if (wv == 2 && P.len_obs > 1) shift_history(P.obs, P.obs_prev, P.obs_bytes, P.len_obs);
+        if (wv == 2 && (fl & TACO_F_OBSERVATION_NOISE)) { gen_obs_noise(); noise_ready = true; }
         if (bat_served && wv == 1) {  // battery server (the reward wavefront, idle until the post-phase): ten voltages, each one substep ahead of wavefront 0
             MB_WAIT(0, 1);
             float bE = mb_bs[el * 4], bu1 = mb_bs[el * 4 + 1], bt = mb_bs[el * 4 + 2];
@@ -1414,24 +1437,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
     // states first (noise-free frame), then obs (possibly noised)
     if (roleS) put_frame(P.states, P.states_prev, P.states_bytes, P.len_states, fr, true);
     if (roleO && (fl & TACO_F_OBSERVATION_NOISE)) {  // FA:402-410
-        float nrm[12];
-#pragma unroll
-        for (int pr = 0; pr < 3; ++pr) {  // uniforms 4..15 of STREAM_OBS = blocks 1..3, two Box-Muller pairs per block
-            U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, P.step, STREAM_OBS, (uint32_t)(1 + pr));
-            float ua = 1.0f - uniform(r.x), ub = uniform(r.y);
-            float rad = __builtin_sqrtf(-2.0f * log(ua));
-            float sn, cs;
-            sincos(kTwoPi * ub, sn, cs);
-            nrm[4 * pr] = rad * cs; nrm[4 * pr + 1] = rad * sn;
-            ua = 1.0f - uniform(r.z); ub = uniform(r.w);
-            rad = __builtin_sqrtf(-2.0f * log(ua));
-            sincos(kTwoPi * ub, sn, cs);
-            nrm[4 * pr + 2] = rad * cs; nrm[4 * pr + 3] = rad * sn;
-        }
-        U4 r0 = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, P.step, STREAM_OBS, 0u);
+        if (!noise_ready) gen_obs_noise();
 #pragma unroll
         for (int k = 0; k < 3; ++k) fr[k] = fr[k] + P.df * (nrm[k] * (float)(0.06 / 3 / 3) + 0.0f);
-        Q4 nq = quat_from_euler(P.nq_sc * uniform(r0.x) + P.nq_lo, P.nq_sc * uniform(r0.y) + P.nq_lo, P.nq_sc * uniform(r0.z) + P.nq_lo);
         quat_to_matrix(quat_mul(rel_q_b, nq), m);
 #pragma unroll
         for (int k = 0; k < 9; ++k) fr[3 + k] = m[k];
