@@ -253,7 +253,7 @@ const char *taco_step_kernel_name(void);
 int taco_launch_geometry(const taco_env *env, int *grid, int *block);
 /* Introspection (profiling aid): bind a DEVICE array of 8 uint64; every following taco_step makes lane 0 of workgroup 0 record
  * the shader clock (s_memtime) at: 0 kernel entry, 1 up-front loads landed, 2 pre-phase done (reset / delay line / slot table),
- * 3 ten substeps done, 4 state stores + frame stacks done, 5 kernel end (in the four-role instantiation used up to 8 192 envs these are
+ * 3 ten substeps done, 4 state stores + frame stacks done, 5 kernel end (in the four-role instantiations these are
  * wavefront 0's: 4 and 5 coincide after its state stores; the role wavefronts finish later).  NULL unbinds.  Costs a scalar branch per phase. */
 int taco_bind_phase_stamps(taco_env *env, uint64_t *stamps);
 
