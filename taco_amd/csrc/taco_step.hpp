@@ -1039,7 +1039,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
                 ++ks;
                 if (rare) break;
             }
-        } else if (BLOCK != 256 && fin && plain) {  // (the 256-thread instantiations keep two forms: more cost them spills at 128 VGPRs)
+        } else if ((BLOCK != 256 || SPLIT) && fin && plain) {  // (the throughput instantiation keeps two forms: a third costs it 80 B of spills)
     #pragma unroll 1
             while (ks < 10) {
                 const bool rare = substep(std::integral_constant<int, 10>{}, ks);
