@@ -122,7 +122,7 @@ def cpu_baseline(cfg, budget_s=12.0):
     orc1.step(acts[0])
     t1 = time.perf_counter()
     steps1 = 0
-    while time.perf_counter() - t1 < 3.0:
+    while time.perf_counter() - t1 < min(3.0, budget_s):
         orc1.step(acts[steps1 % 64])
         steps1 += 1
     dt1 = time.perf_counter() - t1
@@ -171,6 +171,7 @@ def main():
     ap.add_argument("--gather", action="store_true", help="N > 1: put the per-step RCCL all-gather inside the main timed region "
                     "(default: the sharded path alone is timed, the gathered variant is timed separately and reported as with_allgather)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-time budget of the all-cores CPU baseline sample")
     ap.add_argument("--no-large-n", action="store_true")
     args = ap.parse_args()
 
@@ -325,7 +326,7 @@ def main():
                     torch.cuda.empty_cache()
             out["parity"] = parity_check(config.baseline_config(1, num_envs=n_local))
             if not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(config.baseline_config(1, num_envs=n_local))
+                out["cpu_baseline"] = cpu_baseline(config.baseline_config(1, num_envs=n_local), budget_s=args.cpu_seconds)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist:
