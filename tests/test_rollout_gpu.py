@@ -57,7 +57,7 @@ def test_gae_matches_oracle_bitwise(H, N):
     assert_bits_equal(buf.adv_buf.cpu().numpy()[:, :, 0], a1, "normalised advantage, second run")
 
 
-@pytest.mark.parametrize("n,len_obs,len_states,task", [(63, 5, 3, "mix"), (256, 1, 1, "pos"), (130, 1, 4, "flip")])
+@pytest.mark.parametrize("n,len_obs,len_states,task", [(63, 5, 3, "mix"), (256, 1, 1, "pos"), (130, 1, 4, "flip"), (10001, 2, 3, "mix"), (17003, 1, 5, "mix")])
 def test_collect_equals_step_plus_store_and_oracle(n, len_obs, len_states, task):
     """The fused path (kernel writes slot t+1 / rew_buf[t] / done_buf[t]) == env.step_raw + PPOReplayBuffer.store copies
     == the oracle, bit for bit, across two rollouts (reset() carries the last stacks into slot 0).  n = 63 makes every
