@@ -332,7 +332,8 @@ TD float quad_rotate(float qv, float w, float v) {
     const float s = 2.0f * (w * w) - 1.0f;
     const float c = cross_term(rot1(qv), rot2(v), rot2(qv), rot1(v));
     const float pr = qv * v;
-    const float dot = bc0(pr) + bc1(pr) + bc2(pr);
+    // (pr0 + pr1) + pr2 in lane 0 (a + b == b + a exactly), then broadcast: two DPP reads ride on the adds
+    const float dot = bc0((rot1(pr) + pr) + rot2(pr));
     return v * s + c * w * 2.0f + qv * dot * 2.0f;
 }
 // row I (integrate above) in the quad layout.  qq = (x y z w) over the four lanes; pq vq bq Fq tqq components 0..2 in lanes 0..2.
