@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TACO_ABI_VERSION 2
+#define TACO_ABI_VERSION 3
 
 typedef enum taco_status {
     TACO_OK = 0,
@@ -123,11 +123,15 @@ typedef struct taco_env taco_env;
 
 /* ABI version of the loaded library (== TACO_ABI_VERSION of the header it was built from). */
 int taco_abi_version(void);
+/* 16 hex digits identifying the sources (csrc/, this header, compiler flags) the binary was built from; the Python binding rebuilds
+ * a library whose hash differs from the sources on disk. */
+const char *taco_source_hash(void);
 /* Thread-local text of the last error on this thread ("" if none). */
 const char *taco_last_error(void);
 
 /* Bytes of device workspace taco_create needs for `cfg` (17 float4 state chunks + 16 float4 action-history rows +
- * 100 float4 ring slots per env, env count padded to whole wavefronts; the pointer must be 256-byte aligned). */
+ * 100 float4 ring slots per env, laid out in tiles of 64 envs, env count padded to whole tiles; the pointer must be
+ * 256-byte aligned). */
 size_t taco_workspace_bytes(const taco_cfg *cfg);
 
 /* Replaces FpvBase.__init__ -> VecTask.__init__ -> create_sim/prepare_sim (fpv_asymmetry.py:54-200,
@@ -251,6 +255,19 @@ int taco_set_state(taco_env *env, const uint32_t *blob, void *stream);
 /* Diagnostics for bench.py: name of the step kernel (as rocprofv3 reports it) and its launch geometry. */
 const char *taco_step_kernel_name(void);
 int taco_launch_geometry(const taco_env *env, int *grid, int *block);
+/* The step kernel exists in five instantiations of one template -- all the same function bit for bit -- and taco_create picks one from
+ * the env count.  taco_set_kernel_form overrides the choice for this handle (tuning, A/B measurements, and the
+ * tests that run every instantiation at small sizes); TACO_FORM_AUTO restores the default.  No environment variable is read anywhere. */
+enum {
+    TACO_FORM_AUTO = 0,
+    TACO_FORM_QUAD_ROLES = 1,      /* 4 lanes per env, 256-thread workgroups: one step wavefront + three post-phase role wavefronts */
+    TACO_FORM_LANE_ROLES = 2,      /* 1 lane per env, the same four roles (frame stacks, 16 385 ... 65 536 envs)                    */
+    TACO_FORM_QUAD = 3,            /* 4 lanes per env, one wavefront per workgroup                                                  */
+    TACO_FORM_LANE = 4,            /* 1 lane per env, one wavefront per workgroup, registers unconstrained                          */
+    TACO_FORM_LANE_THROUGHPUT = 5  /* 1 lane per env, one wavefront per workgroup, <= 128 VGPRs: four wavefronts per SIMD            */
+};
+int taco_set_kernel_form(taco_env *env, int form);
+int taco_get_kernel_form(const taco_env *env);  /* the TACO_FORM_* in use (never AUTO), or TACO_ERR_INVALID_ARG */
 /* Introspection (profiling aid): bind a DEVICE array of 8 uint64; every following taco_step makes lane 0 of workgroup 0 record
  * the shader clock (s_memtime) at: 0 kernel entry, 1 up-front loads landed, 2 pre-phase done (reset / delay line / slot table),
  * 3 ten substeps done, 4 state stores + frame stacks done, 5 kernel end (in the four-role instantiations these are

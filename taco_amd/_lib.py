@@ -6,12 +6,13 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TACO_ENV_LIB", os.path.join(HERE, "libtaco_env.so"))  # override = A/B builds of the same ABI
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 NUM_FIELDS = 67
 RING_SLOTS = 100
 BLOB_ROWS = NUM_FIELDS + 4 * RING_SLOTS
 
 TASKS = {"pos": 0, "rotate": 1, "flip": 2, "mix": 3}
+FORMS = {"auto": 0, "quad_roles": 1, "lane_roles": 2, "quad": 3, "lane": 4, "lane_throughput": 5}  # TACO_FORM_* (include/taco_env.h)
 FLAG_BITS = {
     "random_copter_pos": 0, "random_copter_quat": 1, "random_copter_vel": 2, "random_target_pos": 3,
     "random_target_yaw": 4, "battery_consumption": 5, "random_voltage": 6, "rotor_noise": 7, "rotor_delay": 8,
@@ -20,9 +21,9 @@ FLAG_BITS = {
     "random_command": 17, "observation_noise": 18,
 }
 # every symbol include/taco_env.h declares
-EXPORTS = ["taco_abi_version", "taco_last_error", "taco_workspace_bytes", "taco_create", "taco_destroy", "taco_step",
+EXPORTS = ["taco_abi_version", "taco_source_hash", "taco_last_error", "taco_workspace_bytes", "taco_create", "taco_destroy", "taco_step",
            "taco_gather_row_floats", "taco_bind_gather_block", "taco_set_difficulty", "taco_get_step_count", "taco_set_step_count", "taco_get_state", "taco_set_state",
-           "taco_step_kernel_name", "taco_launch_geometry", "taco_step_rollout", "taco_gae_workspace_bytes", "taco_gae", "taco_occupancy", "taco_bind_phase_stamps", "taco_policy_blob_floats", "taco_policy_act", "taco_rollout_run", "taco_policy_bind_stamps"]
+           "taco_step_kernel_name", "taco_launch_geometry", "taco_set_kernel_form", "taco_get_kernel_form", "taco_step_rollout", "taco_gae_workspace_bytes", "taco_gae", "taco_occupancy", "taco_bind_phase_stamps", "taco_policy_blob_floats", "taco_policy_act", "taco_rollout_run", "taco_policy_bind_stamps"]
 
 
 class TacoCfg(C.Structure):
@@ -54,30 +55,22 @@ class TacoError(RuntimeError):
 
 
 _lib = None
+_hooks_lib = None
 
 
-def load():
-    """dlopen libtaco_env.so and declare its prototypes; raises if the HIP extension is not built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH) and "TACO_ENV_LIB" not in os.environ:
-        # a fresh checkout has no binary (it is git-ignored): compile the HIP library now if the toolchain is here
-        try:
-            from . import build as _build
-            _build.build()
-        except Exception as e:  # noqa: BLE001 -- report the build failure, never fall back to anything else
-            raise TacoError(f"{LIB_PATH} is missing and building it failed ({e}); run `python -m taco_amd.build` (hipcc, gfx950). "
-                            "There is no CPU fallback for the step path.") from e
-    if not os.path.exists(LIB_PATH):
-        raise TacoError(f"{LIB_PATH} is missing: build it with `python -m taco_amd.build` (hipcc, gfx950). "
-                        "There is no CPU fallback for the step path.")
-    # PyTorch-ROCm ships its own HIP runtime (libamdhip64, same SONAME as /opt/rocm's).  The process must hold ONE runtime, and it has to be
-    # the one torch's other bundled libraries were built against: load torch first, so that libtaco_env.so binds to the runtime already
-    # in the process.  (The other order leaves torch on /opt/rocm's runtime and HIP reports "no ROCm-capable device".)
-    import torch  # noqa: F401
-    lib = C.CDLL(LIB_PATH)
+class _Missing:
+    """stand-in for an entry point an OLDER A/B build (TACO_ENV_LIB override) does not export"""
+    argtypes = restype = None
+
+
+def _declare(lib, ab_build=False):
+    """prototypes of every entry point of include/taco_env.h"""
+    if ab_build:  # A/B comparisons across ABI revisions: tolerate missing newer symbols, skip the version check
+        for name in EXPORTS:
+            if not hasattr(lib, name):
+                setattr(lib, name, _Missing())
     lib.taco_abi_version.restype = C.c_int
+    lib.taco_source_hash.restype = C.c_char_p
     lib.taco_last_error.restype = C.c_char_p
     lib.taco_step_kernel_name.restype = C.c_char_p
     lib.taco_workspace_bytes.argtypes = [C.POINTER(TacoCfg)]
@@ -104,6 +97,10 @@ def load():
     lib.taco_set_state.restype = C.c_int
     lib.taco_launch_geometry.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.taco_launch_geometry.restype = C.c_int
+    lib.taco_set_kernel_form.argtypes = [C.c_void_p, C.c_int]
+    lib.taco_set_kernel_form.restype = C.c_int
+    lib.taco_get_kernel_form.argtypes = [C.c_void_p]
+    lib.taco_get_kernel_form.restype = C.c_int
     lib.taco_policy_blob_floats.argtypes = [C.c_void_p]
     lib.taco_policy_blob_floats.restype = C.c_size_t
     lib.taco_policy_act.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_int,
@@ -124,15 +121,56 @@ def load():
     lib.taco_gae_workspace_bytes.restype = C.c_size_t
     lib.taco_gae.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.taco_gae.restype = C.c_int
-    if lib.taco_abi_version() != ABI_VERSION:
+    if not ab_build and lib.taco_abi_version() != ABI_VERSION:
         raise TacoError(f"libtaco_env.so ABI {lib.taco_abi_version()} != binding ABI {ABI_VERSION}")
-    _lib = lib
     return lib
 
 
-def check(rc):
+def _open(path, test_hooks=False):
+    """(re)build `path` if it is missing or was built from other sources than the ones on disk, then dlopen it.  An explicit
+    TACO_ENV_LIB override (A/B builds of the same ABI) is taken as it is."""
+    overridden = not test_hooks and "TACO_ENV_LIB" in os.environ
+    if not overridden:
+        from . import build as _build
+        if _build.needs_build(path):
+            try:
+                _build.build(test_hooks=test_hooks)
+            except Exception as e:  # noqa: BLE001 -- report the build failure, never fall back to anything else
+                raise TacoError(f"{path} is missing or stale (built from other sources than csrc/) and building it failed ({e}); run "
+                                "`python -m taco_amd.build` (hipcc, gfx950).  There is no CPU fallback for the step path.") from e
+    if not os.path.exists(path):
+        raise TacoError(f"{path} is missing: build it with `python -m taco_amd.build` (hipcc, gfx950). "
+                        "There is no CPU fallback for the step path.")
+    # PyTorch-ROCm ships its own HIP runtime (libamdhip64, same SONAME as /opt/rocm's).  The process must hold ONE runtime, and it has to be
+    # the one torch's other bundled libraries were built against: load torch first, so that libtaco_env.so binds to the runtime already
+    # in the process.  (The other order leaves torch on /opt/rocm's runtime and HIP reports "no ROCm-capable device".)
+    import torch  # noqa: F401
+    return _declare(C.CDLL(path), ab_build=overridden)
+
+
+def load():
+    """dlopen libtaco_env.so and declare its prototypes; raises if the HIP extension is not built and cannot be built."""
+    global _lib
+    if _lib is None:
+        _lib = _open(LIB_PATH)
+    return _lib
+
+
+def load_test_hooks():
+    """the -DTACO_TEST_HOOKS build of the same sources (taco_amd/build.py --test-hooks): adds taco_test_slow_battery_server.  Tests only."""
+    global _hooks_lib
+    if _hooks_lib is None:
+        from . import build as _build
+        lib = _open(_build.LIB_HOOKS, test_hooks=True)
+        lib.taco_test_slow_battery_server.argtypes = [C.c_void_p, C.c_int]
+        lib.taco_test_slow_battery_server.restype = C.c_int
+        _hooks_lib = lib
+    return _hooks_lib
+
+
+def check(rc, lib=None):
     if rc != 0:
-        raise TacoError(f"libtaco_env: status {rc}: {load().taco_last_error().decode()}")
+        raise TacoError(f"libtaco_env: status {rc}: {(lib or load()).taco_last_error().decode()}")
 
 
 def make_cfg(d):

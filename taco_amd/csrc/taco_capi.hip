@@ -29,8 +29,8 @@ int hip_fail(hipError_t e, const char *what) {
     return TACO_ERR_HIP;
 }
 
-constexpr int kBlockSmall = 64;   // one wavefront per workgroup: spreads few envs over as many CUs as possible
-constexpr int kBlockLarge = 256;  // >= 64 Ki envs: 4 wavefronts per workgroup
+constexpr int kBlockSmall = 64;   // one wavefront per workgroup
+constexpr int kBlockLarge = 256;  // the four-role forms: one step wavefront + three role wavefronts
 
 }  // namespace
 
@@ -44,9 +44,10 @@ struct taco_env {
     int64_t step_count;
     int head;  // physical ring slot of logical slot 0; advances by 10 per step (mod 100)
     int hh;    // action-history row the next step writes; advances by 1 per step (mod 16)
-    int lpe;   // lanes per env of the step kernel this handle launches (1 or 4)
-    int block; // its workgroup size (64 or 256)
-    int split; // 1: the four-role form of the quad kernel (<= 8 192 envs, <= 16 384 with frame stacks)
+#ifdef TACO_TEST_HOOKS
+    int slow_server;
+#endif
+    int form;  // TACO_FORM_* the step launches (never TACO_FORM_AUTO here: resolved by choose_form)
     float *gather;  // optional per-rank all-gather block, see taco_bind_gather_block
     unsigned long long *stamps;  // optional phase stamps, see taco_bind_phase_stamps
     taco::StepParams P;
@@ -110,8 +111,9 @@ void derive(taco_env *e) {
     P.mix_n2 = (int)((double)c.num_envs_global / 3 * 2);  // fpv_asymmetry.py:925
     P.len_obs = c.len_obs; P.len_states = c.len_states; P.substeps = c.substeps; P.max_len = c.max_episode_length;
     P.delay_time = c.delay_time; P.flags = c.flags;
-    // test hook: make the battery-server wavefront late on purpose, so that the wait path of the LDS mailbox is exercised (tests only)
-    if (const char *f = std::getenv("TACO_DEBUG_SLOW_SERVER")) { if (std::atoi(f) != 0) P.flags |= taco::kDebugSlowServer; }
+#ifdef TACO_TEST_HOOKS
+    if (e->slow_server) P.flags |= taco::kDebugSlowServer;  // see taco_test_slow_battery_server
+#endif
     P.seed_lo = (uint32_t)c.seed; P.seed_hi = (uint32_t)(c.seed >> 32);
     P.dt = (float)c.dt; P.clip_act = (float)c.clip_actions; P.df = (float)d;
     P.h = (float)(c.dt / (double)c.substeps);
@@ -136,18 +138,19 @@ void derive(taco_env *e) {
 // Initial state = what the reference holds after construction, before the first step (fpv_asymmetry.py:124-200,
 // sub-model constructors): actors at (0,0,4) with identity attitude, nominal rotor / aero parameters, zero everything else.
 __device__ __forceinline__ float &word(float *S, int npad, int i, int field) {
+    (void)npad;
     const int sl = taco::field_slot(field);
-    return S[((size_t)(sl >> 2) * npad + i) * 4 + (sl & 3)];
+    return S[taco::tile_word(taco::NUM_CHUNKS, sl >> 2, i) + (sl & 3)];
 }
 __global__ void init_state_kernel(float *S, float *hist, float *ring, int npad, float tau0, int delay_time) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npad) return;
     for (int c = 0; c < (int)taco::NUM_CHUNKS; ++c)
-        for (int k = 0; k < 4; ++k) S[((size_t)c * npad + i) * 4 + k] = 0.0f;
+        for (int k = 0; k < 4; ++k) S[taco::tile_word(taco::NUM_CHUNKS, c, i) + k] = 0.0f;
     for (int r = 0; r < taco::HIST_ROWS; ++r)
-        for (int k = 0; k < 4; ++k) hist[((size_t)r * npad + i) * 4 + k] = 0.0f;
+        for (int k = 0; k < 4; ++k) hist[taco::tile_word(taco::HIST_ROWS, r, i) + k] = 0.0f;
     for (int r = 0; r < TACO_RING_SLOTS; ++r)
-        for (int k = 0; k < 4; ++k) ring[((size_t)r * npad + i) * 4 + k] = 0.0f;
+        for (int k = 0; k < 4; ++k) ring[taco::tile_word(TACO_RING_SLOTS, r, i) + k] = 0.0f;
     word(S, npad, i, TACO_S_POS + 2) = 4.0f;
     word(S, npad, i, TACO_S_QUAT + 3) = 1.0f;
     word(S, npad, i, TACO_S_TGT_POS + 2) = 4.0f;
@@ -177,25 +180,25 @@ __global__ void export_state_kernel(const float *S, const float *hist, const flo
     if (row == TACO_S_DELAY_LEN) {
         val = __builtin_bit_cast(float, L);
     } else if (row >= TACO_S_ACT && row < TACO_S_ACT + 4) {            // actions = the action of the last step
-        val = hist[((size_t)((hh - 1) & (taco::HIST_ROWS - 1)) * npad + i) * 4 + (row - TACO_S_ACT)];
+        val = hist[taco::tile_word(taco::HIST_ROWS, (hh - 1) & (taco::HIST_ROWS - 1), i) + (row - TACO_S_ACT)];
     } else if (row >= TACO_S_ACT_OLD && row < TACO_S_ACT_OLD + 4) {    // actions_old = the one before, 0 right after a reset (FA:572-573)
         const int progress = __builtin_bit_cast(int, word(Sm, npad, i, TACO_S_PROGRESS));
-        val = (progress <= 1) ? 0.0f : hist[((size_t)((hh - 2) & (taco::HIST_ROWS - 1)) * npad + i) * 4 + (row - TACO_S_ACT_OLD)];
+        val = (progress <= 1) ? 0.0f : hist[taco::tile_word(taco::HIST_ROWS, (hh - 2) & (taco::HIST_ROWS - 1), i) + (row - TACO_S_ACT_OLD)];
     } else if (row < TACO_NUM_FIELDS) {
         val = word(Sm, npad, i, row);
     } else {
         const int r = row - TACO_NUM_FIELDS, slot = r >> 2, ch = r & 3;
         if (dense) {
-            val = ring[((size_t)((head + slot) % TACO_RING_SLOTS) * npad + i) * 4 + ch];
+            val = ring[taco::tile_word(TACO_RING_SLOTS, (head + slot) % TACO_RING_SLOTS, i) + ch];
         } else {  // expand [Z zeros | run_0 (rem0) | run_1 | ... ] ; beyond L: zeros
-            const int lens = __builtin_bit_cast(int, S[((size_t)taco::C_QUEUE * npad + i) * 4 + 0]);
-            const int mr = __builtin_bit_cast(int, S[((size_t)taco::C_QUEUE * npad + i) * 4 + 1]);
+            const int lens = __builtin_bit_cast(int, S[taco::tile_word(taco::NUM_CHUNKS, taco::C_QUEUE, i) + 0]);
+            const int mr = __builtin_bit_cast(int, S[taco::tile_word(taco::NUM_CHUNKS, taco::C_QUEUE, i) + 1]);
             const int m = mr & 0xff, rem0 = (mr >> 8) & 0xff;
             val = 0.0f;
             int pos = Z;
             for (int j = 0; j < m && slot >= pos; ++j) {
                 const int len = (j == 0) ? rem0 : taco::run_len(lens, j);
-                if (slot < pos + len) val = hist[((size_t)((hh - (m - j)) & (taco::HIST_ROWS - 1)) * npad + i) * 4 + ch];
+                if (slot < pos + len) val = hist[taco::tile_word(taco::HIST_ROWS, (hh - (m - j)) & (taco::HIST_ROWS - 1), i) + ch];
                 pos += len;
             }
         }
@@ -210,50 +213,55 @@ __global__ void import_state_kernel(float *S, float *hist, float *ring, const ui
     if (row == TACO_S_DELAY_LEN) {
         // an imported delay line is arbitrary content: the env becomes DENSE (literal slot ring), its run queue empty
         val = __builtin_bit_cast(float, (int)((__builtin_bit_cast(uint32_t, val) & 0xffffu) | 0x80000000u));
-        for (int k = 0; k < 4; ++k) S[((size_t)taco::C_QUEUE * npad + i) * 4 + k] = 0.0f;
+        for (int k = 0; k < 4; ++k) S[taco::tile_word(taco::NUM_CHUNKS, taco::C_QUEUE, i) + k] = 0.0f;
     }
     if (row >= TACO_S_ACT && row < TACO_S_ACT + 4) {
-        hist[((size_t)((hh - 1) & (taco::HIST_ROWS - 1)) * npad + i) * 4 + (row - TACO_S_ACT)] = val;
+        hist[taco::tile_word(taco::HIST_ROWS, (hh - 1) & (taco::HIST_ROWS - 1), i) + (row - TACO_S_ACT)] = val;
     } else if (row >= TACO_S_ACT_OLD && row < TACO_S_ACT_OLD + 4) {
-        hist[((size_t)((hh - 2) & (taco::HIST_ROWS - 1)) * npad + i) * 4 + (row - TACO_S_ACT_OLD)] = val;
+        hist[taco::tile_word(taco::HIST_ROWS, (hh - 2) & (taco::HIST_ROWS - 1), i) + (row - TACO_S_ACT_OLD)] = val;
     } else if (row < TACO_NUM_FIELDS) {
         word(S, npad, i, row) = val;
     } else {
         const int r = row - TACO_NUM_FIELDS, slot = r >> 2, ch = r & 3;
-        ring[((size_t)((head + slot) % TACO_RING_SLOTS) * npad + i) * 4 + ch] = val;
+        ring[taco::tile_word(TACO_RING_SLOTS, (head + slot) % TACO_RING_SLOTS, i) + ch] = val;
     }
 }
 
-// Launch geometry, fixed when the handle is created.  lanes per env: 4 (quad layout) while one lane per env would leave most
-// SIMDs without a wavefront (measured: 19.8 us vs 21.0 us at 16 384 envs, 24.6 us vs 22 us at 20 480); 256-thread workgroups from 65 536 envs.
-// TACO_FORCE_LPE / TACO_FORCE_BLOCK (read at taco_create) override the choice for experiments and for the LPE-equivalence test.
+// The instantiation of the step kernel a handle launches (include/taco_env.h TACO_FORM_*), chosen when the handle is created from the
+// env count (taco_set_kernel_form overrides it).  4 lanes per env (quad layout) while one lane per env would leave most SIMDs without a
+// wavefront (measured: 19.8 us vs 21.0 us at 16 384 envs, 24.6 us vs 22 us at 20 480); the 128-VGPR throughput form from 65 536 envs.
 constexpr int kQuadMaxEnvs = 16384;
 constexpr int kSplitLaneMaxEnvs = 65536;  // 1 024 workgroups (31 KB of LDS, 111 VGPRs): four resident per CU
 constexpr int kSplitMaxEnvs = 8192;  // measured: 16.8 vs 17.6 us at 4 096 envs, 18.4 vs 18.8 at 8 192, no gain at 16 384
-void choose_geometry(taco_env *e) {
-    e->lpe = e->cfg.num_envs <= kQuadMaxEnvs ? 4 : 1;
-    e->block = e->cfg.num_envs >= 65536 ? kBlockLarge : kBlockSmall;
-    if (const char *f = std::getenv("TACO_FORCE_LPE")) {
-        const int l = std::atoi(f);
-        if (l == 1 || l == 4) e->lpe = l;
+constexpr int kThroughputMinEnvs = 65536;
+struct FormInfo { int lpe, block, split; const void *fn; };
+FormInfo form_info(int form) {
+    switch (form) {
+        case TACO_FORM_QUAD_ROLES: return {4, kBlockLarge, 1, (const void *)taco::taco_step_kernel<kBlockLarge, 4, true>};
+        case TACO_FORM_LANE_ROLES: return {1, kBlockLarge, 1, (const void *)taco::taco_step_kernel<kBlockLarge, 1, true>};
+        case TACO_FORM_QUAD: return {4, kBlockSmall, 0, (const void *)taco::taco_step_kernel<kBlockSmall, 4>};
+        case TACO_FORM_LANE_THROUGHPUT: return {1, kBlockSmall, 0, (const void *)taco::taco_step_kernel<kBlockSmall, 1, false, true>};
+        default: return {1, kBlockSmall, 0, (const void *)taco::taco_step_kernel<kBlockSmall, 1>};
     }
-    if (const char *f = std::getenv("TACO_FORCE_BLOCK")) {
-        const int b = std::atoi(f);
-        if (b == kBlockSmall || b == kBlockLarge) e->block = b;
-    }
-    if (e->lpe == 4) e->block = kBlockSmall;
-    // three helper wavefronts per 16 envs take over the post-phase: pays while every wavefront still has a SIMD to itself
-    // With frame stacks the role wavefronts also move the stack history under the substeps, which pays up to the quad limit
-    // (16 384 envs, 5 state frames: 19.2 us vs 22.1 us; 5 + 5 frames: 19.9 us vs 26.0 us; without stacks 18.0 us vs 17.5 us).
-    const bool stacks = e->cfg.len_obs > 1 || e->cfg.len_states > 1;
-    e->split = (e->lpe == 4 && e->cfg.num_envs <= (stacks ? kQuadMaxEnvs : kSplitMaxEnvs)) ? 1 : 0;
-    // One lane per env, 16 385 ... 65 536 envs with frame stacks: the same four-role form (64 envs per workgroup) hides the stack history,
-    // which a lone wavefront moves at only ~5 GB/s (tools/ubench/shift), under the substeps.
-    if (e->lpe == 1 && stacks && e->cfg.num_envs <= kSplitLaneMaxEnvs) e->split = 1;
-    if (const char *f = std::getenv("TACO_FORCE_SPLIT")) e->split = std::atoi(f) != 0 ? 1 : 0;
-    if (e->split) e->block = kBlockLarge;
 }
-bool use_split(const taco_env *e) { return e->split != 0; }
+int choose_form(const taco_cfg &c) {
+    const bool stacks = c.len_obs > 1 || c.len_states > 1;
+    if (c.num_envs <= kQuadMaxEnvs) {
+        // three helper wavefronts per 16 envs take over the post-phase: pays while every wavefront still has a SIMD to itself.  With
+        // frame stacks the role wavefronts also move the stack history under the substeps, which pays up to the quad limit
+        // (16 384 envs, 5 state frames: 19.2 us vs 22.1 us; 5 + 5 frames: 19.9 us vs 26.0 us; without stacks 18.0 us vs 17.5 us).
+        return c.num_envs <= (stacks ? kQuadMaxEnvs : kSplitMaxEnvs) ? TACO_FORM_QUAD_ROLES : TACO_FORM_QUAD;
+    }
+    // One lane per env, 16 385 ... 65 536 envs with frame stacks: the same four-role form (64 envs per workgroup) hides the stack
+    // history, which a lone wavefront moves at only ~5 GB/s (tools/ubench/shift), under the substeps.
+    if (stacks && c.num_envs <= kSplitLaneMaxEnvs) return TACO_FORM_LANE_ROLES;
+    return c.num_envs >= kThroughputMinEnvs ? TACO_FORM_LANE_THROUGHPUT : TACO_FORM_LANE;
+}
+void grid_of(const taco_env *e, int *grid, int *block) {
+    const FormInfo f = form_info(e->form);
+    *block = f.block;
+    *grid = f.split ? (e->cfg.num_envs * f.lpe + 63) / 64 : (e->cfg.num_envs * f.lpe + f.block - 1) / f.block;
+}
 
 }  // namespace
 
@@ -261,7 +269,12 @@ extern "C" {
 
 int taco_gather_row_floats(int len_obs);
 
+#ifndef TACO_SOURCE_HASH
+#define TACO_SOURCE_HASH "unhashed-build-0"
+#endif
 int taco_abi_version(void) { return TACO_ABI_VERSION; }
+// hash of the sources this binary was built from (taco_amd/build.py embeds it; _lib.load() refuses a binary older than csrc/)
+const char *taco_source_hash(void) { static const char tag[] = "taco-src-hash:" TACO_SOURCE_HASH; return tag + 14; }
 const char *taco_last_error(void) { return g_err; }
 const char *taco_step_kernel_name(void) { return "taco_step_kernel"; }
 
@@ -294,7 +307,7 @@ int taco_create(const taco_cfg *cfg, int device, void *workspace, size_t workspa
     e->hh = 0;
     e->gather = nullptr;
     e->stamps = nullptr;
-    choose_geometry(e);
+    e->form = choose_form(e->cfg);
     std::memset(&e->P, 0, sizeof(e->P));
     derive(e);
     hipLaunchKernelGGL(init_state_kernel, dim3((e->npad + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->S, e->hist, e->ring, e->npad,
@@ -332,27 +345,17 @@ int launch_step(taco_env *e, const taco_rollout_io *io, void *stream) {
     P.gather = e->gather;
     P.stamps = e->stamps;
     P.step = (uint32_t)e->step_count;
-    P.s_bytes = (uint32_t)((size_t)taco::NUM_CHUNKS * e->npad * 4 * sizeof(float));
-    P.ring_bytes = (uint32_t)((size_t)TACO_RING_SLOTS * e->npad * 4 * sizeof(float));
     P.obs_bytes = (uint32_t)((size_t)n_envs * e->cfg.len_obs * 26 * sizeof(float));
     P.states_bytes = (uint32_t)((size_t)n_envs * e->cfg.len_states * 26 * sizeof(float));
     P.gather_row = (uint32_t)taco_gather_row_floats(e->cfg.len_obs);
     P.gather_bytes = (uint32_t)((size_t)n_envs * P.gather_row * sizeof(float));
     P.head = e->head;
     P.hh = e->hh;
-    P.hist_bytes = (uint32_t)((size_t)taco::HIST_ROWS * e->npad * 4 * sizeof(float));
-    const int n = e->cfg.num_envs;
-    if (use_split(e) && e->lpe == 4)
-        hipLaunchKernelGGL((taco::taco_step_kernel<kBlockLarge, 4, true>), dim3((n * 4 + 63) / 64), dim3(kBlockLarge), 0, (hipStream_t)stream, P);
-    else if (use_split(e))
-        hipLaunchKernelGGL((taco::taco_step_kernel<kBlockLarge, 1, true>), dim3((n + 63) / 64), dim3(kBlockLarge), 0, (hipStream_t)stream, P);
-    else if (e->lpe == 4)
-        hipLaunchKernelGGL((taco::taco_step_kernel<kBlockSmall, 4>), dim3((n * 4 + kBlockSmall - 1) / kBlockSmall), dim3(kBlockSmall), 0, (hipStream_t)stream, P);
-    else if (e->block == kBlockLarge)
-        hipLaunchKernelGGL((taco::taco_step_kernel<kBlockLarge, 1>), dim3((n + kBlockLarge - 1) / kBlockLarge), dim3(kBlockLarge), 0, (hipStream_t)stream, P);
-    else
-        hipLaunchKernelGGL((taco::taco_step_kernel<kBlockSmall, 1>), dim3((n + kBlockSmall - 1) / kBlockSmall), dim3(kBlockSmall), 0, (hipStream_t)stream, P);
-    hipError_t he = hipGetLastError();
+    int grid, block;
+    grid_of(e, &grid, &block);
+    void *args[] = {&P};
+    hipError_t he = hipLaunchKernel(form_info(e->form).fn, dim3(grid), dim3(block), args, 0, (hipStream_t)stream);
+    if (he == hipSuccess) he = hipGetLastError();
     if (he != hipSuccess) return hip_fail(he, "taco_step_kernel launch");
     e->step_count += 1;
     e->head = (e->head + 10) % TACO_RING_SLOTS;
@@ -446,9 +449,7 @@ int taco_set_state(taco_env *e, const uint32_t *blob, void *stream) {
 
 int taco_launch_geometry(const taco_env *e, int *grid, int *block) {
     if (!e || !grid || !block) return fail(TACO_ERR_INVALID_ARG, "taco_launch_geometry: null argument");
-    if (use_split(e)) { *block = kBlockLarge; *grid = (e->cfg.num_envs * e->lpe + 63) / 64; return TACO_OK; }
-    *block = e->block;
-    *grid = (e->cfg.num_envs * e->lpe + *block - 1) / *block;
+    grid_of(e, grid, block);
     return TACO_OK;
 }
 
@@ -570,6 +571,25 @@ int taco_rollout_run(taco_env *e, const taco_policy_cfg *c, const float *blob, c
     return TACO_OK;
 }
 
+int taco_set_kernel_form(taco_env *e, int form) {
+    if (!e) return fail(TACO_ERR_INVALID_ARG, "env is null");
+    if (form < TACO_FORM_AUTO || form > TACO_FORM_LANE_THROUGHPUT) return fail(TACO_ERR_INVALID_ARG, "taco_set_kernel_form: unknown form");
+    e->form = form == TACO_FORM_AUTO ? choose_form(e->cfg) : form;
+    return TACO_OK;
+}
+int taco_get_kernel_form(const taco_env *e) { return e ? e->form : TACO_ERR_INVALID_ARG; }
+
+#ifdef TACO_TEST_HOOKS
+// test-hooks build only (taco_amd/build.py --test-hooks): make the battery-server wavefront late on purpose, so that the wait path of
+// the LDS mailbox is exercised
+int taco_test_slow_battery_server(taco_env *e, int on) {
+    if (!e) return fail(TACO_ERR_INVALID_ARG, "env is null");
+    e->slow_server = on ? 1 : 0;
+    derive(e);
+    return TACO_OK;
+}
+#endif
+
 int taco_bind_phase_stamps(taco_env *e, uint64_t *stamps) {
     if (!e) return fail(TACO_ERR_INVALID_ARG, "env is null");
     if (stamps && ((uintptr_t)stamps & 7u) != 0) return fail(TACO_ERR_INVALID_ARG, "stamps must be 8-byte aligned");
@@ -579,28 +599,18 @@ int taco_bind_phase_stamps(taco_env *e, uint64_t *stamps) {
 
 int taco_occupancy(const taco_env *e, int *resident_blocks_per_cu, int *lds_bytes_per_block) {
     if (!e || !resident_blocks_per_cu || !lds_bytes_per_block) return fail(TACO_ERR_INVALID_ARG, "taco_occupancy: null argument");
-    if (use_split(e)) {
-        hipFuncAttributes at;
-        const bool q = e->lpe == 4;
-        hipError_t he = hipFuncGetAttributes(&at, q ? (const void *)taco::taco_step_kernel<kBlockLarge, 4, true> : (const void *)taco::taco_step_kernel<kBlockLarge, 1, true>);
-        if (he != hipSuccess) return hip_fail(he, "hipFuncGetAttributes");
-        *lds_bytes_per_block = (int)at.sharedSizeBytes;
-        he = q ? hipOccupancyMaxActiveBlocksPerMultiprocessor(resident_blocks_per_cu, taco::taco_step_kernel<kBlockLarge, 4, true>, kBlockLarge, 0)
-               : hipOccupancyMaxActiveBlocksPerMultiprocessor(resident_blocks_per_cu, taco::taco_step_kernel<kBlockLarge, 1, true>, kBlockLarge, 0);
-        if (he != hipSuccess) return hip_fail(he, "hipOccupancyMaxActiveBlocksPerMultiprocessor");
-        return TACO_OK;
-    }
-    const bool quad = e->lpe == 4;
-    const bool large = !quad && e->block == kBlockLarge;
-    const void *fn = quad ? (const void *)taco::taco_step_kernel<kBlockSmall, 4>
-                          : (large ? (const void *)taco::taco_step_kernel<kBlockLarge, 1> : (const void *)taco::taco_step_kernel<kBlockSmall, 1>);
+    const FormInfo f = form_info(e->form);
     hipFuncAttributes at;
-    hipError_t he = hipFuncGetAttributes(&at, fn);
+    hipError_t he = hipFuncGetAttributes(&at, f.fn);
     if (he != hipSuccess) return hip_fail(he, "hipFuncGetAttributes");
     *lds_bytes_per_block = (int)at.sharedSizeBytes;
-    if (quad) he = hipOccupancyMaxActiveBlocksPerMultiprocessor(resident_blocks_per_cu, taco::taco_step_kernel<kBlockSmall, 4>, kBlockSmall, 0);
-    else if (large) he = hipOccupancyMaxActiveBlocksPerMultiprocessor(resident_blocks_per_cu, taco::taco_step_kernel<kBlockLarge, 1>, kBlockLarge, 0);
-    else he = hipOccupancyMaxActiveBlocksPerMultiprocessor(resident_blocks_per_cu, taco::taco_step_kernel<kBlockSmall, 1>, kBlockSmall, 0);
+    switch (e->form) {
+        case TACO_FORM_QUAD_ROLES: he = hipOccupancyMaxActiveBlocksPerMultiprocessor(resident_blocks_per_cu, taco::taco_step_kernel<kBlockLarge, 4, true>, kBlockLarge, 0); break;
+        case TACO_FORM_LANE_ROLES: he = hipOccupancyMaxActiveBlocksPerMultiprocessor(resident_blocks_per_cu, taco::taco_step_kernel<kBlockLarge, 1, true>, kBlockLarge, 0); break;
+        case TACO_FORM_QUAD: he = hipOccupancyMaxActiveBlocksPerMultiprocessor(resident_blocks_per_cu, taco::taco_step_kernel<kBlockSmall, 4>, kBlockSmall, 0); break;
+        case TACO_FORM_LANE_THROUGHPUT: he = hipOccupancyMaxActiveBlocksPerMultiprocessor(resident_blocks_per_cu, taco::taco_step_kernel<kBlockSmall, 1, false, true>, kBlockSmall, 0); break;
+        default: he = hipOccupancyMaxActiveBlocksPerMultiprocessor(resident_blocks_per_cu, taco::taco_step_kernel<kBlockSmall, 1>, kBlockSmall, 0); break;
+    }
     if (he != hipSuccess) return hip_fail(he, "hipOccupancyMaxActiveBlocksPerMultiprocessor");
     return TACO_OK;
 }

@@ -20,9 +20,9 @@ namespace taco {
 
 struct StepParams {
     // device pointers
-    float *S;            // [NUM_CHUNKS][npad] float4 state chunks
-    float *ring;         // [100][npad] float4 pending-action ring, PHYSICAL slot order (logical slot s lives at (head+s)%100)
-    float *hist;         // [16][npad] float4 action history, row = step count & 15
+    float *S;            // [tiles][NUM_CHUNKS][64] float4 state chunks (tile = 64 consecutive envs, see "workspace layout" below)
+    float *ring;         // [tiles][100][64] float4 pending-action ring, PHYSICAL slot order (logical slot s lives at (head+s)%100)
+    float *hist;         // [tiles][16][64] float4 action history, row = step count & 15
     const float *act_in; // [n][4]
     float *obs;          // [n][len_obs][26]
     float *states;       // [n][len_states][26]
@@ -37,7 +37,6 @@ struct StepParams {
     // geometry / cfg
     int n, npad, env_offset, task_mode, mix_n1, mix_n2, len_obs, len_states, substeps, max_len, delay_time, head;
     uint32_t flags, seed_lo, seed_hi, step;
-    uint32_t s_bytes, ring_bytes, hist_bytes;  // sizes for the buffer descriptors (range-checked accesses)
     int hh;              // history row this step writes (= number of steps taken so far, mod 16)
     uint32_t obs_bytes, states_bytes, gather_bytes, gather_row;  // gather_row = floats per env in the gather block (multiple of 32)
     // fp32 images of the Python doubles the reference feeds into tensor ops
@@ -46,9 +45,13 @@ struct StepParams {
     float flip_xy_sc, flip_xy_lo, flip_v_sc, flip_v_lo, dr_sc, dr_lo, tau_sc, tau_lo, tau_fixed, nq_sc, nq_lo;
 };
 
-// ---- workspace layout ("array of float4 rows"): the 67 state words of an env are packed into 18 float4 CHUNKS;
-// chunk c of env i lives at byte (c * npad + i) * 16, so a wavefront moves a chunk with ONE 16-byte-per-lane access
-// (1 KiB, fully coalesced) instead of four 4-byte ones.  Words that travel together share a chunk.
+// ---- workspace layout (TILE-major float4 rows): the 67 state words of an env are packed into 17 float4 CHUNKS; the envs are
+// grouped in TILES of 64 consecutive envs and chunk c of env i lives at byte ((i / 64) * NUM_CHUNKS + c) * 1024 + (i % 64) * 16.
+// A wavefront still moves a chunk with ONE 16-byte-per-lane access (1 KiB, fully coalesced), and everything a wavefront touches of
+// an array is ONE contiguous block (17 KiB of state, 16 KiB of history) whatever num_envs is.  Round 1 kept whole rows
+// ([chunk][npad]): with num_envs a power of two the 17 + 4 streams of a wavefront were then exactly 2^k bytes apart and fell on the
+// same HBM channels (tools/ubench/layout: 4.2-4.7 TB/s for the step's access pattern at 1 M envs against 5.3-5.7 TB/s tile-major).
+// Words that travel together share a chunk.
 // Pending actions: a run-length queue (C_QUEUE) over the action history hist[16][npad] float4 while an env is in the
 // common regime, the literal slot ring ring[100][npad] float4 (PHYSICAL slot order) once it is DENSE (see the kernel).
 enum Chunk : uint32_t {
@@ -71,7 +74,10 @@ enum Chunk : uint32_t {
     C_AERO1 = 16,   // dy | kt | - | -
     NUM_CHUNKS = 17
 };
-constexpr int HIST_ROWS = 16;  // action history: hist[k][npad] float4, the action of the step whose (count & 15) == k
+constexpr int HIST_ROWS = 16;  // action history: hist[tile][k][64] float4, the action of the step whose (count & 15) == k
+constexpr uint32_t kRowBytes = 1024;  // one row (chunk, history row or ring slot) of one tile: 64 lanes x 16 B
+// float index of word 0 of (row r, env i) in an array with `rows` rows per tile (host-side kernels of taco_capi.hip)
+__host__ __device__ constexpr size_t tile_word(int rows, int r, int i) { return (((size_t)(i >> 6) * rows + r) * 64 + (size_t)(i & 63)) * 4; }
 // blob row (include/taco_env.h "State blob") -> chunk * 4 + component; -1 for the rows that are not stored as such
 // (actions / actions_old live in the action history, see export_state_kernel)
 __host__ __device__ constexpr int field_slot(int f) {
@@ -88,14 +94,15 @@ __host__ __device__ constexpr int field_slot(int f) {
 // two bits per run, oldest run in bits 1:0) and  m | rem0 << 8  (number of runs, slots left in the oldest run)
 __host__ __device__ constexpr int run_len(int lens, int j) { return 9 + ((lens >> (2 * j)) & 3); }
 
-constexpr uint32_t kDebugSlowServer = 1u << 31;  // StepParams.flags: test hook, see taco_capi.hip derive()
+constexpr uint32_t kDebugSlowServer = 1u << 31;  // StepParams.flags: test hook, compiled only under -DTACO_TEST_HOOKS (taco_capi.hip derive())
 enum : uint32_t { STREAM_RESET = 1, STREAM_CMD = 2, STREAM_DEPLOY = 3, STREAM_ROTOR = 4, STREAM_OBS = 5 };
 
 
-// ---- memory access.  State and ring rows are reached through 128-bit buffer descriptors: one VGPR holds the lane's byte
-// offset (4*i) for EVERY row, the row offset (field * npad * 4) rides in the scalar soffset operand.  With plain 64-bit
-// pointers each of the 67 + 40 row addresses would occupy a VGPR pair for the whole kernel (measured: > 130 VGPRs).
-// Out-of-range accesses are dropped / return 0 by the hardware range check instead of faulting.
+// ---- memory access.  State, history and ring rows are reached through 128-bit buffer descriptors BASED AT THE WAVEFRONT'S TILE
+// (the base is wave-uniform scalar arithmetic): one VGPR holds the lane's byte offset inside a row (16 * (i % 64)) for EVERY row of
+// every array, the row offset (row * 1024) rides in the scalar soffset operand.  With plain 64-bit pointers each of the row addresses
+// would occupy a VGPR pair for the whole kernel (measured: > 130 VGPRs).  Accesses outside the tile's block are dropped / return 0
+// by the hardware range check instead of faulting.
 // The intrinsics are declared directly (the composable_kernel idiom): on this toolchain (clang 22 / ROCm 7.2)
 // __builtin_amdgcn_raw_buffer_load_b128 lowers to a ONE-dword load whose value is splat over the vector.
 typedef int rsrc_t __attribute__((ext_vector_type(4)));
@@ -524,9 +531,10 @@ TD void reset_env(const StepParams &P, rsrc_t rS, rsrc_t rR, uint32_t voff, uint
 }
 
 
-// Instantiations (host side: choose_geometry in taco_capi.hip): BLOCK = 64 for the latency regime (few envs: one wavefront per
-// workgroup, spread over as many CUs as possible, registers unconstrained) and BLOCK = 256 for the throughput regime, where the
-// register budget is capped at 128 VGPRs so that 4 wavefronts per SIMD hide each other's dependent-issue latency.
+// Instantiations (host side: choose_form in taco_capi.hip): one wavefront per workgroup everywhere except the four-role forms (a workgroup
+// is then replaced on its CU as soon as ITS wavefront is done, instead of waiting for the slowest of four: 175 vs 182 us at 1 M envs);
+// registers unconstrained in the latency regime, capped at 128 VGPRs (CAP) in the throughput regime so that 4 wavefronts per SIMD hide
+// each other's dependent-issue latency and memory waits.
 // LPE (lanes per env) = 4 for launches that cannot fill the chip with one lane per env (4 096 envs = 64 wavefronts on 1 024 SIMDs):
 // a wavefront then carries 16 envs; everything outside the substep loop runs the scalar code redundantly in the four lanes of an env
 // (sub-lane 0 does the stores), the substep loop runs in the quad layout above.  SPLIT: the four-role form, see the kernel.
@@ -561,9 +569,12 @@ constexpr int CARRY_WORDS = 32;  // 30 used
 // stack) on their own SIMDs while wave 0 stores the state, so the post-phase critical path is the longest part instead of the sum.  While
 // they wait, waves 2 and 3 move the history of the frame stacks (which does not depend on this step) and wave 1 serves the battery model
 // (launches of at most 4 096 envs, where every wavefront has a SIMD to itself).
-template <int BLOCK, int LPE, bool SPLIT = false>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 256 ? 4 : 1, (BLOCK >= 256 && !SPLIT) ? 4 : 8))) void taco_step_kernel(const StepParams P) {
+// CAP (LPE = 1, BLOCK = 64, not SPLIT): the throughput instantiation -- at most 128 VGPRs, so that four wavefronts share a SIMD, and
+// only the loop forms that fit that budget.
+template <int BLOCK, int LPE, bool SPLIT = false, bool CAP = false>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT || CAP) ? 4 : 1, CAP ? 4 : 8))) void taco_step_kernel(const StepParams P) {
     static_assert(!SPLIT || BLOCK == 256, "SPLIT is the four-role form: one step wavefront + three role wavefronts per workgroup");
+    static_assert(!CAP || (BLOCK == 64 && LPE == 1 && !SPLIT), "CAP is the one-wavefront-per-workgroup throughput form");
     // Per-wavefront LDS scratch, used for two things one after the other:
     //   substeps : the 10 pending-action slots this step consumes, slots[s][lane] as float4 (10 KiB) -- keeps 40 values
     //              out of the register file and lets substep k fetch its action with one ds_read_b128;
@@ -590,6 +601,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
     // post-phase roles (SPLIT: wave 0 = the step itself; wave 1 = battery server, then reward + done; wave 2 = obs stack; wave 3 = states stack)
     const bool roleS = !SPLIT || wv == 3, roleO = !SPLIT || wv == 2, roleR = !SPLIT || wv == 1;
     const uint32_t wave_env0 = SPLIT ? (uint32_t)(blockIdx.x * 64 / LPE) : (uint32_t)((blockIdx.x * BLOCK + wv * 64) / LPE);  // first env of this wavefront
+    if (wave_env0 >= (uint32_t)P.n) return;  // a wavefront past the last env has nothing to do (SPLIT: the whole workgroup shares wave_env0, so
+                                             // the two barriers below stay uniform)
     // Frame stacks with len > 1: the wavefront's EPW rows are one contiguous range of EPW * len * 13 eight-byte words.  Word w of the new
     // stack is word w + 13 of the previous one (one frame further) inside the first len - 1 frames of its row (the HISTORY words), and
     // comes from this step's frame in the last frame of the row: the whole wavefront copies 512 contiguous bytes per instruction instead of
@@ -640,10 +653,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
     Carry K;
     const int i = in_range ? i_raw : P.n - 1;  // tail lanes shadow the last env and store nothing
     const int gid = P.env_offset + i;
-    const uint32_t voff = (uint32_t)i * 16u;            // this lane's byte offset inside every float4 row
-    const uint32_t row_bytes = (uint32_t)P.npad * 16u;  // one float4 row (chunk or ring slot)
-    const rsrc_t rS = make_rsrc(P.S, P.s_bytes);
-    const rsrc_t rR = make_rsrc(P.ring, P.ring_bytes);
+    const uint32_t voff = (uint32_t)(i & 63) * 16u;  // this lane's byte offset inside every row of its tile
+    constexpr uint32_t row_bytes = kRowBytes;         // one float4 row (chunk, history row or ring slot) of a tile
+    // all of a wavefront's envs lie in one tile (EPW divides 64; tail lanes shadow env n - 1 of the same wavefront)
+    const uint32_t tile_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wave_env0 >> 6));
+    const rsrc_t rS = make_rsrc(reinterpret_cast<const char *>(P.S) + (size_t)tile_id * (NUM_CHUNKS * kRowBytes), NUM_CHUNKS * kRowBytes);
+    const rsrc_t rR = make_rsrc(reinterpret_cast<const char *>(P.ring) + (size_t)tile_id * (TACO_RING_SLOTS * kRowBytes), TACO_RING_SLOTS * kRowBytes);
     const uint32_t fl = P.flags;
     const int grp = (P.task_mode != TACO_TASK_MIX) ? P.task_mode
                     : (gid < P.mix_n1 ? TACO_TASK_POS : (gid < P.mix_n2 ? TACO_TASK_ROTATE : TACO_TASK_FLIP));
@@ -685,7 +700,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
     float4 c_pos = CLD(C_POS), c_quat = CLD(C_QUAT), c_lin = CLD(C_LINVEL), c_ang = CLD(C_ANGVEL);
     float4 c_pp = CLD(C_PID_PREV), c_pi = CLD(C_PID_INT), c_om = CLD(C_OMEGA), c_que = CLD(C_QUEUE), c_misc = CLD(C_MISC);
     float4 c_tau = CLD(C_TAU), c_op = CLD(C_OPARA), c_a0 = CLD(C_AERO0), c_a1 = CLD(C_AERO1);
-    const rsrc_t rH = make_rsrc(P.hist, P.hist_bytes);
+    const rsrc_t rH = make_rsrc(reinterpret_cast<const char *>(P.hist) + (size_t)tile_id * (HIST_ROWS * kRowBytes), HIST_ROWS * kRowBytes);
     // the four most recent history rows (wave-uniform addresses): they hold the two oldest queued runs whenever the
     // queue is at most 4 runs deep, i.e. for delays up to ~40 ms; deeper queues fetch per lane further down
     float4 hwin[4];
@@ -1040,14 +1055,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
                 ++ks;
                 if (rare) break;
             }
-        } else if ((BLOCK != 256 || SPLIT) && fin && plain) {  // (the throughput instantiation keeps two forms: a third costs it 80 B of spills)
+        } else if (!CAP && fin && plain) {  // (the throughput instantiation keeps two forms: a third costs it 80 B of spills)
     #pragma unroll 1
             while (ks < 10) {
                 const bool rare = substep(std::integral_constant<int, 10>{}, ks);
                 ++ks;
                 if (rare) break;
             }
-        } else if (BLOCK != 256 && fin) {  // (the throughput instantiation keeps two forms: a third costs it spills at 128 VGPRs)
+        } else if (BLOCK != 256 && !CAP && fin) {  // (the 128-VGPR instantiations keep two or three forms: one more costs them spills)
     #pragma unroll 1
             while (ks < 10) {
                 const bool rare = substep(std::integral_constant<int, 1>{}, ks);
@@ -1316,7 +1331,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 
                     b = TACO_DIVC(mb_om[el * 4 + 3] * 2.0f * kPi, 4500.0f); Pm = Pm + 400.0f * ((b * b) * b);
                 }
                 const float V = battery_step(P.dt, Pm, bE, bu1, bt);
+#ifdef TACO_TEST_HOOKS
                 if (P.flags & kDebugSlowServer) { for (int z = 0; z < 40; ++z) __builtin_amdgcn_s_sleep(100); }  // test hook: arrive late
+#endif
                 if (sub == 0) mb_v[el] = V;
                 if (ks == 9 && sub == 0) { mb_bs[el * 4] = bE; mb_bs[el * 4 + 1] = bu1; mb_bs[el * 4 + 2] = bt; }
                 MB_POST(1, ks == 9 ? 11 : ks + 1);

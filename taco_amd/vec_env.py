@@ -41,11 +41,12 @@ class FpvBase:
     num_commands = 2
 
     def __init__(self, cfg, rl_device="cuda:0", sim_device="cuda:0", graphics_device_id=-1, headless=True,
-                 virtual_screen_capture=False, force_render=False, env_offset=0, num_envs_local=None, copy_outputs=True):
+                 virtual_screen_capture=False, force_render=False, env_offset=0, num_envs_local=None, copy_outputs=True, kernel_form="auto",
+                 lib=None):
         self.cfg = cfg
         if self.task_mode is not None:
             cfg["task_mode"] = self.task_mode
-        self.lib = _lib.load()  # raises if libtaco_env.so is missing: no fallback
+        self.lib = lib or _lib.load()  # raises if libtaco_env.so is missing: no fallback
         self.device = torch.device(sim_device)
         if self.device.type != "cuda":
             raise _lib.TacoError("the step kernel runs on an MI355X; sim_device must be a cuda:N (HIP) device")
@@ -92,6 +93,17 @@ class FpvBase:
             _lib.check(self.lib.taco_create(C.byref(self._c), dev.index or 0, C.c_void_p(self._workspace.data_ptr()), nbytes,
                                             _stream_ptr(dev), C.byref(self._h)))
         self._difficulty = float(cfg["difficulty"])
+        if kernel_form != "auto":
+            self.set_kernel_form(kernel_form)
+
+    def set_kernel_form(self, name):
+        """pin one of the five instantiations of the step kernel (`_lib.FORMS`; "auto" = the library's choice for this env count)"""
+        _lib.check(self.lib.taco_set_kernel_form(self._h, _lib.FORMS[name]), self.lib)
+
+    @property
+    def kernel_form(self):
+        f = self.lib.taco_get_kernel_form(self._h)
+        return next(k for k, v in _lib.FORMS.items() if v == f)
 
     # ---- spaces / attributes the callers read (train_fpv_asymmetry_ppo.py:372-393, ppo_asymmetry.py:42-52)
     @property

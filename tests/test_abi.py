@@ -33,8 +33,20 @@ def test_every_declared_symbol_is_exported(lib):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/taco_env.h but not exported"
     assert sorted(_lib.EXPORTS) == names, "binding list out of sync with the header"
-    assert lib.taco_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.taco_abi_version() == _lib.ABI_VERSION == 3
     assert lib.taco_step_kernel_name() == b"taco_step_kernel"
+
+
+def test_binary_is_tied_to_its_sources_and_reads_no_environment(lib):
+    """the library carries the hash of the sources it was built from (a stale binary is rebuilt, never loaded), and the product build
+    has no test hook and no getenv: launch geometry and debug switches are explicit API (taco_set_kernel_form) or a separate
+    -DTACO_TEST_HOOKS build"""
+    from taco_amd import build
+    assert lib.taco_source_hash().decode() == build.source_hash() == build.embedded_hash(build.LIB)
+    syms = subprocess.check_output(["nm", "-D", build.LIB]).decode()
+    assert "getenv" not in syms
+    assert "taco_test_slow_battery_server" not in syms
+    assert lib.taco_set_kernel_form(None, 0) == -1 and lib.taco_get_kernel_form(None) == -1
 
 
 def test_struct_layout_matches_the_header():

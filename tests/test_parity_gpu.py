@@ -21,12 +21,15 @@ def action_stream(n, steps, seed):
     return np.clip(a, -1, 1).astype(np.float32)
 
 
-def run_pair(cfg, steps, seed=0, check_every=1, hover_bias=False):
+def run_pair(cfg, steps, seed=0, check_every=1, hover_bias=False, form="auto", lib=None, slow_server=False):
     from oracle import oracle as O
+    from taco_amd import _lib
     from taco_amd.vec_env import FpvBase
     flat = config.flat_cfg(cfg)
     n = flat["num_envs"]
-    env = FpvBase(cfg, copy_outputs=False)
+    env = FpvBase(cfg, copy_outputs=False, kernel_form=form, lib=lib)
+    if slow_server:
+        _lib.check(lib.taco_test_slow_battery_server(env._h, 1), lib)
     orc = O.OracleEnv(flat, threads=8)
     gids = np.arange(n)
     if flat["task_mode"] == "mix":
@@ -125,23 +128,19 @@ def test_delay_line_overflow_regime():
     run_pair(cfg, steps=500, check_every=5, hover_bias=True)
 
 
-@pytest.mark.parametrize("geom", [None, ("4", "64", "0"), ("1", "64", "0"), ("1", "256", "0"), ("1", "64", "1")])
+@pytest.mark.parametrize("form", ["auto", "quad", "lane", "lane_throughput", "lane_roles"])
 @pytest.mark.parametrize("len_obs", [1, 3])
-def test_gather_block_matches_outputs(len_obs, geom, monkeypatch):
+def test_gather_block_matches_outputs(len_obs, form):
     """the packed per-rank block the kernel fills for the all-gather == pack_block(obs, rew, done, time_outs), in every instantiation
     (role wavefronts: the obs wavefront writes the obs part of a row, the reward wavefront its three tail words)"""
     import ctypes as C
-    if geom:
-        monkeypatch.setenv("TACO_FORCE_LPE", geom[0])
-        monkeypatch.setenv("TACO_FORCE_BLOCK", geom[1])
-        monkeypatch.setenv("TACO_FORCE_SPLIT", geom[2])
     from taco_amd import dist, _lib
     from taco_amd.vec_env import FpvBase
     n = 300
     cfg = config.baseline_config(4, num_envs=n)
     cfg["env"]["lenObservations"] = len_obs
     cfg["env"]["maxEpisodeLength"] = 30
-    env = FpvBase(cfg, copy_outputs=False)
+    env = FpvBase(cfg, copy_outputs=False, kernel_form=form)
     assert env.lib.taco_gather_row_floats(len_obs) == dist.block_row(len_obs)
     block = torch.full((n, dist.block_row(len_obs)), -7.0, device="cuda")
     _lib.check(env.lib.taco_bind_gather_block(env._h, C.c_void_p(block.data_ptr())))
@@ -182,7 +181,7 @@ def test_state_blob_roundtrip_and_restore():
 
 
 @pytest.mark.parametrize("task,n", [("pos", 1000), ("mix", 333), ("flip", 257), ("rotate", 4096)])
-def test_quad_layout_equals_one_lane_per_env(task, n, monkeypatch):
+def test_quad_layout_equals_one_lane_per_env(task, n):
     """The five instantiations of the step kernel (4 lanes per env with and without the role wavefronts / 1 lane per env with 64- and
     256-thread workgroups and with role wavefronts) are the same function: every output and every state word bit-identical, all randomisation on, stacked frames."""
     from taco_amd.vec_env import FpvBase
@@ -190,32 +189,33 @@ def test_quad_layout_equals_one_lane_per_env(task, n, monkeypatch):
     if task == "mix":
         kw.update(rotor_noise=True, observation_noise=True, ramdom_deploy_time=True, ramdom_delay_time=True)
     envs = []
-    for lpe, block, split in (("4", "64", "0"), ("1", "64", "0"), ("1", "256", "0"), ("4", "64", "1"), ("1", "64", "1")):
-        monkeypatch.setenv("TACO_FORCE_LPE", lpe)
-        monkeypatch.setenv("TACO_FORCE_BLOCK", block)
-        monkeypatch.setenv("TACO_FORCE_SPLIT", split)
-        e = FpvBase(config.default_cfg(task, n, **kw), copy_outputs=False)
-        assert e.launch_geometry() == (((n * int(lpe) + 63) // 64, 256) if split == "1" else ((n * int(lpe) + int(block) - 1) // int(block), int(block)))
+    for form, lpe, block in (("quad", 4, 64), ("lane", 1, 64), ("lane_throughput", 1, 64), ("quad_roles", 4, 256), ("lane_roles", 1, 256)):
+        e = FpvBase(config.default_cfg(task, n, **kw), copy_outputs=False, kernel_form=form)
+        assert e.kernel_form == form
+        assert e.launch_geometry() == ((n * lpe + 63) // 64, block)  # one step wavefront per 64 / lpe envs in every form
         envs.append(e)
     acts = torch.from_numpy(action_stream(n, 90, 4)).cuda()
     for t in range(90):
         for e in envs:
             e.step_raw(acts[t])
         ref = envs[1]
-        for e in (envs[0], envs[2], envs[3]):
+        for e in (envs[0], envs[2], envs[3], envs[4]):
             for name in ("obs_buf", "states_buf", "rew_buf", "reset_buf", "timeout_buf"):
                 assert_bits_equal(getattr(e, name).cpu().numpy(), getattr(ref, name).cpu().numpy(), f"step {t} {name}")
         if t % 10 == 9:
             b = [e.get_state().view(torch.int32) for e in envs]
-            assert torch.equal(b[0], b[1]) and torch.equal(b[2], b[1]) and torch.equal(b[3], b[1]), f"step {t} state blob"
+            assert all(torch.equal(x, b[1]) for x in b), f"step {t} state blob"
     assert int(envs[1].reset_buf.sum()) >= 0
 
 
-def test_battery_mailbox_wait_path(monkeypatch):
+def test_battery_mailbox_wait_path():
     """The role-wavefront battery server normally posts each voltage long before wavefront 0 needs it; with the server delayed on purpose
-    (test hook) wavefront 0 has to take the mailbox's wait path every substep -- the results must not change."""
-    monkeypatch.setenv("TACO_DEBUG_SLOW_SERVER", "1")
-    run_pair(config.baseline_config(1, num_envs=512), steps=40)
+    (taco_test_slow_battery_server of the -DTACO_TEST_HOOKS build; the product library has no such hook) wavefront 0 has to take the
+    mailbox's wait path every substep -- the results must not change."""
+    from taco_amd import _lib
+    hooks = _lib.load_test_hooks()
+    assert not hasattr(_lib.load(), "taco_test_slow_battery_server"), "the product library must not carry test hooks"
+    run_pair(config.baseline_config(1, num_envs=512), steps=40, lib=hooks, slow_server=True)
 
 
 def test_random_configurations():
@@ -234,17 +234,13 @@ def test_random_configurations():
             raise AssertionError(f"case {i}: {fuzz.describe(cfg)}: {e}") from e
 
 
-@pytest.mark.parametrize("geom", [None, ("4", "64", "0"), ("1", "64", "0"), ("1", "256", "0"), ("1", "64", "1")])
-def test_loop_forms_hand_over_on_rare_forms_and_nonfinite_inputs(geom, monkeypatch):
+@pytest.mark.parametrize("form", ["auto", "quad", "lane", "lane_throughput", "lane_roles"])
+def test_loop_forms_hand_over_on_rare_forms_and_nonfinite_inputs(form):
     """The substep loop runs a FIN form (no NaN-carrying selects) and a PLAIN form (compile-time flags, unrolled integrator) while a
     wave-uniform predicate says they are the same function as the exact form.  Two stress cases against the oracle, in every
     instantiation: (1) an airframe with 1/3000 of the inertia -- body rates shoot past the integrator's common form within a few
     substeps, at different substeps in different envs (hand-over in mid-step), and run on to inf / NaN; (2) NaN, inf and huge
     actions (the predicate is false from the first substep for the wavefronts that consume them, `delay_time` ms later)."""
-    if geom:
-        monkeypatch.setenv("TACO_FORCE_LPE", geom[0])
-        monkeypatch.setenv("TACO_FORCE_BLOCK", geom[1])
-        monkeypatch.setenv("TACO_FORCE_SPLIT", geom[2])
     from oracle import oracle as O
     from taco_amd.vec_env import FpvBase
     n = 300
@@ -254,12 +250,12 @@ def test_loop_forms_hand_over_on_rare_forms_and_nonfinite_inputs(geom, monkeypat
         _, J = config.composite_body()
         cfg["inertia"] = tuple(j * scale for j in J)
         cfg["env"]["maxEpisodeLength"] = 40
-        run_pair(cfg, steps=60, seed=3, hover_bias=True)
+        run_pair(cfg, steps=60, seed=3, hover_bias=True, form=form)
     # (2) non-finite / huge actions in some envs, some steps
     cfg = config.baseline_config(1, num_envs=n)
     cfg["env"]["maxEpisodeLength"] = 50
     flat = config.flat_cfg(cfg)
-    env = FpvBase(cfg, copy_outputs=False)
+    env = FpvBase(cfg, copy_outputs=False, kernel_form=form)
     orc = O.OracleEnv(flat, threads=8)
     acts = action_stream(n, 70, 5)
     rng = np.random.default_rng(9)
