@@ -129,7 +129,7 @@ const char *taco_source_hash(void);
 /* Thread-local text of the last error on this thread ("" if none). */
 const char *taco_last_error(void);
 
-/* Bytes of device workspace taco_create needs for `cfg` (17 float4 state chunks + 16 float4 action-history rows +
+/* Bytes of device workspace taco_create needs for `cfg` (16 float4 state chunks + 16 float4 action-history rows +
  * 100 float4 ring slots per env, laid out in tiles of 64 envs, env count padded to whole tiles; the pointer must be
  * 256-byte aligned). */
 size_t taco_workspace_bytes(const taco_cfg *cfg);

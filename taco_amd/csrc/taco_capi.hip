@@ -48,6 +48,7 @@ struct taco_env {
     int slow_server;
 #endif
     int form;  // TACO_FORM_* the step launches (never TACO_FORM_AUTO here: resolved by choose_form)
+    int params_imported;  // taco_set_state has been called: rotor / aero parameters may differ per env from now on (see kUniformParams)
     float *gather;  // optional per-rank all-gather block, see taco_bind_gather_block
     unsigned long long *stamps;  // optional phase stamps, see taco_bind_phase_stamps
     taco::StepParams P;
@@ -93,7 +94,8 @@ bool cfg_ok(const taco_cfg *c) {
     if (c->control_freq_inv != 10) return fail(0, "control_freq_inv must be 10 (the delay line holds 10 one-ms slots per action)"), false;
     if (c->substeps < 1 || c->substeps > 8) return fail(0, "substeps must be in 1..8"), false;
     if (c->delay_time < 0 || c->delay_time > 90) return fail(0, "delay_time must be in 0..90 ms"), false;
-    if (c->max_episode_length < 2) return fail(0, "max_episode_length must be >= 2"), false;
+    if (c->max_episode_length < 2 || c->max_episode_length > taco::kProgressMax)
+        return fail(0, "max_episode_length must be in 2..65535 (progress_buf is kept in 16 bits)"), false;
     if (c->dt > 0 && !div_const_is_exact((float)c->dt))
         return fail(0, "this dt is not supported: x / dt cannot be evaluated exactly as a multiply-and-correct (use dt = 0.001, the rotor model's fixed sample time)"), false;
     if (!(c->dt > 0) || !(c->mass > 0) || !(c->inertia[0] > 0) || !(c->inertia[1] > 0) || !(c->inertia[2] > 0))
@@ -133,6 +135,22 @@ void derive(taco_env *e) {
     P.tau_lo = (float)(c.rotor_response_time - 0.001);
     P.tau_fixed = (float)c.rotor_response_time;
     P.nq_sc = (float)((d * 0.05) - (-(d * 0.05))); P.nq_lo = (float)(-(d * 0.05));                        // fpv_asymmetry.py:405
+    {   // how many history rows the up-front loads fetch = the deepest run queue this configuration reaches before a push: with the deploy
+        // length fixed at 10 slots an env that starts from L pending slots never queues more than max(1, ceil(L / 10)) runs (brute-forced
+        // over L = 0..40 in DESIGN.md section 3); a random deploy length lets the queue grow until the env turns DENSE
+        const int l_max = c.delay_time + ((c.flags & TACO_F_RANDOM_DELAY_TIME) ? 3 : 0);
+        int rows = (c.flags & TACO_F_RANDOM_DEPLOY_TIME) ? 4 : (l_max + 9) / 10;
+        P.hw_rows = rows < 1 ? 1 : (rows > 4 ? 4 : rows);
+        if (e->params_imported) P.hw_rows = 4;  // an imported blob may hold any queue
+        // rotor / aero parameters identical in every env: init_state_kernel and reset_env write the same nominal values when nothing
+        // randomises them (reset_env writes tau = rotor_response_time only with ROTOR_RESPONSE on) and no blob has been imported
+        const uint32_t rnd = TACO_F_RANDOM_ROTORDYNAMIC_COE | TACO_F_RANDOM_AERODYNAMIC_COE | TACO_F_RANDOM_ROTOR_RESPONSE;
+        if (!(c.flags & rnd) && (c.flags & TACO_F_ROTOR_RESPONSE) && !e->params_imported) P.flags |= taco::kUniformParams;
+    }
+    {   // the PLAIN loop forms of the one-lane kernels carry the default airframe's constants as literals (taco_step.hpp kDefaultConsts)
+        const taco::Consts mine{P.dt, P.rdt, P.h, P.half_h, P.inv_m, P.g, P.J0, P.J1, P.J2, P.hJi0, P.hJi1, P.hJi2, P.arm_x, P.arm_y};
+        if (std::memcmp(&mine, &taco::kDefaultConsts, sizeof(mine)) == 0) P.flags |= taco::kPlainConsts;
+    }
 }
 
 // Initial state = what the reference holds after construction, before the first step (fpv_asymmetry.py:124-200,
@@ -163,7 +181,8 @@ __global__ void init_state_kernel(float *S, float *hist, float *ring, int npad, 
     word(S, npad, i, TACO_S_DX) = -0.386f;
     word(S, npad, i, TACO_S_DY) = -0.53f;
     word(S, npad, i, TACO_S_KT) = 0.009f;
-    word(S, npad, i, TACO_S_DELAY_LEN) = __builtin_bit_cast(float, delay_time | (delay_time << 16));  // L | Z << 16: all implied zeros
+    word(S, npad, i, TACO_S_DELAY_LEN) = __builtin_bit_cast(float, (int)taco::make_dw(delay_time, delay_time, 0, 0, 0, false));  // Z = L: all implied zeros
+    word(S, npad, i, TACO_S_PROGRESS) = __builtin_bit_cast(float, (int)taco::make_pw(0, 0));
 }
 
 // blob (include/taco_env.h layout: field-major words, logical dense delay line) <-> workspace (float4 chunks; pending
@@ -173,17 +192,20 @@ __global__ void export_state_kernel(const float *S, const float *hist, const flo
     const int row = blockIdx.y;
     if (i >= n) return;
     float *Sm = const_cast<float *>(S);
-    const int dl = __builtin_bit_cast(int, word(Sm, npad, i, TACO_S_DELAY_LEN));
-    const int L = dl & 0xffff, Z = (dl >> 16) & 0xff;
-    const bool dense = dl < 0;
+    const uint32_t dl = __builtin_bit_cast(uint32_t, word(Sm, npad, i, TACO_S_DELAY_LEN));  // taco_step.hpp "queue words"
+    const uint32_t pw = __builtin_bit_cast(uint32_t, word(Sm, npad, i, TACO_S_PROGRESS));
+    const int L = taco::dw_L(dl), Z = taco::dw_Z(dl);
+    const bool dense = taco::dw_dense(dl);
     float val;
     if (row == TACO_S_DELAY_LEN) {
         val = __builtin_bit_cast(float, L);
     } else if (row >= TACO_S_ACT && row < TACO_S_ACT + 4) {            // actions = the action of the last step
         val = hist[taco::tile_word(taco::HIST_ROWS, (hh - 1) & (taco::HIST_ROWS - 1), i) + (row - TACO_S_ACT)];
     } else if (row >= TACO_S_ACT_OLD && row < TACO_S_ACT_OLD + 4) {    // actions_old = the one before, 0 right after a reset (FA:572-573)
-        const int progress = __builtin_bit_cast(int, word(Sm, npad, i, TACO_S_PROGRESS));
+        const int progress = taco::pw_progress(pw);
         val = (progress <= 1) ? 0.0f : hist[taco::tile_word(taco::HIST_ROWS, (hh - 2) & (taco::HIST_ROWS - 1), i) + (row - TACO_S_ACT_OLD)];
+    } else if (row == TACO_S_PROGRESS) {
+        val = __builtin_bit_cast(float, taco::pw_progress(pw));
     } else if (row < TACO_NUM_FIELDS) {
         val = word(Sm, npad, i, row);
     } else {
@@ -191,9 +213,7 @@ __global__ void export_state_kernel(const float *S, const float *hist, const flo
         if (dense) {
             val = ring[taco::tile_word(TACO_RING_SLOTS, (head + slot) % TACO_RING_SLOTS, i) + ch];
         } else {  // expand [Z zeros | run_0 (rem0) | run_1 | ... ] ; beyond L: zeros
-            const int lens = __builtin_bit_cast(int, S[taco::tile_word(taco::NUM_CHUNKS, taco::C_QUEUE, i) + 0]);
-            const int mr = __builtin_bit_cast(int, S[taco::tile_word(taco::NUM_CHUNKS, taco::C_QUEUE, i) + 1]);
-            const int m = mr & 0xff, rem0 = (mr >> 8) & 0xff;
+            const int lens = taco::qw_lens(dl, pw), m = taco::dw_m(dl), rem0 = taco::dw_rem0(dl);
             val = 0.0f;
             int pos = Z;
             for (int j = 0; j < m && slot >= pos; ++j) {
@@ -212,9 +232,10 @@ __global__ void import_state_kernel(float *S, float *hist, float *ring, const ui
     float val = __builtin_bit_cast(float, blob[(size_t)row * n + i]);
     if (row == TACO_S_DELAY_LEN) {
         // an imported delay line is arbitrary content: the env becomes DENSE (literal slot ring), its run queue empty
-        val = __builtin_bit_cast(float, (int)((__builtin_bit_cast(uint32_t, val) & 0xffffu) | 0x80000000u));
-        for (int k = 0; k < 4; ++k) S[taco::tile_word(taco::NUM_CHUNKS, taco::C_QUEUE, i) + k] = 0.0f;
+        const int L = (int)(__builtin_bit_cast(uint32_t, val) & 0x7fu);
+        val = __builtin_bit_cast(float, (int)taco::make_dw(L > TACO_RING_SLOTS ? TACO_RING_SLOTS : L, 0, 0, 0, 0, true));
     }
+    if (row == TACO_S_PROGRESS) val = __builtin_bit_cast(float, (int)taco::make_pw(__builtin_bit_cast(int, val) < 0 ? 0 : __builtin_bit_cast(int, val), 0));
     if (row >= TACO_S_ACT && row < TACO_S_ACT + 4) {
         hist[taco::tile_word(taco::HIST_ROWS, (hh - 1) & (taco::HIST_ROWS - 1), i) + (row - TACO_S_ACT)] = val;
     } else if (row >= TACO_S_ACT_OLD && row < TACO_S_ACT_OLD + 4) {
@@ -307,6 +328,7 @@ int taco_create(const taco_cfg *cfg, int device, void *workspace, size_t workspa
     e->hh = 0;
     e->gather = nullptr;
     e->stamps = nullptr;
+    e->params_imported = 0;
     e->form = choose_form(e->cfg);
     std::memset(&e->P, 0, sizeof(e->P));
     derive(e);
@@ -444,7 +466,12 @@ int taco_set_state(taco_env *e, const uint32_t *blob, void *stream) {
     hipLaunchKernelGGL(import_state_kernel, dim3((n + 255) / 256, TACO_BLOB_ROWS), dim3(256), 0, (hipStream_t)stream, e->S, e->hist, e->ring, blob, n,
                        e->npad, e->head, e->hh);
     hipError_t he = hipGetLastError();
-    return he == hipSuccess ? TACO_OK : hip_fail(he, "import_state_kernel launch");
+    if (he != hipSuccess) return hip_fail(he, "import_state_kernel launch");
+    if (!e->params_imported) {  // the blob may carry per-env rotor / aero parameters and any queue depth: stop assuming otherwise
+        e->params_imported = 1;
+        derive(e);
+    }
+    return TACO_OK;
 }
 
 int taco_launch_geometry(const taco_env *e, int *grid, int *block) {

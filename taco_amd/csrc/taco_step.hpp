@@ -38,6 +38,8 @@ struct StepParams {
     int n, npad, env_offset, task_mode, mix_n1, mix_n2, len_obs, len_states, substeps, max_len, delay_time, head;
     uint32_t flags, seed_lo, seed_hi, step;
     int hh;              // history row this step writes (= number of steps taken so far, mod 16)
+    int hw_rows;         // how many of the most recent history rows the up-front loads fetch (1..4): the deepest run queue this configuration
+                         // can reach (taco_capi.hip derive()); lanes with a deeper queue gather per lane -- a performance hint, never semantics
     uint32_t obs_bytes, states_bytes, gather_bytes, gather_row;  // gather_row = floats per env in the gather block (multiple of 32)
     // fp32 images of the Python doubles the reference feeds into tensor ops
     float dt, rdt, clip_act, df;  // rdt = RN(1/dt); taco_create refuses a dt for which div_const(x, dt, rdt) != x / dt
@@ -52,27 +54,27 @@ struct StepParams {
 // ([chunk][npad]): with num_envs a power of two the 17 + 4 streams of a wavefront were then exactly 2^k bytes apart and fell on the
 // same HBM channels (tools/ubench/layout: 4.2-4.7 TB/s for the step's access pattern at 1 M envs against 5.3-5.7 TB/s tile-major).
 // Words that travel together share a chunk.
-// Pending actions: a run-length queue (C_QUEUE) over the action history hist[16][npad] float4 while an env is in the
-// common regime, the literal slot ring ring[100][npad] float4 (PHYSICAL slot order) once it is DENSE (see the kernel).
+// Pending actions: a run-length queue (packed into the spare bits of C_POS.w / C_LINVEL.w, see below) over the action history
+// hist[tile][16][64] float4 while an env is in the common regime, the literal slot ring ring[tile][100][64] float4 (PHYSICAL slot order)
+// once it is DENSE (see the kernel).
 enum Chunk : uint32_t {
-    C_POS = 0,      // p.x p.y p.z | progress (int)
+    C_POS = 0,      // p.x p.y p.z | progress (16 bits) + run-length codes 0..7 (see "queue words")
     C_QUAT = 1,     // q.x q.y q.z q.w
-    C_LINVEL = 2,   // v.x v.y v.z | delay word (see the kernel)
+    C_LINVEL = 2,   // v.x v.y v.z | delay word (see "queue words")
     C_ANGVEL = 3,   // w.x w.y w.z | battery voltage
     C_PID_PREV = 4, // previous_error xyz | battery E_c
     C_PID_INT = 5,  // integral xyz | battery u_1
     C_OMEGA = 6,    // rotor speeds
-    C_QUEUE = 7,    // pending-action run queue: run-length codes | count + remainder of the oldest run | - | -
-    C_MISC = 8,     // battery time | command[0] | command[1] | flip_radian
-    C_RPY_OLD = 9,  // xyz | -
-    C_RPY_CONT = 10,
-    C_TGT_POS = 11, // xyz | -
-    C_TGT_QUAT = 12,
-    C_TAU = 13,     // rotor response times
-    C_OPARA = 14,   // omega_para[0..3]
-    C_AERO0 = 15,   // omega_para[4] | cf | ct | dx
-    C_AERO1 = 16,   // dy | kt | - | -
-    NUM_CHUNKS = 17
+    C_MISC = 7,     // battery time | command[0] | command[1] | flip_radian
+    C_RPY_OLD = 8,  // xyz | -
+    C_RPY_CONT = 9,
+    C_TGT_POS = 10, // xyz | -
+    C_TGT_QUAT = 11,
+    C_TAU = 12,     // rotor response times
+    C_OPARA = 13,   // omega_para[0..3]
+    C_AERO0 = 14,   // omega_para[4] | cf | ct | dx
+    C_AERO1 = 15,   // dy | kt | - | -
+    NUM_CHUNKS = 16
 };
 constexpr int HIST_ROWS = 16;  // action history: hist[tile][k][64] float4, the action of the step whose (count & 15) == k
 constexpr uint32_t kRowBytes = 1024;  // one row (chunk, history row or ring slot) of one tile: 64 lanes x 16 B
@@ -90,10 +92,42 @@ __host__ __device__ constexpr int field_slot(int f) {
          : f < 59 ? C_OPARA * 4 + (f - 55) : f == 59 ? C_AERO0 * 4 + 0 : f == 60 ? C_AERO0 * 4 + 1 : f == 61 ? C_AERO0 * 4 + 2
          : f == 62 ? C_AERO0 * 4 + 3 : f == 63 ? C_AERO1 * 4 + 0 : f == 64 ? C_AERO1 * 4 + 1 : f == 65 ? C_POS * 4 + 3 : C_LINVEL * 4 + 3;
 }
-// delay word (C_LINVEL.w): bits 0..15 L, bits 16..23 Z, bit 31 DENSE.  queue words (C_QUEUE.x/.y): run-length codes (T - 9,
-// two bits per run, oldest run in bits 1:0) and  m | rem0 << 8  (number of runs, slots left in the oldest run)
+// queue words.  The pending-action bookkeeping of an env is 43 bits and rides in the fourth words of two chunks the step rewrites anyway
+// (round 1 gave it a chunk of its own: 16 B read + 16 B written per env-step for 8 B of content):
+//   C_LINVEL.w  bits 0..6 L (pending slots) | 7..13 Z (leading reset-zeros) | 14..17 m (queued runs) | 18..21 rem0 (slots left in the oldest
+//               run) | 22..25 run-length codes 8, 9 | 31 DENSE
+//   C_POS.w     bits 0..15 progress_buf (saturates at 65 535; taco_create refuses max_episode_length > 65 535) | 16..31 run-length codes 0..7
+// run-length code = T - 9, two bits per run, oldest run first (at most 10 runs are ever queued: L + T <= 90 and every full run >= 9 slots)
+constexpr int kProgressMax = 0xffff;
+__host__ __device__ constexpr int dw_L(uint32_t a) { return (int)(a & 0x7fu); }
+__host__ __device__ constexpr int dw_Z(uint32_t a) { return (int)((a >> 7) & 0x7fu); }
+__host__ __device__ constexpr int dw_m(uint32_t a) { return (int)((a >> 14) & 0xfu); }
+__host__ __device__ constexpr int dw_rem0(uint32_t a) { return (int)((a >> 18) & 0xfu); }
+__host__ __device__ constexpr bool dw_dense(uint32_t a) { return (a >> 31) != 0u; }
+__host__ __device__ constexpr int qw_lens(uint32_t a, uint32_t pw) { return (int)((pw >> 16) | (((a >> 22) & 0xfu) << 16)); }
+__host__ __device__ constexpr int pw_progress(uint32_t pw) { return (int)(pw & 0xffffu); }
+__host__ __device__ constexpr uint32_t make_dw(int L, int Z, int m, int rem0, int lens, bool dense) {
+    return (uint32_t)L | ((uint32_t)Z << 7) | ((uint32_t)m << 14) | ((uint32_t)rem0 << 18) | ((((uint32_t)lens >> 16) & 0xfu) << 22) | (dense ? 0x80000000u : 0u);
+}
+__host__ __device__ constexpr uint32_t make_pw(int progress, int lens) {
+    return (uint32_t)(progress > kProgressMax ? kProgressMax : progress) | (((uint32_t)lens & 0xffffu) << 16);
+}
 __host__ __device__ constexpr int run_len(int lens, int j) { return 9 + ((lens >> (2 * j)) & 3); }
 
+// The fp32 constants of the PID / battery / rigid-body arithmetic.  As kernel arguments they are SGPR operands, and a VALU instruction with an
+// SGPR source costs TWO issue passes on gfx950 once the SIMD is shared (2.0-2.1 ns against 1.05 ns for VGPR / literal / inline operands:
+// tools/ubench/bank2, profiles/r02_a_ubench_bank2.txt) -- 52 of the 520 VALU instructions of a substep.  The PLAIN loop forms therefore
+// exist for the DEFAULT airframe and time step only (dt = 0.001, two sub-iterations, assets/xml/fpv_without_duct.xml, g = -9.81), with
+// these values as literals; taco_capi.hip derive() sets kPlainConsts when the handle's derived constants equal them bit for bit, any
+// other configuration runs the general forms.
+struct Consts { float dt, rdt, h, half_h, inv_m, g, J0, J1, J2, hJi0, hJi1, hJi2, arm_x, arm_y; };
+constexpr Consts kDefaultConsts = {0x1.0624dep-10f, 0x1.f3fffep+9f, 0x1.0624dep-11f, 0x1.0624dep-12f, 0x1.1642a8p+1f, -0x1.39eb86p+3f,
+                                   0x1.0690a2p-11f, 0x1.6f6c0ap-11f, 0x1.a3da2ap-11f, 0x1.ff2ddap-1f, 0x1.6d4bbap-1f, 0x1.3fadb2p-1f,
+                                   0x1.810624p-5f, 0x1.e353f8p-5f};
+constexpr uint32_t kPlainConsts = 1u << 30;      // StepParams.flags: the handle's constants are kDefaultConsts
+// StepParams.flags: rotor / aero parameters are the SAME for every env (none of them is randomised, the handle never imported a state
+// blob): the step then takes them from the kernel arguments instead of loading four chunks (64 B of the 329 B an env-step reads)
+constexpr uint32_t kUniformParams = 1u << 29;
 constexpr uint32_t kDebugSlowServer = 1u << 31;  // StepParams.flags: test hook, compiled only under -DTACO_TEST_HOOKS (taco_capi.hip derive())
 enum : uint32_t { STREAM_RESET = 1, STREAM_CMD = 2, STREAM_DEPLOY = 3, STREAM_ROTOR = 4, STREAM_OBS = 5 };
 
@@ -226,6 +260,9 @@ template <bool FIN = false> TD float pid_axis(float dt, float rdt, float kp, flo
     float FF = 0.0f * des;
     integ = I;
     prev = e;
+    // FIN: I and des are finite, so I_term and FF are +-0 and ((P + I_term) + D) + FF == P + D up to the sign of a zero result -- which no
+    // consumer can see: the allocator adds it to a sum that starts from u0 * 1 (never -0), and clamps an all-zero row to 100
+    if constexpr (FIN) return 0.4f * (P + D);
     return 0.4f * (P + I_term + D + FF);
 }
 TD float two_level(float d) { return 1.0f / (1.0f + d * d) + 1.0f / (1.0f + 10.0f * d * d); }
@@ -262,7 +299,7 @@ TD V3 quat_sandwich(Q4 q, V3 u) {
 // selected per lane, so the common case has no divergent control flow at all.
 // Returns (wave-uniformly) whether some lane took a rare form, i.e. whether the new body rates may be large, infinite or NaN.
 // SUBS: the sub-iteration count when it is known at compile time (the PLAIN loop form: 2, unrolled), 0 = P.substeps.
-template <int SUBS = 0> TD bool integrate(const StepParams &P, V3 &p, Q4 &q, V3 &v, V3 &wb, V3 F, V3 tq) {
+template <int SUBS = 0> TD bool integrate(const Consts &P, int substeps, V3 &p, Q4 &q, V3 &v, V3 &wb, V3 F, V3 tq) {
     float b0 = wb.x, b1 = wb.y, b2 = wb.z;
     bool any_big = false;
     auto iteration = [&]() {
@@ -311,7 +348,7 @@ template <int SUBS = 0> TD bool integrate(const StepParams &P, V3 &p, Q4 &q, V3 
         q.x = nx * inv; q.y = ny * inv; q.z = nz * inv; q.w = nw * inv;
     };
     if constexpr (SUBS == 2) { iteration(); iteration(); }
-    else for (int it = 0; it < P.substeps; ++it) iteration();
+    else for (int it = 0; it < substeps; ++it) iteration();
     wb = V3{b0, b1, b2};
     return any_big;
 }
@@ -439,7 +476,7 @@ TD void reset_env(const StepParams &P, rsrc_t rS, rsrc_t rR, uint32_t voff, uint
     } else {
         p.x = 0.0f; p.y = 0.0f; p.z = 2.5f;
     }
-    CST(C_POS, make_float4(p.x, p.y, p.z, as_f(0)));  // progress <- 0 (FA:510-511)
+    CST(C_POS, make_float4(p.x, p.y, p.z, as_f((int)make_pw(0, 0))));  // progress <- 0 (FA:510-511), no runs queued
     Q4 q{0.0f, 0.0f, 0.0f, 1.0f};
     if (fl & TACO_F_RANDOM_COPTER_QUAT) {  // rand_quat FA:698-704 (flip: limits (pi, 0, 0))
         const float l_sc = (grp == TACO_TASK_FLIP) ? 0.0f : pi_sc;
@@ -481,7 +518,8 @@ TD void reset_env(const StepParams &P, rsrc_t rS, rsrc_t rR, uint32_t voff, uint
             v = V3{3.0f * (2.0f * u6 + -1.0f), 3.0f * (2.0f * u7 + -1.0f), 3.0f * (2.0f * a0 + -1.0f)};
             w = V3{3.0f * (2.0f * a1 + -1.0f), 3.0f * (2.0f * a2 + -1.0f), 3.0f * (2.0f * a3 + -1.0f)};
         }
-        CST(C_LINVEL, make_float4(v.x, v.y, v.z, as_f(L | (L << 16))));  // Z = L: the whole pending line is reset-zeros
+        CST(C_LINVEL, make_float4(v.x, v.y, v.z, as_f((int)make_dw(L, L, 0, 0, 0, false))));  // Z = L: the whole pending line is reset-zeros
+                                                                                               // (FA:572-574), the run queue empty
         CST(C_ANGVEL, make_float4(w.x, w.y, w.z, 0.0f));  // battery_voltage <- 0 (FA:566)
     }
     // ---- reset_target_idx FA:523-548
@@ -526,7 +564,6 @@ TD void reset_env(const StepParams &P, rsrc_t rS, rsrc_t rR, uint32_t voff, uint
                                  ra ? 0.05f * (P.dr_sc * g0 + P.dr_lo) : ae0.z, ra ? -0.386f * (P.dr_sc * g1 + P.dr_lo) : ae0.w));
         CST(C_AERO1, make_float4(ra ? -0.53f * (P.dr_sc * g2 + P.dr_lo) : ae1.x, ra ? 0.009f * (P.dr_sc * g3 + P.dr_lo) : ae1.y, 0.0f, 0.0f));
     }
-    CST(C_QUEUE, make_float4(0.0f, 0.0f, 0.0f, 0.0f));  // empty run queue: the pending line is Z implied zeros (FA:572-574)
     (void)rR;  // the ring is NOT zeroed (FA:574): the delay-line word marks every pending slot as an implied zero
 }
 
@@ -698,22 +735,35 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
     const bool is_reset = P.reset[i] != 0;
     const float4 a_in = reinterpret_cast<const float4 *>(P.act_in)[i];
     float4 c_pos = CLD(C_POS), c_quat = CLD(C_QUAT), c_lin = CLD(C_LINVEL), c_ang = CLD(C_ANGVEL);
-    float4 c_pp = CLD(C_PID_PREV), c_pi = CLD(C_PID_INT), c_om = CLD(C_OMEGA), c_que = CLD(C_QUEUE), c_misc = CLD(C_MISC);
-    float4 c_tau = CLD(C_TAU), c_op = CLD(C_OPARA), c_a0 = CLD(C_AERO0), c_a1 = CLD(C_AERO1);
+    float4 c_pp = CLD(C_PID_PREV), c_pi = CLD(C_PID_INT), c_om = CLD(C_OMEGA), c_misc = CLD(C_MISC);
+    // rotor / aero parameters: per env only if something randomises them (launch-uniform switch, see kUniformParams)
+    const bool uniform_params = (P.flags & kUniformParams) != 0;
+    float4 c_tau, c_op, c_a0, c_a1;
+    if (uniform_params) {
+        const float t0 = P.tau_fixed * 1.0f;  // what reset_env and init_state_kernel hold for every env
+        c_tau = make_float4(t0, t0, t0, t0); c_op = make_float4(0.0f, 12.9466f, 0.1872f, -5.1220f);
+        c_a0 = make_float4(0.5906f, 1.13e-05f, 0.05f, -0.386f); c_a1 = make_float4(-0.53f, 0.009f, 0.0f, 0.0f);
+    } else {
+        c_tau = CLD(C_TAU); c_op = CLD(C_OPARA); c_a0 = CLD(C_AERO0); c_a1 = CLD(C_AERO1);
+    }
     const rsrc_t rH = make_rsrc(reinterpret_cast<const char *>(P.hist) + (size_t)tile_id * (HIST_ROWS * kRowBytes), HIST_ROWS * kRowBytes);
     // the four most recent history rows (wave-uniform addresses): they hold the two oldest queued runs whenever the
     // queue is at most 4 runs deep, i.e. for delays up to ~40 ms; deeper queues fetch per lane further down
     float4 hwin[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) hwin[k] = buf_ld4(rH, voff, (uint32_t)((P.hh - 1 - k) & (HIST_ROWS - 1)) * row_bytes);
+    for (int k = 0; k < 4; ++k) {  // (rows this configuration's queue never reaches are not fetched: P.hw_rows)
+        hwin[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (k < P.hw_rows) hwin[k] = buf_ld4(rH, voff, (uint32_t)((P.hh - 1 - k) & (HIST_ROWS - 1)) * row_bytes);
+    }
     // reset_idx (FA:475-517) writes the fresh state straight to the env's chunks (none of its 37 random draws or
     // temporaries stay live); a wavefront that holds a reset lane then simply loads its chunks again.
-    if (__builtin_amdgcn_ballot_w64(is_reset)) {
+    const bool wave_has_reset = __builtin_amdgcn_ballot_w64(is_reset) != 0;
+    if (wave_has_reset) {
         if (is_reset) reset_env(P, rS, rR, voff, row_bytes, gid, grp, mix, active);
         if (LPE > 1) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // sub-lane 0 stored, the whole quad reloads
         c_pos = CLD(C_POS); c_quat = CLD(C_QUAT); c_lin = CLD(C_LINVEL); c_ang = CLD(C_ANGVEL);
-        c_pp = CLD(C_PID_PREV); c_pi = CLD(C_PID_INT); c_om = CLD(C_OMEGA); c_que = CLD(C_QUEUE); c_misc = CLD(C_MISC);
-        c_tau = CLD(C_TAU); c_op = CLD(C_OPARA); c_a0 = CLD(C_AERO0); c_a1 = CLD(C_AERO1);
+        c_pp = CLD(C_PID_PREV); c_pi = CLD(C_PID_INT); c_om = CLD(C_OMEGA); c_misc = CLD(C_MISC);
+        if (!uniform_params) { c_tau = CLD(C_TAU); c_op = CLD(C_OPARA); c_a0 = CLD(C_AERO0); c_a1 = CLD(C_AERO1); }
     }
     if (P.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TACO_STAMP(1); }  // all up-front loads have landed
     V3 p{c_pos.x, c_pos.y, c_pos.z};
@@ -743,7 +793,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
     }
     float cmd0 = c_misc.y, cmd1 = c_misc.z, flip_radian = c_misc.w;
     const float cf = c_a0.y, ct = c_a0.z, dx = c_a0.w, dy = c_a1.x, kt = c_a1.y;
-    int progress = as_i(c_pos.w);
+    int progress = pw_progress((uint32_t)as_i(c_pos.w));
     // ---- pending actions (actions_remained_buffer [4,100] + actions_remained_length, FA:189-193, :323-332, :366, :378-380).
     // Every step appends its action T times at logical slots [L, L+T) and consumes slots 0..9, so the dense buffer is a
     // queue of RUNS.  While no write of an env has reached the tail slots [90,100) since its reset (L + T <= 90 always; with
@@ -756,13 +806,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
     // literal slot ring (logical slot s at physical (head + s) % 100, head advancing by 10 per step on the host), and from
     // then on the reference's buffer semantics are followed to the letter (truncated mask write, the shift that leaves
     // [90,100) stale, stale reads: SURVEY section 7 "overflow regime").  Exact in every regime.
-    const int dl_word = as_i(c_lin.w);
-    int dlen = dl_word & 0xffff;        // L
-    int zlead = (dl_word >> 16) & 0xff; // Z
-    bool dense = dl_word < 0;
-    int q_lens = as_i(c_que.x);
-    int q_m = as_i(c_que.y) & 0xff;
-    int q_rem0 = (as_i(c_que.y) >> 8) & 0xff;
+    const uint32_t dl_word = (uint32_t)as_i(c_lin.w);  // "queue words" at the top of this file
+    int dlen = dw_L(dl_word);    // L
+    int zlead = dw_Z(dl_word);   // Z
+    bool dense = dw_dense(dl_word);
+    int q_lens = qw_lens(dl_word, (uint32_t)as_i(c_pos.w));
+    int q_m = dw_m(dl_word);
+    int q_rem0 = dw_rem0(dl_word);
     const bool at_time = !is_reset && progress == 500;  // reset_command_condition FA:595-598 (a reset env has progress 0 here;
                                                         // its own progress==500 case is overwritten by the reset branch below)
     if (is_reset || at_time) {  // reset_command_idx: FA:758-759, :814-821, :886-917, :1058-1112
@@ -838,8 +888,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
         float4 v0 = act4, v1 = act4;  // the pushed run itself is run_0 (empty queue) or run_1 (one run queued)
         v0 = sel4(q_m == 1, hwin[0], v0); v0 = sel4(q_m == 2, hwin[1], v0); v0 = sel4(q_m == 3, hwin[2], v0); v0 = sel4(q_m >= 4, hwin[3], v0);
         v1 = sel4(q_m == 2, hwin[0], v1); v1 = sel4(q_m == 3, hwin[1], v1); v1 = sel4(q_m >= 4, hwin[2], v1);
-        if (__builtin_amdgcn_ballot_w64(!dense && q_m > 4)) {  // deep queue (delay > ~40 ms): fetch the two oldest runs per lane
-            const bool deep = !dense && q_m > 4;
+        if (__builtin_amdgcn_ballot_w64(!dense && q_m > P.hw_rows)) {  // queue deeper than the rows fetched up front: the two oldest runs per lane
+            const bool deep = !dense && q_m > P.hw_rows;
             const float4 g0 = run_value(0), g1 = run_value(1);
             v0 = sel4(deep, g0, v0); v1 = sel4(deep, g1, v1);
         }
@@ -865,8 +915,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
         float v0 = ac, v1 = ac;
         v0 = (q_m == 1) ? h0 : v0; v0 = (q_m == 2) ? h1 : v0; v0 = (q_m == 3) ? h2 : v0; v0 = (q_m >= 4) ? h3 : v0;
         v1 = (q_m == 2) ? h0 : v1; v1 = (q_m == 3) ? h1 : v1; v1 = (q_m >= 4) ? h2 : v1;
-        if (__builtin_amdgcn_ballot_w64(!dense && q_m > 4)) {  // deep queue (delay > ~40 ms): fetch the two oldest runs per lane
-            const bool deep = !dense && q_m > 4;
+        if (__builtin_amdgcn_ballot_w64(!dense && q_m > P.hw_rows)) {  // queue deeper than the rows fetched up front: the two oldest runs per lane
+            const bool deep = !dense && q_m > P.hw_rows;
             const float4 g0 = run_value(0), g1 = run_value(1);
             v0 = deep ? pick4(sub, g0.x, g0.y, g0.z, g0.w) : v0;
             v1 = deep ? pick4(sub, g1.x, g1.y, g1.z, g1.w) : v1;
@@ -937,13 +987,18 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
     // `plain` (launch-uniform): no rotor noise, the battery model is on and PhysX runs its default two sub-iterations; together with the
     // wave-uniform euler/unwrap switch (flip envs) the PLAIN forms of the loop have these decided at compile time (no branches over the unused blocks, integrator
     // unrolled; a lone wavefront pays ~10 issue slots for every taken branch)
-    const bool plain = !(fl & TACO_F_ROTOR_NOISE) && P.substeps == 2 && (fl & TACO_F_BATTERY_CONSUMPTION) != 0;  // (+ bit 3 of the form: euler/unwrap on or off)
+    const Consts Crt{P.dt, P.rdt, P.h, P.half_h, P.inv_m, P.g, P.J0, P.J1, P.J2, P.hJi0, P.hJi1, P.hJi2, P.arm_x, P.arm_y};
+    const bool plain1 = !(fl & TACO_F_ROTOR_NOISE) && P.substeps == 2 && (fl & TACO_F_BATTERY_CONSUMPTION) != 0;  // (+ bit 3 of the form: euler/unwrap on or off)
+    // one lane per env: the PLAIN forms also carry the default airframe's constants as literals (kPlainConsts: the handle has exactly those)
+    const bool plain = plain1 && (LPE != 1 || (fl & kPlainConsts) != 0);
     if constexpr (LPE == 1) {
         // one substep; FIN: see `fin` above.  Returns whether the integrator took a rare form in some lane (wave-uniform).
         auto substep = [&](auto fin_c, const int ks) -> bool {
             // loop forms: 0 exact, 1 FIN, 2 FIN + PLAIN, 10 FIN + PLAIN with euler/unwrap (wavefronts that hold flip envs)
             constexpr int MODE = decltype(fin_c)::value;
             constexpr bool FIN = MODE >= 1, PLAIN = (MODE & 2) != 0;
+            Consts C;  // PLAIN: the default airframe as literals; otherwise the handle's values (SGPR operands)
+            if constexpr (PLAIN) C = kDefaultConsts; else C = Crt;
             // refresh_state, the part the inner loop consumes FA:339-350
             if (PLAIN ? (MODE & 8) != 0 : wave_tracks_rpy) {
                 V3 e = euler_xyz_v1(q);
@@ -961,9 +1016,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
             {
                 // angular_vel_control FA:637-650
                 float u0 = (d0 + 1.0f) / 2.0f * 1000.0f;
-                float u1 = pid_axis<FIN>(P.dt, P.rdt, 27.5f, d1 * 20.0f, wb.x, pid_prev[0], pid_int[0]);
-                float u2 = pid_axis<FIN>(P.dt, P.rdt, 50.0f, d2 * 20.0f, wb.y, pid_prev[1], pid_int[1]);
-                float u3 = pid_axis<FIN>(P.dt, P.rdt, 200.0f, d3 * 20.0f, wb.z, pid_prev[2], pid_int[2]);
+                float u1 = pid_axis<FIN>(C.dt, C.rdt, 27.5f, d1 * 20.0f, wb.x, pid_prev[0], pid_int[0]);
+                float u2 = pid_axis<FIN>(C.dt, C.rdt, 50.0f, d2 * 20.0f, wb.y, pid_prev[1], pid_int[1]);
+                float u3 = pid_axis<FIN>(C.dt, C.rdt, 200.0f, d3 * 20.0f, wb.z, pid_prev[2], pid_int[2]);
                 // control_allocator CTRL/fpv_dynamics.py:35-46
                 u3 = clampf(u3, -u0 / 2.0f, u0 / 2.0f);
                 float f0 = ((u0 * 1.0f + u1 * -1.0f) + u2 * 1.0f) + u3 * -1.0f;
@@ -994,15 +1049,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
             }
             // Battery_Dynamics.sim_process CTRL/battery_dynamics.py:47-75
             if (PLAIN || bat_on) {
-                bat_t = bat_t + P.dt;
+                bat_t = bat_t + C.dt;
                 float p_c = TACO_DIVC(TACO_DIVC(Pm, 0.75f), 9000.0f);
-                bat_E = bat_E + p_c * P.dt;
+                bat_E = bat_E + p_c * C.dt;
                 float P_avg = bat_E / bat_t;
                 float r0_ = 0.0015778f + -7.7608e-5f * P_avg + (float)(0.0069498 * 1500.0);
                 float r0 = (r0_ > 4.5f) ? r0_ : 4.5f;
                 float uo = 4.35f + -0.1102178f * bat_E + 0.0103368f * (bat_E * bat_E) + -4.3778e-4f * ((bat_E * bat_E) * bat_E);
                 float u1_dot = TACO_DIVC(0.00104846f * p_c - bat_u1, 3.3f);
-                bat_u1 = bat_u1 + u1_dot * P.dt;
+                bat_u1 = bat_u1 + u1_dot * C.dt;
                 float dd = uo - bat_u1;
                 float rad = dd * dd - 4.0f * r0 * p_c;
                 bat_V = 0.5f * (dd + __builtin_sqrtf(rad)) * 6.0f;
@@ -1039,12 +1094,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
                 F.x = dx * vb.x;
                 F.y = dy * vb.y;
                 F.z = kt * vxy * vxy + ((fs0 + fs1) + (fs2 + fs3));
-                tq.x = P.arm_y * ((fs0 + fs1) - (fs2 + fs3));
-                tq.y = -P.arm_x * ((fs0 - fs1) - (fs2 - fs3));
+                tq.x = C.arm_y * ((fs0 + fs1) - (fs2 + fs3));
+                tq.y = -C.arm_x * ((fs0 - fs1) - (fs2 - fs3));
                 tq.z = (ts0 + ts1) + (ts2 + ts3);
             }
-            if (is_reset) { F = V3{0.0f, 0.0f, 0.0f}; tq = V3{0.0f, 0.0f, 0.0f}; }  // FA:629-630: no force during the reset step
-            return integrate<PLAIN ? 2 : 0>(P, p, q, v, wb, F, tq);
+            if (wave_has_reset) {  // (wave-uniform: normally skipped)
+                if (is_reset) { F = V3{0.0f, 0.0f, 0.0f}; tq = V3{0.0f, 0.0f, 0.0f}; }  // FA:629-630: no force during the reset step
+            }
+            return integrate<PLAIN ? 2 : 0>(C, P.substeps, p, q, v, wb, F, tq);
         };
         // the FIN form of the loop runs while `fin` holds (normally all ten substeps), the exact form takes over at the first rare form
         int ks = 0;
@@ -1279,7 +1336,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
     if (active) {
         // Everything the substep loop evolved goes back to its SoA row NOW, so the registers are free for the
         // observation / reward code below.
-        CST(C_POS, make_float4(p.x, p.y, p.z, as_f(progress)));
         CST(C_QUAT, make_float4(q.x, q.y, q.z, q.w));
         CST(C_ANGVEL, make_float4(w.x, w.y, w.z, bat_V));
         CST(C_PID_PREV, make_float4(pid_prev[0], pid_prev[1], pid_prev[2], bat_E));
@@ -1307,8 +1363,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
             }
         }
         dlen = dlen - 10 < 0 ? 0 : dlen - 10;
-        CST(C_QUEUE, make_float4(as_f(q_lens), as_f(q_m | (q_rem0 << 8)), 0.0f, 0.0f));
-        CST(C_LINVEL, make_float4(v.x, v.y, v.z, as_f((dlen & 0xffff) | (zlead << 16) | (dense ? (int)0x80000000 : 0))));
+        CST(C_POS, make_float4(p.x, p.y, p.z, as_f((int)make_pw(progress, q_lens))));
+        CST(C_LINVEL, make_float4(v.x, v.y, v.z, as_f((int)make_dw(dlen, zlead, q_m, q_rem0, q_lens, dense))));
         CST(C_MISC, make_float4(bat_t, cmd0, cmd1, flip_radian));
     }
     if (SPLIT) { TACO_STAMP(4); TACO_STAMP(5); return; }  // wave 0 is done; the roles below belong to the other three wavefronts

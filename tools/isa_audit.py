@@ -7,12 +7,7 @@ Compiles taco_capi.hip to gfx950 assembly with the product flags (taco_amd/build
 loops (a backward branch to a label), and prints for every loop that contains VALU work an instruction census priced with the issue
 costs measured by tools/ubench/issue_mix (profiles/r01_e_ubench_issue_mix.txt, ns per wave-instruction at 4 waves per SIMD):
 
-    class                                              ns
-    VALU, at most two VGPR sources (VOP1/VOP2/VOP3)    1.2
-    VALU, three VGPR sources (v_fma/v_med3/v_bfi ...)  1.8
-    v_cmp* / v_cndmask                                 1.8
-    v_rcp / v_sqrt / v_rsq / v_exp / v_log             3.5
-    SALU / branch / waitcnt                            (listed, not priced: issued from the scalar port)
+    (the table is PRICE below; SALU / branch / waitcnt are listed, not priced: they issue from the scalar port)
 
 The census is static: a loop body's branches over rare blocks (ballot-guarded) are listed as separate inner regions.
 """
@@ -27,9 +22,19 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-PRICE = {"valu2": 1.2, "valu3": 1.8, "cmp": 1.8, "cndmask": 1.8, "trans": 3.5, "dpp": 1.2}
+# ns per wave-instruction on a SHARED SIMD (4 wavefronts per SIMD), measured by tools/ubench/issue_mix, bank and bank2 on MI355X
+# (profiles/r01_e_ubench_issue_mix.txt, profiles/r02_a_ubench_bank.txt, profiles/r02_a_ubench_bank2.txt)
+PRICE = {"vop2": 1.05,     # VOP1 / VOP2 with VGPR, literal or inline-constant sources (v_mul 1.04-1.06, v_fmaak 1.05, v_fmac 1.08-1.10)
+         "vop3": 1.2,      # the same operands in a 64-bit encoding (v_fma 1.20, v_mul_e64 1.15, modifiers 1.21-1.24)
+         "sgpr": 2.05,     # ANY VALU instruction with an SGPR source operand (v_mul s 2.10, v_fmac s 2.07, v_fma ..s 1.89, v_mov s 2.04)
+         "med3": 1.9,      # v_med3 / v_max3 / v_min3 (1.78-2.03)
+         "cmp": 1.9,       # v_cmp* (to VCC 2.02, to an SGPR pair 1.85)
+         "cndmask": 2.0,   # v_cndmask (reads VCC or an SGPR pair: 2.02)
+         "trans": 3.7,     # v_rcp / v_sqrt / v_rsq / v_exp / v_log (3.5-3.9)
+         "dpp": 1.2}
 TRANS = ("v_rcp_", "v_sqrt_", "v_rsq_", "v_exp_", "v_log_", "v_sin_", "v_cos_")
 VREG = re.compile(r"\bv(\d+|\[\d+:\d+\])")
+SREG = re.compile(r"(?<![a-z_])(s\d+|s\[\d+:\d+\]|vcc|exec)\b")
 
 
 def compile_asm():
@@ -68,12 +73,17 @@ def classify(ins):
     if op.startswith("v_"):
         args = ins[len(op):]
         srcs = args.split(",")[1:]  # first operand is the destination
-        nv = sum(1 for s in srcs if VREG.search(s))
-        if op.startswith(("v_fmac", "v_mac")):  # the destination is also a source
-            nv += 1
+        if op.startswith(("v_div_scale", "v_readlane", "v_readfirstlane")):
+            srcs = srcs[1:] if op.startswith("v_div_scale") else srcs  # v_div_scale has two destinations
         if "dpp" in ins or "quad_perm" in ins or "row_" in ins:
             return "dpp"
-        return "valu3" if nv >= 3 else "valu2"
+        if any(SREG.search(x) for x in srcs) or op.startswith("v_div_fmas"):  # (v_div_fmas reads VCC implicitly)
+            return "sgpr"
+        if op.startswith(("v_med3", "v_max3", "v_min3")):
+            return "med3"
+        three = op.endswith("_e64") or op.startswith(("v_fma_", "v_mad_", "v_bfi", "v_lshl_add", "v_lshl_or", "v_add3", "v_div_fixup", "v_div_scale", "v_mul_hi", "v_mul_lo",
+                                                       "v_and_or", "v_or3", "v_xad", "v_alignbit", "v_perm", "v_cvt_pk", "v_ldexp", "v_mbcnt", "v_readlane", "v_writelane"))
+        return "vop3" if three else "vop2"
     return "other"
 
 
@@ -130,7 +140,7 @@ def main():
     # innermost-first: report loops that are not strictly containing another reported loop with the same VALU mass
     for lo, hi, tgt in sorted(loops, key=lambda t: t[1] - t[0]):
         c, ops = census(prog, lo, hi)
-        valu = sum(c[k] for k in ("valu2", "valu3", "cmp", "cndmask", "trans", "dpp"))
+        valu = sum(c[k] for k in PRICE)
         if valu < args.min_valu:
             continue
         ns = sum(c[k] * PRICE[k] for k in PRICE)
