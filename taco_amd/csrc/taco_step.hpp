@@ -438,25 +438,37 @@ TD bool integrate_quad(const StepParams &P, uint32_t k3, float &pq, float &qq, f
 }
 
 // reset_idx for one env (FA:475-517), in the reference's call order: reset_copter_idx -> reset_controller_idx ->
-// reset_env_idx -> reset_target_idx.  Every new value goes straight to the env's chunks; the 37 uniforms come from
-// 10 Philox blocks of STREAM_RESET, each generated where it is consumed.
+// reset_env_idx -> reset_target_idx.  The chunks the step evolves come back IN REGISTERS (the caller's up-front loads are overwritten
+// for the lanes that reset: no store -> reload round trip, and the three values a reset keeps -- angular velocity of a flip env, command,
+// aero parameters -- are taken from those loads instead of being fetched again: round 1 paid three dependent memory round trips in every
+// wavefront that held a reset lane, i.e. in half of them at the benchmark's 1.1 % resets per step); the chunks the step only reads
+// (target pose, unwrapped angles, rotor / aero parameters) are stored here, by the lane that stores for its env.  The 37 uniforms come
+// from 10 Philox blocks of STREAM_RESET; a block whose consumers are all switched off (launch-uniform flags) is not generated.
 #define CST(c, val) buf_st4(rS, (val), voff, (uint32_t)(c) * row_bytes)
 #define CLD(c) buf_ld4(rS, voff, (uint32_t)(c) * row_bytes)
-TD void reset_env(const StepParams &P, rsrc_t rS, rsrc_t rR, uint32_t voff, uint32_t row_bytes, int gid, int grp, bool mix, bool active) {
-    if (!active) return;
+TD void reset_env(const StepParams &P, rsrc_t rS, uint32_t voff, uint32_t row_bytes, int gid, int grp, bool mix, bool store, float4 &c_pos,
+                  float4 &c_quat, float4 &c_lin, float4 &c_ang, float4 &c_pp, float4 &c_pi, float4 &c_om, float4 &c_misc, float4 &c_tau,
+                  float4 &c_op, float4 &c_a0, float4 &c_a1) {
     const uint32_t fl = P.flags;
-    auto block = [&](uint32_t b, float &u0, float &u1, float &u2, float &u3) {
-        U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, P.step, STREAM_RESET, b);
-        u0 = uniform(r.x); u1 = uniform(r.y); u2 = uniform(r.z); u3 = uniform(r.w);
+    auto block = [&](bool wanted, uint32_t b, float &u0, float &u1, float &u2, float &u3) {
+        u0 = u1 = u2 = u3 = 0.0f;
+        if (wanted) {  // (launch-uniform)
+            U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, P.step, STREAM_RESET, b);
+            u0 = uniform(r.x); u1 = uniform(r.y); u2 = uniform(r.z); u3 = uniform(r.w);
+        }
     };
+    const bool rc = (fl & TACO_F_RANDOM_ROTORDYNAMIC_COE) != 0, ra = (fl & TACO_F_RANDOM_AERODYNAMIC_COE) != 0;
+    const bool rtau = (fl & TACO_F_ROTOR_RESPONSE) && (fl & TACO_F_RANDOM_ROTOR_RESPONSE), rspd = (fl & TACO_F_RANDOM_ROTOR_SPEED) != 0;
+    const bool rpos = (fl & TACO_F_RANDOM_COPTER_POS) != 0, rquat = (fl & TACO_F_RANDOM_COPTER_QUAT) != 0, rvel = (fl & TACO_F_RANDOM_COPTER_VEL) != 0;
     float u0, u1, u2, u3, u4, u5, u6, u7;
     const float pi_sc = (float)(3.14159265358979323846 - (-3.14159265358979323846)), pi_lo = (float)(-3.14159265358979323846);
     // ---- reset_copter_idx: FA:725-756 pos, :783-812 rotate, :850-884 flip, :981-1056 mix (pos-style ranges for all groups)
-    block(0, u0, u1, u2, u3);  // uniforms 0..3: pos x y z, euler a
-    block(1, u4, u5, u6, u7);  // uniforms 4..7: euler b c, linvel x y
+    // (flip and rotate draw x, y even without random_copter_pos)
+    block(true, 0, u0, u1, u2, u3);                 // uniforms 0..3: pos x y z, euler a
+    block(rquat || rvel, 1, u4, u5, u6, u7);        // uniforms 4..7: euler b c, linvel x y
     V3 p;
     if (grp == TACO_TASK_FLIP && !mix) {
-        if (fl & TACO_F_RANDOM_COPTER_POS) {
+        if (rpos) {
             p.x = P.flip_xy_sc * u0 + P.flip_xy_lo;
             p.y = P.flip_xy_sc * u1 + P.flip_xy_lo;
             p.z = 3.0f + P.df * (4.0f * u2 + -2.0f);
@@ -465,38 +477,40 @@ TD void reset_env(const StepParams &P, rsrc_t rS, rsrc_t rR, uint32_t voff, uint
             p.y = 1.0f * u1 + -0.5f;
             p.z = 3.0f;
         }
-    } else if (grp == TACO_TASK_ROTATE && !mix && !(fl & TACO_F_RANDOM_COPTER_POS)) {
+    } else if (grp == TACO_TASK_ROTATE && !mix && !rpos) {
         p.x = 1.0f * u0 + -0.5f;
         p.y = 1.0f * u1 + -0.5f;
         p.z = 2.5f;
-    } else if (fl & TACO_F_RANDOM_COPTER_POS) {
+    } else if (rpos) {
         p.x = 4.0f * u0 + -2.0f;
         p.y = 4.0f * u1 + -2.0f;
         p.z = 2.5f + (4.0f * u2 + -2.0f);
     } else {
         p.x = 0.0f; p.y = 0.0f; p.z = 2.5f;
     }
-    CST(C_POS, make_float4(p.x, p.y, p.z, as_f((int)make_pw(0, 0))));  // progress <- 0 (FA:510-511), no runs queued
+    c_pos = make_float4(p.x, p.y, p.z, as_f((int)make_pw(0, 0)));  // progress <- 0 (FA:510-511), no runs queued
     Q4 q{0.0f, 0.0f, 0.0f, 1.0f};
-    if (fl & TACO_F_RANDOM_COPTER_QUAT) {  // rand_quat FA:698-704 (flip: limits (pi, 0, 0))
+    if (rquat) {  // rand_quat FA:698-704 (flip: limits (pi, 0, 0))
         const float l_sc = (grp == TACO_TASK_FLIP) ? 0.0f : pi_sc;
         const float l_lo = (grp == TACO_TASK_FLIP) ? -0.0f : pi_lo;
         q = quat_from_euler(pi_sc * u3 + pi_lo, l_sc * u4 + l_lo, l_sc * u5 + l_lo);
     }
-    CST(C_QUAT, make_float4(q.x, q.y, q.z, q.w));
+    c_quat = make_float4(q.x, q.y, q.z, q.w);
     {
         const V3 e0 = euler_xyz_v1(q);  // FA:752-754
-        CST(C_RPY_OLD, make_float4(e0.x, e0.y, e0.z, 0.0f));
-        CST(C_RPY_CONT, make_float4(e0.x, e0.y, e0.z, 0.0f));
+        if (store) {
+            CST(C_RPY_OLD, make_float4(e0.x, e0.y, e0.z, 0.0f));
+            CST(C_RPY_CONT, make_float4(e0.x, e0.y, e0.z, 0.0f));
+        }
     }
     float a0, a1, a2, a3, b0, b1, b2, b3;
-    block(2, a0, a1, a2, a3);  // uniforms 8..11: linvel z, angvel x y z
-    block(3, b0, b1, b2, b3);  // uniforms 12..15: flip sign, target x y z
+    block(rvel, 2, a0, a1, a2, a3);                                          // uniforms 8..11: linvel z, angvel x y z
+    block(rvel || (fl & TACO_F_RANDOM_TARGET_POS), 3, b0, b1, b2, b3);       // uniforms 12..15: flip sign, target x y z
     float c0, c1, c2, c3, d0, d1, d2, d3;
-    block(4, c0, c1, c2, c3);  // uniforms 16..19: target yaw, battery E, omega_para 0 1
-    block(5, d0, d1, d2, d3);  // uniforms 20..23: omega_para 2 3 4, tau 0
+    block((fl & (TACO_F_RANDOM_TARGET_YAW | TACO_F_RANDOM_VOLTAGE)) || rc, 4, c0, c1, c2, c3);  // uniforms 16..19: target yaw, battery E, omega_para 0 1
+    block(rc || rtau, 5, d0, d1, d2, d3);                                    // uniforms 20..23: omega_para 2 3 4, tau 0
     float h0, h1, h2, h3;
-    block(9, h0, h1, h2, h3);  // uniform 36: delay length
+    block((fl & TACO_F_RANDOM_DELAY_TIME) != 0, 9, h0, h1, h2, h3);          // uniform 36: delay length
     // ---- reset_env_idx FA:560-581: delay length
     int L = P.delay_time;
     if (fl & TACO_F_RANDOM_DELAY_TIME) {
@@ -506,44 +520,42 @@ TD void reset_env(const StepParams &P, rsrc_t rS, rsrc_t rR, uint32_t voff, uint
     {
         V3 v{0.0f, 0.0f, 0.0f}, w{0.0f, 0.0f, 0.0f};
         if (grp == TACO_TASK_FLIP) {
-            const float4 w_old = CLD(C_ANGVEL);
-            w = V3{w_old.x, w_old.y, w_old.z};  // standalone FpvFlip leaves angvel untouched unless told otherwise (FA:876-878)
-            if (fl & TACO_F_RANDOM_COPTER_VEL) {
+            w = V3{c_ang.x, c_ang.y, c_ang.z};  // standalone FpvFlip leaves angvel untouched unless told otherwise (FA:876-878)
+            if (rvel) {
                 v = V3{P.flip_v_sc * u6 + P.flip_v_lo, P.flip_v_sc * u7 + P.flip_v_lo, P.flip_v_sc * a0 + P.flip_v_lo};
                 w.x = 10.0f * (b0 < 0.5f ? -1.0f : 1.0f);  // w.y, w.z keep their values (FA:876, :1047)
             } else if (mix) {
                 w = V3{0.0f, 0.0f, 0.0f};  // FA:1050
             }
-        } else if (fl & TACO_F_RANDOM_COPTER_VEL) {
+        } else if (rvel) {
             v = V3{3.0f * (2.0f * u6 + -1.0f), 3.0f * (2.0f * u7 + -1.0f), 3.0f * (2.0f * a0 + -1.0f)};
             w = V3{3.0f * (2.0f * a1 + -1.0f), 3.0f * (2.0f * a2 + -1.0f), 3.0f * (2.0f * a3 + -1.0f)};
         }
-        CST(C_LINVEL, make_float4(v.x, v.y, v.z, as_f((int)make_dw(L, L, 0, 0, 0, false))));  // Z = L: the whole pending line is reset-zeros
-                                                                                               // (FA:572-574), the run queue empty
-        CST(C_ANGVEL, make_float4(w.x, w.y, w.z, 0.0f));  // battery_voltage <- 0 (FA:566)
+        c_lin = make_float4(v.x, v.y, v.z, as_f((int)make_dw(L, L, 0, 0, 0, false)));  // Z = L: the whole pending line is reset-zeros
+                                                                                        // (FA:572-574), the run queue empty
+        c_ang = make_float4(w.x, w.y, w.z, 0.0f);  // battery_voltage <- 0 (FA:566)
     }
     // ---- reset_target_idx FA:523-548
-    if (fl & TACO_F_RANDOM_TARGET_POS) CST(C_TGT_POS, make_float4(P.df * (4.0f * b1 + -2.0f), P.df * (4.0f * b2 + -2.0f), 3.0f + P.df * (4.0f * b3 + -2.0f), 0.0f));
-    else CST(C_TGT_POS, make_float4(0.0f, 0.0f, 3.0f, 0.0f));
+    if (store) {
+        if (fl & TACO_F_RANDOM_TARGET_POS) CST(C_TGT_POS, make_float4(P.df * (4.0f * b1 + -2.0f), P.df * (4.0f * b2 + -2.0f), 3.0f + P.df * (4.0f * b3 + -2.0f), 0.0f));
+        else CST(C_TGT_POS, make_float4(0.0f, 0.0f, 3.0f, 0.0f));
+    }
     {
         const float yaw = (fl & TACO_F_RANDOM_TARGET_YAW) ? pi_sc * c0 + pi_lo : 0.0f;
         const Q4 qt = quat_from_euler(0.0f, 0.0f, yaw);
-        CST(C_TGT_QUAT, make_float4(qt.x, qt.y, qt.z, qt.w));
+        if (store) CST(C_TGT_QUAT, make_float4(qt.x, qt.y, qt.z, qt.w));
     }
     // ---- reset_controller_idx FA:550-558
-    CST(C_PID_PREV, make_float4(0.0f, 0.0f, 0.0f, (fl & TACO_F_RANDOM_VOLTAGE) ? (float)2.2 * c1 + 0.0f : 0.0f));  // + battery E_c
-    CST(C_PID_INT, make_float4(0.0f, 0.0f, 0.0f, 0.0f));                                                          // + battery u_1
-    {
-        const float4 misc = CLD(C_MISC);  // command / flip_radian survive a reset until reset_command_idx rewrites them
-        CST(C_MISC, make_float4(0.0f, misc.y, misc.z, misc.w));  // battery time <- 0
-    }
-    const bool rc = (fl & TACO_F_RANDOM_ROTORDYNAMIC_COE) != 0;
-    CST(C_OPARA, make_float4(rc ? 0.0f * (P.dr_sc * c2 + P.dr_lo) : 0.0f, rc ? 12.9466f * (P.dr_sc * c3 + P.dr_lo) : 12.9466f,
-                             rc ? 0.1872f * (P.dr_sc * d0 + P.dr_lo) : 0.1872f, rc ? -5.1220f * (P.dr_sc * d1 + P.dr_lo) : -5.1220f));
+    c_pp = make_float4(0.0f, 0.0f, 0.0f, (fl & TACO_F_RANDOM_VOLTAGE) ? (float)2.2 * c1 + 0.0f : 0.0f);  // + battery E_c
+    c_pi = make_float4(0.0f, 0.0f, 0.0f, 0.0f);                                                          // + battery u_1
+    c_misc = make_float4(0.0f, c_misc.y, c_misc.z, c_misc.w);  // battery time <- 0; command / flip_radian survive a reset until
+                                                               // reset_command_idx rewrites them
+    c_op = make_float4(rc ? 0.0f * (P.dr_sc * c2 + P.dr_lo) : 0.0f, rc ? 12.9466f * (P.dr_sc * c3 + P.dr_lo) : 12.9466f,
+                       rc ? 0.1872f * (P.dr_sc * d0 + P.dr_lo) : 0.1872f, rc ? -5.1220f * (P.dr_sc * d1 + P.dr_lo) : -5.1220f);
     float e0, e1, e2, e3, f0, f1, f2, f3, g0, g1, g2, g3;
-    block(6, e0, e1, e2, e3);  // uniforms 24..27: tau 1 2 3, omega0 0
-    block(7, f0, f1, f2, f3);  // uniforms 28..31: omega0 1 2 3, cf
-    block(8, g0, g1, g2, g3);  // uniforms 32..35: ct, dx, dy, kt
+    block(rtau || rspd, 6, e0, e1, e2, e3);  // uniforms 24..27: tau 1 2 3, omega0 0
+    block(rspd || ra, 7, f0, f1, f2, f3);    // uniforms 28..31: omega0 1 2 3, cf
+    block(ra, 8, g0, g1, g2, g3);            // uniforms 32..35: ct, dx, dy, kt
     {
         const float tu[4] = {d3, e0, e1, e2};
         const float ou[4] = {e3, f0, f1, f2};
@@ -552,19 +564,21 @@ TD void reset_env(const StepParams &P, rsrc_t rS, rsrc_t rR, uint32_t voff, uint
         for (int k = 0; k < 4; ++k) {
             if (fl & TACO_F_ROTOR_RESPONSE) t[k] = (fl & TACO_F_RANDOM_ROTOR_RESPONSE) ? P.tau_sc * tu[k] + P.tau_lo : P.tau_fixed * 1.0f;
             else t[k] = 0.001f * 1.0f;
-            o[k] = (fl & TACO_F_RANDOM_ROTOR_SPEED) ? 400.0f * ou[k] + 0.0f : 0.0f;
+            o[k] = rspd ? 400.0f * ou[k] + 0.0f : 0.0f;
         }
-        CST(C_TAU, make_float4(t[0], t[1], t[2], t[3]));
-        CST(C_OMEGA, make_float4(o[0], o[1], o[2], o[3]));
+        c_tau = make_float4(t[0], t[1], t[2], t[3]);
+        c_om = make_float4(o[0], o[1], o[2], o[3]);
     }
-    {
-        const float4 ae0 = CLD(C_AERO0), ae1 = CLD(C_AERO1);  // aero parameters keep their values unless re-randomised
-        const bool ra = (fl & TACO_F_RANDOM_AERODYNAMIC_COE) != 0;  // CTRL/thrust_dynamics.py:201-210 (a no-op when off)
-        CST(C_AERO0, make_float4(rc ? 0.5906f * (P.dr_sc * d2 + P.dr_lo) : 0.5906f, ra ? 1.13e-05f * (P.dr_sc * f3 + P.dr_lo) : ae0.y,
-                                 ra ? 0.05f * (P.dr_sc * g0 + P.dr_lo) : ae0.z, ra ? -0.386f * (P.dr_sc * g1 + P.dr_lo) : ae0.w));
-        CST(C_AERO1, make_float4(ra ? -0.53f * (P.dr_sc * g2 + P.dr_lo) : ae1.x, ra ? 0.009f * (P.dr_sc * g3 + P.dr_lo) : ae1.y, 0.0f, 0.0f));
+    {   // aero parameters keep their values unless re-randomised: CTRL/thrust_dynamics.py:201-210 (a no-op when off)
+        const float4 ae0 = c_a0, ae1 = c_a1;
+        c_a0 = make_float4(rc ? 0.5906f * (P.dr_sc * d2 + P.dr_lo) : 0.5906f, ra ? 1.13e-05f * (P.dr_sc * f3 + P.dr_lo) : ae0.y,
+                           ra ? 0.05f * (P.dr_sc * g0 + P.dr_lo) : ae0.z, ra ? -0.386f * (P.dr_sc * g1 + P.dr_lo) : ae0.w);
+        c_a1 = make_float4(ra ? -0.53f * (P.dr_sc * g2 + P.dr_lo) : ae1.x, ra ? 0.009f * (P.dr_sc * g3 + P.dr_lo) : ae1.y, 0.0f, 0.0f);
     }
-    (void)rR;  // the ring is NOT zeroed (FA:574): the delay-line word marks every pending slot as an implied zero
+    if (store) {  // the parameter chunks are only ever written here
+        CST(C_TAU, c_tau); CST(C_OPARA, c_op); CST(C_AERO0, c_a0); CST(C_AERO1, c_a1);
+    }
+    // the ring is NOT zeroed (FA:574): the delay-line word marks every pending slot as an implied zero
 }
 
 
@@ -755,15 +769,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
         hwin[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (k < P.hw_rows) hwin[k] = buf_ld4(rH, voff, (uint32_t)((P.hh - 1 - k) & (HIST_ROWS - 1)) * row_bytes);
     }
-    // reset_idx (FA:475-517) writes the fresh state straight to the env's chunks (none of its 37 random draws or
-    // temporaries stay live); a wavefront that holds a reset lane then simply loads its chunks again.
+    // reset_idx (FA:475-517): the lanes that reset get their fresh state in the registers the up-front loads filled (see reset_env)
     const bool wave_has_reset = __builtin_amdgcn_ballot_w64(is_reset) != 0;
     if (wave_has_reset) {
-        if (is_reset) reset_env(P, rS, rR, voff, row_bytes, gid, grp, mix, active);
-        if (LPE > 1) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // sub-lane 0 stored, the whole quad reloads
-        c_pos = CLD(C_POS); c_quat = CLD(C_QUAT); c_lin = CLD(C_LINVEL); c_ang = CLD(C_ANGVEL);
-        c_pp = CLD(C_PID_PREV); c_pi = CLD(C_PID_INT); c_om = CLD(C_OMEGA); c_misc = CLD(C_MISC);
-        if (!uniform_params) { c_tau = CLD(C_TAU); c_op = CLD(C_OPARA); c_a0 = CLD(C_AERO0); c_a1 = CLD(C_AERO1); }
+        if (is_reset) reset_env(P, rS, voff, row_bytes, gid, grp, mix, active, c_pos, c_quat, c_lin, c_ang, c_pp, c_pi, c_om, c_misc, c_tau, c_op, c_a0, c_a1);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // (the target pose and the unwrapped angles it stored are loaded further down)
     }
     if (P.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TACO_STAMP(1); }  // all up-front loads have landed
     V3 p{c_pos.x, c_pos.y, c_pos.z};
