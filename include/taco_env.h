@@ -150,9 +150,11 @@ void taco_destroy(taco_env *env);
  *   reset_buf   [num_envs]               i64 in/out  non-zero on entry = reset this env first (ones before step 1)
  *   timeout_buf [num_envs]               u8  out     extras["time_outs"]
  * One kernel launch, asynchronous on `stream`; no host synchronisation. */
-/* Not capturable into a HIP graph: the step index, ring head and history row are kernel arguments that advance on the host with every
- * call (a replayed launch would repeat one step index); taco_step returns TACO_ERR_INVALID_ARG on a capturing stream.  For launch-bound
- * loops enqueue the whole rollout with taco_rollout_run. */
+/* HIP graphs: the step index, ring head and history row advance with every call.  On the eager path they are kernel arguments (and every
+ * launch leaves the next values in the workspace's control block); a call on a CAPTURING stream enqueues the step kernel reading that
+ * device-resident clock plus a one-thread kernel that advances it, so the captured graph can be replayed any number of times and continues
+ * exactly where the eager steps (or earlier replays) stopped.  After a capture the host's copy of the clock is stale: every later call
+ * takes the device path (two launches) until taco_get_step_count / taco_set_step_count / taco_get_state have re-read it (they block). */
 int taco_step(taco_env *env, const float *actions, float *obs_buf, float *states_buf, float *rew_buf, int64_t *reset_buf,
               uint8_t *timeout_buf, void *stream);
 
@@ -172,6 +174,9 @@ typedef struct taco_rollout_io {
     int64_t *reset_buf;        /* [num_envs]  in/out, as taco_step                                                */
     uint8_t *timeout_buf;      /* [num_envs]                                                                      */
     float *done_f32;           /* [num_envs]  done_buf[t] (buffer_asymmetry.py:67, 82), or NULL                   */
+    float *obs_out;            /* [num_envs][len_obs][26]     clamp(obs_next, +-cfg.clip_obs): the copy VecTask.step returns      */
+    float *states_out;         /* [num_envs][len_states][26]  clamp(states_next, +-cfg.clip_states) (vec_task_asymmetry.py:331-332);
+                                  either may be NULL; 16-byte aligned; written by the same launch                                 */
 } taco_rollout_io;
 int taco_step_rollout(taco_env *env, const taco_rollout_io *io, void *stream);
 
@@ -244,9 +249,18 @@ int taco_bind_gather_block(taco_env *env, float *block);
 /* env.difficulty = x (ppo_asymmetry.py:173-175, :376); takes effect at the next taco_step. */
 int taco_set_difficulty(taco_env *env, double difficulty);
 
-/* Number of taco_step calls so far (keys the counter-based random streams); settable for checkpoint/restore. */
-int64_t taco_get_step_count(const taco_env *env);
+/* Number of steps taken so far (keys the counter-based random streams); settable for checkpoint/restore.  After graph replays both
+ * calls first re-read the device-resident clock (hipDeviceSynchronize). */
+int64_t taco_get_step_count(taco_env *env);
 int taco_set_step_count(taco_env *env, int64_t n);
+
+/* Health check (BLOCKS on `stream`): TACO_ERR_STATE if any step kernel since taco_create recorded a sticky error in the workspace's status
+ * word -- today one condition: a bounded wait of the four-role form's battery mailbox gave up (the voltage of the affected envs was set to
+ * NaN instead of a stale value).  Never observed; the steps themselves return TACO_OK because they never synchronise. */
+int taco_check(taco_env *env, void *stream);
+
+/* One row of the state blob (TACO_S_* except actions_old) for every env -> DEVICE array out[num_envs]; e.g. TACO_S_PROGRESS = progress_buf. */
+int taco_get_field(taco_env *env, int field, uint32_t *out, void *stream);
 
 /* Copy the per-env state to / from a DEVICE blob of TACO_BLOB_ROWS * num_envs words (layout above). */
 int taco_get_state(taco_env *env, uint32_t *blob, void *stream);

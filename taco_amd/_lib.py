@@ -23,7 +23,7 @@ FLAG_BITS = {
 # every symbol include/taco_env.h declares
 EXPORTS = ["taco_abi_version", "taco_source_hash", "taco_last_error", "taco_workspace_bytes", "taco_create", "taco_destroy", "taco_step",
            "taco_gather_row_floats", "taco_bind_gather_block", "taco_set_difficulty", "taco_get_step_count", "taco_set_step_count", "taco_get_state", "taco_set_state",
-           "taco_step_kernel_name", "taco_launch_geometry", "taco_set_kernel_form", "taco_get_kernel_form", "taco_step_rollout", "taco_gae_workspace_bytes", "taco_gae", "taco_occupancy", "taco_bind_phase_stamps", "taco_policy_blob_floats", "taco_policy_act", "taco_rollout_run", "taco_policy_bind_stamps"]
+           "taco_step_kernel_name", "taco_launch_geometry", "taco_set_kernel_form", "taco_get_kernel_form", "taco_check", "taco_get_field", "taco_step_rollout", "taco_gae_workspace_bytes", "taco_gae", "taco_occupancy", "taco_bind_phase_stamps", "taco_policy_blob_floats", "taco_policy_act", "taco_rollout_run", "taco_policy_bind_stamps"]
 
 
 class TacoCfg(C.Structure):
@@ -41,7 +41,7 @@ class RolloutIO(C.Structure):
     """struct taco_rollout_io (include/taco_env.h)"""
     _fields_ = [("actions", C.c_void_p), ("obs_prev", C.c_void_p), ("obs_next", C.c_void_p), ("states_prev", C.c_void_p),
                 ("states_next", C.c_void_p), ("rew", C.c_void_p), ("reset_buf", C.c_void_p), ("timeout_buf", C.c_void_p),
-                ("done_f32", C.c_void_p)]
+                ("done_f32", C.c_void_p), ("obs_out", C.c_void_p), ("states_out", C.c_void_p)]
 
 
 class RolloutBufs(C.Structure):
@@ -101,6 +101,10 @@ def _declare(lib, ab_build=False):
     lib.taco_set_kernel_form.restype = C.c_int
     lib.taco_get_kernel_form.argtypes = [C.c_void_p]
     lib.taco_get_kernel_form.restype = C.c_int
+    lib.taco_check.argtypes = [C.c_void_p, C.c_void_p]
+    lib.taco_check.restype = C.c_int
+    lib.taco_get_field.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.taco_get_field.restype = C.c_int
     lib.taco_policy_blob_floats.argtypes = [C.c_void_p]
     lib.taco_policy_blob_floats.restype = C.c_size_t
     lib.taco_policy_act.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_int,

@@ -48,6 +48,9 @@ struct taco_env {
     int slow_server;
 #endif
     int form;  // TACO_FORM_* the step launches (never TACO_FORM_AUTO here: resolved by choose_form)
+    uint32_t *ctl;        // control block (last 256 bytes of the workspace): device-resident step clock + sticky status word
+    int clock_on_device;  // a launch was captured into a HIP graph: replays advance the device clock only, the fields above may be stale
+                          // (taco_get_step_count re-reads them); until then every launch reads the device clock
     int params_imported;  // taco_set_state has been called: rotor / aero parameters may differ per env from now on (see kUniformParams)
     float *gather;  // optional per-rank all-gather block, see taco_bind_gather_block
     unsigned long long *stamps;  // optional phase stamps, see taco_bind_phase_stamps
@@ -118,6 +121,7 @@ void derive(taco_env *e) {
 #endif
     P.seed_lo = (uint32_t)c.seed; P.seed_hi = (uint32_t)(c.seed >> 32);
     P.dt = (float)c.dt; P.clip_act = (float)c.clip_actions; P.df = (float)d;
+    P.clip_obs = (float)c.clip_obs; P.clip_states = (float)c.clip_states;
     P.h = (float)(c.dt / (double)c.substeps);
     P.half_h = (float)(0.5 * (c.dt / (double)c.substeps));
     P.inv_m = (float)(1.0 / c.mass); P.g = (float)c.gravity_z;
@@ -160,8 +164,14 @@ __device__ __forceinline__ float &word(float *S, int npad, int i, int field) {
     const int sl = taco::field_slot(field);
     return S[taco::tile_word(taco::NUM_CHUNKS, sl >> 2, i) + (sl & 3)];
 }
-__global__ void init_state_kernel(float *S, float *hist, float *ring, int npad, float tau0, int delay_time) {
+__global__ void advance_clock_kernel(uint32_t *ctl) {  // behind every step that took its clock from the control block (graph replays)
+    ctl[taco::kCtlStep] += 1u;
+    ctl[taco::kCtlHead] = (ctl[taco::kCtlHead] + 10u) % TACO_RING_SLOTS;
+    ctl[taco::kCtlHh] = (ctl[taco::kCtlHh] + 1u) % taco::HIST_ROWS;
+}
+__global__ void init_state_kernel(float *S, float *hist, float *ring, uint32_t *ctl, int npad, float tau0, int delay_time) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (int)(taco::kCtlBytes / 4)) ctl[i] = 0u;
     if (i >= npad) return;
     for (int c = 0; c < (int)taco::NUM_CHUNKS; ++c)
         for (int k = 0; k < 4; ++k) S[taco::tile_word(taco::NUM_CHUNKS, c, i) + k] = 0.0f;
@@ -302,7 +312,7 @@ const char *taco_step_kernel_name(void) { return "taco_step_kernel"; }
 size_t taco_workspace_bytes(const taco_cfg *cfg) {
     if (!cfg || cfg->num_envs <= 0) return 0;
     const size_t npad = (size_t)round_up(cfg->num_envs, 64);
-    return (size_t)(taco::NUM_CHUNKS + taco::HIST_ROWS + TACO_RING_SLOTS) * npad * 4 * sizeof(float);
+    return (size_t)(taco::NUM_CHUNKS + taco::HIST_ROWS + TACO_RING_SLOTS) * npad * 4 * sizeof(float) + taco::kCtlBytes;
 }
 
 int taco_create(const taco_cfg *cfg, int device, void *workspace, size_t workspace_bytes, void *stream, taco_env **out) {
@@ -323,6 +333,8 @@ int taco_create(const taco_cfg *cfg, int device, void *workspace, size_t workspa
     e->S = (float *)workspace;
     e->hist = e->S + (size_t)taco::NUM_CHUNKS * e->npad * 4;
     e->ring = e->hist + (size_t)taco::HIST_ROWS * e->npad * 4;
+    e->ctl = (uint32_t *)(e->ring + (size_t)TACO_RING_SLOTS * e->npad * 4);
+    e->clock_on_device = 0;
     e->step_count = 0;
     e->head = 0;
     e->hh = 0;
@@ -332,7 +344,7 @@ int taco_create(const taco_cfg *cfg, int device, void *workspace, size_t workspa
     e->form = choose_form(e->cfg);
     std::memset(&e->P, 0, sizeof(e->P));
     derive(e);
-    hipLaunchKernelGGL(init_state_kernel, dim3((e->npad + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->S, e->hist, e->ring, e->npad,
+    hipLaunchKernelGGL(init_state_kernel, dim3((e->npad + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->S, e->hist, e->ring, e->ctl, e->npad,
                        (float)cfg->rotor_response_time, cfg->delay_time);
     he = hipGetLastError();
     if (he != hipSuccess) { delete e; return hip_fail(he, "init_state_kernel launch"); }
@@ -347,12 +359,14 @@ int launch_step(taco_env *e, const taco_rollout_io *io, void *stream) {
     if (!io->actions || !io->obs_next || !io->states_next || !io->rew || !io->reset_buf || !io->timeout_buf)
         return fail(TACO_ERR_INVALID_ARG, "taco_step: null buffer pointer");
     if (((uintptr_t)io->actions & 15u) != 0) return fail(TACO_ERR_INVALID_ARG, "actions must be 16-byte aligned");
-    {   // The step counter, the ring head and the history row travel in the kernel arguments and advance on the host with every call: a
-        // captured launch would replay ONE step index for ever (same Philox stream, same ring slots).  Refuse instead of going wrong quietly.
+    // The step counter, the ring head and the history row travel in the kernel arguments and advance on the host with every call; a launch
+    // that is being CAPTURED into a HIP graph would replay one step index for ever, so it reads the device-resident copy of the clock
+    // instead (every eager launch leaves the next values there) and is followed by a one-thread kernel that advances it.  Once a capture
+    // has happened the host's copy may be stale (replays advance the device clock only): every launch then takes the device path until
+    // taco_get_step_count has re-read it.
+    {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (stream != nullptr && hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
-            return fail(TACO_ERR_INVALID_ARG, "taco_step cannot be captured into a HIP graph (the step index lives in the kernel arguments); "
-                                              "enqueue a whole rollout with taco_rollout_run instead");
+        if (stream != nullptr && hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) e->clock_on_device = 1;
     }
     const size_t n_envs = (size_t)e->cfg.num_envs;
     taco::StepParams P = e->P;
@@ -366,6 +380,10 @@ int launch_step(taco_env *e, const taco_rollout_io *io, void *stream) {
     P.reset = (long long *)io->reset_buf; P.timeout = io->timeout_buf;
     P.gather = e->gather;
     P.stamps = e->stamps;
+    P.obs_out = io->obs_out; P.states_out = io->states_out;
+    if ((((uintptr_t)P.obs_out | (uintptr_t)P.states_out) & 15u) != 0) return fail(TACO_ERR_INVALID_ARG, "obs_out / states_out must be 16-byte aligned");
+    P.ctl = e->ctl;
+    P.use_ctl = e->clock_on_device;
     P.step = (uint32_t)e->step_count;
     P.obs_bytes = (uint32_t)((size_t)n_envs * e->cfg.len_obs * 26 * sizeof(float));
     P.states_bytes = (uint32_t)((size_t)n_envs * e->cfg.len_states * 26 * sizeof(float));
@@ -379,6 +397,11 @@ int launch_step(taco_env *e, const taco_rollout_io *io, void *stream) {
     hipError_t he = hipLaunchKernel(form_info(e->form).fn, dim3(grid), dim3(block), args, 0, (hipStream_t)stream);
     if (he == hipSuccess) he = hipGetLastError();
     if (he != hipSuccess) return hip_fail(he, "taco_step_kernel launch");
+    if (e->clock_on_device) {
+        hipLaunchKernelGGL(advance_clock_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, e->ctl);
+        he = hipGetLastError();
+        if (he != hipSuccess) return hip_fail(he, "advance_clock_kernel launch");
+    }
     e->step_count += 1;
     e->head = (e->head + 10) % TACO_RING_SLOTS;
     e->hh = (e->hh + 1) % taco::HIST_ROWS;
@@ -444,15 +467,76 @@ int taco_bind_gather_block(taco_env *e, float *block) {
     return TACO_OK;
 }
 
-int64_t taco_get_step_count(const taco_env *e) { return e ? e->step_count : -1; }
+namespace {
+// re-read the clock the graph replays advanced (blocking): afterwards the host's copy is current again and launches go back to the eager path
+int refresh_clock(taco_env *e) {
+    if (!e->clock_on_device) return TACO_OK;
+    uint32_t c[3];
+    hipError_t he = hipDeviceSynchronize();
+    if (he == hipSuccess) he = hipMemcpy(c, e->ctl, sizeof(c), hipMemcpyDeviceToHost);
+    if (he != hipSuccess) return hip_fail(he, "reading the device-resident step clock");
+    e->step_count = (e->step_count & ~(int64_t)0xffffffff) | c[taco::kCtlStep];  // (the kernel's Philox counter is the low 32 bits)
+    e->head = (int)c[taco::kCtlHead];
+    e->hh = (int)c[taco::kCtlHh];
+    e->clock_on_device = 0;
+    return TACO_OK;
+}
+}  // namespace
+
+int64_t taco_get_step_count(taco_env *e) {
+    if (!e) return -1;
+    if (refresh_clock(e) != TACO_OK) return -1;
+    return e->step_count;
+}
 int taco_set_step_count(taco_env *e, int64_t n) {
     if (!e || n < 0) return fail(TACO_ERR_INVALID_ARG, "taco_set_step_count: bad argument");
+    const int rc = refresh_clock(e);
+    if (rc != TACO_OK) return rc;
     e->step_count = n;
     return TACO_OK;
 }
 
+int taco_check(taco_env *e, void *stream) {
+    if (!e) return fail(TACO_ERR_INVALID_ARG, "env is null");
+    uint32_t status = 0;
+    hipError_t he = hipMemcpyAsync(&status, e->ctl + taco::kCtlStatus, sizeof(status), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (he == hipSuccess) he = hipStreamSynchronize((hipStream_t)stream);
+    if (he != hipSuccess) return hip_fail(he, "taco_check");
+    if (status & taco::kStatusMailboxTimeout)
+        return fail(TACO_ERR_STATE, "a step kernel gave up waiting on its battery mailbox (role wavefronts out of step): the affected envs' voltage "
+                                    "was set to NaN; results since the last clean taco_check are suspect");
+    return TACO_OK;
+}
+
+namespace {
+__global__ void export_field_kernel(const float *S, const float *hist, uint32_t *out, int field, int n, int npad, int hh) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float *Sm = const_cast<float *>(S);
+    float val;
+    if (field == TACO_S_PROGRESS) val = __builtin_bit_cast(float, taco::pw_progress(__builtin_bit_cast(uint32_t, word(Sm, npad, i, TACO_S_PROGRESS))));
+    else if (field == TACO_S_DELAY_LEN) val = __builtin_bit_cast(float, taco::dw_L(__builtin_bit_cast(uint32_t, word(Sm, npad, i, TACO_S_DELAY_LEN))));
+    else if (field >= TACO_S_ACT && field < TACO_S_ACT + 4) val = hist[taco::tile_word(taco::HIST_ROWS, (hh - 1) & (taco::HIST_ROWS - 1), i) + (field - TACO_S_ACT)];
+    else val = word(Sm, npad, i, field);
+    out[i] = __builtin_bit_cast(uint32_t, val);
+}
+}  // namespace
+
+int taco_get_field(taco_env *e, int field, uint32_t *out, void *stream) {
+    if (!e || !out) return fail(TACO_ERR_INVALID_ARG, "taco_get_field: null argument");
+    if (field < 0 || field >= TACO_NUM_FIELDS || (field >= TACO_S_ACT_OLD && field < TACO_S_ACT_OLD + 4))
+        return fail(TACO_ERR_INVALID_ARG, "taco_get_field: field must be a TACO_S_* row other than actions_old (use taco_get_state for that)");
+    const int rc = refresh_clock(e);
+    if (rc != TACO_OK) return rc;
+    const int n = e->cfg.num_envs;
+    hipLaunchKernelGGL(export_field_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->S, e->hist, out, field, n, e->npad, e->hh);
+    hipError_t he = hipGetLastError();
+    return he == hipSuccess ? TACO_OK : hip_fail(he, "export_field_kernel launch");
+}
+
 int taco_get_state(taco_env *e, uint32_t *blob, void *stream) {
     if (!e || !blob) return fail(TACO_ERR_INVALID_ARG, "taco_get_state: null argument");
+    if (refresh_clock(e) != TACO_OK) return TACO_ERR_HIP;
     const int n = e->cfg.num_envs;
     hipLaunchKernelGGL(export_state_kernel, dim3((n + 255) / 256, TACO_BLOB_ROWS), dim3(256), 0, (hipStream_t)stream, e->S, e->hist, e->ring, blob, n,
                        e->npad, e->head, e->hh);
@@ -462,6 +546,7 @@ int taco_get_state(taco_env *e, uint32_t *blob, void *stream) {
 
 int taco_set_state(taco_env *e, const uint32_t *blob, void *stream) {
     if (!e || !blob) return fail(TACO_ERR_INVALID_ARG, "taco_set_state: null argument");
+    if (refresh_clock(e) != TACO_OK) return TACO_ERR_HIP;
     const int n = e->cfg.num_envs;
     hipLaunchKernelGGL(import_state_kernel, dim3((n + 255) / 256, TACO_BLOB_ROWS), dim3(256), 0, (hipStream_t)stream, e->S, e->hist, e->ring, blob, n,
                        e->npad, e->head, e->hh);

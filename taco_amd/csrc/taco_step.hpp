@@ -34,6 +34,10 @@ struct StepParams {
     float *done_f32;     // optional [n] f32 image of the new reset flags (PPOReplayBuffer.done_buf, buffer_asymmetry.py:67)
     unsigned long long *stamps;  // optional [8]: shader-clock stamps of workgroup 0 at the phase boundaries (taco_bind_phase_stamps)
     float *gather;       // optional [n][len_obs*26 + 3] f32: obs stack | reward | done | time-out (one all-gather block per rank)
+    float *obs_out;      // optional [n][len_obs][26]: clamp(new obs stack, +-clip_obs), the copy VecTask.step returns (VT:331); NULL = none
+    float *states_out;   // optional [n][len_states][26]: clamp(new states stack, +-clip_states) (VT:332)
+    uint32_t *ctl;       // control block in the workspace (kCtl*): the device-resident step clock + the sticky status word
+    int use_ctl;         // 1: take step / head / hh from ctl (launch captured into a HIP graph: kernel arguments are frozen); 0: from below
     // geometry / cfg
     int n, npad, env_offset, task_mode, mix_n1, mix_n2, len_obs, len_states, substeps, max_len, delay_time, head;
     uint32_t flags, seed_lo, seed_hi, step;
@@ -43,6 +47,7 @@ struct StepParams {
     uint32_t obs_bytes, states_bytes, gather_bytes, gather_row;  // gather_row = floats per env in the gather block (multiple of 32)
     // fp32 images of the Python doubles the reference feeds into tensor ops
     float dt, rdt, clip_act, df;  // rdt = RN(1/dt); taco_create refuses a dt for which div_const(x, dt, rdt) != x / dt
+    float clip_obs, clip_states;  // bounds of obs_out / states_out (+inf = none)
     float h, half_h, inv_m, g, J0, J1, J2, hJi0, hJi1, hJi2, arm_x, arm_y;
     float flip_xy_sc, flip_xy_lo, flip_v_sc, flip_v_lo, dr_sc, dr_lo, tau_sc, tau_lo, tau_fixed, nq_sc, nq_lo;
 };
@@ -77,6 +82,10 @@ enum Chunk : uint32_t {
     NUM_CHUNKS = 16
 };
 constexpr int HIST_ROWS = 16;  // action history: hist[tile][k][64] float4, the action of the step whose (count & 15) == k
+// control block: the last 256 bytes of the workspace.  Words: 0 step count, 1 ring head, 2 history row (the step CLOCK: every eager launch
+// leaves the next values here, a graph-captured launch reads them and is followed by advance_clock_kernel), 3 -, 4 sticky status bits
+enum : uint32_t { kCtlStep = 0, kCtlHead = 1, kCtlHh = 2, kCtlStatus = 4, kCtlBytes = 256 };
+constexpr uint32_t kStatusMailboxTimeout = 1u;  // a battery-mailbox wait gave up (the affected envs' voltage was poisoned with NaN)
 constexpr uint32_t kRowBytes = 1024;  // one row (chunk, history row or ring slot) of one tile: 64 lanes x 16 B
 // float index of word 0 of (row r, env i) in an array with `rows` rows per tile (host-side kernels of taco_capi.hip)
 __host__ __device__ constexpr size_t tile_word(int rows, int r, int i) { return (((size_t)(i >> 6) * rows + r) * 64 + (size_t)(i & 63)) * 4; }
@@ -446,14 +455,14 @@ TD bool integrate_quad(const StepParams &P, uint32_t k3, float &pq, float &qq, f
 // from 10 Philox blocks of STREAM_RESET; a block whose consumers are all switched off (launch-uniform flags) is not generated.
 #define CST(c, val) buf_st4(rS, (val), voff, (uint32_t)(c) * row_bytes)
 #define CLD(c) buf_ld4(rS, voff, (uint32_t)(c) * row_bytes)
-TD void reset_env(const StepParams &P, rsrc_t rS, uint32_t voff, uint32_t row_bytes, int gid, int grp, bool mix, bool store, float4 &c_pos,
+TD void reset_env(const StepParams &P, uint32_t step, rsrc_t rS, uint32_t voff, uint32_t row_bytes, int gid, int grp, bool mix, bool store, float4 &c_pos,
                   float4 &c_quat, float4 &c_lin, float4 &c_ang, float4 &c_pp, float4 &c_pi, float4 &c_om, float4 &c_misc, float4 &c_tau,
                   float4 &c_op, float4 &c_a0, float4 &c_a1) {
     const uint32_t fl = P.flags;
     auto block = [&](bool wanted, uint32_t b, float &u0, float &u1, float &u2, float &u3) {
         u0 = u1 = u2 = u3 = 0.0f;
         if (wanted) {  // (launch-uniform)
-            U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, P.step, STREAM_RESET, b);
+            U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, step, STREAM_RESET, b);
             u0 = uniform(r.x); u1 = uniform(r.y); u2 = uniform(r.z); u3 = uniform(r.w);
         }
     };
@@ -632,6 +641,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
     //   post-step: the 64 x 26 frame tile that transposes lane-major registers into env-major bytes (6.5 KiB).
 #define TACO_STAMP(k) do { if (P.stamps && blockIdx.x == 0 && threadIdx.x == 0) P.stamps[k] = __builtin_readcyclecounter(); } while (0)
     TACO_STAMP(0);
+    // the step clock: kernel arguments on the eager path (which also leaves the NEXT values in the control block, so that a capture can start
+    // at any time); the device-resident copy when this launch was captured into a HIP graph (its arguments are frozen)
+    struct { uint32_t step; int head, hh; } clk{P.step, P.head, P.hh};
+    if (P.use_ctl) {
+        clk.step = P.ctl[kCtlStep]; clk.head = (int)P.ctl[kCtlHead]; clk.hh = (int)P.ctl[kCtlHh];
+    } else if (blockIdx.x == 0 && threadIdx.x == 0) {
+        P.ctl[kCtlStep] = P.step + 1u; P.ctl[kCtlHead] = (uint32_t)((P.head + 10) % TACO_RING_SLOTS); P.ctl[kCtlHh] = (uint32_t)((P.hh + 1) % HIST_ROWS);
+    }
     constexpr int EPW = 64 / LPE;  // envs per wavefront
     constexpr int WAVE_LDS_WORDS = 10 * EPW * 4;
     static_assert(WAVE_LDS_WORDS >= EPW * 26, "tile must fit in the per-wave scratch");
@@ -660,8 +677,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
     // 64 rows 104 * len bytes apart.  In place (prev == buf) the reads run 13 words ahead of the writes; loads are issued in batches of eight
     // ahead of their stores.  shift_history moves the history words only -- they do not depend on this step, so the role wavefronts of the
     // SPLIT form do it while wavefront 0 runs the substeps and only the newest frame is left for the post-phase.
-    auto shift_history = [&](float *buf, const float *prev, uint32_t buf_bytes, int len) {
-        const rsrc_t rB = make_rsrc(buf, buf_bytes), rP = make_rsrc(prev, buf_bytes);
+    // `out` (optional): the clamped copy VecTask.step hands to the caller (VT:331-332) receives clamp(word, +-clip) next to every word moved
+    auto clamp2 = [](f32x2_t v, float c) { return f32x2_t{clampf(v.x, -c, c), clampf(v.y, -c, c)}; };
+    auto clamp4 = [](f32x4_t v, float c) { return f32x4_t{clampf(v.x, -c, c), clampf(v.y, -c, c), clampf(v.z, -c, c), clampf(v.w, -c, c)}; };
+    auto shift_history = [&](float *buf, const float *prev, uint32_t buf_bytes, int len, float *out, float clip) {
+        const rsrc_t rB = make_rsrc(buf, buf_bytes), rP = make_rsrc(prev, buf_bytes), rO = make_rsrc(out, out ? buf_bytes : 0u);
         const uint32_t L13 = (uint32_t)len * 13u, hist = L13 - 13u, tot = (uint32_t)EPW * L13;
         const uint32_t magic = 0xFFFFFFFFu / L13 + 1u;  // row = (w * magic) >> 32 for w < 2^16
         const uint32_t base = wave_env0 * L13;          // first word of the wavefront's range
@@ -680,6 +700,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
             for (int k = 0; k < 8; ++k) {
                 const uint32_t w = w0 + (uint32_t)k * 64u + (uint32_t)lane;
                 if (mine[k]) llvm_amdgcn_raw_buffer_store_v2f32(v[k], rB, (int)((base + w) * 8u), 0, 0);
+                if (out && mine[k]) llvm_amdgcn_raw_buffer_store_v2f32(clamp2(v[k], clip), rO, (int)((base + w) * 8u), 0, 0);
             }
         }
     };
@@ -690,12 +711,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
     __shared__ float mb_om[SPLIT ? 64 : 4], mb_v[SPLIT ? 16 : 4], mb_bs[SPLIT ? 64 : 4];
     __shared__ int mb_seq[4];
     // The arrays are named directly at every use (macros, not lambdas or pointer parameters) so that the accesses stay LDS instructions;
-    // through a generic pointer they become flat loads.  MB_WAIT is bounded: a protocol bug shows up as a parity failure, never as a hung GPU.
+    // through a generic pointer they become flat loads.  MB_WAIT is bounded, so a protocol bug can never hang the GPU; a wait that gives up
+    // sets kStatusMailboxTimeout in the workspace's sticky status word (taco_check reports TACO_ERR_STATE) and poisons the voltage with NaN.
     // The LDS executes one wavefront's operations in order (data before counter on the writer's side, counter before data on the
     // reader's), so the fences only have to stop the compiler: wavefront scope, no s_waitcnt on the critical path.
 #define MB_SEQ(idx) __hip_atomic_load(&mb_seq[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define MB_WAIT(idx, want) do { int spins_ = 0; while (MB_SEQ(idx) < (want) && ++spins_ < (1 << 20)) __builtin_amdgcn_s_sleep(1); \
-                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); if (spins_ >= (1 << 20)) mb_timeout = true; } while (0)
+    bool mb_timeout = false;  // a bounded wait gave up: reported through the sticky status word and a NaN voltage, see below
 #define MB_POST(idx, value) do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
                                  __hip_atomic_store(&mb_seq[idx], (value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
     // (only while every wavefront of the launch has a SIMD to itself -- 1 024 on the MI355X -- or the server would take issue slots
@@ -728,7 +751,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
     auto gen_obs_noise = [&]() {
 #pragma unroll
         for (int pr = 0; pr < 3; ++pr) {  // uniforms 4..15 of STREAM_OBS = blocks 1..3, two Box-Muller pairs per block
-            U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, P.step, STREAM_OBS, (uint32_t)(1 + pr));
+            U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, clk.step, STREAM_OBS, (uint32_t)(1 + pr));
             float ua = 1.0f - uniform(r.x), ub = uniform(r.y);
             float rad = __builtin_sqrtf(-2.0f * log(ua));
             float sn, cs;
@@ -739,7 +762,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
             sincos(kTwoPi * ub, sn, cs);
             nrm[4 * pr + 2] = rad * cs; nrm[4 * pr + 3] = rad * sn;
         }
-        U4 r0 = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, P.step, STREAM_OBS, 0u);
+        U4 r0 = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, clk.step, STREAM_OBS, 0u);
         nq = quat_from_euler(P.nq_sc * uniform(r0.x) + P.nq_lo, P.nq_sc * uniform(r0.y) + P.nq_lo, P.nq_sc * uniform(r0.z) + P.nq_lo);
     };
     if (!SPLIT || wv == 0) {
@@ -767,12 +790,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
 #pragma unroll
     for (int k = 0; k < 4; ++k) {  // (rows this configuration's queue never reaches are not fetched: P.hw_rows)
         hwin[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (k < P.hw_rows) hwin[k] = buf_ld4(rH, voff, (uint32_t)((P.hh - 1 - k) & (HIST_ROWS - 1)) * row_bytes);
+        if (k < P.hw_rows) hwin[k] = buf_ld4(rH, voff, (uint32_t)((clk.hh - 1 - k) & (HIST_ROWS - 1)) * row_bytes);
     }
     // reset_idx (FA:475-517): the lanes that reset get their fresh state in the registers the up-front loads filled (see reset_env)
     const bool wave_has_reset = __builtin_amdgcn_ballot_w64(is_reset) != 0;
     if (wave_has_reset) {
-        if (is_reset) reset_env(P, rS, voff, row_bytes, gid, grp, mix, active, c_pos, c_quat, c_lin, c_ang, c_pp, c_pi, c_om, c_misc, c_tau, c_op, c_a0, c_a1);
+        if (is_reset) reset_env(P, clk.step, rS, voff, row_bytes, gid, grp, mix, active, c_pos, c_quat, c_lin, c_ang, c_pp, c_pi, c_om, c_misc, c_tau, c_op, c_a0, c_a1);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // (the target pose and the unwrapped angles it stored are loaded further down)
     }
     if (P.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TACO_STAMP(1); }  // all up-front loads have landed
@@ -829,7 +852,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
         if (grp == TACO_TASK_POS) {
             cmd0 = 0.0f; cmd1 = 0.0f;
         } else {
-            U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, P.step, STREAM_CMD, 0u);
+            U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, clk.step, STREAM_CMD, 0u);
             if (grp == TACO_TASK_ROTATE) {
                 cmd0 = 1.0f;
                 cmd1 = (fl & TACO_F_RANDOM_COMMAND) ? 12.0f * uniform(r.x) + -6.0f : 1.0f;
@@ -855,15 +878,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
     act[3] = clampf(a_in.w, -P.clip_act, P.clip_act);
     const float4 act4 = make_float4(act[0], act[1], act[2], act[3]);
     const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (active) buf_st4(rH, act4, voff, (uint32_t)(P.hh & (HIST_ROWS - 1)) * row_bytes);  // this step's action, row hh
+    if (active) buf_st4(rH, act4, voff, (uint32_t)(clk.hh & (HIST_ROWS - 1)) * row_bytes);  // this step's action, row hh
     int T = 10;
     if (fl & TACO_F_RANDOM_DEPLOY_TIME) {
-        U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, P.step, STREAM_DEPLOY, 0u);
+        U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, clk.step, STREAM_DEPLOY, 0u);
         T = 10 - rounded_normal(uniform(r.x), 1);
     }
     // value of queued run j (0 = oldest) BEFORE this step's push: the action of (m - j) steps ago
     auto run_value = [&](int j) -> float4 {
-        const uint32_t row = (uint32_t)((P.hh - (q_m - j)) & (HIST_ROWS - 1));
+        const uint32_t row = (uint32_t)((clk.hh - (q_m - j)) & (HIST_ROWS - 1));
         return buf_ld4(rH, row * row_bytes + voff, 0u);
     };
     if (!dense && dlen + T > TACO_RING_SLOTS - 10) {
@@ -871,19 +894,19 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
         if (active) {
             int pos = 0;
             for (; pos < zlead; ++pos) {
-                int ph = P.head + pos; ph = ph >= TACO_RING_SLOTS ? ph - TACO_RING_SLOTS : ph;
+                int ph = clk.head + pos; ph = ph >= TACO_RING_SLOTS ? ph - TACO_RING_SLOTS : ph;
                 buf_st4(rR, zero4, (uint32_t)ph * row_bytes + voff, 0u);
             }
             for (int j = 0; j < q_m; ++j) {
                 const float4 val = run_value(j);
                 const int len = (j == 0) ? q_rem0 : run_len(q_lens, j);
                 for (int t = 0; t < len; ++t, ++pos) {
-                    int ph = P.head + pos; ph = ph >= TACO_RING_SLOTS ? ph - TACO_RING_SLOTS : ph;
+                    int ph = clk.head + pos; ph = ph >= TACO_RING_SLOTS ? ph - TACO_RING_SLOTS : ph;
                     buf_st4(rR, val, (uint32_t)ph * row_bytes + voff, 0u);
                 }
             }
             for (; pos < TACO_RING_SLOTS; ++pos) {
-                int ph = P.head + pos; ph = ph >= TACO_RING_SLOTS ? ph - TACO_RING_SLOTS : ph;
+                int ph = clk.head + pos; ph = ph >= TACO_RING_SLOTS ? ph - TACO_RING_SLOTS : ph;
                 buf_st4(rR, zero4, (uint32_t)ph * row_bytes + voff, 0u);
             }
         }
@@ -910,7 +933,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
         if (__builtin_expect(wave_dense, 0)) {  // DENSE lanes overwrite their entries from the ring (kept out of the common path)
 #pragma unroll 1
             for (int s = 0; s < 10; ++s) {
-                int ph = P.head + s; ph = ph >= TACO_RING_SLOTS ? ph - TACO_RING_SLOTS : ph;
+                int ph = clk.head + s; ph = ph >= TACO_RING_SLOTS ? ph - TACO_RING_SLOTS : ph;
                 const float4 r = buf_ld4(rR, voff, (uint32_t)ph * row_bytes);  // physical row is wave-uniform: coalesced
                 const bool fresh = (s >= dlen) && (s < dlen + T);             // covered by this step's write: from registers
                 if (dense) slots[s * EPW + el] = sel4(fresh, act4, r);
@@ -938,7 +961,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
         if (__builtin_expect(wave_dense, 0)) {  // DENSE lanes overwrite their entries from the ring (kept out of the common path)
 #pragma unroll 1
             for (int s = 0; s < 10; ++s) {
-                int ph = P.head + s; ph = ph >= TACO_RING_SLOTS ? ph - TACO_RING_SLOTS : ph;
+                int ph = clk.head + s; ph = ph >= TACO_RING_SLOTS ? ph - TACO_RING_SLOTS : ph;
                 const float4 r = buf_ld4(rR, voff, (uint32_t)ph * row_bytes);  // physical row is wave-uniform: coalesced
                 const bool fresh = (s >= dlen) && (s < dlen + T);             // covered by this step's write: from registers
                 if (dense) slotsw[(s * EPW + el) * 4 + sub] = fresh ? ac : pick4(sub, r.x, r.y, r.z, r.w);
@@ -956,7 +979,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
             for (int j = 0; j < 11; ++j) {
                 int sl = dlen + j;
                 if (j < T && sl < TACO_RING_SLOTS) {
-                    int ph = P.head + sl; ph = ph >= TACO_RING_SLOTS ? ph - TACO_RING_SLOTS : ph;
+                    int ph = clk.head + sl; ph = ph >= TACO_RING_SLOTS ? ph - TACO_RING_SLOTS : ph;
                     buf_st4(rR, act4, (uint32_t)ph * row_bytes + voff, 0u);
                 }
             }
@@ -967,8 +990,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
             // Done ahead of the substeps so that its traffic drains while the loop computes.
 #pragma unroll
             for (int j = 0; j < 10; ++j) {
-                int src = P.head + 90 + j; src = src >= TACO_RING_SLOTS ? src - TACO_RING_SLOTS : src;
-                int dst = P.head + j;  // old logical j == new logical 90+j
+                int src = clk.head + 90 + j; src = src >= TACO_RING_SLOTS ? src - TACO_RING_SLOTS : src;
+                int dst = clk.head + j;  // old logical j == new logical 90+j
                 dst = dst >= TACO_RING_SLOTS ? dst - TACO_RING_SLOTS : dst;
                 const bool fresh = (90 + j >= dlen) && (90 + j < dlen_after);
                 float4 old = buf_ld4(rR, voff, (uint32_t)src * row_bytes);
@@ -1085,7 +1108,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
                 }
             }
             if (!PLAIN && (fl & TACO_F_ROTOR_NOISE)) {  // CTRL/thrust_dynamics.py:68-78
-                U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, P.step, STREAM_ROTOR, (uint32_t)ks);
+                U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, clk.step, STREAM_ROTOR, (uint32_t)ks);
                 const float n_sc = (float)((1 + 10.0 / 700) - (1 - 10.0 / 700)), n_lo = (float)(1 - 10.0 / 700);
                 omega[0] = omega[0] * (n_sc * uniform(r.x) + n_lo);
                 omega[1] = omega[1] * (n_sc * uniform(r.y) + n_lo);
@@ -1250,7 +1273,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
                 omq = omq + itq * (target - omq);
             }
             if (!PLAIN && (fl & TACO_F_ROTOR_NOISE)) {  // CTRL/thrust_dynamics.py:68-78
-                U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, P.step, STREAM_ROTOR, (uint32_t)ks);
+                U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, clk.step, STREAM_ROTOR, (uint32_t)ks);
                 const float n_sc = (float)((1 + 10.0 / 700) - (1 - 10.0 / 700)), n_lo = (float)(1 - 10.0 / 700);
                 const uint32_t rk = sub == 0 ? r.x : (sub == 1 ? r.y : (sub == 2 ? r.z : r.w));
                 omq = omq * (n_sc * uniform(rk) + n_lo);
@@ -1309,6 +1332,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
         if (bat_served) {
             MB_WAIT(1, 11);
             bat_E = mb_bs[el * 4]; bat_u1 = mb_bs[el * 4 + 1]; bat_t = mb_bs[el * 4 + 2];
+            if (__builtin_expect(mb_timeout, 0)) {  // never silently: sticky status + a voltage no consumer can mistake for a result
+                if (lane == 0) atomicOr(&P.ctl[kCtlStatus], kStatusMailboxTimeout);
+                bat_V = nanf32();
+            }
         }
         p = V3{bc0(pq), bc1(pq), bc2(pq)};
         q = Q4{bc0(qq), bc1(qq), bc2(qq), bc3(qq)};
@@ -1381,8 +1408,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
     } else {
         if (wv == 1 && lane < 4) mb_seq[lane] = 0;
         __syncthreads();  // barrier 1 of 2
-        if (wv == 3 && P.len_states > 1) shift_history(P.states, P.states_prev, P.states_bytes, P.len_states);
-        if (wv == 2 && P.len_obs > 1) shift_history(P.obs, P.obs_prev, P.obs_bytes, P.len_obs);
+        if (wv == 3 && P.len_states > 1) shift_history(P.states, P.states_prev, P.states_bytes, P.len_states, P.states_out, P.clip_states);
+        if (wv == 2 && P.len_obs > 1) shift_history(P.obs, P.obs_prev, P.obs_bytes, P.len_obs, P.obs_out, P.clip_obs);
         if (wv == 2 && (fl & TACO_F_OBSERVATION_NOISE)) { gen_obs_noise(); noise_ready = true; }
         if (bat_served && wv == 1) {  // battery server (the reward wavefront, idle until the post-phase): ten voltages, each one substep ahead of wavefront 0
             MB_WAIT(0, 1);
@@ -1460,8 +1487,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
     //  len  > 1 : each lane shifts its own row by one frame (8-byte accesses, in place, ascending) and appends the frame.
     // Stores go through range-checked buffer descriptors, so ragged tails need no special casing.
     // fill_tile = false: the tile already holds this frame (the obs frame equals the states frame when there is no observation noise)
-    auto put_frame = [&](float *buf, const float *prev, uint32_t buf_bytes, int len, const float (&f)[26], bool fill_tile) {
-        const rsrc_t rB = make_rsrc(buf, buf_bytes);
+    auto put_frame = [&](float *buf, const float *prev, uint32_t buf_bytes, int len, const float (&f)[26], bool fill_tile, float *out, float clip) {
+        const rsrc_t rB = make_rsrc(buf, buf_bytes), rO = make_rsrc(out, out ? buf_bytes : 0u);
         if (fill_tile) {
             // the scratch is private to the wavefront and its LDS operations execute in order: only the compiler needs the fence
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -1479,6 +1506,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
             for (int it = 0; it < (int)((TILE_W4 + 63u) / 64u); ++it) {
                 const uint32_t w4 = (uint32_t)(it * 64 + lane);
                 if (w4 < TILE_W4) llvm_amdgcn_raw_buffer_store_v4f32(t4[w4], rB, (int)(wave_env0 * 104u + w4 * 16u), 0, 0);
+                if (out && w4 < TILE_W4) llvm_amdgcn_raw_buffer_store_v4f32(clamp4(t4[w4], clip), rO, (int)(wave_env0 * 104u + w4 * 16u), 0, 0);
             }
         } else if (SPLIT) {
             // the history words were moved by shift_history while the substeps ran: only the newest frame of every row is left
@@ -1490,6 +1518,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
                 const uint32_t t = (uint32_t)(it * 64 + lane);  // word t of the tile = word (t % 13) of row t / 13
                 const uint32_t row = t / 13u;
                 if (t < (uint32_t)EPW * 13u) llvm_amdgcn_raw_buffer_store_v2f32(tp[t], rB, (int)((base + row * L13 + hist + (t - row * 13u)) * 8u), 0, 0);
+                if (out && t < (uint32_t)EPW * 13u) llvm_amdgcn_raw_buffer_store_v2f32(clamp2(tp[t], clip), rO, (int)((base + row * L13 + hist + (t - row * 13u)) * 8u), 0, 0);
             }
         } else {
             // one wavefront does everything: history words from the previous stack, the newest frame from the LDS tile, in one pass
@@ -1514,12 +1543,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
                 for (int k = 0; k < 8; ++k) {
                     const uint32_t w = w0 + (uint32_t)k * 64u + (uint32_t)lane;
                     if (w < tot) llvm_amdgcn_raw_buffer_store_v2f32(v[k], rB, (int)((base + w) * 8u), 0, 0);
+                    if (out && w < tot) llvm_amdgcn_raw_buffer_store_v2f32(clamp2(v[k], clip), rO, (int)((base + w) * 8u), 0, 0);
                 }
             }
         }
     };
     // states first (noise-free frame), then obs (possibly noised)
-    if (roleS) put_frame(P.states, P.states_prev, P.states_bytes, P.len_states, fr, true);
+    if (roleS) put_frame(P.states, P.states_prev, P.states_bytes, P.len_states, fr, true, P.states_out, P.clip_states);
     if (roleO && (fl & TACO_F_OBSERVATION_NOISE)) {  // FA:402-410
         if (!noise_ready) gen_obs_noise();
 #pragma unroll
@@ -1534,7 +1564,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
         fr[18] = fr[18] + P.df * (nrm[9] * (float)(0.06 / 3) + 0.0f);
         fr[23] = fr[23] + P.df * (nrm[10] * (float)(0.06 / 3 / 3) + 0.0f);
     }
-    if (roleO) put_frame(P.obs, P.obs_prev, P.obs_bytes, P.len_obs, fr, SPLIT || (fl & TACO_F_OBSERVATION_NOISE) != 0);
+    if (roleO) put_frame(P.obs, P.obs_prev, P.obs_bytes, P.len_obs, fr, SPLIT || (fl & TACO_F_OBSERVATION_NOISE) != 0, P.obs_out, P.clip_obs);
     // Optional all-gather block, one 128-byte-aligned row per env: [obs stack | reward | done | time-out | pad].  The obs part is written by
     // the wavefront that holds the obs frame (the newest frame from registers, older frames re-read from this env's just-written obs row),
     // the three tail words by the reward wavefront below.

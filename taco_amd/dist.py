@@ -5,6 +5,17 @@ here has a reference counterpart; it follows SURVEY.md section 8(e): envs are in
 contiguous slice of GLOBAL env ids (which key the random streams and the FpvMix thirds -- results do not depend on the
 number of ranks), and one all-gather per step publishes the packed per-rank block [obs stack | reward | done | time-out].
 The step kernel fills that block itself (taco_bind_gather_block), so a step is one kernel launch + one collective.
+
+Layout of the gathered result: `world_size` slabs of `m = max shard size` rows each (the PADDED layout: every rank
+contributes m rows, the first `hi - lo` of them live), i.e. rank r's envs are rows [r * m, r * m + size_r).  Equal
+shards make that the global env order; ragged shards (numEnvs not a multiple of the world size) are exposed as views
+(`GatheredBlocks.rank_rows`, `.global_rows()`), never re-copied.
+
+Overlap (the gather of ~12-25 us is comparable to the step itself): `ShardedEnv.step_async` issues the
+collective with async_op=True -- RCCL runs it on the process group's own stream, ordered behind the step kernel -- and
+returns a handle; the next step's launch does not wait for it.  Two block / result buffers alternate, and a step that
+is about to refill a block first waits (stream-side) for the gather that last read it.  `step_gathered` = step_async +
+wait is the serial form a single learner that needs obs(t) before action(t+1) uses.
 """
 import torch
 
@@ -16,6 +27,10 @@ def shard_bounds(n_global, world_size, rank):
     base, rem = divmod(int(n_global), int(world_size))
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_sizes(n_global, world_size):
+    return [hi - lo for lo, hi in (shard_bounds(n_global, world_size, r) for r in range(world_size))]
 
 
 def block_row(len_obs):
@@ -32,34 +47,60 @@ def unpack_block(block, len_obs):
     return obs, block[:, row], block[:, row + 1].to(torch.long), block[:, row + 2] != 0
 
 
-def pack_block(obs, rew, done, timeout):
-    """Host-side packer with the kernel's block layout (used by the CPU tests, where no kernel fills the block)."""
+def pack_block(obs, rew, done, timeout, rows=None):
+    """Host-side packer with the kernel's block layout (used by the CPU tests, where no kernel fills the block).
+    `rows` >= n allocates the padded block of the gather layout (rows beyond n stay zero)."""
     n = obs.shape[0]
     row = obs.shape[1] * 26
-    blk = torch.zeros((n, block_row(obs.shape[1])), dtype=torch.float32, device=obs.device)
-    blk[:, :row] = obs.reshape(n, -1)
-    blk[:, row] = rew.float()
-    blk[:, row + 1] = done.float()
-    blk[:, row + 2] = timeout.float()
+    blk = torch.zeros((rows or n, block_row(obs.shape[1])), dtype=torch.float32, device=obs.device)
+    blk[:n, :row] = obs.reshape(n, -1)
+    blk[:n, row] = rew.float()
+    blk[:n, row + 1] = done.float()
+    blk[:n, row + 2] = timeout.float()
     return blk
 
 
-def all_gather_blocks(block, n_global, world_size, group=None):
-    """ONE collective: every rank's [n_r, row] block -> [n_global, row] in global env order.  Equal shards use
-    all_gather_into_tensor directly; ragged shards are padded to the largest shard and compacted afterwards."""
+class GatheredBlocks:
+    """The result of one all-gather in the padded layout [world_size * m, row]; `wait()` makes the CURRENT stream (and, for
+    CPU backends, the host) wait for the collective."""
+
+    def __init__(self, out, sizes, work=None):
+        self.out, self.sizes, self.work = out, sizes, work
+        self.m = out.shape[0] // len(sizes)
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        return self
+
+    def rank_rows(self, r):
+        """view of rank r's live rows"""
+        return self.out[r * self.m: r * self.m + self.sizes[r]]
+
+    def global_rows(self):
+        """[n_global, row] in global env order: the buffer itself for equal shards (no copy), one index_select for ragged shards"""
+        if len(set(self.sizes)) == 1:
+            return self.out
+        idx = torch.cat([torch.arange(r * self.m, r * self.m + s, device=self.out.device) for r, s in enumerate(self.sizes)])
+        return self.out.index_select(0, idx)
+
+
+def all_gather_blocks(block, n_global, world_size, group=None, out=None, async_op=False):
+    """ONE collective: every rank's [m, row] block (m = the largest shard; a rank with fewer envs leaves its last row unused) ->
+    GatheredBlocks over [world_size * m, row].  A block with exactly this rank's shard size is accepted too and padded here
+    (tests, callers that do not pre-allocate)."""
     import torch.distributed as dist
-    row = block.shape[1]
-    sizes = [hi - lo for lo, hi in (shard_bounds(n_global, world_size, r) for r in range(world_size))]
-    if len(set(sizes)) == 1:
-        out = torch.empty((n_global, row), dtype=block.dtype, device=block.device)
-        dist.all_gather_into_tensor(out, block, group=group)
-        return out
+    sizes = shard_sizes(n_global, world_size)
     m = max(sizes)
-    padded = torch.zeros((m, row), dtype=block.dtype, device=block.device)
-    padded[: block.shape[0]] = block
-    out = torch.empty((world_size * m, row), dtype=block.dtype, device=block.device)
-    dist.all_gather_into_tensor(out, padded, group=group)
-    return torch.cat([out[r * m: r * m + sizes[r]] for r in range(world_size)], dim=0)
+    if block.shape[0] != m:
+        padded = torch.zeros((m, block.shape[1]), dtype=block.dtype, device=block.device)
+        padded[: block.shape[0]] = block
+        block = padded
+    if out is None:
+        out = torch.empty((world_size * m, block.shape[1]), dtype=block.dtype, device=block.device)
+    work = dist.all_gather_into_tensor(out, block, group=group, async_op=async_op)
+    return GatheredBlocks(out, sizes, work if async_op else None)
 
 
 class ShardedEnv:
@@ -70,20 +111,48 @@ class ShardedEnv:
         self.rank, self.world_size, self.group, self.gather = rank, world_size, group, gather
         self.n_global = int(cfg["env"]["numEnvs"])
         self.lo, self.hi = shard_bounds(self.n_global, world_size, rank)
+        self.sizes = shard_sizes(self.n_global, world_size)
+        self.m = max(self.sizes)
         self.env = FpvBase(cfg, rl_device=str(device), sim_device=str(device), env_offset=self.lo, num_envs_local=self.hi - self.lo,
                            copy_outputs=False)
         self.len_obs = self.env.len_obs
-        self.block = torch.zeros((self.hi - self.lo, block_row(self.len_obs)), dtype=torch.float32, device=self.env.device)
+        row = block_row(self.len_obs)
+        # two block / result pairs alternate so that step t + 1 can fill its block while the gather of step t is still reading the other
+        self.blocks = [torch.zeros((self.m, row), dtype=torch.float32, device=self.env.device) for _ in range(2)]
+        self.outs = [torch.empty((world_size * self.m, row), dtype=torch.float32, device=self.env.device) for _ in range(2)]
+        self.pending = [None, None]
+        self.k = 0
+        self.block = self.blocks[0]
         _lib.check(self.env.lib.taco_bind_gather_block(self.env._h, self.block.data_ptr()))
-        self.gathered = None
+
+    def step_async(self, local_actions):
+        """One step of this rank's envs + the all-gather of its block, issued without waiting for it: returns a GatheredBlocks whose
+        `wait()` orders the current stream behind the collective.  (gather off / one rank: the local block, nothing pending)"""
+        k = self.k
+        if self.pending[k] is not None:  # the gather that last read this block / wrote this result must be done before both are reused
+            self.pending[k].wait()
+            self.pending[k] = None
+        self.block = self.blocks[k]
+        _lib.check(self.env.lib.taco_bind_gather_block(self.env._h, self.block.data_ptr()))
+        self.env.step_raw(local_actions)
+        self.k = 1 - k
+        if not self.gather or self.world_size == 1:
+            return GatheredBlocks(self.block[: self.hi - self.lo], [self.hi - self.lo])
+        g = all_gather_blocks(self.block, self.n_global, self.world_size, self.group, out=self.outs[k], async_op=True)
+        self.pending[k] = g
+        return g
 
     def step_gathered(self, local_actions):
-        """One step of this rank's envs; returns the all-gathered block (or the local one if gather is off)."""
-        self.env.step_raw(local_actions)
-        if not self.gather or self.world_size == 1:
-            return self.block
-        self.gathered = all_gather_blocks(self.block, self.n_global, self.world_size, self.group)
-        return self.gathered
+        """step_async + wait: the gathered block of THIS step in global env order (or the local one if gather is off)."""
+        g = self.step_async(local_actions).wait()
+        self.gathered = g
+        return g.global_rows()
+
+    def drain(self):
+        for k in range(2):
+            if self.pending[k] is not None:
+                self.pending[k].wait()
+                self.pending[k] = None
 
     def step(self, local_actions):
         """-> (obs [N_global,len_obs,26], rew, done, time_outs) for the whole job, plus this rank's critic states."""

@@ -85,6 +85,13 @@ class FpvBase:
         self.timeout_buf = torch.zeros(self.num_envs, device=dev, dtype=torch.bool)
         self.extras = {}
         self.obs_dict = {}
+        # What step() returns as obs / states (vec_task_asymmetry.py:331-332: a clamped COPY of the buffers) is written by the step kernel
+        # itself into these buffers -- no torch.clamp launch, no allocation per step.  Two pairs alternate, so a tensor returned by one
+        # step() stays untouched by the next (the reference returns a fresh tensor every time; the PPO loop copies it straight away).
+        self._want_out = bool(copy_outputs or math.isfinite(self.clip_obs) or math.isfinite(self.clip_states))
+        self._out = [(torch.zeros_like(self.obs_buf), torch.zeros_like(self.states_buf)) for _ in range(2)] if self._want_out else None
+        self._out_k = 0
+        self._progress = torch.zeros(self.num_envs, device=dev, dtype=torch.int32)
 
         nbytes = self.lib.taco_workspace_bytes(C.byref(self._c))
         self._workspace = torch.empty(nbytes, device=dev, dtype=torch.uint8)
@@ -126,7 +133,13 @@ class FpvBase:
 
     @property
     def progress_buf(self):
-        return self.get_state()[_lib.NUM_FIELDS - 2].view(torch.int32).to(torch.long)
+        """progress_buf of the reference (fpv_asymmetry.py:375): one row of the state, exported by a one-row kernel"""
+        _lib.check(self.lib.taco_get_field(self._h, _lib.NUM_FIELDS - 2, self._progress.data_ptr(), _stream_ptr(self.device).value), self.lib)
+        return self._progress.to(torch.long)
+
+    def check(self):
+        """raise if any step kernel recorded a sticky error since the env was created (blocks on the current stream)"""
+        _lib.check(self.lib.taco_check(self._h, _stream_ptr(self.device).value), self.lib)
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -179,10 +192,23 @@ class FpvBase:
         _lib.check(self.lib.taco_step_rollout(self._h, C.byref(io), _stream_ptr(self.device)))
 
     def step(self, actions):
-        """vec_task_asymmetry.py:290-334."""
-        self.step_raw(actions)
+        """vec_task_asymmetry.py:290-334: ONE kernel launch (the clamped obs / states copies are written by the step kernel)."""
+        if not self._want_out:
+            self.step_raw(actions)
+            self.obs_dict["obs"], self.obs_dict["states"] = self.obs_buf.to(self.rl_device), self.states_buf.to(self.rl_device)
+        else:
+            if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.device != self.device:
+                actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
+            if actions.shape != (self.num_envs, self.num_acts):
+                raise ValueError(f"actions must be [{self.num_envs}, {self.num_acts}], got {tuple(actions.shape)}")
+            obs_out, states_out = self._out[self._out_k]
+            self._out_k ^= 1
+            io = _lib.RolloutIO(actions.data_ptr(), None, self.obs_buf.data_ptr(), None, self.states_buf.data_ptr(), self.rew_buf.data_ptr(),
+                                self.reset_buf.data_ptr(), self.timeout_buf.data_ptr(), None, obs_out.data_ptr(), states_out.data_ptr())
+            _lib.check(self.lib.taco_step_rollout(self._h, C.byref(io), _stream_ptr(self.device)), self.lib)
+            self.obs_dict["obs"], self.obs_dict["states"] = obs_out.to(self.rl_device), states_out.to(self.rl_device)
         self.extras["time_outs"] = self.timeout_buf.to(self.rl_device)
-        return self._outputs(), self.rew_buf.to(self.rl_device), self.reset_buf.to(self.rl_device), self.extras
+        return self.obs_dict, self.rew_buf.to(self.rl_device), self.reset_buf.to(self.rl_device), self.extras
 
     def reset_idx(self, env_ids):
         """Mark envs for reset; like the reference, the re-initialisation itself runs at the start of the next step()."""

@@ -202,30 +202,73 @@ def test_training_example_runs_and_learns_something(tmp_path):
     assert torch.jit.load(str(tmp_path / "actor.pt"))(torch.zeros(1, 1, 26)).shape == (1, 4)
 
 
-def test_step_refuses_graph_capture():
-    """taco_step carries the step index in its kernel arguments, so a captured launch would replay one step for ever: the library refuses
-    to be captured (the supported launch-bound path is taco_rollout_run) and keeps working afterwards."""
+def test_step_is_graph_capturable_and_replays_continue_the_run():
+    """taco_step on a capturing stream enqueues the step kernel reading the DEVICE-resident clock (step index, ring head, history row) plus
+    the one-thread kernel that advances it, so a captured step can be replayed: eager steps, then 100 replays, then eager steps again are
+    bit-identical to 100 + k eager steps of a twin env -- every output and every state word, resets and command re-draws included."""
     import torch
-    from taco_amd import config, _lib
+    from taco_amd import config
     from taco_amd.vec_env import FpvBase
-    env = FpvBase(config.baseline_config(1, num_envs=256), copy_outputs=False)
-    a = torch.zeros((256, 4), device="cuda")
-    env.step_raw(a)
+    n = 700
+    kw = dict(env_maxEpisodeLength=40, env_lenStates=3, seed=5, ramdom_deploy_time=True, observation_noise=True, rotor_noise=True)
+    a_env = FpvBase(config.default_cfg("mix", n, **kw), copy_outputs=False)
+    b_env = FpvBase(config.default_cfg("mix", n, **kw), copy_outputs=False)
+    g = torch.Generator().manual_seed(3)
+    acts = (0.3 * torch.randn((8, n, 4), generator=g)).clamp(-1, 1).cuda()
+    act = torch.zeros((n, 4), device="cuda")      # the graph reads its action from this fixed buffer
+    for t in range(7):                            # eager prefix on both
+        a_env.step_raw(acts[t % 8]); b_env.step_raw(acts[t % 8])
     torch.cuda.synchronize()
     s = torch.cuda.Stream()
-    g = torch.cuda.CUDAGraph()
-    with pytest.raises(_lib.TacoError, match="cannot be captured"):
-        with torch.cuda.stream(s):
-            g.capture_begin()
-            try:
-                env.step_raw(a)
-            finally:
-                g.capture_end()
-    torch.cuda.synchronize()
-    n0 = env.step_count
-    env.step_raw(a)
-    torch.cuda.synchronize()
-    assert env.step_count == n0 + 1
+    s.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        graph.capture_begin()
+        a_env.step_raw(act)                       # captured, not executed
+        graph.capture_end()
+    torch.cuda.current_stream().wait_stream(s)
+    for t in range(7, 107):
+        act.copy_(acts[t % 8])
+        graph.replay()
+        b_env.step_raw(acts[t % 8])
+        if t % 10 == 0 or t == 106:
+            for name in ("obs_buf", "states_buf", "rew_buf", "reset_buf", "timeout_buf"):
+                assert_bits_equal(getattr(a_env, name).cpu().numpy(), getattr(b_env, name).cpu().numpy(), f"replay {t} {name}")
+    assert a_env.step_count == b_env.step_count == 107        # re-reads the device clock the replays advanced
+    assert torch.equal(a_env.get_state().view(torch.int32), b_env.get_state().view(torch.int32))
+    for t in range(107, 130):                     # and eagerly on
+        a_env.step_raw(acts[t % 8]); b_env.step_raw(acts[t % 8])
+    assert torch.equal(a_env.get_state().view(torch.int32), b_env.get_state().view(torch.int32))
+    assert_bits_equal(a_env.obs_buf.cpu().numpy(), b_env.obs_buf.cpu().numpy(), "eager steps after the replays")
+    a_env.check(); b_env.check()
+
+
+@pytest.mark.parametrize("n,len_states,form", [(300, 1, "auto"), (300, 5, "auto"), (70000, 1, "auto"), (20000, 5, "auto"), (300, 3, "lane"), (300, 3, "quad")])
+def test_step_returns_kernel_written_clamped_copies(n, len_states, form):
+    """VecTask.step returns clamp(obs_buf, +-clipObservations) / clamp(states_buf, +-clipStates) (vec_task_asymmetry.py:331-332).  The step
+    kernel writes those copies itself -- step() is one launch -- in every store path (single frame, stacks moved by the role wavefronts,
+    stacks moved by the step wavefront); they equal torch.clamp of the buffers bit for bit, NaN frames included, and a returned tensor
+    survives the next step (two buffers alternate)."""
+    from taco_amd.vec_env import FpvBase
+    cfg = config.default_cfg("mix", n, env_lenStates=len_states, env_lenObservations=2 if len_states == 3 else 1, env_clipObservations=0.6,
+                             env_clipStates=0.9, env_maxEpisodeLength=30, observation_noise=True)
+    env = FpvBase(cfg, kernel_form=form)
+    g = torch.Generator().manual_seed(1)
+    acts = (0.3 * torch.randn((6, n, 4), generator=g)).clamp(-1, 1).cuda()
+    acts[3, :5, 1] = float("nan")                 # a NaN action reaches the frames `delay_time` ms later: clamp must pass it through
+    prev = None
+    for t in range(40):
+        d, rew, done, info = env.step(acts[t % 6])
+        assert torch.equal(d["obs"].view(torch.int32), torch.clamp(env.obs_buf, -0.6, 0.6).view(torch.int32)), t
+        assert torch.equal(d["states"].view(torch.int32), torch.clamp(env.states_buf, -0.9, 0.9).view(torch.int32)), t
+        assert d["obs"].data_ptr() != env.obs_buf.data_ptr()
+        if prev is not None:
+            assert torch.equal(prev[0].view(torch.int32), prev[1].view(torch.int32)), "the previous step's tensors must survive this step"
+        prev = (d["states"], d["states"].clone())
+    assert torch.isnan(env.states_buf).any() or n > 1000
+    prog = env.progress_buf
+    assert torch.equal(prog, env.get_state()[65].view(torch.int32).to(torch.long))
+    env.check()
 
 
 def test_bench_line_contract():

@@ -37,8 +37,17 @@ def _worker(rank, world, port, n_global, idx, steps, q):
         for t in range(steps):
             a = np.clip(0.3 * rng.standard_normal((n_global, 4)), -1, 1).astype(np.float32)  # same stream on every rank
             obs, st, rew, done, tmo = env.step(a[lo:hi])
-            blk = dist.pack_block(torch.from_numpy(obs.copy()), torch.from_numpy(rew.copy()), torch.from_numpy(done.copy()), torch.from_numpy(tmo.copy()))
-            full = dist.all_gather_blocks(blk, n_global, world)
+            m = max(dist.shard_sizes(n_global, world))
+            blk = dist.pack_block(torch.from_numpy(obs.copy()), torch.from_numpy(rew.copy()), torch.from_numpy(done.copy()), torch.from_numpy(tmo.copy()),
+                                  rows=m if t % 2 else None)   # pre-padded block (what ShardedEnv binds) and exact-size block alike
+            g = dist.all_gather_blocks(blk, n_global, world, async_op=bool(t % 3))   # the async form (handle + wait) and the blocking one
+            g.wait()
+            for r in range(world):   # padded layout: rank r's live rows are a VIEW of the result
+                lo_r, hi_r = dist.shard_bounds(n_global, world, r)
+                assert g.rank_rows(r).shape[0] == hi_r - lo_r and g.rank_rows(r).data_ptr() == g.out[r * g.m:].data_ptr()
+            full = g.global_rows()
+            if len(set(g.sizes)) == 1:
+                assert full.data_ptr() == g.out.data_ptr()   # equal shards: no copy at all
             outs.append(full.numpy().copy())
         if rank == 0:
             q.put(np.stack(outs))
