@@ -2,23 +2,30 @@
 """bench.py -- env-steps/s of the fused VecTask.step() on MI355X (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" is one VecTask.step() of the whole batch = ONE taco_step launch through the C ABI.  Envs are independent, so
-for N > 1 the timed region holds no collective (each rank steps its slice); the variant with the north-star's single RCCL
-all-gather of the packed obs|reward|done|time-out block per step is timed right after and reported as "with_allgather".  Workload at N = 1: BASELINE configs[1]
-(task_mode=pos, 4 096 envs, rotor_response_time=0.017).  For N > 1 every rank holds 4 096 envs (weak scaling; global
-env ids are disjoint contiguous slices), value = N * 4096 * K / max-over-ranks time.
-Inputs (the action stream a_t = clamp(0.3 N(0,1) + (-0.45,0,0,0), -1, 1)) are resident in HBM before the timed region.
+N > 1 without torchrun's environment: bench.py launches its own N ranks (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1 ...` as a child process, BEFORE anything in this process touches the GPU), relays rank 0's JSON line and exits with
+the children's status.  Under torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as usual.
 
-Extra objects on the JSON line: "roofline" (step kernel vs HBM peak, 820 algorithmic bytes per env-step),
-"cpu_baseline" (the CPU oracle timed on this host's cores on a bounded sample; rank 0, N = 1 only), "parity"
-(HIP vs oracle on the first steps of this very workload), "large_n" (the same kernel at 262 144 and 1 048 576 envs, where
-the HBM roofline is the meaningful bound).
+A "step" is one VecTask.step() of the whole batch = ONE taco_step launch through the C ABI.  Workload at N = 1: BASELINE configs[1]
+(task_mode=pos, 4 096 envs, rotor_response_time=0.017).  For N > 1 every rank holds 4 096 envs (weak scaling; global env ids are disjoint
+contiguous slices) and the timed region holds no collective (envs are independent); value = N * 4096 * K / max-over-ranks time.  The
+north-star's single RCCL all-gather of the packed obs|reward|done|time-out block per step is timed right after ("with_allgather": the
+serial form a single learner needs, and the overlapped form with the gather of step t running under step t + 1), then a strong-scaling
+leg (4 096 envs in TOTAL).  Inputs (the action stream a_t = clamp(0.3 N(0,1) + (-0.45,0,0,0), -1, 1)) are resident in HBM before any
+timed region.
+
+Extra objects on the JSON line (rank 0, N = 1): "roofline" (the step kernel at the bench workload vs the HBM peak, 820 algorithmic bytes
+per env-step), "steady_state" (median of 5 x 2 000-step windows), "step_api" (VecTask.step(), the clamped copies included),
+"configs" (BASELINE configs 2-5 at their per-GPU shapes, config 5's rollout incl. the policy), "large_n" (the same kernel at 262 144 and
+1 048 576 envs after a time-based warm-up: the GPU needs ~40 ms of sustained load to reach its steady clock), "parity" (HIP vs oracle
+on the first steps of this very workload) and "cpu_baseline" (the CPU oracle on this host's cores, bounded samples, configs 1-3).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,7 +33,32 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_ENV_STEP = 820.0   # 205 fp32 words (88 read + 117 written), len_obs = len_states = 1
+EXTRA_BYTES_PER_STATE_FRAME = 104.0   # + 104 B per extra materialised states frame (config 5 => 1 236 B)
 HBM_PEAK_GBPS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s"
+
+
+def algo_bytes(len_states):
+    return ALGO_BYTES_PER_ENV_STEP + EXTRA_BYTES_PER_STATE_FRAME * (len_states - 1)
+
+
+def self_launch(args, argv):
+    """--gpus N > 1 outside torchrun: start the ranks as a child process tree.  Nothing here touches the GPU."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    else:
+        sys.stderr.write(p.stdout[-4000:])
+    sys.exit(p.returncode if p.returncode != 0 or lines else 1)
 
 
 def make_actions(n, steps, seed, device):
@@ -62,52 +94,76 @@ def time_kernel_launches(env, acts, steps, torch):
     return back_to_back, d[len(d) // 2]
 
 
-def time_kernel_settled(env, acts, steps, torch, tries=3):
-    """time_kernel_launches, repeated (at most `tries` times) while the back-to-back average sits more than 30 % above the median of
-    the bracketed launches: on a shared host a multi-millisecond stall of the GPU now and then lands inside a 100-launch window and
-    doubles its average.  Returns (average, bracketed median, windows measured).  Only the informational large-N / stacked entries
-    use it; the headline window is never re-measured."""
-    for k in range(tries):
-        avg, med = time_kernel_launches(env, acts, steps, torch)
-        if avg <= 1.3 * med:
-            break
-    return avg, med, k + 1
+def steady_windows(step_fn, acts, torch, warm_seconds, windows, steps_per_window):
+    """Back-to-back launches: `warm_seconds` of untimed steps (the GPU reaches its steady clock only after ~40 ms of sustained load: a
+    100-launch window right after creating a large env reads 10-25 % slow, profiles/r02_c_step_time_vs_step_index.txt), then `windows`
+    event-bracketed windows.  -> (median us/step, all windows sorted, us/step of the first 100 launches)"""
+    na = acts.shape[0]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for t in range(100):
+        step_fn(acts[t % na])
+    e1.record()
+    torch.cuda.synchronize()
+    first = e0.elapsed_time(e1) * 10.0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < warm_seconds:
+        for t in range(200):
+            step_fn(acts[t % na])
+        torch.cuda.synchronize()
+    ws = []
+    for _ in range(windows):
+        e0.record()
+        for t in range(steps_per_window):
+            step_fn(acts[t % na])
+        e1.record()
+        torch.cuda.synchronize()
+        ws.append(e0.elapsed_time(e1) * 1e3 / steps_per_window)
+    ws.sort()
+    return ws[len(ws) // 2], ws, first
 
 
 def pmc_traffic(n_envs):
     """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC summary (FETCH_SIZE x2 per the gfx950 note in
-    MI355X_MICROARCH.md + WRITE_SIZE, separate passes; profiles/README.md).  bench.py cannot run rocprofv3 on itself, so the
-    figure is the one measured for the build that produced profiles/; None if no summary is committed."""
+    MI355X_MICROARCH.md + WRITE_SIZE, separate passes; profiles/README.md).  bench.py cannot run rocprofv3 on itself, so the figure is
+    the one measured for the build that produced the summary: it is reported only if that build's source hash is THIS build's."""
     import glob
+    from taco_amd import build
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
     if not files:
         return None, None
-    d = json.load(open(files[-1])).get("derived", {})
-    key = f"hbm_bytes_per_launch_{n_envs}"
-    return d.get(key), os.path.basename(files[-1])
+    d = json.load(open(files[-1]))
+    name = os.path.basename(files[-1])
+    if d.get("source_hash") != build.source_hash():
+        return None, f"{name} is from another build ({d.get('source_hash')} != {build.source_hash()})"
+    return d.get("derived", {}).get(f"hbm_bytes_per_launch_{n_envs}"), name
 
 
-def cpu_baseline(cfg, budget_s=12.0):
-    """The CPU oracle (oracle/, kind 'port') on this host: all cores through OpenMP, bounded by wall time."""
+def cpu_sample(cfg, threads, budget_s):
+    """the CPU oracle (oracle/, kind 'port') stepping `cfg` on `threads` OpenMP threads for about budget_s seconds"""
     import numpy as np
     from taco_amd import config
     from oracle import oracle as O
-    cores = os.cpu_count() or 1
-    threads = min(cores, 64)
     flat = config.flat_cfg(cfg)
     n = flat["num_envs"]
     orc = O.OracleEnv(flat, threads=threads)
     rng = np.random.default_rng(0)
-    acts = np.clip(0.3 * rng.standard_normal((64, n, 4)) + np.array([-0.45, 0, 0, 0]), -1, 1).astype(np.float32)
-    for t in range(5):
-        orc.step(acts[t])
+    acts = np.clip(0.3 * rng.standard_normal((16, n, 4)) + np.array([-0.45, 0, 0, 0]), -1, 1).astype(np.float32)
+    orc.step(acts[0])
     t0 = time.perf_counter()
     steps = 0
     while time.perf_counter() - t0 < budget_s:
-        for _ in range(10):
-            orc.step(acts[steps % 64])
-            steps += 1
+        orc.step(acts[steps % 16])
+        steps += 1
     dt = time.perf_counter() - t0
+    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": threads, "sample": f"{steps} steps x {n} envs, {dt:.1f} s"}
+
+
+def cpu_baseline(budget_s=12.0):
+    """SURVEY 8(d) configs 1-3 on this host: all cores (bounded by wall time) and one thread.  The headline object is config 2 (pos, 4 096 envs) on all cores."""
+    from taco_amd import config
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
     model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -117,18 +173,16 @@ def cpu_baseline(cfg, budget_s=12.0):
                     break
     except OSError:
         pass
-    # the same oracle on ONE thread (SURVEY 8d asks for both ends), a 3 s sample
-    orc1 = O.OracleEnv(flat, threads=1)
-    orc1.step(acts[0])
-    t1 = time.perf_counter()
-    steps1 = 0
-    while time.perf_counter() - t1 < min(3.0, budget_s):
-        orc1.step(acts[steps1 % 64])
-        steps1 += 1
-    dt1 = time.perf_counter() - t1
-    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
-            "sample": f"{steps} steps x {n} envs of the same workload through the CPU oracle (OpenMP over envs), {dt:.1f} s on {model or 'host CPU'}",
-            "single_thread": {"value": n * steps1 / dt1, "unit": "env-steps/s", "cores": 1, "sample": f"{steps1} steps x {n} envs, {dt1:.1f} s"}}
+    main = cpu_sample(config.baseline_config(1, num_envs=4096), threads, budget_s)
+    out = {"value": main["value"], "unit": "env-steps/s", "cores": threads, "kind": "port",
+           "sample": f"{main['sample']} of the same workload through the CPU oracle (OpenMP over envs) on {model or 'host CPU'}",
+           "single_thread": cpu_sample(config.baseline_config(1, num_envs=4096), 1, min(3.0, budget_s)), "configs": []}
+    side = max(1.0, min(3.0, budget_s / 4))
+    for label, idx, n in ((1, 0, 64), (3, 2, 16384)):   # SURVEY 8(d) numbering: 1 = pos @ 64 (plumbing), 2 = the headline above, 3 = rotate @ 16 384
+        cfg = config.baseline_config(idx, num_envs=n)
+        out["configs"].append({"config": label, "task_mode": cfg["task_mode"], "envs": n, "all_cores": cpu_sample(cfg, min(threads, max(1, n // 16)), side),
+                               "single_thread": cpu_sample(cfg, 1, side)})
+    return out
 
 
 def parity_check(cfg, steps=60):
@@ -159,7 +213,73 @@ def parity_check(cfg, steps=60):
             flags_equal &= bool((env.reset_buf.cpu().numpy() == orc.reset_buf).all())
             bits_equal &= bool((env.obs_buf.cpu().numpy().view(np.uint32) == orc.obs_buf.view(np.uint32)).all())
             bits_equal &= bool((env.rew_buf.cpu().numpy().view(np.uint32) == orc.rew_buf.view(np.uint32)).all())
+    env.check()
     return {"steps": steps, "envs": n, "traj_linf_vs_oracle": linf, "done_flags_equal": flags_equal, "all_words_bit_equal": bits_equal}
+
+
+def config_entry(idx, n, dev, torch, warm=0.1):
+    """one BASELINE config at its per-GPU shape: steady-state kernel time, env-steps/s, fraction of the HBM roofline"""
+    from taco_amd import config
+    from taco_amd.vec_env import FpvBase
+    cfg = config.baseline_config(idx, num_envs=n)
+    env = FpvBase(cfg, sim_device=str(dev), rl_device=str(dev), copy_outputs=False)
+    acts = make_actions(n, 8, 11, dev)
+    med, ws, _ = steady_windows(env.step_raw, acts, torch, warm, 5, 400)
+    b = algo_bytes(env.len_states)
+    grid, block = env.launch_geometry()
+    flags = [k for k in ("random_rotordynamic_coe", "random_rotor_response", "random_aerodynamic_coe", "observation_noise", "rotor_noise",
+                         "ramdom_delay_time", "ramdom_deploy_time", "random_command") if cfg.get(k)]
+    return {"config": idx + 1, "task_mode": cfg["task_mode"], "envs": n, "len_states": env.len_states, "flags_on": flags, "kernel_us": med,
+            "env_steps_per_s": n / (med * 1e-6), "algorithmic_bytes_per_env_step": b, "achieved_GBps": b * n / (med * 1e-6) / 1e9,
+            "frac_of_hbm_peak": b * n / (med * 1e-6) / 1e9 / HBM_PEAK_GBPS, "kernel_form": env.kernel_form, "grid": grid, "block": block}
+
+
+def rollout_entry(n, horizon, dev, torch):
+    """config 5's 'LSTM-critic rollout' at its per-GPU shape: one taco_rollout_run call = horizon x (policy forward -> clipped action -> env
+    step writing the next replay slot) + final value + time-out bootstrap, then GAE.  Random-init weights of the documented architecture
+    (actor MLP 26-128-128-128-4, critic LSTM 26->128 over 5 frames + MLP 128-128-128-1)."""
+    import numpy as np
+    from taco_amd import config, policy as P
+    from taco_amd.rollout import RolloutBuffer
+    from taco_amd.vec_env import FpvBase
+    cfg = config.baseline_config(4, num_envs=n)
+    env = FpvBase(cfg, sim_device=str(dev), rl_device=str(dev), copy_outputs=False)
+    buf = RolloutBuffer(n, 26, 1, 26, env.len_states, 4, horizon, 4, 0.99, 0.95, str(dev))
+    rng = np.random.default_rng(0)
+    hd = 128
+    sd = {"log_std": np.zeros(4, np.float32)}
+    dims = [26, hd, hd, hd, 4]
+    for i in range(4):
+        sd[f"actor_mlp.layers.{2 * i}.weight"] = (rng.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32)
+        sd[f"actor_mlp.layers.{2 * i}.bias"] = np.zeros(dims[i + 1], np.float32)
+    sd["critic_encoder.layers.weight_ih_l0"] = (rng.standard_normal((4 * hd, 26)) * 0.2).astype(np.float32)
+    sd["critic_encoder.layers.weight_hh_l0"] = (rng.standard_normal((4 * hd, hd)) / np.sqrt(hd)).astype(np.float32)
+    sd["critic_encoder.layers.bias_ih_l0"] = np.zeros(4 * hd, np.float32)
+    sd["critic_encoder.layers.bias_hh_l0"] = np.zeros(4 * hd, np.float32)
+    dims = [hd, hd, hd, 1]
+    for i in range(3):
+        sd[f"critic_mlp.layers.{2 * i}.weight"] = (rng.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32)
+        sd[f"critic_mlp.layers.{2 * i}.bias"] = np.zeros(dims[i + 1], np.float32)
+    pol = P.ActorCritic(sd, 1, env.len_states)
+
+    def run():
+        buf.reset()
+        last = buf.run(env, pol)
+        buf.compute_returns_and_advantage(last)
+
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        for _ in range(4):
+            run()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) / 4)
+    ts.sort()
+    return {"config": 5, "what": "taco_rollout_run (policy forward + env step, replay store fused) + GAE", "envs": n, "horizon": horizon,
+            "len_states": env.len_states, "ms_per_rollout": ts[2] * 1e3, "env_steps_per_s": n * horizon / ts[2]}
 
 
 def main():
@@ -169,23 +289,25 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU (BASELINE configs[1]: 4096)")
     ap.add_argument("--gather", action="store_true", help="N > 1: put the per-step RCCL all-gather inside the main timed region "
-                    "(default: the sharded path alone is timed, the gathered variant is timed separately and reported as with_allgather)")
+                    "(default: the sharded path alone is timed, the gathered variants are timed separately and reported as with_allgather)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-time budget of the all-cores CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall-time budget of the all-cores CPU baseline sample of config 1")
     ap.add_argument("--no-large-n", action="store_true")
+    ap.add_argument("--no-configs", action="store_true")
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+        self_launch(args, sys.argv[1:])   # never returns
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import torch
     from taco_amd import config
     from taco_amd.vec_env import FpvBase
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # rehearsal knobs (not used by the driver): run N ranks on ONE GPU over gloo to exercise the N > 1 code path on a 1-GPU box
     backend = os.environ.get("TACO_BENCH_BACKEND", "nccl")
     if os.environ.get("TACO_BENCH_ONE_DEVICE") == "1":
@@ -214,50 +336,87 @@ def main():
     n_act = 64
     acts = make_actions(n_local, n_act, 1000 + rank, dev)
 
-    for t in range(args.warmup):
-        step(acts[t % n_act])
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for t in range(args.steps):
-        step(acts[t % n_act])
-    ev1.record()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    def timed(step_fn, a, steps, warmup, finish=None):
+        """W untimed steps, then exactly K steps bracketed by barrier + synchronize; max over ranks"""
+        na = a.shape[0]
+        for t in range(warmup):
+            step_fn(a[t % na])
+        if finish:
+            finish()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(steps):
+            step_fn(a[t % na])
+        if finish:
+            finish()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if dist:
+            tmax = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax.item())
+        return el
+
+    elapsed = timed(step, acts, args.steps, args.warmup)
     value = n_global * args.steps / elapsed
 
-    with_gather = None
-    if dist and not args.gather:
-        # the same K steps with the north-star's single all-gather of [obs|rew|done|timeout] per step (one learner sees all envs).
-        # The headline above is already measured: a failure of this optional leg is reported, it does not cost the result line.
+    multi = None
+    if dist:
+        multi = {}
+        # which ranks the collective library actually connected (one all-gather of rank ids)
+        ids = torch.full((world,), -1, device=dev, dtype=torch.int64)
+        dist.all_gather_into_tensor(ids, torch.tensor([rank], device=dev, dtype=torch.int64))
+        multi["ranks_seen"] = sorted(int(x) for x in ids.tolist())
+        multi["backend"] = backend
+        if not args.gather:
+            # The same K steps with the north-star's single all-gather of [obs|rew|done|timeout] per step (one learner sees all envs).
+            # The headline above is already measured: a failure of this optional leg is reported, it does not cost the result line.
+            try:
+                env.gather = True
+                el_serial = timed(env.step_gathered, acts, args.steps, min(args.warmup, 50))
+                pend = []
+
+                def step_overlapped(a):   # the gather of step t is waited for only after step t + 1 has been launched
+                    pend.append(env.step_async(a))
+                    if len(pend) > 1:
+                        pend.pop(0).wait()
+
+                def finish():
+                    while pend:
+                        pend.pop(0).wait()
+                    env.drain()
+
+                el_over = timed(step_overlapped, acts, args.steps, min(args.warmup, 50), finish)
+                multi["with_allgather"] = {
+                    "value": n_global * args.steps / el_serial, "unit": "env-steps/s", "ms_per_step": el_serial / args.steps * 1e3,
+                    "overlapped": {"value": n_global * args.steps / el_over, "ms_per_step": el_over / args.steps * 1e3,
+                                   "what": "step t + 1 is launched before the gather of step t is waited for (two alternating blocks)"},
+                    "collective": "1 all_gather_into_tensor of the kernel-filled [obs|rew|done|timeout] block per step",
+                    "bytes_per_rank": int(env.block.numel() * 4)}
+            except Exception as e:  # noqa: BLE001
+                multi["with_allgather"] = {"error": repr(e)[:300]}
+            env.gather = False
+        # strong scaling: BASELINE's "4 096 envs" spread over the N GPUs (512-2 048 envs per rank: the latency regime, expected to lose)
         try:
-            env.gather = True
-            for t in range(min(args.warmup, 50)):
-                step(acts[t % n_act])
-            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for t in range(args.steps):
-                step(acts[t % n_act])
-            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-            el = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
-            dist.all_reduce(el, op=dist.ReduceOp.MAX)
-            with_gather = {"value": n_global * args.steps / float(el.item()), "unit": "env-steps/s", "ms_per_step": float(el.item()) / args.steps * 1e3,
-                           "collective": "1 all_gather_into_tensor of the kernel-filled [obs|rew|done|timeout] block per step",
-                           "bytes_per_rank": int(env.block.numel() * 4)}
+            from taco_amd.dist import ShardedEnv
+            n_s = 4096
+            senv = ShardedEnv(config.baseline_config(1, num_envs=n_s), rank=rank, world_size=world, device=dev, gather=False)
+            sacts = make_actions(senv.hi - senv.lo, n_act, 2000 + rank, dev)
+            el_s = timed(senv.step_gathered, sacts, args.steps, min(args.warmup, 50))
+            senv.gather = True
+            el_sg = timed(senv.step_gathered, sacts, args.steps, min(args.warmup, 50))
+            multi["strong_scaling"] = {"envs_total": n_s, "envs_per_rank": senv.hi - senv.lo, "value": n_s * args.steps / el_s, "unit": "env-steps/s",
+                                       "ms_per_step": el_s / args.steps * 1e3, "with_allgather_value": n_s * args.steps / el_sg,
+                                       "with_allgather_ms_per_step": el_sg / args.steps * 1e3}
+            del senv
         except Exception as e:  # noqa: BLE001
-            with_gather = {"error": repr(e)[:300]}
-        env.gather = False
+            multi["strong_scaling"] = {"error": repr(e)[:300]}
 
     out = None
     if rank == 0:
@@ -267,7 +426,7 @@ def main():
         grid, block = base.launch_geometry()
         traffic, traffic_src = pmc_traffic(n_local)
         out = {
-            "metric": "env-steps/s at 4096 envs per GPU, fpv_asymmetry.step() hot path (task_mode=pos)",
+            "metric": "env-steps/s at 4096 envs per GPU, fpv_asymmetry.step() hot path (task_mode=pos); one taco_step launch per step",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -276,57 +435,54 @@ def main():
                        "envs_per_gpu": n_local, "envs_total": n_global, "parallelism": f"env-sharded x{world}",
                        "collective": ("1 RCCL all-gather of [obs|rew|done|timeout] per step" if (world > 1 and args.gather) else
                                       "none in the timed region: envs are independent, each rank steps its own slice"),
-                       "kernel": base.lib.taco_step_kernel_name().decode(), "grid": grid, "block": block,
-                       "lanes_per_env": 4 if grid * block >= 4 * n_local else 1,
-                       "role_wavefronts": bool(block == 256 and grid * 64 >= 4 * n_local)},
+                       "kernel": base.lib.taco_step_kernel_name().decode(), "kernel_form": base.kernel_form, "grid": grid, "block": block},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel_avg_us": k_avg_us, "kernel_bracketed_median_us": k_med_us,
                          "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
-                         "note": "4096 envs = 256 step wavefronts (4 lanes per env, one per CU) + 3 post-phase role wavefronts each: instruction-latency regime, see large_n for the throughput regime"},
-            "gpu_event_ms_per_step": ev0.elapsed_time(ev1) / args.steps,
+                         "note": "4096 envs = 256 step wavefronts (4 lanes per env, one per CU) + 3 post-phase role wavefronts each: instruction-latency "
+                                 "regime (SURVEY 8d); the throughput regime is large_n"},
         }
-        if with_gather is not None:
-            out["with_allgather"] = with_gather
+        if multi:
+            out.update(multi)
         if world == 1:
+            med, ws, _ = steady_windows(env.step_raw, acts, torch, 0.05, 5, 2000)
+            out["steady_state"] = {"us_per_step": med, "env_steps_per_s": n_local / (med * 1e-6), "windows_us": ws,
+                                   "protocol": "median of 5 event-bracketed windows of 2000 back-to-back steps after 50 ms of warm-up"}
+            aenv = FpvBase(config.baseline_config(1, num_envs=n_local), sim_device=str(dev), rl_device=str(dev))   # copy_outputs=True: the reference's contract
+            amed, aws, _ = steady_windows(aenv.step, acts, torch, 0.05, 5, 1000)
+            out["step_api"] = {"us_per_step": amed, "env_steps_per_s": n_local / (amed * 1e-6),
+                               "what": "VecTask.step(): the same launch also writes the clamped obs / states copies it returns (no torch op, no allocation)"}
+            del aenv
+            if not args.no_configs:
+                # SURVEY 8(d)'s numbering: 3 = rotate @ 16 384, 4 = flip @ 16 384 per rank, 5 = mix @ 32 768 per rank with every flag + 5 state frames
+                out["configs"] = [config_entry(2, 16384, dev, torch), config_entry(3, 16384, dev, torch), config_entry(4, 32768, dev, torch)]
+                try:
+                    out["configs"].append(rollout_entry(32768, 16, dev, torch))
+                except Exception as e:  # noqa: BLE001
+                    out["configs"].append({"config": 5, "error": repr(e)[:300]})
+                torch.cuda.empty_cache()
             if not args.no_large_n:
                 out["large_n"] = []
-                for big_n in (262144, 1048576):   # one full residency round (BASELINE configs[4]'s env count) / four rounds (steady state)
-                    benv = FpvBase(config.baseline_config(1, num_envs=big_n), sim_device=str(dev), rl_device=str(dev), copy_outputs=False)
+                for big_n, ls in ((262144, 1), (1048576, 1), (262144, 5)):   # BASELINE configs[4]'s env count; four residency rounds; 5 state frames
+                    bcfg = config.baseline_config(1, num_envs=big_n)
+                    bcfg["env"]["lenStates"] = ls
+                    benv = FpvBase(bcfg, sim_device=str(dev), rl_device=str(dev), copy_outputs=False)
                     bacts = make_actions(big_n, 4, 7, dev)
-                    for t in range(20):
-                        benv.step_raw(bacts[t % 4])
-                    torch.cuda.synchronize()
-                    b_avg, b_med, b_win = time_kernel_settled(benv, bacts, 100, torch)
+                    b_med, b_ws, b_first = steady_windows(benv.step_raw, bacts, torch, 0.25, 5, 200)
                     bg, bb = benv.launch_geometry()
-                    ach = ALGO_BYTES_PER_ENV_STEP * big_n / (b_avg * 1e-6) / 1e9
-                    tr, _ = pmc_traffic(big_n)
-                    out["large_n"].append({"envs": big_n, "kernel_avg_us": b_avg, "env_steps_per_s": big_n / (b_avg * 1e-6), "achieved_GBps": ach,
-                                           "frac_of_hbm_peak": ach / HBM_PEAK_GBPS, "traffic": tr, "grid": bg, "block": bb,
-                                           "kernel_bracketed_median_us": b_med, "windows_measured": b_win})
+                    nbytes = algo_bytes(ls)
+                    ach = nbytes * big_n / (b_med * 1e-6) / 1e9
+                    tr, _ = pmc_traffic(big_n) if ls == 1 else (None, None)
+                    out["large_n"].append({"envs": big_n, "len_states": ls, "kernel_avg_us": b_med, "env_steps_per_s": big_n / (b_med * 1e-6),
+                                           "algorithmic_bytes_per_env_step": nbytes, "achieved_GBps": ach, "frac_of_hbm_peak": ach / HBM_PEAK_GBPS,
+                                           "traffic": tr, "kernel_form": benv.kernel_form, "grid": bg, "block": bb, "windows_us": b_ws,
+                                           "first_100_launches_us": b_first,
+                                           "protocol": "median of 5 windows of 200 back-to-back launches after 0.25 s of warm-up launches"})
                     del benv, bacts
-                    torch.cuda.empty_cache()
-                # the documented training configuration stacks 5 state frames for the LSTM critic (README.md:60-66 of the reference):
-                # + (len - 1) * 104 B read and len * 104 B written per env-step for the stack (936 B at len 5)
-                out["stacked_states"] = []
-                for sn in (n_local, 262144):
-                    scfg = config.baseline_config(1, num_envs=sn)
-                    scfg["env"]["lenStates"] = 5
-                    senv = FpvBase(scfg, sim_device=str(dev), rl_device=str(dev), copy_outputs=False)
-                    sacts = make_actions(sn, 4, 7, dev)
-                    for t in range(20):
-                        senv.step_raw(sacts[t % 4])
-                    torch.cuda.synchronize()
-                    s_avg, s_med, s_win = time_kernel_settled(senv, sacts, 100, torch)
-                    sbytes = ALGO_BYTES_PER_ENV_STEP + 4 * 104 + 5 * 104 - 104   # the len-1 state frame is already in the 820 B
-                    out["stacked_states"].append({"envs": sn, "len_states": 5, "kernel_avg_us": s_avg, "env_steps_per_s": sn / (s_avg * 1e-6),
-                                                  "algorithmic_bytes_per_env_step": sbytes, "achieved_GBps": sbytes * sn / (s_avg * 1e-6) / 1e9,
-                                                  "frac_of_hbm_peak": sbytes * sn / (s_avg * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                                                  "kernel_bracketed_median_us": s_med, "windows_measured": s_win})
-                    del senv, sacts
                     torch.cuda.empty_cache()
             out["parity"] = parity_check(config.baseline_config(1, num_envs=n_local))
             if not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(config.baseline_config(1, num_envs=n_local), budget_s=args.cpu_seconds)
+                out["cpu_baseline"] = cpu_baseline(budget_s=args.cpu_seconds)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist:

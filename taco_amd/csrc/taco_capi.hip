@@ -266,13 +266,23 @@ constexpr int kSplitLaneMaxEnvs = 65536;  // 1 024 workgroups (31 KB of LDS, 111
 constexpr int kSplitMaxEnvs = 8192;  // measured: 16.8 vs 17.6 us at 4 096 envs, 18.4 vs 18.8 at 8 192, no gain at 16 384
 constexpr int kThroughputMinEnvs = 65536;
 struct FormInfo { int lpe, block, split; const void *fn; };
-FormInfo form_info(int form) {
+template <bool OUT> const void *kernel_of(int form) {
     switch (form) {
-        case TACO_FORM_QUAD_ROLES: return {4, kBlockLarge, 1, (const void *)taco::taco_step_kernel<kBlockLarge, 4, true>};
-        case TACO_FORM_LANE_ROLES: return {1, kBlockLarge, 1, (const void *)taco::taco_step_kernel<kBlockLarge, 1, true>};
-        case TACO_FORM_QUAD: return {4, kBlockSmall, 0, (const void *)taco::taco_step_kernel<kBlockSmall, 4>};
-        case TACO_FORM_LANE_THROUGHPUT: return {1, kBlockSmall, 0, (const void *)taco::taco_step_kernel<kBlockSmall, 1, false, true>};
-        default: return {1, kBlockSmall, 0, (const void *)taco::taco_step_kernel<kBlockSmall, 1>};
+        case TACO_FORM_QUAD_ROLES: return (const void *)taco::taco_step_kernel<kBlockLarge, 4, true, false, OUT>;
+        case TACO_FORM_LANE_ROLES: return (const void *)taco::taco_step_kernel<kBlockLarge, 1, true, false, OUT>;
+        case TACO_FORM_QUAD: return (const void *)taco::taco_step_kernel<kBlockSmall, 4, false, false, OUT>;
+        case TACO_FORM_LANE_THROUGHPUT: return (const void *)taco::taco_step_kernel<kBlockSmall, 1, false, true, OUT>;
+        default: return (const void *)taco::taco_step_kernel<kBlockSmall, 1, false, false, OUT>;
+    }
+}
+// `out`: the instantiation that also writes the clamped obs / states copies (taco_rollout_io.obs_out / states_out)
+FormInfo form_info(int form, bool out = false) {
+    const void *fn = out ? kernel_of<true>(form) : kernel_of<false>(form);
+    switch (form) {
+        case TACO_FORM_QUAD_ROLES: return {4, kBlockLarge, 1, fn};
+        case TACO_FORM_LANE_ROLES: return {1, kBlockLarge, 1, fn};
+        case TACO_FORM_QUAD: return {4, kBlockSmall, 0, fn};
+        default: return {1, kBlockSmall, 0, fn};
     }
 }
 int choose_form(const taco_cfg &c) {
@@ -394,7 +404,7 @@ int launch_step(taco_env *e, const taco_rollout_io *io, void *stream) {
     int grid, block;
     grid_of(e, &grid, &block);
     void *args[] = {&P};
-    hipError_t he = hipLaunchKernel(form_info(e->form).fn, dim3(grid), dim3(block), args, 0, (hipStream_t)stream);
+    hipError_t he = hipLaunchKernel(form_info(e->form, P.obs_out != nullptr || P.states_out != nullptr).fn, dim3(grid), dim3(block), args, 0, (hipStream_t)stream);
     if (he == hipSuccess) he = hipGetLastError();
     if (he != hipSuccess) return hip_fail(he, "taco_step_kernel launch");
     if (e->clock_on_device) {
@@ -716,13 +726,7 @@ int taco_occupancy(const taco_env *e, int *resident_blocks_per_cu, int *lds_byte
     hipError_t he = hipFuncGetAttributes(&at, f.fn);
     if (he != hipSuccess) return hip_fail(he, "hipFuncGetAttributes");
     *lds_bytes_per_block = (int)at.sharedSizeBytes;
-    switch (e->form) {
-        case TACO_FORM_QUAD_ROLES: he = hipOccupancyMaxActiveBlocksPerMultiprocessor(resident_blocks_per_cu, taco::taco_step_kernel<kBlockLarge, 4, true>, kBlockLarge, 0); break;
-        case TACO_FORM_LANE_ROLES: he = hipOccupancyMaxActiveBlocksPerMultiprocessor(resident_blocks_per_cu, taco::taco_step_kernel<kBlockLarge, 1, true>, kBlockLarge, 0); break;
-        case TACO_FORM_QUAD: he = hipOccupancyMaxActiveBlocksPerMultiprocessor(resident_blocks_per_cu, taco::taco_step_kernel<kBlockSmall, 4>, kBlockSmall, 0); break;
-        case TACO_FORM_LANE_THROUGHPUT: he = hipOccupancyMaxActiveBlocksPerMultiprocessor(resident_blocks_per_cu, taco::taco_step_kernel<kBlockSmall, 1, false, true>, kBlockSmall, 0); break;
-        default: he = hipOccupancyMaxActiveBlocksPerMultiprocessor(resident_blocks_per_cu, taco::taco_step_kernel<kBlockSmall, 1>, kBlockSmall, 0); break;
-    }
+    he = hipOccupancyMaxActiveBlocksPerMultiprocessor(resident_blocks_per_cu, f.fn, f.block, 0);
     if (he != hipSuccess) return hip_fail(he, "hipOccupancyMaxActiveBlocksPerMultiprocessor");
     return TACO_OK;
 }

@@ -631,7 +631,10 @@ constexpr int CARRY_WORDS = 32;  // 30 used
 // (launches of at most 4 096 envs, where every wavefront has a SIMD to itself).
 // CAP (LPE = 1, BLOCK = 64, not SPLIT): the throughput instantiation -- at most 128 VGPRs, so that four wavefronts share a SIMD, and
 // only the loop forms that fit that budget.
-template <int BLOCK, int LPE, bool SPLIT = false, bool CAP = false>
+// OUT: the instantiation that also writes the clamped copies VecTask.step returns (obs_out / states_out).  A template parameter, not a
+// run-time switch: the copy code sits in the role wavefronts' post-phase, the critical path of the 4 096-env launch, where its mere
+// presence cost 0.75 us of 13.8 (SGPR spills, skipped branches) -- profiles/r02_d_ab_out_copy_paths.txt.
+template <int BLOCK, int LPE, bool SPLIT = false, bool CAP = false, bool OUT = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT || CAP) ? 4 : 1, CAP ? 4 : 8))) void taco_step_kernel(const StepParams P) {
     static_assert(!SPLIT || BLOCK == 256, "SPLIT is the four-role form: one step wavefront + three role wavefronts per workgroup");
     static_assert(!CAP || (BLOCK == 64 && LPE == 1 && !SPLIT), "CAP is the one-wavefront-per-workgroup throughput form");
@@ -643,10 +646,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
     TACO_STAMP(0);
     // the step clock: kernel arguments on the eager path (which also leaves the NEXT values in the control block, so that a capture can start
     // at any time); the device-resident copy when this launch was captured into a HIP graph (its arguments are frozen)
-    struct { uint32_t step; int head, hh; } clk{P.step, P.head, P.hh};
-    if (P.use_ctl) {
-        clk.step = P.ctl[kCtlStep]; clk.head = (int)P.ctl[kCtlHead]; clk.hh = (int)P.ctl[kCtlHh];
-    } else if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // (read unconditionally by scalar loads through the constant address space and selected without a branch: while a captured step kernel
+    // runs nothing writes the clock -- the advance kernel comes after it -- and on the eager path the loaded values are simply not used)
+    const __attribute__((address_space(4))) uint32_t *ctl_c = (const __attribute__((address_space(4))) uint32_t *)P.ctl;
+    const uint32_t c_step = ctl_c[kCtlStep], c_head = ctl_c[kCtlHead], c_hh = ctl_c[kCtlHh];
+    const bool from_ctl = P.use_ctl != 0;
+    const struct { uint32_t step; int head, hh; } clk{from_ctl ? c_step : P.step, from_ctl ? (int)c_head : P.head, from_ctl ? (int)c_hh : P.hh};
+    if (!from_ctl && blockIdx.x == 0 && threadIdx.x == 0) {
         P.ctl[kCtlStep] = P.step + 1u; P.ctl[kCtlHead] = (uint32_t)((P.head + 10) % TACO_RING_SLOTS); P.ctl[kCtlHh] = (uint32_t)((P.hh + 1) % HIST_ROWS);
     }
     constexpr int EPW = 64 / LPE;  // envs per wavefront
@@ -681,7 +687,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
     auto clamp2 = [](f32x2_t v, float c) { return f32x2_t{clampf(v.x, -c, c), clampf(v.y, -c, c)}; };
     auto clamp4 = [](f32x4_t v, float c) { return f32x4_t{clampf(v.x, -c, c), clampf(v.y, -c, c), clampf(v.z, -c, c), clampf(v.w, -c, c)}; };
     auto shift_history = [&](float *buf, const float *prev, uint32_t buf_bytes, int len, float *out, float clip) {
-        const rsrc_t rB = make_rsrc(buf, buf_bytes), rP = make_rsrc(prev, buf_bytes), rO = make_rsrc(out, out ? buf_bytes : 0u);
+        const rsrc_t rB = make_rsrc(buf, buf_bytes), rP = make_rsrc(prev, buf_bytes);
+        // (the clamped copies go out through plain global stores with an explicit range check: a third buffer descriptor here cost the
+        // 4 096-env launch 68 more SGPR spills and 1 us, profiles/r02_d_ab_out_copy_paths.txt)
+        char *const ob = reinterpret_cast<char *>(out);
         const uint32_t L13 = (uint32_t)len * 13u, hist = L13 - 13u, tot = (uint32_t)EPW * L13;
         const uint32_t magic = 0xFFFFFFFFu / L13 + 1u;  // row = (w * magic) >> 32 for w < 2^16
         const uint32_t base = wave_env0 * L13;          // first word of the wavefront's range
@@ -700,7 +709,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
             for (int k = 0; k < 8; ++k) {
                 const uint32_t w = w0 + (uint32_t)k * 64u + (uint32_t)lane;
                 if (mine[k]) llvm_amdgcn_raw_buffer_store_v2f32(v[k], rB, (int)((base + w) * 8u), 0, 0);
-                if (out && mine[k]) llvm_amdgcn_raw_buffer_store_v2f32(clamp2(v[k], clip), rO, (int)((base + w) * 8u), 0, 0);
+                if (OUT && out && mine[k] && (base + w) * 8u < buf_bytes) *reinterpret_cast<f32x2_t *>(ob + (size_t)(base + w) * 8u) = clamp2(v[k], clip);
             }
         }
     };
@@ -1408,8 +1417,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
     } else {
         if (wv == 1 && lane < 4) mb_seq[lane] = 0;
         __syncthreads();  // barrier 1 of 2
-        if (wv == 3 && P.len_states > 1) shift_history(P.states, P.states_prev, P.states_bytes, P.len_states, P.states_out, P.clip_states);
-        if (wv == 2 && P.len_obs > 1) shift_history(P.obs, P.obs_prev, P.obs_bytes, P.len_obs, P.obs_out, P.clip_obs);
+        if (wv == 3 && P.len_states > 1) shift_history(P.states, P.states_prev, P.states_bytes, P.len_states, OUT ? P.states_out : nullptr, P.clip_states);
+        if (wv == 2 && P.len_obs > 1) shift_history(P.obs, P.obs_prev, P.obs_bytes, P.len_obs, OUT ? P.obs_out : nullptr, P.clip_obs);
         if (wv == 2 && (fl & TACO_F_OBSERVATION_NOISE)) { gen_obs_noise(); noise_ready = true; }
         if (bat_served && wv == 1) {  // battery server (the reward wavefront, idle until the post-phase): ten voltages, each one substep ahead of wavefront 0
             MB_WAIT(0, 1);
@@ -1488,7 +1497,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
     // Stores go through range-checked buffer descriptors, so ragged tails need no special casing.
     // fill_tile = false: the tile already holds this frame (the obs frame equals the states frame when there is no observation noise)
     auto put_frame = [&](float *buf, const float *prev, uint32_t buf_bytes, int len, const float (&f)[26], bool fill_tile, float *out, float clip) {
-        const rsrc_t rB = make_rsrc(buf, buf_bytes), rO = make_rsrc(out, out ? buf_bytes : 0u);
+        const rsrc_t rB = make_rsrc(buf, buf_bytes);
+        char *const ob = reinterpret_cast<char *>(out);
         if (fill_tile) {
             // the scratch is private to the wavefront and its LDS operations execute in order: only the compiler needs the fence
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -1506,7 +1516,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
             for (int it = 0; it < (int)((TILE_W4 + 63u) / 64u); ++it) {
                 const uint32_t w4 = (uint32_t)(it * 64 + lane);
                 if (w4 < TILE_W4) llvm_amdgcn_raw_buffer_store_v4f32(t4[w4], rB, (int)(wave_env0 * 104u + w4 * 16u), 0, 0);
-                if (out && w4 < TILE_W4) llvm_amdgcn_raw_buffer_store_v4f32(clamp4(t4[w4], clip), rO, (int)(wave_env0 * 104u + w4 * 16u), 0, 0);
+            }
+            if (OUT && out) {
+#pragma unroll
+                for (int it = 0; it < (int)((TILE_W4 + 63u) / 64u); ++it) {
+                    const uint32_t w4 = (uint32_t)(it * 64 + lane), off = wave_env0 * 104u + w4 * 16u;
+                    if (w4 < TILE_W4 && off < buf_bytes) *reinterpret_cast<f32x4_t *>(ob + off) = clamp4(t4[w4], clip);
+                }
             }
         } else if (SPLIT) {
             // the history words were moved by shift_history while the substeps ran: only the newest frame of every row is left
@@ -1518,7 +1534,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
                 const uint32_t t = (uint32_t)(it * 64 + lane);  // word t of the tile = word (t % 13) of row t / 13
                 const uint32_t row = t / 13u;
                 if (t < (uint32_t)EPW * 13u) llvm_amdgcn_raw_buffer_store_v2f32(tp[t], rB, (int)((base + row * L13 + hist + (t - row * 13u)) * 8u), 0, 0);
-                if (out && t < (uint32_t)EPW * 13u) llvm_amdgcn_raw_buffer_store_v2f32(clamp2(tp[t], clip), rO, (int)((base + row * L13 + hist + (t - row * 13u)) * 8u), 0, 0);
+            }
+            if (OUT && out) {
+#pragma unroll
+                for (int it = 0; it < (EPW * 13 + 63) / 64; ++it) {
+                    const uint32_t t = (uint32_t)(it * 64 + lane), row = t / 13u, off = (base + row * L13 + hist + (t - row * 13u)) * 8u;
+                    if (t < (uint32_t)EPW * 13u && off < buf_bytes) *reinterpret_cast<f32x2_t *>(ob + off) = clamp2(tp[t], clip);
+                }
             }
         } else {
             // one wavefront does everything: history words from the previous stack, the newest frame from the LDS tile, in one pass
@@ -1543,13 +1565,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
                 for (int k = 0; k < 8; ++k) {
                     const uint32_t w = w0 + (uint32_t)k * 64u + (uint32_t)lane;
                     if (w < tot) llvm_amdgcn_raw_buffer_store_v2f32(v[k], rB, (int)((base + w) * 8u), 0, 0);
-                    if (out && w < tot) llvm_amdgcn_raw_buffer_store_v2f32(clamp2(v[k], clip), rO, (int)((base + w) * 8u), 0, 0);
+                    if (OUT && out && w < tot && (base + w) * 8u < buf_bytes) *reinterpret_cast<f32x2_t *>(ob + (size_t)(base + w) * 8u) = clamp2(v[k], clip);
                 }
             }
         }
     };
     // states first (noise-free frame), then obs (possibly noised)
-    if (roleS) put_frame(P.states, P.states_prev, P.states_bytes, P.len_states, fr, true, P.states_out, P.clip_states);
+    if (roleS) put_frame(P.states, P.states_prev, P.states_bytes, P.len_states, fr, true, OUT ? P.states_out : nullptr, P.clip_states);
     if (roleO && (fl & TACO_F_OBSERVATION_NOISE)) {  // FA:402-410
         if (!noise_ready) gen_obs_noise();
 #pragma unroll
@@ -1564,7 +1586,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
         fr[18] = fr[18] + P.df * (nrm[9] * (float)(0.06 / 3) + 0.0f);
         fr[23] = fr[23] + P.df * (nrm[10] * (float)(0.06 / 3 / 3) + 0.0f);
     }
-    if (roleO) put_frame(P.obs, P.obs_prev, P.obs_bytes, P.len_obs, fr, SPLIT || (fl & TACO_F_OBSERVATION_NOISE) != 0, P.obs_out, P.clip_obs);
+    if (roleO) put_frame(P.obs, P.obs_prev, P.obs_bytes, P.len_obs, fr, SPLIT || (fl & TACO_F_OBSERVATION_NOISE) != 0, OUT ? P.obs_out : nullptr, P.clip_obs);
     // Optional all-gather block, one 128-byte-aligned row per env: [obs stack | reward | done | time-out | pad].  The obs part is written by
     // the wavefront that holds the obs frame (the newest frame from registers, older frames re-read from this env's just-written obs row),
     // the three tail words by the reward wavefront below.

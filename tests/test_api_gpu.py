@@ -271,24 +271,28 @@ def test_step_returns_kernel_written_clamped_copies(n, len_states, form):
     env.check()
 
 
-def test_bench_line_contract():
-    """bench.py prints ONE JSON line with the fields the driver reads (metric/value/unit/n_gpus/steps/warmup/ms_per_step/
-    higher_is_better/scaling/vs_baseline/dtype/data/config) plus roofline and cpu_baseline objects."""
+def _run_bench(extra, env_extra=None, timeout=420):
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "100", "--warmup", "20", "--no-large-n", "--cpu-seconds", "1.5"], cwd=root, env=env,
-                         capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stderr[-2000:]
+    env.update(env_extra or {})
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
-    d = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract():
+    """bench.py prints ONE JSON line with the fields the driver reads (metric/value/unit/n_gpus/steps/warmup/ms_per_step/
+    higher_is_better/scaling/vs_baseline/dtype/data/config) plus roofline, cpu_baseline, steady_state, step_api and the configs array."""
+    d = _run_bench(["--steps", "100", "--warmup", "20", "--no-large-n", "--cpu-seconds", "1.5"])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
-              "roofline", "cpu_baseline", "parity"):
+              "roofline", "cpu_baseline", "parity", "steady_state", "step_api", "configs"):
         assert k in d, k
     assert d["unit"] == "env-steps/s" and d["n_gpus"] == 1 and d["steps"] == 100 and d["warmup"] == 20 and d["higher_is_better"] is True
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None and "workload" in d["config"]
@@ -297,8 +301,26 @@ def test_bench_line_contract():
         assert k in r, k
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     c = d["cpu_baseline"]
-    for k in ("value", "unit", "cores", "kind", "sample"):
+    for k in ("value", "unit", "cores", "kind", "sample", "single_thread", "configs"):
         assert k in c, k
-    assert c["kind"] == "port" and c["cores"] >= 1
+    assert c["kind"] == "port" and c["cores"] >= 1 and [x["config"] for x in c["configs"]] == [1, 3]
     assert d["parity"]["all_words_bit_equal"] and d["parity"]["done_flags_equal"]
     assert abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    # SURVEY 8(d) configs 3-5 at their per-GPU shapes; config 5's stacked states priced at SURVEY's 1 236 B
+    cfgs = d["configs"]
+    assert [(x["config"], x.get("task_mode"), x["envs"]) for x in cfgs[:3]] == [(3, "rotate", 16384), (4, "flip", 16384), (5, "mix", 32768)]
+    assert cfgs[2]["len_states"] == 5 and cfgs[2]["algorithmic_bytes_per_env_step"] == 1236.0 and "observation_noise" in cfgs[2]["flags_on"]
+    assert cfgs[3]["config"] == 5 and cfgs[3]["env_steps_per_s"] > 0, cfgs[3]
+    assert d["step_api"]["us_per_step"] < 1.25 * d["steady_state"]["us_per_step"], "step() is one launch: it must cost about what step_raw costs"
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` outside torchrun starts the two ranks itself (as children, before touching the GPU), relays rank 0's
+    line and exits 0.  Rehearsed here on ONE GPU over gloo (TACO_BENCH_BACKEND / TACO_BENCH_ONE_DEVICE); the driver runs it over RCCL."""
+    d = _run_bench(["--gpus", "2", "--steps", "60", "--warmup", "10"], {"TACO_BENCH_BACKEND": "gloo", "TACO_BENCH_ONE_DEVICE": "1"})
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == [0, 1] and d["config"]["envs_total"] == 8192 and d["scaling"] == "weak"
+    assert abs(d["value"] - 8192 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    w = d["with_allgather"]
+    assert "error" not in w and w["value"] > 0 and w["overlapped"]["value"] > 0 and w["bytes_per_rank"] == 4096 * 32 * 4
+    s = d["strong_scaling"]
+    assert "error" not in s and s["envs_total"] == 4096 and s["envs_per_rank"] == 2048 and s["value"] > 0

@@ -50,6 +50,9 @@ if "SQ_WAVES" in sq and sq["SQ_WAVES"]["mean_per_launch"]:
     w = sq["SQ_WAVES"]["mean_per_launch"]
     der["per_wave_262144"] = {k: v["mean_per_launch"] / w for k, v in sq.items() if k != "SQ_WAVES"}
 S["derived"] = der
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from taco_amd import build as _build  # noqa: E402
+S["source_hash"] = _build.source_hash()  # bench.py reports roofline.traffic only for the build it was measured on
 json.dump(S, open(os.path.join(O, f"{tag}_pmc_summary.json"), "w"), indent=1)
 for f in glob.glob(os.path.join(O, f"{tag}_stats", "*", "*kernel_stats.csv")):
     shutil.copy(f, os.path.join(O, f"{tag}_kernel_stats_bench_4096.csv"))
