@@ -58,6 +58,7 @@ def lib():
         _lib.orc_destroy.argtypes = [C.c_void_p]
         _lib.orc_set_difficulty.argtypes = [C.c_void_p, C.c_double]
         _lib.orc_set_threads.argtypes = [C.c_void_p, C.c_int]
+        _lib.orc_set_world_rate_roundtrip.argtypes = [C.c_void_p, C.c_int]
         _lib.orc_step.argtypes = [C.c_void_p] + [C.c_void_p] * 6
         _lib.orc_step.restype = C.c_int
         _lib.orc_get_state.argtypes = [C.c_void_p, C.c_void_p]
@@ -121,7 +122,7 @@ def _f32(a):
 class OracleEnv:
     """The reference's VecTask.step() semantics on CPU (numpy in/out)."""
 
-    def __init__(self, cfg_dict, threads=1):
+    def __init__(self, cfg_dict, threads=1, world_rate_roundtrip=False):
         self.cfg = make_cfg(cfg_dict)
         self.n = self.cfg.num_envs
         self._h = C.c_void_p()
@@ -129,6 +130,8 @@ class OracleEnv:
         if rc != 0:
             raise ValueError("orc_create rejected the configuration")
         lib().orc_set_threads(self._h, threads)
+        if world_rate_roundtrip:  # the reference's data flow for the angular rate (see orc_set_world_rate_roundtrip)
+            lib().orc_set_world_rate_roundtrip(self._h, 1)
         self.obs_buf = np.zeros((self.n, self.cfg.len_obs, 26), np.float32)
         self.states_buf = np.zeros((self.n, self.cfg.len_states, 26), np.float32)
         self.rew_buf = np.zeros(self.n, np.float32)

@@ -536,6 +536,7 @@ struct orc_env {
     env_state *s;
     int64_t step_count;
     int threads;
+    int world_rate_roundtrip; /* orc_set_world_rate_roundtrip: see step_env */
     int mix_n1, mix_n2;
     integ_par ip;
     float rdt; /* 1/dt if div_const is exact for this dt, else 0 (true division is used) */
@@ -583,6 +584,13 @@ int orc_create(const orc_cfg *cfg, orc_env **out) {
 void orc_destroy(orc_env *e) { if (e) { free(e->s); free(e); } }
 void orc_set_difficulty(orc_env *e, double d) { e->cfg.difficulty = d; }
 void orc_set_threads(orc_env *e, int n) { e->threads = n < 1 ? 1 : n; }
+/* Data flow of the angular rate between substeps.  0 (default, = the product kernel): row I carries the BODY rates from one gym.simulate
+ * to the next and only the 10th substep writes the root state's world-frame angular velocity.  1: every substep goes through the root
+ * state, as the reference does (simulate leaves w_world = R(q) b, the next refresh_state computes b = R(q)^T w_world, FA:350) -- two
+ * rotations and two roundings more per substep.  Mode 1 is what tests/golden/make_glue_golden.py reproduces when it drives the
+ * reference's own fpv_asymmetry.py with row I plugged in as gym.simulate; it exists so that the glue (everything but row I) can be
+ * compared with that run bit for bit. */
+void orc_set_world_rate_roundtrip(orc_env *e, int on) { e->world_rate_roundtrip = on ? 1 : 0; }
 int64_t orc_step_count(const orc_env *e) { return e->step_count; }
 void orc_set_step_count(orc_env *e, int64_t n) { e->step_count = n; }
 
@@ -841,6 +849,7 @@ static void step_env(const orc_env *e, int i, const float *actions, float *obs_b
             tq[2] = (ts[0] + ts[1]) + (ts[2] + ts[3]);
         }
         integrate_substep(&e->ip, s->p, s->q, s->v, wb, F, tq); /* gym.simulate VT:313 */
+        if (e->world_rate_roundtrip) { quat_sandwich(s->q, wb, s->w); rotate_inv(s->q, s->w, wb); }
     }
 
     quat_sandwich(s->q, wb, s->w); /* root state: world-frame angular velocity */

@@ -95,6 +95,7 @@ int orc_create(const orc_cfg *cfg, orc_env **out);
 void orc_destroy(orc_env *e);
 void orc_set_difficulty(orc_env *e, double difficulty);
 void orc_set_threads(orc_env *e, int nthreads);
+void orc_set_world_rate_roundtrip(orc_env *e, int on); /* 1: body rates go through the root state every substep, as in the reference */
 /* One VecTask.step() (vec_task_asymmetry.py:290-334).  obs/states are the PERSISTENT frame stacks
  * [num_envs][len][26] (shifted in place, newest frame last, unclamped -- the caller clamps like the reference's
  * torch.clamp at :331-332); reset_buf is int64 in/out (ones before the first step, :246-247). */

@@ -1,0 +1,427 @@
+#!/usr/bin/env python3
+"""Golden traces of the reference's OWN task glue -- `fpv_asymmetry.py` + `vec_task_asymmetry.py` -- driven end to end on CPU.
+
+    python tests/golden/make_glue_golden.py [/root/reference]          (build container only; writes tests/golden/glue_*.npz)
+
+`fpv_asymmetry.py` cannot be imported as it stands (it needs the Isaac Gym binary, gym, matplotlib/TkAgg).  Here its module is loaded
+from the reference tree with in-memory STUB modules for those dependencies (no reference text is copied or stored):
+  * `isaacgym.{gymapi, gymtorch, gymutil}`, `gym`, `isaacgymenvs.utils.dr_utils`: empty shells with the few names the
+    import statements and the methods on the path touch; `isaacgym.torch_utils` / `torch_jit_utils` / `tasks/control/*.py` are the
+    reference's real files (two of them with the hard-coded 'cuda:0' replaced in memory, as make_golden.py does);
+  * `VecTask.__init__` (which creates the PhysX sim) is replaced by a dozen assignments; the REAL `FpvBase.__init__` then builds every
+    tensor, controller and delay buffer, and the REAL `VecTask.step()` drives pre_physics_step / 10 x mid_physics_step /
+    post_physics_step / reset_idx / reset_command_condition / compute_observation_state / compute_reward;
+  * `self.gym` is a mock whose `simulate()` IS SURVEY section 8a row I: it assembles the body wrench from the force / torque tensors the
+    task handed to `apply_rigid_body_force_tensors` and calls the oracle's `orc_integrate` on the root-state tensor.  (Row I is the one
+    stage with no reference arithmetic -- PhysX is a missing binary -- so any closed-loop run has to plug something in; everything else in
+    the loop is the reference's own code.)
+  * random draws: `torch_rand_float`, `torch.normal`, `torch.rand` are replaced (inside the task module's namespace / for the duration of
+    a step) by functions that return the uniforms of the build's counter-based generator for (seed, env id, step, stream, index), fed
+    through the REFERENCE's own affine expressions -- so both sides consume the same numbers and every reset value, deploy length and
+    command re-draw can be compared exactly.  A draw with an unexpected shape or order aborts the script.
+
+What is stored per case: the action stream, and after every step the outputs (obs / states stacks, reward, reset, time-out) and the
+full task state in the layout of the state blob (include/taco_env.h TACO_S_*), delay line included.
+tests/test_oracle_golden.py replays the actions through the oracle (in its "world-rate round trip" mode, see oracle/taco_oracle.c
+orc_set_world_rate_roundtrip) and requires bit equality: that pins SURVEY rows A, B, D, J, O, P (dispatch) and R (dispatch / ordering /
+what is zeroed) to the reference's code instead of to a reading of it.
+"""
+import ctypes as C
+import importlib
+import linecache
+import pathlib
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = pathlib.Path(__file__).resolve().parent
+ROOT = HERE.parent.parent
+sys.path.insert(0, str(ROOT))
+REF = pathlib.Path(sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else "/root/reference")
+TASKS = REF / "IsaacGymEnvs/isaacgymenvs/tasks"
+
+from oracle import oracle as O  # noqa: E402  (test infrastructure: the Philox generator and row I)
+from taco_amd import config  # noqa: E402
+
+torch.set_num_threads(1)
+f32 = torch.float32
+
+
+# ------------------------------------------------------------------------------------------------ module loading
+def stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def load_file(name, path, device_patch=False):
+    path = str(path)
+    if not device_patch:
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+        return mod
+    src = open(path).read().replace("'cuda:0'", "'cpu'")
+    fn = f"<patched:{name}>"
+    linecache.cache[fn] = (len(src), None, src.splitlines(True), fn)
+    mod = types.ModuleType(name)
+    mod.__file__ = fn
+    mod.__package__ = name.rpartition(".")[0]
+    sys.modules[name] = mod
+    exec(compile(src, fn, "exec"), mod.__dict__)
+    return mod
+
+
+class _Anything:
+    """attribute sink for gymapi names that are only touched by code paths the traces never reach"""
+
+    def __getattr__(self, k):
+        return _Anything()
+
+    def __call__(self, *a, **k):
+        return _Anything()
+
+
+import importlib.util  # noqa: E402
+
+pkg = stub("isaacgym")
+pkg.__path__ = []
+gymapi = stub("isaacgym.gymapi", LOCAL_SPACE=1, SIM_PHYSX=0, SIM_FLEX=1, UP_AXIS_Z=1, UP_AXIS_Y=0, Vec3=lambda *a: a, SimParams=_Anything,
+              acquire_gym=lambda: None)
+gymtorch = stub("isaacgym.gymtorch", wrap_tensor=lambda t: t, unwrap_tensor=lambda t: t)
+gymutil = stub("isaacgym.gymutil")
+pkg.gymapi, pkg.gymtorch, pkg.gymutil = gymapi, gymtorch, gymutil
+TU = load_file("isaacgym.torch_utils", REF / "python/isaacgym/torch_utils.py")
+
+
+class _Box:
+    def __init__(self, low, high):
+        self.low, self.high, self.shape = low, high, np.shape(low)
+
+
+stub("gym", Space=object, spaces=stub("gym.spaces", Box=_Box))
+import matplotlib  # noqa: E402  (the real package: the control modules import pyplot)
+
+matplotlib.use = lambda *a, **k: None   # fpv_asymmetry.py:30 asks for TkAgg; there is no display here
+for n in ("isaacgymenvs", "isaacgymenvs.utils"):
+    stub(n).__path__ = []
+TJ = load_file("isaacgymenvs.utils.torch_jit_utils", REF / "IsaacGymEnvs/isaacgymenvs/utils/torch_jit_utils.py")
+stub("isaacgymenvs.utils.dr_utils", **{k: None for k in ("get_property_setter_map", "get_property_getter_map", "get_default_setter_args",
+                                                          "apply_random_samples", "check_buckets", "generate_random_samples")})
+stub("isaacgymenvs.tasks").__path__ = [str(TASKS)]
+stub("isaacgymenvs.tasks.control").__path__ = [str(TASKS / "control")]
+stub("isaacgymenvs.tasks.base").__path__ = [str(TASKS / "base")]
+load_file("isaacgymenvs.tasks.control.task_reward", TASKS / "control/task_reward.py", device_patch=True)
+load_file("isaacgymenvs.tasks.control.fpv_dynamics", TASKS / "control/fpv_dynamics.py", device_patch=True)
+VT = importlib.import_module("isaacgymenvs.tasks.base.vec_task_asymmetry")
+FA = importlib.import_module("isaacgymenvs.tasks.fpv_asymmetry")
+np.Inf = np.inf  # (numpy 2 dropped the alias vec_task_asymmetry.py uses)
+
+
+# ------------------------------------------------------------------------------------------------ the build's random numbers
+STREAM_RESET, STREAM_CMD, STREAM_DEPLOY = 1, 2, 3
+RU = dict(POS=0, EULER=3, LINVEL=6, ANGVEL=9, FLIP_SIGN=12, TGT_XY=13, TGT_Z=15, TGT_YAW=16, DELAY=36)
+_lib = O.lib()
+_lib.orc_philox.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+_lib.orc_uniform.argtypes = [C.c_uint32]
+_lib.orc_uniform.restype = C.c_float
+
+
+def uniform(seed, gid, step, stream, idx):
+    out = (C.c_uint32 * 4)()
+    _lib.orc_philox(seed, gid, step, stream, idx >> 2, out)
+    return np.float32(_lib.orc_uniform(out[idx & 3]))
+
+
+_T = np.array([0.0062096653, 0.0668072013, 0.3085375387, 0.6914624613, 0.9331927987, 0.9937903347], np.float32)
+
+
+def rounded_normal(u, lim):
+    """round(N(0,1)) clamped to +-lim by inverse CDF on one uniform: the build's stand-in for torch.round(torch.normal(0, 1)) clamped
+    (FA:324, FA:576); the value handed to the reference is this integer, which its own round / clamp leave unchanged"""
+    k = -3 + int((np.float32(u) >= _T).sum())
+    return max(-lim, min(lim, k))
+
+
+class Draws:
+    """what the patched generators return; `expect` is the queue of torch_rand_float calls the reset method in flight will make"""
+
+    def __init__(self, seed, n):
+        self.seed, self.n, self.step, self.expect = seed, n, 0, []
+
+    def u(self, gid, stream, idx):
+        return uniform(self.seed, gid, self.step, stream, idx)
+
+    def rand_float(self, lower, upper, shape, device):
+        assert self.expect, f"unexpected torch_rand_float{shape} (step {self.step})"
+        ids, stream, cols = self.expect.pop(0)
+        assert tuple(shape) == (len(ids), len(cols)), f"torch_rand_float{tuple(shape)} where ({len(ids)}, {len(cols)}) was expected (step {self.step})"
+        U = torch.tensor([[self.u(g, stream, c) for c in cols] for g in ids], dtype=f32).reshape(len(ids), len(cols))
+        return (upper - lower) * U + lower   # the reference's own expression (torch_utils.py torch_rand_float) on the build's uniforms
+
+
+def stabiliser(env):
+    """level the airframe (body rates that turn body z towards world up), hold 2.5 m, damp the climb rate: actions from the task's own state"""
+    q = env.copter_quat
+    up_b = FA.quat_rotate(FA.quat_conjugate(q), torch.tensor([[0.0, 0.0, 1.0]]).expand(q.shape[0], 3))
+    e3 = torch.tensor([[0.0, 0.0, 1.0]]).expand_as(up_b)
+    rate = 6.0 * torch.cross(e3, up_b, dim=1)
+    a = torch.zeros((q.shape[0], 4))
+    a[:, 1:] = rate / 20.0
+    a[:, 0] = 0.6 * (env.target_pos[:, 2] - 0.5 - env.copter_pos[:, 2]) - 0.35 * env.copter_linvel[:, 2]
+    return a.numpy().astype(np.float32)
+
+
+def run_case(name, task, n, steps, seed, act_fn, **kw):
+    cfg = config.default_cfg(task, n, seed=seed, **{k: v for k, v in kw.items() if not k.startswith("_")})
+    flat = config.flat_cfg(cfg)
+    cls = {"pos": FA.FpvPos, "rotate": FA.FpvRotate, "flip": FA.FpvFlip, "mix": FA.FpvMix}[task]
+    D = Draws(seed, n)
+    ocfg = O.make_cfg(flat)
+    arm_x, arm_y = np.float32(flat["arm_x"]), np.float32(flat["arm_y"])
+
+    class MockGym:
+        def __init__(self, env):
+            self.env = env
+            self.root = torch.zeros((n * 2, 13), dtype=f32)
+            self.root[:, 6] = 1.0   # identity attitudes
+            self.root[:, 2] = 4.0   # the actors are created at (0, 0, 4) (fpv_asymmetry.py create_envs)
+
+        def acquire_actor_root_state_tensor(self, sim):
+            return self.root
+
+        def acquire_dof_state_tensor(self, sim):
+            return torch.zeros(1)
+
+        def refresh_actor_root_state_tensor(self, sim, *a):
+            pass
+
+        refresh_dof_state_tensor = fetch_results = refresh_actor_root_state_tensor
+
+        def set_actor_root_state_tensor_indexed(self, *a):
+            pass   # the task writes through views of the root tensor: the new state is already in place
+
+        def apply_rigid_body_force_tensors(self, sim, forces, torques, space):
+            assert space == gymapi.LOCAL_SPACE
+            self.forces, self.torques = forces, torques
+
+        def simulate(self, sim):
+            """net body-frame wrench on the composite body (rotor forces along z at (+-arm_x, +-arm_y), drag force at the
+            chassis, rotor reaction torques about z), summed in the order of the spec, then `substeps` sub-iterations of the integrator"""
+            f, t = self.forces.numpy(), self.torques.numpy()
+            bf = f[:, 0, :]
+            fs, ts = f[:, [2, 4, 6, 8], 2], t[:, [2, 4, 6, 8], 2]
+            w6 = np.zeros((n, 6), np.float32)
+            w6[:, 0], w6[:, 1] = bf[:, 0], bf[:, 1]
+            w6[:, 2] = bf[:, 2] + ((fs[:, 0] + fs[:, 1]) + (fs[:, 2] + fs[:, 3]))
+            w6[:, 3] = arm_y * ((fs[:, 0] + fs[:, 1]) - (fs[:, 2] + fs[:, 3]))
+            w6[:, 4] = -arm_x * ((fs[:, 0] - fs[:, 1]) - (fs[:, 2] - fs[:, 3]))
+            w6[:, 5] = (ts[:, 0] + ts[:, 1]) + (ts[:, 2] + ts[:, 3])
+            root = np.ascontiguousarray(self.env.root_states.numpy())
+            _lib.orc_integrate(C.byref(ocfg), n, root.ctypes.data_as(C.c_void_p), w6.ctypes.data_as(C.c_void_p))
+            self.env.root_states.copy_(torch.from_numpy(root))
+
+    def vt_init(self, config, rl_device, sim_device, graphics_device_id, headless, virtual_screen_capture=False, force_render=False):
+        """stands in for VecTask.__init__ (vec_task_asymmetry.py:146-200): everything but create_sim / prepare_sim / set_viewer"""
+        config_ = config
+        VT.Env.__init__(self, config_, rl_device, sim_device, graphics_device_id, headless)
+        self.virtual_screen_capture, self.virtual_display, self.force_render = False, None, False
+        self.dr_randomizations, self.extern_actor_params, self.original_props = {}, {}, {}
+        self.first_randomization, self.sim_initialized, self.sim, self.viewer = True, True, None, None
+        self.dt = config_["sim"]["dt"]
+        self.gym = MockGym(self)
+        self.allocate_buffers()
+        self.obs_dict = {}
+
+    # ---- which draws each reset method makes, in call order (checked against the shapes the reference asks for)
+    g = lambda *names: [RU[a] + b for a, b in names]
+    rpos, rquat, rvel = cfg["random_copter_pos"], cfg["random_copter_quat"], cfg["random_copter_vel"]
+
+    def copter_queue(ids, kind):
+        q = []
+        if kind == "pos":
+            if rpos:
+                q += [(ids, STREAM_RESET, [RU["POS"] + k]) for k in range(3)]
+        elif kind in ("rotate", "flip"):
+            q += [(ids, STREAM_RESET, g(("POS", 0), ("POS", 1)))] + ([(ids, STREAM_RESET, g(("POS", 2)))] if rpos else [])
+        else:  # the three groups of FpvMix use the pos-style ranges: (n, 2) then (n, 1)
+            if rpos:
+                q += [(ids, STREAM_RESET, g(("POS", 0), ("POS", 1))), (ids, STREAM_RESET, g(("POS", 2)))]
+        if rquat:
+            q += [(ids, STREAM_RESET, [RU["EULER"] + k]) for k in range(3)]
+        if rvel:
+            q += [(ids, STREAM_RESET, [RU["LINVEL"] + k for k in range(3)])]
+            if kind not in ("flip", "mixflip"):
+                q += [(ids, STREAM_RESET, [RU["ANGVEL"] + k for k in range(3)])]
+        return q
+
+    orig = {k: getattr(cls, k) for k in ("reset_copter_idx", "reset_command_idx")}
+    orig_target = FA.FpvBase.reset_target_idx
+
+    def reset_copter_idx(self, env_ids):
+        ids = env_ids.tolist()
+        if task == "mix":
+            n1, n2 = self.task_group_index[1], self.task_group_index[2]
+            D.expect = copter_queue([i for i in ids if i < n1], "mixpos") + copter_queue([i for i in ids if n1 <= i < n2], "mixrot") + \
+                copter_queue([i for i in ids if i >= n2], "mixflip")
+        else:
+            D.expect = copter_queue(ids, task)
+        r = orig["reset_copter_idx"](self, env_ids)
+        assert not D.expect, "reset_copter_idx made fewer draws than expected"
+        return r
+
+    def reset_target_idx(self, env_ids):
+        ids = env_ids.tolist()
+        D.expect = ([(ids, STREAM_RESET, g(("TGT_XY", 0), ("TGT_XY", 1))), (ids, STREAM_RESET, g(("TGT_Z", 0)))] if cfg["random_target_pos"] else []) + \
+            ([(ids, STREAM_RESET, g(("TGT_YAW", 0)))] if cfg["random_target_yaw"] else [])
+        r = orig_target(self, env_ids)
+        assert not D.expect
+        return r
+
+    def reset_command_idx(self, env_ids):
+        ids = env_ids.tolist()
+        D.expect = []
+        if cfg["random_command"]:
+            if task == "rotate":
+                D.expect = [(ids, STREAM_CMD, [0])]
+            elif task == "mix":
+                n1, n2 = self.task_group_index[1], self.task_group_index[2]
+                rot = [i for i in ids if n1 <= i < n2]
+                D.expect = [(rot, STREAM_CMD, [0])] if rot else []
+        D.rand_calls = 0
+        r = orig["reset_command_idx"](self, env_ids)
+        assert not D.expect
+        return r
+
+    def fake_normal(mean, std, size=None, **k):
+        who = sys._getframe(1).f_code.co_name
+        if who == "pre_physics_step":      # FA:324 deploy length: 10 - clamp(round(N), +-1)
+            return torch.tensor([[float(rounded_normal(D.u(i, STREAM_DEPLOY, 0), 1))] for i in range(n)], dtype=f32)
+        if who == "reset_env_idx":         # FA:576 delay length: clamp(delay_time - clamp(round(N), +-3), min 0)
+            return torch.tensor([[float(rounded_normal(D.u(i, STREAM_RESET, RU["DELAY"]), 3))] for i in D.reset_ids], dtype=f32).reshape(size)
+        if who == "__init__":              # (the lengths drawn by the constructor are overwritten by the first reset of every env)
+            return torch.zeros(size, dtype=f32)
+        raise AssertionError(f"torch.normal from {who}")
+
+    def fake_rand(*size, **k):
+        who = sys._getframe(1).f_code.co_name
+        if who == "reset_copter_idx":      # FA:873-875 / :1044-1046: sign of the flip envs' initial roll rate, one value per env
+            return torch.tensor([D.u(i, STREAM_RESET, RU["FLIP_SIGN"]) for i in range(n)], dtype=f32)
+        if who == "reset_command_idx":     # FA:892 / :1081 the number of flips added at progress 500 (first call); :905 / :1103 an unused draw
+            D.rand_calls += 1
+            return torch.tensor([D.u(i, STREAM_CMD, 1) for i in range(n)], dtype=f32) if D.rand_calls == 1 and D.flip_first_is_time else \
+                torch.full((n,), 0.5, dtype=f32)
+        raise AssertionError(f"torch.rand from {who}")
+
+    # ---- install, build the env with the reference's own constructor, run
+    saved = (VT.VecTask.__init__, FA.torch_rand_float, torch.normal, torch.rand, FA.FpvBase.reset_target_idx, FA.FpvBase.reset_env_idx)
+    orig_env_idx = FA.FpvBase.reset_env_idx
+
+    def reset_env_idx(self, env_ids):
+        D.reset_ids = env_ids.tolist()
+        return orig_env_idx(self, env_ids)
+
+    VT.VecTask.__init__ = vt_init
+    FA.torch_rand_float = D.rand_float
+    FA.FpvBase.reset_target_idx, FA.FpvBase.reset_env_idx = reset_target_idx, reset_env_idx
+    cls.reset_copter_idx, cls.reset_command_idx = reset_copter_idx, reset_command_idx
+    torch.normal, torch.rand = fake_normal, fake_rand
+    try:
+        env = cls(cfg, "cpu", "cpu", -1, True, False, False)
+        rec = {k: [] for k in ("step", "obs", "states", "rew", "reset", "timeout", "blob")}
+        record = kw.get("_record", lambda t: True)   # long cases keep the steps around the events of interest only (all actions are kept)
+        n_resets = n_tmo = 0
+        acts = act_fn(n, steps)
+        hold = kw.get("_hold", False)
+        for t in range(steps):
+            D.step = t
+            if hold:  # a crude attitude / altitude stabiliser on top of the noise, so that envs live long enough to reach progress 500
+                acts[t] = np.clip(acts[t] + stabiliser(env), -1, 1)
+            # reset_command_idx draws the "flips to add" vector only if some env sits at progress 500 (FA:888-890); otherwise the first
+            # torch.rand it makes is the unused one
+            D.flip_first_is_time = bool(torch.isin(env.progress_buf, env.time_index).any()) if hasattr(env, "time_index") else False
+            obs_d, rew, done, info = env.step(torch.from_numpy(acts[t]))
+            n_resets += int(done.sum()); n_tmo += int(info["time_outs"].sum())
+            if record(t):
+                rec["step"].append(t)
+                rec["obs"].append(env.obs_buf.numpy().copy()); rec["states"].append(env.states_buf.numpy().copy())
+                rec["rew"].append(rew.numpy().copy()); rec["reset"].append(done.numpy().copy())
+                rec["timeout"].append(info["time_outs"].numpy().astype(np.uint8))
+                rec["blob"].append(blob_of(env, n))
+    finally:
+        VT.VecTask.__init__, FA.torch_rand_float, torch.normal, torch.rand, FA.FpvBase.reset_target_idx, FA.FpvBase.reset_env_idx = saved
+        for k, v in orig.items():
+            setattr(cls, k, v)
+    out = {k: np.stack(v) for k, v in rec.items()}
+    out["actions"] = acts
+    out["cfg_task"] = np.array(task)
+    out["cfg_n"] = np.array(n)
+    out["cfg_seed"] = np.array(seed)
+    out["cfg_kw"] = np.array(repr(sorted((k, v) for k, v in kw.items() if not k.startswith("_"))))
+    np.savez_compressed(HERE / f"glue_{name}.npz", **out)
+    print(f"glue_{name}.npz: {steps} steps x {n} envs ({len(rec['step'])} recorded), {n_resets} resets, {n_tmo} time-outs, "
+          f"max delay length {int(out['blob'][:, 66].view(np.int32).max())}, max progress {int(out['blob'][:, 65].view(np.int32).max())}")
+
+
+def blob_of(env, n):
+    """the task's state in the row order of the state blob (include/taco_env.h TACO_S_*)"""
+    b = np.zeros((67 + 400, n), np.float32)
+    rs = env.root_states.numpy()
+    b[0:13] = rs.T
+    b[13:20] = env.target_states.numpy()[:, 0:7].T
+    b[20:23] = env.copter_rpy_old.numpy().T
+    b[23:26] = env.copter_rpy_continuous.numpy().T
+    b[26:29] = env.angvel_controller.previous_error.numpy().T
+    b[29:32] = env.angvel_controller.integral.numpy().T
+    bat = env.battery_dynamics
+    b[32], b[33], b[34] = bat.E_c.numpy()[:, 0], bat.u_1.numpy()[:, 0], bat.time.numpy()[:, 0]
+    b[35] = env.battery_voltage.numpy().reshape(n)
+    b[36:40] = env.rotor_speed.numpy().T
+    b[40:44] = env.actions.numpy().T
+    b[44:48] = env.actions_old.numpy().T
+    b[48:50] = env.command.numpy().T
+    if hasattr(env, "flip_radian"):
+        b[50] = env.flip_radian.numpy()
+    rot, aero = env.rotor_dynamics, env.aero_dynamics
+    b[51:55] = rot.response_time.numpy().T
+    b[55:60] = rot.omega_para.numpy().T
+    b[60], b[61] = aero.para_force_torque.numpy()[:, 0], aero.para_force_torque.numpy()[:, 1]
+    b[62], b[63], b[64] = aero.para_d.numpy()[:, 0], aero.para_d.numpy()[:, 1], aero.para_t.numpy()[:, 0]
+    b[65] = env.progress_buf.numpy().astype(np.int32).view(np.float32)
+    b[66] = env.actions_remained_length.numpy().reshape(n).astype(np.int32).view(np.float32)
+    b[67:] = env.actions_remained_buffer.numpy().transpose(2, 1, 0).reshape(400, n)   # [env, ch, slot] -> row 67 + slot * 4 + ch
+    return b
+
+
+def actions(seed, thrust_bias, crash_every=0, noise=0.3):
+    def f(n, steps):
+        rng = np.random.default_rng(seed)
+        a = noise * rng.standard_normal((steps, n, 4)).astype(np.float32)
+        a[:, :, 0] += thrust_bias
+        if crash_every:  # a few envs cut the throttle for a while: they fall below z = 0.1 and die
+            for e in range(0, n, crash_every):
+                t0 = 15 + 7 * (e % 9)
+                a[t0:t0 + 60, e, 0] = -1.0
+        return np.clip(a, -1, 1).astype(np.float32)
+    return f
+
+
+if __name__ == "__main__":
+    common = dict(random_voltage=False, random_rotor_speed=False, env_lenObservations=2, env_lenStates=3)
+    # (1) pos task, every random_* of the pose on: reset dispatch / ordering / zeroing, delay line in the common regime, frame stacks,
+    #     reward + done + time-outs (episodes of 70 steps), deaths
+    run_case("pos", "pos", 48, 170, 11, actions(1, 0.05, crash_every=5), env_maxEpisodeLength=70, **common)
+    # (2) delay-line overflow: delay_time = 85 (L + T > 100: truncated mask write, stale tail) ...
+    run_case("overflow", "pos", 32, 150, 12, actions(2, 0.05, crash_every=7), env_maxEpisodeLength=60, delay_time=85, **common)
+    # (3) ... and 75 ms with random deploy and delay lengths: the line random-walks into the overflow regime
+    run_case("deploy", "pos", 32, 220, 13, actions(3, 0.05, crash_every=6), env_maxEpisodeLength=90, delay_time=75, ramdom_deploy_time=True,
+             ramdom_delay_time=True, **common)
+    # (4) rotate with a random command, (5) flip and (6) mix across progress 500 (command re-draw; FpvMix thirds by global env id)
+    run_case("rotate", "rotate", 32, 160, 14, actions(4, 0.05, crash_every=5), env_maxEpisodeLength=75, **common)
+    around = lambda t: t < 40 or t % 50 == 0 or 495 <= t   # the first resets, a sparse middle, and the steps around progress 500
+    run_case("flip", "flip", 24, 520, 15, actions(5, -0.5, noise=0.05), env_maxEpisodeLength=1000, _hold=True, _record=around, **common)
+    run_case("mix", "mix", 36, 520, 16, actions(6, -0.5, crash_every=11, noise=0.05), env_maxEpisodeLength=1000, _hold=True, _record=around, **common)
