@@ -210,15 +210,29 @@ size_t taco_policy_blob_floats(const taco_policy_cfg *cfg);   /* 0 (and taco_las
 int taco_policy_act(const taco_policy_cfg *cfg, const float *blob, int n, const float *obs, const float *states, uint64_t seed, uint32_t call,
                     int deterministic, int action_only, float *action, float *logp, float *value, float *mu, float *sigma, void *stream);
 
-/* Profiling aid: DEVICE array of 16 uint64 (NULL unbinds); workgroup x = 0 of every following policy launch records the shader clock at
+/* Profiling aid: taco_policy_act with `stamps` = DEVICE array of 16 uint64; workgroup x = 0 of this launch records the shader clock at
  * [0..3] actor: entry, inputs staged, MLP done, end; [8..12] critic: entry, inputs staged, LSTM done, MLP done, end. */
-int taco_policy_bind_stamps(uint64_t *stamps);
+int taco_policy_act_stamped(const taco_policy_cfg *cfg, const float *blob, int n, const float *obs, const float *states, uint64_t seed, uint32_t call,
+                            int deterministic, int action_only, float *action, float *logp, float *value, float *mu, float *sigma, uint64_t *stamps,
+                            void *stream);
+
+/* The critic alone (nets_asymmetry.py:348-352, 128-136) over `rows` state stacks [rows][states_len][states_dim] -> value[rows], ONE launch.
+ * Bit-identical to the `value` output of taco_policy_act on the same stacks.  The documented architecture (LSTM hidden 128 over <= 8 frames
+ * of <= 32 features, two MLP layers of 128) runs in the batched form, two launches: a persistent LSTM kernel (one workgroup per CU walking
+ * 32-row blocks, W_ih / W_hh register-resident, the SIMD's two wavefronts one phase apart so one's MFMAs run beside the other's gate
+ * activations) writing h_T to `workspace`, then the MLP with resident weights; other geometries run the critic role of the policy kernel
+ * (workspace unused).  This is what takes the critic off the rollout's serial chain (taco_rollout_run). */
+size_t taco_critic_workspace_bytes(const taco_policy_cfg *cfg, int64_t rows);   /* the LSTM's h_T between the two kernels: rows x 128 floats */
+int taco_critic_values(const taco_policy_cfg *cfg, const float *blob, int64_t rows, const float *states, float *value, void *workspace,
+                       uint64_t *stamps, void *stream);   /* stamps: NULL, or a DEVICE array of 259 uint64 (profiling; taco_policy.hpp) */
 
 /* One PPO rollout (ppo_asymmetry.py:308-342) enqueued from C on `stream`: for t < horizon { act on replay slot t -> action / log-prob /
  * value / mean / log-std of step t; the action clipped to [act_lo, act_hi] (:310) drives taco_step_rollout, which writes slot t + 1,
  * rew_buf[t], done_buf[t], timeout_buf[t] }, then the value of the final state (:341) and the time-out bootstrap
  * rew[t] += gamma * value[t] where an env was truncated (:314-324; the value of the pre-step state IS value_buf[t]).
- * 2 * horizon + 2 launches, no host work between the steps; the policy's noise counter runs call0 .. call0 + horizon.
+ * Per step only the ACTOR runs (nothing before GAE consumes `value`): the critic is evaluated afterwards for all horizon + 1 slots in one
+ * batched launch (taco_critic_values' kernel), same bits as a per-step act().  2 * horizon + 2 launches, no host work between the steps;
+ * the policy's noise counter runs call0 .. call0 + horizon (the last number is reserved for the final state's act(), which draws nothing).
  * All arrays are DEVICE memory in the replay-buffer layout (taco_amd/rollout.py::RolloutBuffer.run). */
 typedef struct taco_rollout_bufs {
     float *obs_store;     /* [horizon + 1][num_envs][len_obs][26]    slot 0 = the stacks to start from */
@@ -233,7 +247,7 @@ typedef struct taco_rollout_bufs {
     float *sigma_buf;     /* [horizon][num_envs][4] */
     uint8_t *timeout_buf; /* [horizon][num_envs] */
     float *last_value;    /* [num_envs] */
-    float *scratch;       /* [num_envs][13] */
+    float *critic_ws;     /* taco_critic_workspace_bytes(cfg, (horizon + 1) * num_envs) bytes, 16-byte aligned */
 } taco_rollout_bufs;
 int taco_rollout_run(taco_env *env, const taco_policy_cfg *cfg, const float *blob, const taco_rollout_bufs *bufs, int horizon, uint64_t seed,
                      uint32_t call0, double gamma, double act_lo, double act_hi, int64_t *reset_buf, void *stream);

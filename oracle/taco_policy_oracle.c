@@ -17,7 +17,6 @@
 
 static inline uint32_t pf2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float pu2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
-static inline float pow2i(int k) { return pu2f((uint32_t)(k + 127) << 23); }
 
 float orc_expf(float x) {
     const float xc = fminf(fmaxf(x, -87.33654475055310898657f), 88.72283905206835f);
@@ -32,8 +31,7 @@ float orc_expf(float x) {
     p = fmaf(p, r, 1.6666665459e-1f);
     p = fmaf(p, r, 5.0000001201e-1f);
     p = fmaf(p, z, r) + 1.0f;
-    const int ki = (int)k, k1 = ki >> 1, k2 = ki - k1;
-    const float e = (p * pow2i(k1)) * pow2i(k2);
+    const float e = ldexpf(p, (int)k);   /* exact: the clamp keeps p * 2^k normal */
     return (x != x) ? x : e;
 }
 float orc_sigmoidf(float x) { return 1.0f / (1.0f + orc_expf(-x)); }

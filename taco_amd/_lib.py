@@ -23,7 +23,7 @@ FLAG_BITS = {
 # every symbol include/taco_env.h declares
 EXPORTS = ["taco_abi_version", "taco_source_hash", "taco_last_error", "taco_workspace_bytes", "taco_create", "taco_destroy", "taco_step",
            "taco_gather_row_floats", "taco_bind_gather_block", "taco_set_difficulty", "taco_get_step_count", "taco_set_step_count", "taco_get_state", "taco_set_state",
-           "taco_step_kernel_name", "taco_launch_geometry", "taco_set_kernel_form", "taco_get_kernel_form", "taco_check", "taco_get_field", "taco_step_rollout", "taco_gae_workspace_bytes", "taco_gae", "taco_occupancy", "taco_bind_phase_stamps", "taco_policy_blob_floats", "taco_policy_act", "taco_rollout_run", "taco_policy_bind_stamps"]
+           "taco_step_kernel_name", "taco_launch_geometry", "taco_set_kernel_form", "taco_get_kernel_form", "taco_check", "taco_get_field", "taco_step_rollout", "taco_gae_workspace_bytes", "taco_gae", "taco_occupancy", "taco_bind_phase_stamps", "taco_policy_blob_floats", "taco_policy_act", "taco_rollout_run", "taco_policy_act_stamped", "taco_critic_values", "taco_critic_workspace_bytes"]
 
 
 class TacoCfg(C.Structure):
@@ -47,7 +47,7 @@ class RolloutIO(C.Structure):
 class RolloutBufs(C.Structure):
     """struct taco_rollout_bufs (include/taco_env.h)"""
     _fields_ = [(k, C.c_void_p) for k in ("obs_store", "states_store", "act_buf", "act_env", "rew_buf", "done_buf", "value_buf", "logp_buf",
-                                          "mu_buf", "sigma_buf", "timeout_buf", "last_value", "scratch")]
+                                          "mu_buf", "sigma_buf", "timeout_buf", "last_value", "critic_ws")]
 
 
 class TacoError(RuntimeError):
@@ -110,8 +110,13 @@ def _declare(lib, ab_build=False):
     lib.taco_policy_act.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_int,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.taco_policy_act.restype = C.c_int
-    lib.taco_policy_bind_stamps.argtypes = [C.c_void_p]
-    lib.taco_policy_bind_stamps.restype = C.c_int
+    lib.taco_policy_act_stamped.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_int,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.taco_policy_act_stamped.restype = C.c_int
+    lib.taco_critic_values.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.taco_critic_values.restype = C.c_int
+    lib.taco_critic_workspace_bytes.argtypes = [C.c_void_p, C.c_int64]
+    lib.taco_critic_workspace_bytes.restype = C.c_size_t
     lib.taco_rollout_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(RolloutBufs), C.c_int, C.c_uint64, C.c_uint32, C.c_double,
                                      C.c_double, C.c_double, C.c_void_p, C.c_void_p]
     lib.taco_rollout_run.restype = C.c_int

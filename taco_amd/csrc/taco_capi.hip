@@ -4,6 +4,7 @@
 // buffer (PyTorch-ROCm tensors in the Python host layer), the handle only keeps the configuration, the derived fp32
 // constants and two integers that advance with every step (step counter, ring head).
 #include <hip/hip_runtime.h>
+#include <limits.h>
 
 #include <cmath>
 #include <cstdio>
@@ -617,36 +618,105 @@ size_t taco_policy_blob_floats(const taco_policy_cfg *c) {
     return n;
 }
 
-static unsigned long long *g_policy_stamps = nullptr;
-int taco_policy_bind_stamps(uint64_t *stamps) { g_policy_stamps = (unsigned long long *)stamps; return TACO_OK; }
-
 static int launch_policy(const taco_policy_cfg *c, const float *blob, int n, const float *obs, const float *states, uint64_t seed, uint32_t call,
                          int deterministic, int action_only, float *action, float *logp, float *value, float *mu, float *sigma,
-                         float *action_env, float act_lo, float act_hi, void *stream) {
+                         float *action_env, float act_lo, float act_hi, void *stream, uint64_t *stamps = nullptr) {
     taco::PolicyParams P{};
     P.obs_len = c->obs_len; P.obs_dim = c->obs_dim; P.states_len = c->states_len; P.states_dim = c->states_dim; P.act_dim = c->act_dim;
     P.n_actor_hidden = c->n_actor_hidden; P.lstm_hidden = c->lstm_hidden; P.n_critic_hidden = c->n_critic_hidden;
     for (int l = 0; l < 4; ++l) { P.actor_hidden[l] = c->actor_hidden[l]; P.critic_hidden[l] = c->critic_hidden[l]; }
     P.blob = blob; P.obs = obs; P.states = states; P.action = action; P.logp = logp; P.value = value; P.mu = mu; P.sigma = sigma;
     P.action_env = action_env; P.act_lo = act_lo; P.act_hi = act_hi;
-    P.stamps = g_policy_stamps;
+    P.stamps = (unsigned long long *)stamps;
     P.n = n; P.deterministic = deterministic ? 1 : 0;
     P.seed_lo = (uint32_t)seed; P.seed_hi = (uint32_t)(seed >> 32); P.call = call;
+    P.role0 = 0; P.value_tail = nullptr; P.value_split = INT_MAX;
     hipLaunchKernelGGL(taco::taco_policy_kernel, dim3((n + taco::POL_ROWS - 1) / taco::POL_ROWS, action_only ? 1 : 2), dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
     hipError_t he = hipGetLastError();
     if (he != hipSuccess) return hip_fail(he, "taco_policy_kernel launch");
     return TACO_OK;
 }
 
-int taco_policy_act(const taco_policy_cfg *c, const float *blob, int n, const float *obs, const float *states, uint64_t seed, uint32_t call,
-                    int deterministic, int action_only, float *action, float *logp, float *value, float *mu, float *sigma, void *stream) {
+// the critic alone over `rows` state stacks: value[row] for row < split, value_tail[row - split] beyond.  The batched form
+// (taco_critic_kernel) covers the documented architecture; any other geometry runs the critic role of taco_policy_kernel, same results.
+static bool critic_batched_form(const taco_policy_cfg *c) {
+    auto p16 = [](int x) { return (x + 15) / 16 * 16; };
+    return c->lstm_hidden > 0 && p16(c->lstm_hidden) == 128 && p16(c->states_dim) == 32 && c->states_len <= taco::POL_MAXT && c->n_critic_hidden == 2 &&
+           p16(c->critic_hidden[0]) == 128 && p16(c->critic_hidden[1]) == 128;
+}
+static int device_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        else return 256;
+    }
+    return cus;
+}
+// cu_limit > 0: the persistent LSTM kernel uses at most that many workgroups (a stream that owns fewer CUs than the device has)
+static int launch_critic(const taco_policy_cfg *c, const float *blob, size_t rows, const float *states, float *value, float *value_tail, size_t split,
+                         float *workspace, int cu_limit, void *stream, uint64_t *stamps = nullptr) {
+    if (rows > (size_t)INT_MAX - 64) return fail(TACO_ERR_INVALID_ARG, "critic: too many rows for one launch");
+    taco::PolicyParams P{};
+    P.obs_len = c->obs_len; P.obs_dim = c->obs_dim; P.states_len = c->states_len; P.states_dim = c->states_dim; P.act_dim = c->act_dim;
+    P.n_actor_hidden = c->n_actor_hidden; P.lstm_hidden = c->lstm_hidden; P.n_critic_hidden = c->n_critic_hidden;
+    for (int l = 0; l < 4; ++l) { P.actor_hidden[l] = c->actor_hidden[l]; P.critic_hidden[l] = c->critic_hidden[l]; }
+    P.blob = blob; P.states = states; P.value = value; P.value_tail = value_tail;
+    P.value_split = split > rows ? INT_MAX : (int)split;
+    P.n = (int)rows; P.role0 = 1; P.hT = workspace; P.stamps = (unsigned long long *)stamps;
+    if (critic_batched_form(c)) {
+        if (!workspace || ((uintptr_t)workspace & 15u) != 0) return fail(TACO_ERR_INVALID_ARG, "critic: the batched form needs a 16-byte aligned workspace (taco_critic_workspace_bytes)");
+        if (((uintptr_t)states & 15u) != 0) return fail(TACO_ERR_INVALID_ARG, "critic: the batched form needs 16-byte aligned state stacks");
+        const int cus = cu_limit > 0 ? cu_limit : device_cus();
+        // a persistent workgroup per CU walking blocks b, b + grid, ...: shrink the grid to the smallest that keeps the longest walk as short
+        const size_t nblocks = (rows + taco::CR_ROWS - 1) / taco::CR_ROWS;
+        const size_t walk = (nblocks + cus - 1) / cus;
+        const unsigned grid = (unsigned)((nblocks + walk - 1) / walk);
+        hipLaunchKernelGGL(taco::taco_critic_lstm_kernel, dim3(grid), dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
+        hipError_t he = hipGetLastError();
+        if (he != hipSuccess) return hip_fail(he, "taco_critic_lstm_kernel launch");
+        const size_t nchunks = (rows + taco::CR_MLP_ROWS - 1) / taco::CR_MLP_ROWS;
+        const size_t cap = (size_t)2 * cus;
+        hipLaunchKernelGGL(taco::taco_critic_mlp_kernel, dim3((unsigned)(nchunks < cap ? nchunks : cap)), dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
+    } else {
+        hipLaunchKernelGGL(taco::taco_policy_kernel, dim3((unsigned)((rows + taco::POL_ROWS - 1) / taco::POL_ROWS), 1), dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
+    }
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) return hip_fail(he, "critic kernel launch");
+    return TACO_OK;
+}
+
+size_t taco_critic_workspace_bytes(const taco_policy_cfg *c, int64_t rows) {
+    if (policy_cfg_ok(c) != TACO_OK || rows < 1) return 0;
+    return critic_batched_form(c) ? (size_t)rows * 128 * sizeof(float) : 16;
+}
+
+int taco_critic_values(const taco_policy_cfg *c, const float *blob, int64_t rows, const float *states, float *value, void *workspace, uint64_t *stamps,
+                       void *stream) {
+    const int rc = policy_cfg_ok(c);
+    if (rc != TACO_OK) return rc;
+    if (!blob || !states || !value) return fail(TACO_ERR_INVALID_ARG, "taco_critic_values: null buffer pointer");
+    if (rows < 1) return fail(TACO_ERR_INVALID_ARG, "taco_critic_values: rows must be >= 1");
+    if (((uintptr_t)blob & 15u) != 0) return fail(TACO_ERR_INVALID_ARG, "taco_critic_values: the weight blob must be 16-byte aligned");
+    if (stamps && ((uintptr_t)stamps & 7u) != 0) return fail(TACO_ERR_INVALID_ARG, "taco_critic_values: stamps must be 8-byte aligned");
+    return launch_critic(c, blob, (size_t)rows, states, value, nullptr, (size_t)rows + 1, (float *)workspace, 0, stream, stamps);
+}
+
+int taco_policy_act_stamped(const taco_policy_cfg *c, const float *blob, int n, const float *obs, const float *states, uint64_t seed, uint32_t call,
+                            int deterministic, int action_only, float *action, float *logp, float *value, float *mu, float *sigma, uint64_t *stamps,
+                            void *stream) {
     const int rc = policy_cfg_ok(c);
     if (rc != TACO_OK) return rc;
     if (!blob || !obs || !action || !logp || !mu || !sigma) return fail(TACO_ERR_INVALID_ARG, "taco_policy_act: null buffer pointer");
     if (!action_only && (!states || !value)) return fail(TACO_ERR_INVALID_ARG, "taco_policy_act: states / value are needed unless action_only");
     if (n < 1) return fail(TACO_ERR_INVALID_ARG, "taco_policy_act: n must be >= 1");
     if (((uintptr_t)blob & 15u) != 0) return fail(TACO_ERR_INVALID_ARG, "taco_policy_act: the weight blob must be 16-byte aligned");
-    return launch_policy(c, blob, n, obs, states, seed, call, deterministic, action_only, action, logp, value, mu, sigma, nullptr, 0.0f, 0.0f, stream);
+    if (stamps && ((uintptr_t)stamps & 7u) != 0) return fail(TACO_ERR_INVALID_ARG, "taco_policy_act: stamps must be 8-byte aligned");
+    return launch_policy(c, blob, n, obs, states, seed, call, deterministic, action_only, action, logp, value, mu, sigma, nullptr, 0.0f, 0.0f, stream, stamps);
+}
+int taco_policy_act(const taco_policy_cfg *c, const float *blob, int n, const float *obs, const float *states, uint64_t seed, uint32_t call,
+                    int deterministic, int action_only, float *action, float *logp, float *value, float *mu, float *sigma, void *stream) {
+    return taco_policy_act_stamped(c, blob, n, obs, states, seed, call, deterministic, action_only, action, logp, value, mu, sigma, nullptr, stream);
 }
 
 // ---- a whole PPO rollout (ppo_asymmetry.py:308-342) enqueued from C: 2 H + 2 launches, no host work between the steps
@@ -657,7 +727,7 @@ int taco_rollout_run(taco_env *e, const taco_policy_cfg *c, const float *blob, c
     if (rc != TACO_OK) return rc;
     if (!b || !blob || !reset_buf) return fail(TACO_ERR_INVALID_ARG, "taco_rollout_run: null argument");
     if (!b->obs_store || !b->states_store || !b->act_buf || !b->act_env || !b->rew_buf || !b->done_buf || !b->value_buf || !b->logp_buf || !b->mu_buf ||
-        !b->sigma_buf || !b->timeout_buf || !b->last_value || !b->scratch)
+        !b->sigma_buf || !b->timeout_buf || !b->last_value || !b->critic_ws)
         return fail(TACO_ERR_INVALID_ARG, "taco_rollout_run: null buffer pointer");
     if (horizon < 1) return fail(TACO_ERR_INVALID_ARG, "taco_rollout_run: horizon must be >= 1");
     if (((uintptr_t)blob & 15u) != 0) return fail(TACO_ERR_INVALID_ARG, "taco_rollout_run: the weight blob must be 16-byte aligned");
@@ -668,8 +738,8 @@ int taco_rollout_run(taco_env *e, const taco_policy_cfg *c, const float *blob, c
     const size_t obs_slot = n * ec.len_obs * 26, st_slot = n * ec.len_states * 26;
     for (int t = 0; t < horizon; ++t) {
         float *act_t = b->act_buf + (size_t)t * n * 4;
-        rc = launch_policy(c, blob, (int)n, b->obs_store + (size_t)t * obs_slot, b->states_store + (size_t)t * st_slot, seed, call0 + (uint32_t)t, 0, 0,
-                           act_t, b->logp_buf + (size_t)t * n, b->value_buf + (size_t)t * n, b->mu_buf + (size_t)t * n * 4, b->sigma_buf + (size_t)t * n * 4,
+        rc = launch_policy(c, blob, (int)n, b->obs_store + (size_t)t * obs_slot, nullptr, seed, call0 + (uint32_t)t, 0, 1,
+                           act_t, b->logp_buf + (size_t)t * n, nullptr, b->mu_buf + (size_t)t * n * 4, b->sigma_buf + (size_t)t * n * 4,
                            b->act_env, (float)act_lo, (float)act_hi, stream);
         if (rc != TACO_OK) return rc;
         taco_rollout_io io{};
@@ -681,11 +751,10 @@ int taco_rollout_run(taco_env *e, const taco_policy_cfg *c, const float *blob, c
         rc = launch_step(e, &io, stream);
         if (rc != TACO_OK) return rc;
     }
-    // value of the final state (:341), deterministic: only the critic's output is kept
-    rc = launch_policy(c, blob, (int)n, b->obs_store + (size_t)horizon * obs_slot, b->states_store + (size_t)horizon * st_slot, seed, call0 + (uint32_t)horizon, 1, 0,
-                       b->scratch, b->scratch + n * 4, b->last_value, b->scratch + n * 5, b->scratch + n * 9, nullptr, 0.0f, 0.0f, stream);
-    if (rc != TACO_OK) return rc;
+    // the values of all H + 1 state stacks (:311 value of slot t, :341 of the final state) in one launch: slots 0..H-1 -> value_buf, H -> last_value
     const size_t count = (size_t)horizon * n;
+    rc = launch_critic(c, blob, count + n, b->states_store, b->value_buf, b->last_value, count, b->critic_ws, 0, stream);
+    if (rc != TACO_OK) return rc;
     hipLaunchKernelGGL(taco::timeout_bootstrap_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, b->rew_buf, b->value_buf, b->done_buf,
                        b->timeout_buf, count, (float)gamma);
     hipError_t he = hipGetLastError();

@@ -138,10 +138,10 @@ TD float log(float x) {
 }
 
 // ---- exp / tanh / sigmoid for the policy forward (Cephes single-precision kernels, explicit fma, one division in sigmoid/tanh)
-TD float pow2i(int k) { return from_bits((uint32_t)(k + 127) << 23); }  // 2^k, k in [-126, 127]
 TD float expf_own(float x) {
     // the argument is clamped to the range in which p * 2^k neither overflows nor goes subnormal: exp(x >= 88.72) = 3.4e38,
-    // exp(x <= -87.34) = 1.2e-38 (sigmoid / tanh saturate long before); straight-line code, a NaN comes back as NaN
+    // exp(x <= -87.34) = 1.2e-38 (sigmoid / tanh saturate long before); straight-line code, a NaN comes back as NaN.
+    // p * 2^k is one v_ldexp_f32 (= C's ldexpf: exact here, the clamp keeps the result normal).
     const float xc = __builtin_fminf(__builtin_fmaxf(x, -87.33654475055310898657f), 88.72283905206835f);
     const float k = __builtin_rintf(xc * 1.44269504088896341f);
     float r = fma(-k, 0.693359375f, xc);
@@ -154,8 +154,7 @@ TD float expf_own(float x) {
     p = fma(p, r, 1.6666665459e-1f);
     p = fma(p, r, 5.0000001201e-1f);
     p = fma(p, z, r) + 1.0f;
-    const int ki = (int)k, k1 = ki >> 1, k2 = ki - k1;
-    const float e = (p * pow2i(k1)) * pow2i(k2);
+    const float e = __builtin_amdgcn_ldexpf(p, (int)k);
     return (x != x) ? x : e;
 }
 TD float sigmoid_own(float x) { return 1.0f / (1.0f + expf_own(-x)); }

@@ -33,9 +33,13 @@ struct PolicyParams {
     float *action, *logp, *value, *mu, *sigma;
     float *action_env;  // optional [n][act_dim]: the action clipped to [act_lo, act_hi], what the env executes (ppo_asymmetry.py:310)
     float act_lo, act_hi;
-    unsigned long long *stamps;  // optional [16]: shader-clock stamps of workgroup x = 0 (actor: 0..3, critic: 8..13), taco_policy_bind_stamps
+    unsigned long long *stamps;  // optional: shader-clock stamps of workgroup x = 0 ([16], actor: 0..3, critic: 8..13; batched critic: [259], see its loop)
     int n, deterministic;
     uint32_t seed_lo, seed_hi, call;
+    int role0;          // taco_policy_kernel: role of blockIdx.y == 0 (0: actor [+ critic at y == 1], 1: critic only)
+    float *value_tail;  // batched critic: rows >= value_split write value_tail[row - value_split] (the rollout's last_value)
+    int value_split;
+    float *hT;          // batched critic: workspace [n][128], the LSTM's h_T between the two kernels
 };
 
 typedef float pf32x4 __attribute__((ext_vector_type(4)));
@@ -396,7 +400,11 @@ TD void critic_body(const PolicyParams &P, float *bufA, float *bufB, float *xs) 
         float *t = x; x = y; y = t;
     }
     POL_STAMP(3);
-    if (tid < POL_ROWS && row0 + tid < P.n) P.value[row0 + tid] = x[tid * POL_LD];
+    if (tid < POL_ROWS && row0 + tid < P.n) {
+        const int row = row0 + tid;
+        if (row < P.value_split) P.value[row] = x[tid * POL_LD];
+        else P.value_tail[row - P.value_split] = x[tid * POL_LD];
+    }
     POL_STAMP(4);
 }
 #undef POL_STAMP
@@ -406,8 +414,319 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_policy_kernel(const PolicyPa
     __shared__ __attribute__((aligned(16))) float bufA[POL_ROWS * POL_LD];
     __shared__ __attribute__((aligned(16))) float bufB[POL_ROWS * POL_LD];
     __shared__ __attribute__((aligned(16))) float xs[POL_MAXT * POL_ROWS * POL_XLD];
-    if (blockIdx.y == 0) actor_body<POL_NW>(P, bufA, bufB);
+    if (blockIdx.y + P.role0 == 0) actor_body<POL_NW>(P, bufA, bufB);
     else critic_body<POL_NW, true>(P, bufA, bufB, xs);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The critic alone over MANY rows (taco_critic_values; the rollout's H x N + N state stacks, off the per-step chain: nothing before GAE
+// consumes `value`, ppo_asymmetry.py:308-342).  Same arithmetic as critic_body -- the same v_mfma_f32_16x16x4_f32 chains in the same k
+// order, so the same bits -- as two kernels shaped by what tools/ubench/mfma_valu.hip measures on gfx950:
+//   * an f32 MFMA occupies the SIMD's FP32 lanes for its 32 cycles: plain VALU work does NOT run beside it, neither from the same
+//     wavefront nor from the SIMD's other one (MFMA + 4 v_fma = 57 cycles; the bf16 MFMA + 4 v_fma = 35), and a pending MFMA of either
+//     wavefront is served before any VALU instruction.  The gate activations (5 exp + 3 div per cell) are therefore pure ADDED time,
+//     and the matrix pipe's share of a timestep is MFMA / (MFMA + VALU), whatever the schedule;
+//   * one wavefront alone issues a VALU instruction every ~5.6 cycles, two together one every ~2.7: the activations must be done by BOTH
+//     wavefronts of a SIMD at the same time.  (A first form ran the SIMD partners one phase apart -- one's MFMAs beside the other's
+//     activations -- and lost 20 % to exactly this: profiles/r02_g_critic_forms.txt.)
+// taco_critic_lstm_kernel: PERSISTENT, one workgroup (8 wavefronts, two per SIMD) per CU, W_ih / W_hh fragments of hidden columns
+//   16 w .. 16 w + 15 (all four gates) resident in 160 registers of wavefront w for the whole launch; the workgroup walks 32-row blocks
+//   (blocks b, b + grid, ...).  Per timestep every wavefront runs its 320 MFMAs (two 16-row tiles), then its 8 cells, then ONE
+//   s_barrier; h_t is double-buffered in LDS.  The next block's state stacks are staged into the other half of xs around the cells of
+//   timestep 0 (loads issued before them, LDS stores after).  h_T goes to a global workspace.
+//   The first timestep skips the W_hh h_{-1} chain: h_{-1} = +0, and fma(+0, w, acc) leaves every acc but a zero unchanged -- a zero acc
+//   becomes +0 unless it is -0 and every weight of the column has its sign bit set, which `allneg` reproduces (finite weights assumed).
+// taco_critic_mlp_kernel: the MLP on h_T, 64 rows per pass, W1 / W2 / W3 fragments register-resident, two workgroups per CU.
+constexpr int CR_ROWS = 32;   // rows per LSTM block (two 16-row MFMA tiles)
+constexpr int CR_LD = 132;    // h / MLP activation row stride in floats (width 128): 528 B, 8 consecutive rows cover all 32 banks
+constexpr int CR_MLP_ROWS = 64;
+
+// requirements (checked by the host, which falls back to taco_policy_kernel's critic role otherwise): pad16(states_dim) == 32,
+// pad16(lstm_hidden) == 128, states_len <= POL_MAXT, critic MLP = two hidden layers padded to 128
+__global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_kernel(const PolicyParams P) {
+    __shared__ __attribute__((aligned(16))) float xs[2][POL_MAXT * CR_ROWS * 32];   // the block's state stacks as they lie in memory: [row][t][sd]
+    __shared__ __attribute__((aligned(16))) float hb[2][CR_ROWS * CR_LD];
+    constexpr int KSX = 2, KSH = 8, hp = 128, ip = 32, RT = CR_ROWS / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int T = P.states_len, sd = P.states_dim;
+    const int nblocks = (P.n + CR_ROWS - 1) / CR_ROWS;
+    const int nb = ((int)blockIdx.x < nblocks) ? (nblocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;  // blocks of this workgroup
+    if (nb == 0) return;
+    const float *w = P.blob;
+    {
+        int in_a = pad16(P.obs_len * P.obs_dim);
+        for (int l = 0; l <= P.n_actor_hidden; ++l) {
+            const int out = pad16(l == P.n_actor_hidden ? P.act_dim : P.actor_hidden[l]);
+            w += (size_t)out * in_a + out;
+            in_a = out;
+        }
+        w += 16;  // log_std
+    }
+    const float *Wih = w, *Whh = w + (size_t)4 * hp * ip, *bs = Whh + (size_t)4 * hp * hp;
+
+    // ---- this wavefront's weight fragments (hidden tile = wave)
+    const int col = wave * 16 + r;
+    float4 wx[4][KSX], wh[4][KSH];
+    float bq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        bq[q] = bs[q * hp + col];
+#pragma unroll
+        for (int s = 0; s < KSX; ++s) wx[q][s] = *reinterpret_cast<const float4 *>(Wih + (size_t)q * hp * ip + ((size_t)(wave * KSX + s) * 64 + lane) * 4);
+#pragma unroll
+        for (int s = 0; s < KSH; ++s) wh[q][s] = *reinterpret_cast<const float4 *>(Whh + (size_t)q * hp * hp + ((size_t)(wave * KSH + s) * 64 + lane) * 4);
+    }
+    // ---- staging of one block's state stacks: the block's bytes are contiguous in memory (32 rows x T x sd floats), and they are copied
+    // AS THEY LIE into xs[half] by LDS-DMA (global_load_lds_dwordx4: no registers -- this kernel has none to spare -- 1 KiB per wavefront
+    // instruction); the fragment reads below do the [row][t][sd] addressing and zero the columns beyond sd.
+    const size_t total_bytes = (size_t)P.n * T * sd * sizeof(float);
+    const int block_bytes = CR_ROWS * T * sd * (int)sizeof(float);
+    auto stage = [&](int blk, int half) {
+        const size_t base = (size_t)blk * block_bytes;
+        if (base + block_bytes <= total_bytes) {  // wave-uniform
+            const char *src = reinterpret_cast<const char *>(P.states) + base;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {  // 32 rows x 8 frames x 32 floats = 2048 pieces of 16 B at most = 4 per thread
+                const int piece0 = 512 * j + 64 * wave;   // this wavefront instruction's first piece
+                if (piece0 * 16 < block_bytes) {            // wave-uniform
+                    const int off = (piece0 + lane) * 16;
+                    if (off < block_bytes)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off),
+                                                         (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(xs[half]) + piece0 * 16), 16, 0, 0);
+                }
+            }
+        } else {  // the array's last, partial block (once per launch): plain loads, zeros for the missing rows
+            const size_t first = base / sizeof(float), total = total_bytes / sizeof(float);
+#pragma unroll 1
+            for (int e = tid; e < block_bytes / (int)sizeof(float); e += 64 * POL_NW) xs[half][e] = first + e < total ? P.states[first + e] : 0.0f;
+        }
+    };
+    stage((int)blockIdx.x, 0);
+    // which of the 4 floats this lane reads in the LAST k block of the x operand exist (k = 16 (KSX - 1) + 4 g + j < sd)
+    bool xvalid[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xvalid[j] = 16 * (KSX - 1) + 4 * g + j < sd;
+    const bool sd_even = (sd & 1) == 0;
+    // ---- sign bookkeeping of the skipped first h chain (see above): does every W_hh weight of (gate q, column col) have its sign bit set?
+    bool allneg[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint32_t m = 0x80000000u;
+#pragma unroll
+        for (int s = 0; s < KSH; ++s)
+            m &= __builtin_bit_cast(uint32_t, wh[q][s].x) & __builtin_bit_cast(uint32_t, wh[q][s].y) & __builtin_bit_cast(uint32_t, wh[q][s].z) &
+                 __builtin_bit_cast(uint32_t, wh[q][s].w);
+        m &= (uint32_t)__shfl_xor((int)m, 16, 64);
+        m &= (uint32_t)__shfl_xor((int)m, 32, 64);
+        allneg[q] = m != 0;
+    }
+    __syncthreads();
+
+    pf32x4 acc[RT][4];  // [row tile][gate], rows 16 rt + 4 g + i, column col
+    float cst[RT][4];   // cell state
+    auto mfma_x = [&](const float *xh, int t) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[rt][q] = pf32x4{bq[q], bq[q], bq[q], bq[q]};
+        const float *xt = xh + (r * T + t) * sd + 4 * g;
+#pragma unroll
+        for (int s = 0; s < KSX; ++s) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const float *at = xt + 16 * rt * T * sd + 16 * s;
+                float4 a4;
+                if (sd_even) {  // frames start 8-byte aligned
+                    const float2 lo = *reinterpret_cast<const float2 *>(at), hi = *reinterpret_cast<const float2 *>(at + 2);
+                    a4 = float4{lo.x, lo.y, hi.x, hi.y};
+                } else {
+                    a4 = float4{at[0], at[1], at[2], at[3]};
+                }
+                if (s == KSX - 1) {  // beyond the frame: what lies there is the next frame, not the zero padding of the weights' k range
+                    a4.x = xvalid[0] ? a4.x : 0.0f; a4.y = xvalid[1] ? a4.y : 0.0f; a4.z = xvalid[2] ? a4.z : 0.0f; a4.w = xvalid[3] ? a4.w : 0.0f;
+                } else if (16 * (s + 1) > sd) {
+                    a4.x = 16 * s + 4 * g + 0 < sd ? a4.x : 0.0f; a4.y = 16 * s + 4 * g + 1 < sd ? a4.y : 0.0f;
+                    a4.z = 16 * s + 4 * g + 2 < sd ? a4.z : 0.0f; a4.w = 16 * s + 4 * g + 3 < sd ? a4.w : 0.0f;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[rt][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, wx[q][s].x, acc[rt][q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[rt][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, wx[q][s].y, acc[rt][q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[rt][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, wx[q][s].z, acc[rt][q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[rt][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wx[q][s].w, acc[rt][q], 0, 0, 0);
+            }
+        }
+    };
+    auto mfma_h = [&](const float *hprev) {
+        const float *hrow = hprev + r * CR_LD + 4 * g;
+#pragma unroll
+        for (int s = 0; s < KSH; ++s) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const float4 a4 = *reinterpret_cast<const float4 *>(hrow + 16 * rt * CR_LD + 16 * s);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[rt][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, wh[q][s].x, acc[rt][q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[rt][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, wh[q][s].y, acc[rt][q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[rt][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, wh[q][s].z, acc[rt][q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[rt][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wh[q][s].w, acc[rt][q], 0, 0, 0);
+            }
+        }
+    };
+    // the gate activations of timestep t; h_t to LDS, or (last timestep) h_T to the workspace rows of the block
+    auto cells = [&](int t, int blk, bool first) {
+        float hv[RT][4];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float cn;
+                lstm_cell(acc[rt][0][i], acc[rt][1][i], acc[rt][2][i], acc[rt][3][i], first ? 0.0f : cst[rt][i], cn, hv[rt][i]);
+                cst[rt][i] = cn;
+            }
+        if (t + 1 < T) {
+            float *hout = hb[t & 1] + (4 * g) * CR_LD + col;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hout[(16 * rt + i) * CR_LD] = hv[rt][i];
+        } else {
+            const size_t row = (size_t)blk * CR_ROWS + 4 * g;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (row + 16 * rt + i < (size_t)P.n) P.hT[(row + 16 * rt + i) * hp + col] = hv[rt][i];
+        }
+    };
+    // profiling (P.stamps): workgroup 0, wavefronts 0 and 4: shader clock at the start of a timestep, after its MFMAs, after its cells, for the
+    // first 21 timesteps ([wave >> 2][21][3] uint64); [256] = the 100 MHz wall clock at entry, [257] at exit, [258] shader clock at exit
+    const bool stamping = P.stamps != nullptr && blockIdx.x == 0 && (wave & 3) == 0 && lane == 0;
+    if (stamping && wave == 0) P.stamps[256] = wall_clock64();
+    int step = 0;
+    for (int k = 0; k < nb; ++k) {
+        const int blk = (int)blockIdx.x + k * (int)gridDim.x;
+        const float *xh = xs[k & 1];
+        // the next block's stacks: the DMA lands during timestep 0 (the barrier that ends it waits for it; xs[(k + 1) & 1] was last read
+        // in block k - 1)
+        if (k + 1 < nb) stage(blk + (int)gridDim.x, (k + 1) & 1);
+        // ---- timestep 0: the x chain only (+ the sign rule)
+        if (stamping && step < 21) P.stamps[(wave >> 2) * 64 + 3 * step] = __builtin_readcyclecounter();
+        mfma_x(xh, 0);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v = acc[rt][q][i];
+                    acc[rt][q][i] = (v == 0.0f && !allneg[q]) ? 0.0f : v;
+                }
+        if (stamping && step < 21) P.stamps[(wave >> 2) * 64 + 3 * step + 1] = __builtin_readcyclecounter();
+        cells(0, blk, true);
+        if (stamping && step < 21) P.stamps[(wave >> 2) * 64 + 3 * step + 2] = __builtin_readcyclecounter();
+        ++step;
+        __syncthreads();
+        for (int t = 1; t < T; ++t) {
+            if (stamping && step < 21) P.stamps[(wave >> 2) * 64 + 3 * step] = __builtin_readcyclecounter();
+            mfma_x(xh, t);
+            mfma_h(hb[(t - 1) & 1]);
+            if (stamping && step < 21) P.stamps[(wave >> 2) * 64 + 3 * step + 1] = __builtin_readcyclecounter();
+            cells(t, blk, false);
+            if (stamping && step < 21) P.stamps[(wave >> 2) * 64 + 3 * step + 2] = __builtin_readcyclecounter();
+            ++step;
+            __syncthreads();
+        }
+    }
+    if (stamping && wave == 0) { P.stamps[257] = wall_clock64(); P.stamps[258] = __builtin_readcyclecounter(); }
+}
+
+// value = W3 relu(W2 relu(W1 h_T + b1) + b2) + b3 over the workspace rows (critic_body's dense layers; same chains, same bits)
+__global__ __launch_bounds__(64 * POL_NW, 4) void taco_critic_mlp_kernel(const PolicyParams P) {
+    __shared__ __attribute__((aligned(16))) float xb[CR_MLP_ROWS * CR_LD];
+    __shared__ __attribute__((aligned(16))) float yb[CR_MLP_ROWS * CR_LD];
+    constexpr int hp = 128, ip = 32, KS = 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const float *w = P.blob;
+    {
+        int in_a = pad16(P.obs_len * P.obs_dim);
+        for (int l = 0; l <= P.n_actor_hidden; ++l) {
+            const int out = pad16(l == P.n_actor_hidden ? P.act_dim : P.actor_hidden[l]);
+            w += (size_t)out * in_a + out;
+            in_a = out;
+        }
+        w += 16 + (size_t)4 * hp * ip + (size_t)4 * hp * hp + (size_t)4 * hp;
+    }
+    const float *W1 = w, *b1 = W1 + hp * hp, *W2 = b1 + hp, *b2 = W2 + hp * hp, *W3 = b2 + hp, *b3 = W3 + 16 * hp;
+    const int col = wave * 16 + r;
+    float4 w1[KS], w2[KS], w3[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        w1[s] = *reinterpret_cast<const float4 *>(W1 + ((size_t)(wave * KS + s) * 64 + lane) * 4);
+        w2[s] = *reinterpret_cast<const float4 *>(W2 + ((size_t)(wave * KS + s) * 64 + lane) * 4);
+        w3[s] = *reinterpret_cast<const float4 *>(W3 + ((size_t)s * 64 + lane) * 4);
+    }
+    const float c1 = b1[col], c2 = b2[col], c3 = b3[r];
+    auto layer = [&](const float *in, float *out, const float4 (&wf)[KS], float bias) {
+#pragma unroll
+        for (int rt = 0; rt < CR_MLP_ROWS / 16; ++rt) {
+            const float *arow = in + (16 * rt + r) * CR_LD + 4 * g;
+            pf32x4 acc = {bias, bias, bias, bias};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const float4 a4 = *reinterpret_cast<const float4 *>(arow + 16 * s);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, wf[s].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, wf[s].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, wf[s].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wf[s].w, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) out[(16 * rt + 4 * g + i) * CR_LD + col] = acc[i] < 0.0f ? 0.0f : acc[i];
+        }
+    };
+    const int nchunks = (P.n + CR_MLP_ROWS - 1) / CR_MLP_ROWS;
+    for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const size_t row0 = (size_t)c * CR_MLP_ROWS;
+        for (int e = tid; e < CR_MLP_ROWS * (hp / 4); e += 64 * POL_NW) {  // 64 rows x 32 float4
+            const int row = e >> 5, k4 = e & 31;
+            const float4 v = (row0 + row < (size_t)P.n) ? *reinterpret_cast<const float4 *>(P.hT + (row0 + row) * hp + 4 * k4) : float4{0.0f, 0.0f, 0.0f, 0.0f};
+            *reinterpret_cast<float4 *>(xb + row * CR_LD + 4 * k4) = v;
+        }
+        __syncthreads();
+        layer(xb, yb, w1, c1);
+        __syncthreads();
+        layer(yb, xb, w2, c2);
+        __syncthreads();
+        if (wave < CR_MLP_ROWS / 16) {  // the 128 -> 1 head (padded to a 16-column tile): wavefront w takes row tile w
+            const float *arow = xb + (16 * wave + r) * CR_LD + 4 * g;
+            pf32x4 acc = {c3, c3, c3, c3};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const float4 a4 = *reinterpret_cast<const float4 *>(arow + 16 * s);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, w3[s].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, w3[s].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, w3[s].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, w3[s].w, acc, 0, 0, 0);
+            }
+            if (r == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const size_t row = row0 + 16 * wave + 4 * g + i;
+                    if (row < (size_t)P.n) {
+                        if (row < (size_t)P.value_split) P.value[row] = acc[i];
+                        else P.value_tail[row - (size_t)P.value_split] = acc[i];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
 }
 
 }  // namespace taco

@@ -130,6 +130,7 @@ class ActorCritic:
         self.seed = int(seed)
         self.calls = 0  # Philox counter of the action noise: (seed, env index, call number)
         self.reuse_outputs = False  # True: act() returns the same five tensors every call (no allocations on the hot loop)
+        self.stamps = None          # profiling: a [16] int64 device tensor that workgroup 0 of every act() launch fills with shader-clock stamps
         self._out = None
         n = self.lib.taco_policy_blob_floats(C.byref(self.cfg))
         if n == 0:
@@ -164,9 +165,10 @@ class ActorCritic:
             logp, value = torch.empty(n, device=dev), torch.empty(n, 1, device=dev)
             self._out = (action, logp, value, mu, sigma)
         s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        _lib.check(self.lib.taco_policy_act(C.byref(self.cfg), self._blob.data_ptr(), n, obs.data_ptr(), st.data_ptr() if st is not None else None,
-                                            C.c_uint64(self.seed), C.c_uint32(self.calls), 1 if deterministic else 0, 1 if action_only else 0,
-                                            action.data_ptr(), logp.data_ptr(), value.data_ptr(), mu.data_ptr(), sigma.data_ptr(), s))
+        _lib.check(self.lib.taco_policy_act_stamped(C.byref(self.cfg), self._blob.data_ptr(), n, obs.data_ptr(), st.data_ptr() if st is not None else None,
+                                                    C.c_uint64(self.seed), C.c_uint32(self.calls), 1 if deterministic else 0, 1 if action_only else 0,
+                                                    action.data_ptr(), logp.data_ptr(), value.data_ptr(), mu.data_ptr(), sigma.data_ptr(),
+                                                    self.stamps.data_ptr() if self.stamps is not None else None, s))
         self.calls += 1
         return action, logp, value, mu, sigma
 
@@ -176,6 +178,30 @@ class ActorCritic:
         if action_only:
             return action
         return action, logp, value, mu, sigma
+
+    def values(self, critic_input, stamps=None):
+        """The critic alone (nets_asymmetry.py:348-352) over any number of state stacks [..., states_len, states_dim] -> [..., 1], one
+        launch (taco_critic_values): bit-identical to act()'s `value` on the same stacks."""
+        lead = critic_input.shape[:-2]
+        st = critic_input
+        if st.dtype != torch.float32 or not st.is_contiguous() or st.device != self.device:
+            st = st.to(device=self.device, dtype=torch.float32).contiguous()
+        if tuple(st.shape[-2:]) != (self.cfg.states_len, self.cfg.states_dim):
+            raise ValueError(f"input of shape {tuple(st.shape)} does not match the critic ({self.cfg.states_len} x {self.cfg.states_dim} per row)")
+        rows = st.numel() // (self.cfg.states_len * self.cfg.states_dim)
+        out = torch.empty(rows, device=self.device)
+        ws = self.critic_workspace(rows)
+        s = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(self.lib.taco_critic_values(C.byref(self.cfg), self._blob.data_ptr(), rows, st.data_ptr(), out.data_ptr(), ws.data_ptr(),
+                                               stamps.data_ptr() if stamps is not None else None, s))
+        return out.view(*lead, 1)
+
+    def critic_workspace(self, rows):
+        """the batched critic's workspace for `rows` state stacks (kept and reused while it is large enough)"""
+        need = int(self.lib.taco_critic_workspace_bytes(C.byref(self.cfg), rows))
+        if getattr(self, "_critic_ws", None) is None or self._critic_ws.numel() < need:
+            self._critic_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._critic_ws
 
     def forward(self, actor_input):
         """nets_asymmetry.py:380-387: the action mean (what the TorchScript export traces)."""

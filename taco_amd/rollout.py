@@ -116,8 +116,8 @@ class RolloutBuffer:
 
     def run(self, env, policy, act_low=-1.0, act_high=1.0):
         """The whole rollout of ppo_asymmetry.py:308-342 as ONE C call (taco_rollout_run): horizon x (policy.act on slot t, clipped
-        action -> env step writing slot t + 1) + the value of the final state + the time-out bootstrap, 2 H + 2 launches enqueued
-        back to back with no host work in between.  Fills every buffer `store` fills; returns last_values [N, 1] for
+        action -> env step writing slot t + 1), then the critic over all H + 1 slots in one batched pass (nothing before GAE reads a
+        value) + the time-out bootstrap: 2 H + 3 launches enqueued back to back with no host work in between.  Fills every buffer `store` fills; returns last_values [N, 1] for
         compute_returns_and_advantage.  Equivalent, bit for bit, to the act()/collect() loop (tests/test_rollout_gpu.py)."""
         if self.step != 0:
             raise AssertionError("run() fills a whole rollout: call reset() first")
@@ -130,11 +130,11 @@ class RolloutBuffer:
             self._act_env = torch.empty(N, self.act_dim, device=dev)
             self._timeouts = torch.zeros(H, N, dtype=torch.uint8, device=dev)
             self._last_value = torch.empty(N, 1, device=dev)
-            self._run_scratch = torch.empty(N, 13, device=dev)
+            self._run_scratch = True
         b = _lib.RolloutBufs(self._obs_store.data_ptr(), self._states_store.data_ptr(), self.act_buf.data_ptr(), self._act_env.data_ptr(),
                              self.rew_buf.data_ptr(), self.done_buf.data_ptr(), self.value_buf.data_ptr(), self.logp_buf.data_ptr(),
                              self.mu_buf.data_ptr(), self.sigma_buf.data_ptr(), self._timeouts.data_ptr(), self._last_value.data_ptr(),
-                             self._run_scratch.data_ptr())
+                             policy.critic_workspace((H + 1) * N).data_ptr())
         s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(self.lib.taco_rollout_run(env._h, C.byref(policy.cfg), policy._blob.data_ptr(), C.byref(b), H, C.c_uint64(policy.seed),
                                              C.c_uint32(policy.calls), float(self.gamma), float(act_low), float(act_high),

@@ -122,3 +122,58 @@ def test_torchscript_export_agrees_with_the_hip_forward(tmp_path):
     ts = torch.jit.load(str(tmp_path / "actor_1.pt"))
     obs = torch.from_numpy(g["obs"])
     np.testing.assert_allclose(pol.forward(obs.cuda()).cpu().numpy(), ts(obs).detach().numpy(), rtol=0, atol=1e-6)
+
+
+# ---- the batched critic (taco_critic_values): what takes the critic off the rollout's per-step chain
+@pytest.mark.parametrize("rows,states_len,lstm,critic_hidden", [
+    (1, 5, 128, [128, 128]), (31, 1, 128, [128, 128]), (33, 2, 128, [128, 128]), (4133, 5, 128, [128, 128]), (20000, 8, 128, [128, 128]),
+    (700, 5, 120, [128, 116]),      # ragged widths inside the batched form's padding
+    (300, 4, 64, [128, 128]),       # narrower LSTM: runs the policy kernel's critic role
+    (300, 3, 128, [64]),            # another MLP: likewise
+    (300, 2, 0, [256, 32]),         # no encoder
+])
+def test_batched_critic_equals_act_and_oracle_bitwise(rows, states_len, lstm, critic_hidden):
+    from oracle import oracle as O
+    from taco_amd import policy as P
+    rng = np.random.default_rng(rows + lstm)
+    sd = _random_policy(rng, 1, states_len, [32], lstm, critic_hidden)
+    pol = P.ActorCritic(sd, 1, states_len, seed=3)
+    st = rng.standard_normal((rows, states_len, 26)).astype(np.float32)
+    st[rows // 2] = 0.0                                   # an all-zero stack
+    st[0, 0, :3] = [1e4, -1e4, 0.0]
+    std = torch.from_numpy(st).cuda()
+    got = pol.values(std)
+    assert got.shape == (rows, 1)
+    ref = pol.act(torch.zeros(rows, 1, 26, device="cuda"), std, deterministic=True)[2]
+    assert_bits_equal(got.cpu().numpy(), ref.cpu().numpy(), "batched critic vs act()")
+    m = min(rows, 200)                                    # the CPU oracle on a slice (it takes seconds per thousand rows)
+    pick = np.unique(np.concatenate([np.arange(m // 2), rows - 1 - np.arange(m // 2), [rows // 2]]))
+    oc = O.policy_cfg(1, states_len, [32], lstm, critic_hidden)
+    exp = O.policy_act(oc, P.pack_state_dict(pol.cfg, sd), np.zeros((len(pick), 1, 26), np.float32), st[pick], deterministic=True)[2]
+    assert_bits_equal(got.cpu().numpy()[pick].reshape(exp.shape), exp, "batched critic vs oracle")
+    # leading dimensions are kept: [H, N, T, 26] -> [H, N, 1]
+    if rows % 3 == 0:
+        assert torch.equal(pol.values(std.view(3, rows // 3, states_len, 26)), got.view(3, rows // 3, 1))
+
+
+def test_batched_critic_first_timestep_shortcut_keeps_the_sign_of_zero():
+    """The batched LSTM skips the W_hh h_{-1} chain of the first timestep (h_{-1} = +0).  fma(+0, w, acc) changes acc only when acc is a
+    zero: -0 survives iff every weight of the column is negative.  Build exactly that: zero input rows, biases of -0.0, one gate column
+    all-negative, another mixed -- and compare with the kernel that runs the whole chain."""
+    from taco_amd import policy as P
+    rng = np.random.default_rng(5)
+    sd = _random_policy(rng, 1, 3, [32], 128, [128, 128])
+    whh = sd["critic_encoder.layers.weight_hh_l0"]
+    whh[7] = -np.abs(whh[7])                 # gate i, column 7: every weight negative
+    whh[128 + 9] = -np.abs(whh[128 + 9])     # gate f, column 9
+    whh[256 + 9, 5] = 0.0                    # gate g, column 9: a +0 among them (not "all negative")
+    sd["critic_encoder.layers.bias_ih_l0"][:] = 0.0
+    sd["critic_encoder.layers.bias_hh_l0"][:] = -0.0
+    sd["critic_encoder.layers.bias_ih_l0"][:] = -0.0
+    pol = P.ActorCritic(sd, 1, 3, seed=3)
+    st = rng.standard_normal((96, 3, 26)).astype(np.float32)
+    st[::2, 0] = 0.0                          # first frame zero: the x chain leaves the -0 bias in place
+    st[1::4, 0] = -0.0
+    std = torch.from_numpy(st).cuda()
+    ref = pol.act(torch.zeros(96, 1, 26, device="cuda"), std, deterministic=True)[2]
+    assert_bits_equal(pol.values(std).cpu().numpy(), ref.cpu().numpy(), "batched critic vs act(), zero-sign case")

@@ -106,15 +106,17 @@ def test_collect_refuses_what_it_cannot_do_exactly():
     assert len(buf.batch_idx_generator()) == 4 and sorted(sum(buf.batch_idx_generator(), [])) == list(range(64 * 4))
 
 
-@pytest.mark.parametrize("n,task,len_states", [(300, "pos", 5), (96, "mix", 3)])
-def test_rollout_run_equals_the_python_loop(n, task, len_states):
-    """taco_rollout_run (one C call, 2 H + 2 launches) == the act() / collect() / bootstrap loop of ppo_asymmetry.py:308-342, bit for bit."""
+@pytest.mark.parametrize("n,task,len_states,arch", [(300, "pos", 5, ([48, 32], 32, [40])), (96, "mix", 3, ([48, 32], 32, [40])),
+                                                     (333, "mix", 5, ([128, 128, 128], 128, [128, 128]))])   # the last: the batched critic's form
+def test_rollout_run_equals_the_python_loop(n, task, len_states, arch):
+    """taco_rollout_run (one C call: the actor + the env step per step, the critic batched over all H + 1 slots afterwards) == the act() /
+    collect() / bootstrap loop of ppo_asymmetry.py:308-342, bit for bit."""
     from taco_amd import policy as P
     from taco_amd.vec_env import FpvBase
     import test_policy_gpu as TP
     H = 12
     rng = np.random.default_rng(5)
-    sd = TP._random_policy(rng, 1, len_states, [48, 32], 32, [40])
+    sd = TP._random_policy(rng, 1, len_states, *arch)
     cfg = config.default_cfg(task, n, env_lenStates=len_states, env_maxEpisodeLength=7, seed=3)
     outs = []
     for mode in ("run", "loop"):

@@ -72,12 +72,12 @@ _, _, v_t, mu_t, _ = torch_act()
 flops = 2 * N * (26 * H + 2 * H * H + H * 4 + T * 4 * H * (26 + H) + 2 * H * H + H)
 t_actor = timed(lambda: pol.act(obs, None, action_only=True))
 st_ = torch.zeros(16, dtype=torch.int64, device=dev)
-pol.lib.taco_policy_bind_stamps(st_.data_ptr())
+pol.stamps = st_
 acc_ = torch.zeros(16, dtype=torch.float64)
 for _ in range(20):
     pol.act(obs, st)
     acc_ += st_.cpu().double()
-pol.lib.taco_policy_bind_stamps(None)
+pol.stamps = None
 acc_ /= 20
 phases = {"actor_stage": acc_[1] - acc_[0], "actor_mlp": acc_[2] - acc_[1], "actor_tail": acc_[3] - acc_[2],
           "critic_stage": acc_[9] - acc_[8], "critic_lstm": acc_[10] - acc_[9], "critic_mlp": acc_[11] - acc_[10], "critic_tail": acc_[12] - acc_[11]}
