@@ -235,9 +235,10 @@ def config_entry(idx, n, dev, torch, warm=0.1):
 
 
 def rollout_entry(n, horizon, dev, torch):
-    """config 5's 'LSTM-critic rollout' at its per-GPU shape: one taco_rollout_run call = horizon x (policy forward -> clipped action -> env
-    step writing the next replay slot) + final value + time-out bootstrap, then GAE.  Random-init weights of the documented architecture
-    (actor MLP 26-128-128-128-4, critic LSTM 26->128 over 5 frames + MLP 128-128-128-1)."""
+    """config 5's 'LSTM-critic rollout': one taco_rollout_run call = horizon x (actor forward -> clipped action -> env step writing the next
+    replay slot), then the critic over all horizon + 1 slots in one batched pass + time-out bootstrap, then GAE.  Random-init weights of the
+    documented architecture (actor MLP 26-128-128-128-4, critic LSTM 26->128 over 5 frames + MLP 128-128-128-1).  The critic is timed alone
+    as well (taco_critic_values over the same (horizon + 1) x n state stacks) and priced against the f32 MFMA peak."""
     import numpy as np
     from taco_amd import config, policy as P
     from taco_amd.rollout import RolloutBuffer
@@ -278,8 +279,26 @@ def rollout_entry(n, horizon, dev, torch):
         torch.cuda.synchronize()
         ts.append((time.perf_counter() - t0) / 4)
     ts.sort()
-    return {"config": 5, "what": "taco_rollout_run (policy forward + env step, replay store fused) + GAE", "envs": n, "horizon": horizon,
-            "len_states": env.len_states, "ms_per_rollout": ts[2] * 1e3, "env_steps_per_s": n * horizon / ts[2]}
+    rows, T, hd2 = (horizon + 1) * n, env.len_states, hd
+    st = buf._states_store.view(rows, T, 26)
+    for _ in range(3):
+        pol.values(st)
+    torch.cuda.synchronize()
+    cs = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(4):
+            pol.values(st)
+        e1.record()
+        torch.cuda.synchronize()
+        cs.append(e0.elapsed_time(e1) * 1e-3 / 4)
+    cs.sort()
+    flops = 2 * rows * (T * 4 * hd2 * (26 + hd2) + 2 * hd2 * hd2 + hd2)
+    return {"config": 5, "what": "taco_rollout_run (actor forward + env step per step, replay store fused; critic batched over all slots afterwards) + GAE",
+            "envs": n, "horizon": horizon, "len_states": T, "ms_per_rollout": ts[2] * 1e3, "env_steps_per_s": n * horizon / ts[2],
+            "critic": {"rows": rows, "ms": cs[2] * 1e3, "tflops": flops / cs[2] / 1e12, "frac_of_f32_mfma_peak": flops / cs[2] / 157.3e12,
+                       "note": "model flops 2 rows (T 4 H (26 + H) + 2 H H + H) over the LSTM + MLP kernels' time; peak 157.3 TFLOP/s (MI355X_MICROARCH.md)"}}
 
 
 def main():
@@ -458,6 +477,7 @@ def main():
                 out["configs"] = [config_entry(2, 16384, dev, torch), config_entry(3, 16384, dev, torch), config_entry(4, 32768, dev, torch)]
                 try:
                     out["configs"].append(rollout_entry(32768, 16, dev, torch))
+                    out["configs"].append(dict(rollout_entry(4096, 32, dev, torch), config="5 at 4096 envs x 32 steps"))
                 except Exception as e:  # noqa: BLE001
                     out["configs"].append({"config": 5, "error": repr(e)[:300]})
                 torch.cuda.empty_cache()

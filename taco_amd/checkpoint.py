@@ -2,8 +2,10 @@
 
 The reference never checkpoints environment state (ppo_asymmetry.py:452-456 saves the agent only).  Here the whole
 simulation state is one blob (taco_get_state) + the step counter that keys the random streams + the caller-owned
-buffers, so a run can be resumed bit-exactly -- also on a different number of GPUs, because everything is keyed by
-global env id."""
+buffers, so a run can be resumed bit-exactly -- also on a different number of GPUs: every per-env word is a column of the blob
+and every random stream is keyed by the GLOBAL env id, so a checkpoint that covers an env's [env_offset, env_offset + num_envs)
+range restores it whatever the sharding was when it was written (load_state_dict slices; merge() joins the shards of a
+multi-rank run into one checkpoint).  tests/test_api_gpu.py::test_checkpoint_restores_across_shardings."""
 import torch
 
 from . import _lib
@@ -20,18 +22,51 @@ def state_dict(env):
     }
 
 
+_PER_ENV = ("obs_buf", "states_buf", "rew_buf", "reset_buf", "timeout_buf")
+
+
+def merge(state_dicts):
+    """the shards of one multi-rank run (same step, adjoining env ranges) -> one checkpoint covering their union"""
+    sds = sorted(state_dicts, key=lambda d: d["flat_cfg"]["env_offset"])
+    first = sds[0]
+    at = first["flat_cfg"]["env_offset"]
+    for d in sds:
+        for k in ("format", "abi", "step_count", "difficulty"):
+            if d[k] != first[k]:
+                raise ValueError(f"shards differ in {k}: {d[k]!r} vs {first[k]!r}")
+        for k in ("num_envs_global", "task_mode", "len_obs", "len_states", "seed"):
+            if d["flat_cfg"][k] != first["flat_cfg"][k]:
+                raise ValueError(f"shards differ in {k}")
+        if d["flat_cfg"]["env_offset"] != at:
+            raise ValueError(f"shards do not adjoin: expected a shard starting at env {at}, got {d['flat_cfg']['env_offset']}")
+        at += d["flat_cfg"]["num_envs"]
+    out = dict(first)
+    out["flat_cfg"] = dict(first["flat_cfg"], num_envs=at - first["flat_cfg"]["env_offset"])
+    out["blob"] = torch.cat([d["blob"] for d in sds], dim=1)
+    for name in _PER_ENV:
+        out[name] = torch.cat([d[name] for d in sds], dim=0)
+    return out
+
+
 def load_state_dict(env, sd, strict=True):
+    """Restore `env` from a checkpoint that covers its env range (the same range, or a larger one: the env's columns are sliced out).
+    strict=False skips the check that the run's identity (task, stack lengths, seed, global env count) is the same."""
     if sd.get("format") != FORMAT:
         raise ValueError(f"unknown checkpoint format {sd.get('format')}")
     if strict:
-        for k in ("num_envs", "env_offset", "num_envs_global", "task_mode", "len_obs", "len_states", "seed"):
+        for k in ("num_envs_global", "task_mode", "len_obs", "len_states", "seed"):
             if sd["flat_cfg"][k] != env._flat[k]:
                 raise ValueError(f"checkpoint was taken with {k}={sd['flat_cfg'][k]!r}, this env has {env._flat[k]!r}")
+    lo = env._flat["env_offset"] - sd["flat_cfg"]["env_offset"]
+    n = env._flat["num_envs"]
+    if lo < 0 or lo + n > sd["flat_cfg"]["num_envs"]:
+        raise ValueError(f"checkpoint covers envs [{sd['flat_cfg']['env_offset']}, {sd['flat_cfg']['env_offset'] + sd['flat_cfg']['num_envs']}), this env needs "
+                         f"[{env._flat['env_offset']}, {env._flat['env_offset'] + n}): merge() the shards first")
     env.difficulty = sd["difficulty"]
     env.step_count = sd["step_count"]
-    env.set_state(sd["blob"])
-    for name in ("obs_buf", "states_buf", "rew_buf", "reset_buf", "timeout_buf"):
-        getattr(env, name).copy_(sd[name].to(env.device))
+    env.set_state(sd["blob"][:, lo:lo + n].contiguous())
+    for name in _PER_ENV:
+        getattr(env, name).copy_(sd[name][lo:lo + n].to(env.device))
 
 
 def save(env, path):

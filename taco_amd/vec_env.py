@@ -230,7 +230,9 @@ class FpvBase:
 
     def set_state(self, blob):
         blob = blob.to(device=self.device).contiguous()
-        assert blob.shape == (_lib.BLOB_ROWS, self.num_envs) and blob.element_size() == 4
+        if tuple(blob.shape) != (_lib.BLOB_ROWS, self.num_envs) or blob.element_size() != 4:
+            raise ValueError(f"state blob of shape {tuple(blob.shape)} ({blob.dtype}) does not fit this env: expected ({_lib.BLOB_ROWS}, {self.num_envs}) 32-bit "
+                             "words -- a blob holds one fixed set of envs (num_envs, len_obs and len_states are part of its layout)")
         _lib.check(self.lib.taco_set_state(self._h, blob.data_ptr(), _stream_ptr(self.device).value))
 
     @property

@@ -175,6 +175,42 @@ def test_checkpoint_file_roundtrip_and_recorder(tmp_path):
     assert pos.ndim == 2 and pos.shape[1] == 3
 
 
+def test_checkpoint_restores_across_shardings():
+    """A checkpoint of one 600-env run restores two shards of it (250 + 350 envs, as two ranks would hold them), and the two shards'
+    checkpoints merge()d restore a 600-env run again -- everything continues bit-identically (every per-env word is a blob column and
+    every random stream is keyed by the global env id)."""
+    from taco_amd import checkpoint
+    from taco_amd.vec_env import FpvBase
+    cfg = config.default_cfg("mix", 600, observation_noise=True, rotor_noise=True, ramdom_deploy_time=True, env_lenStates=3, env_maxEpisodeLength=45, seed=5)
+    whole = FpvBase(cfg, copy_outputs=False)
+    acts = (0.3 * torch.randn(90, 600, 4, device="cuda") + torch.tensor([-0.45, 0, 0, 0], device="cuda")).clamp(-1, 1)
+    for t in range(30):
+        whole.step_raw(acts[t])
+    sd = checkpoint.state_dict(whole)
+    parts = [FpvBase(cfg, copy_outputs=False, env_offset=lo, num_envs_local=n) for lo, n in ((0, 250), (250, 350))]
+    for p in parts:
+        checkpoint.load_state_dict(p, sd)
+    for t in range(30, 60):
+        whole.step_raw(acts[t])
+        for p, (lo, n) in zip(parts, ((0, 250), (250, 350))):
+            p.step_raw(acts[t, lo:lo + n].contiguous())
+            assert torch.equal(p.obs_buf.view(torch.int32), whole.obs_buf[lo:lo + n].view(torch.int32)), (t, lo)
+            assert torch.equal(p.rew_buf.view(torch.int32), whole.rew_buf[lo:lo + n].view(torch.int32)) and torch.equal(p.reset_buf, whole.reset_buf[lo:lo + n])
+    merged = checkpoint.merge([checkpoint.state_dict(parts[1]), checkpoint.state_dict(parts[0])])
+    again = FpvBase(cfg, copy_outputs=False)
+    checkpoint.load_state_dict(again, merged)
+    for t in range(60, 90):
+        whole.step_raw(acts[t]); again.step_raw(acts[t])
+    assert torch.equal(again.get_state().view(torch.int32), whole.get_state().view(torch.int32))
+    assert torch.equal(again.obs_buf.view(torch.int32), whole.obs_buf.view(torch.int32)) and whole.reset_buf.sum() >= 0
+    with pytest.raises(ValueError, match="merge"):
+        checkpoint.load_state_dict(again, checkpoint.state_dict(parts[0]))     # one shard does not cover the whole run
+    with pytest.raises(ValueError, match="adjoin"):
+        checkpoint.merge([checkpoint.state_dict(parts[1])] * 2)
+    with pytest.raises(ValueError, match="does not fit"):
+        again.set_state(torch.zeros(3, 600))
+
+
 def test_c_abi_consumer_without_torch():
     """examples/c_api_demo.cpp (plain HIP runtime + include/taco_env.h, built by __graft_entry__.build()) steps the env
     through the C ABI alone and checks the error path; it exits 0 when its own checks pass."""
@@ -324,3 +360,41 @@ def test_bench_launches_its_own_ranks():
     assert "error" not in w and w["value"] > 0 and w["overlapped"]["value"] > 0 and w["bytes_per_rank"] == 4096 * 32 * 4
     s = d["strong_scaling"]
     assert "error" not in s and s["envs_total"] == 4096 and s["envs_per_rank"] == 2048 and s["value"] > 0
+
+
+def test_yaml_launcher_equals_the_python_built_config(tmp_path):
+    """SURVEY 8f row N4 end to end: a YAML in the reference's layout + CLI overrides -> examples/run_env.py (the launcher's call sequence,
+    train_fpv_asymmetry_ppo.py:363-371) -> 50 steps, against the same configuration built in Python and stepped in this process:
+    the last step's tensors and the env's whole raw state, bit for bit."""
+    import subprocess
+    import sys
+    from taco_amd import cfg_io, config
+    from taco_amd.vec_env import isaacgym_task_map
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    yml = cfg_io.write_default_yaml(str(tmp_path / "Fpv_asymmetry_PPO_mix.yaml"), "mix", delay_time=30)
+    dump = str(tmp_path / "out.npz")
+    cli = ["--task_mode=mix", "--num_envs=777", "--lenStates=3", "--rotor_noise=True", "--observation_noise=True", "--ramdom_deploy_time=True",
+           "--rotor_response_time=0.018", "--seed=11"]
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "run_env.py"), "--cfg", yml, "--steps", "50", "--dump", dump] + cli,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.load(dump)
+    # the same configuration, built in Python
+    cfg = config.default_cfg("mix", 777, delay_time=30, rotor_noise=True, observation_noise=True, ramdom_deploy_time=True, rotor_response_time=0.018, seed=11,
+                             env_lenStates=3)
+    ap = cfg_io.add_env_arguments(__import__("argparse").ArgumentParser())
+    task = cfg_io.apply_overrides({"Task": cfg}, ap.parse_args(["--task_mode=mix"]))
+    env = isaacgym_task_map[task["name"]](task, "cuda:0", "cuda:0", -1, True, False, False)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    W = 0.3 * torch.randn(env.len_obs * env.num_obs, env.num_acts, device="cuda", generator=g)
+    b = torch.tensor([-0.3, 0.0, 0.0, 0.0], device="cuda")
+    obs = env.reset()["obs"]
+    for _ in range(50):
+        act = torch.tanh(obs.reshape(env.num_envs, -1).nan_to_num() @ W + b)
+        od, rew, done, info = env.step(torch.clip(act, -1, 1))
+        obs = od["obs"]
+    assert_bits_equal(obs.cpu().numpy(), got["obs"], "obs")
+    assert_bits_equal(od["states"].cpu().numpy(), got["states"], "states")
+    assert_bits_equal(rew.cpu().numpy(), got["rew"], "rew")
+    assert np.array_equal(done.cpu().numpy(), got["done"])
+    assert np.array_equal(env.get_state().view(torch.int32).cpu().numpy(), got["state"].view(np.int32))

@@ -3,6 +3,8 @@ inputs.  Bar: every state word, observation, reward and flag BIT-EXACT after eve
 implement the same IEEE-754 operation sequence; see DESIGN.md "arithmetic contract").  The north-star tolerance
 (trajectory L-inf <= 1e-5 over 1 000 steps, integer flags exact) is asserted as well, as the weaker documented bar.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -232,6 +234,25 @@ def test_random_configurations():
             run_pair(cfg, steps, seed=i, check_every=1 if steps > 8 else 2, hover_bias=bool(i & 1))
         except AssertionError as e:
             raise AssertionError(f"case {i}: {fuzz.describe(cfg)}: {e}") from e
+
+
+@pytest.mark.slow
+@pytest.mark.skipif(not os.environ.get("TACO_FUZZ_CASES"), reason="opt-in: TACO_FUZZ_CASES=1500 python -m pytest tests -m gpu -k full_fuzz (about 25 min)")
+def test_full_fuzz_run():
+    """The whole generator of tools/fuzz.py (the run recorded in profiles/README.md), as a test: TACO_FUZZ_CASES cases from TACO_FUZZ_SEED (0)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz
+    cases, seed = int(os.environ["TACO_FUZZ_CASES"]), int(os.environ.get("TACO_FUZZ_SEED", "0"))
+    rng = np.random.default_rng(seed)
+    for i in range(cases):
+        cfg, steps = fuzz.draw_case(rng)
+        try:
+            run_pair(cfg, steps, seed=i, check_every=1 if steps > 8 else 2, hover_bias=bool(i & 1))
+        except AssertionError as e:
+            raise AssertionError(f"seed {seed} case {i}: {fuzz.describe(cfg)}: {e}") from e
+        if i % 50 == 49:
+            print(f"fuzz: {i + 1} / {cases} cases clean", flush=True)
 
 
 @pytest.mark.parametrize("form", ["auto", "quad", "lane", "lane_throughput", "lane_roles"])
