@@ -234,6 +234,38 @@ def config_entry(idx, n, dev, torch, warm=0.1):
             "frac_of_hbm_peak": b * n / (med * 1e-6) / 1e9 / HBM_PEAK_GBPS, "kernel_form": env.kernel_form, "grid": grid, "block": block}
 
 
+def graph_entry(n, acts, dev, torch, steps_in_graph=64):
+    """the same workload as ONE HIP graph of `steps_in_graph` steps (each step = the step kernel reading the device-resident clock + the
+    one-thread clock advance), replayed back to back: what the per-step kernel boundary costs when the host is out of the loop"""
+    from taco_amd import config
+    from taco_amd.vec_env import FpvBase
+    env = FpvBase(config.baseline_config(1, num_envs=n), sim_device=str(dev), rl_device=str(dev), copy_outputs=False)
+    for t in range(8):
+        env.step_raw(acts[t % acts.shape[0]])
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for t in range(steps_in_graph):
+            env.step_raw(acts[t % acts.shape[0]])
+    t_end = time.perf_counter() + 0.05
+    while time.perf_counter() < t_end:
+        g.replay()
+    torch.cuda.synchronize()
+    ws = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        ws.append(e0.elapsed_time(e1) * 1e3 / (20 * steps_in_graph))
+    ws.sort()
+    env.check()
+    return {"steps_per_graph": steps_in_graph, "us_per_step": ws[2], "env_steps_per_s": n / (ws[2] * 1e-6), "windows_us": ws,
+            "what": "taco_step captured into a HIP graph (2 kernel nodes per step: step + clock advance), 20 replays per window"}
+
+
 def rollout_entry(n, horizon, dev, torch):
     """config 5's 'LSTM-critic rollout': one taco_rollout_run call = horizon x (actor forward -> clipped action -> env step writing the next
     replay slot), then the critic over all horizon + 1 slots in one batched pass + time-out bootstrap, then GAE.  Random-init weights of the
@@ -472,6 +504,10 @@ def main():
             out["step_api"] = {"us_per_step": amed, "env_steps_per_s": n_local / (amed * 1e-6),
                                "what": "VecTask.step(): the same launch also writes the clamped obs / states copies it returns (no torch op, no allocation)"}
             del aenv
+            try:
+                out["graph_replay"] = graph_entry(n_local, acts, dev, torch)
+            except Exception as e:  # noqa: BLE001
+                out["graph_replay"] = {"error": repr(e)[:300]}
             if not args.no_configs:
                 # SURVEY 8(d)'s numbering: 3 = rotate @ 16 384, 4 = flip @ 16 384 per rank, 5 = mix @ 32 768 per rank with every flag + 5 state frames
                 out["configs"] = [config_entry(2, 16384, dev, torch), config_entry(3, 16384, dev, torch), config_entry(4, 32768, dev, torch)]
