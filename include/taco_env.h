@@ -180,6 +180,12 @@ typedef struct taco_rollout_io {
 } taco_rollout_io;
 int taco_step_rollout(taco_env *env, const taco_rollout_io *io, void *stream);
 
+/* VecTask.reset_done (vec_task_asymmetry.py:363-375): reset_idx on the envs whose reset_buf is set, NOW, outside a step -- fresh state and
+ * command, reset_buf / progress_buf cleared (fpv_asymmetry.py:475-517); like the reference's, it also re-draws the command of envs at
+ * progress 500 (:500-503).  The step clock does not advance.  The next taco_step then steps those envs WITH thrust (it sees no reset flag),
+ * exactly as the reference does after reset_done(); observations are not recomputed (the reference returns the buffers as they are). */
+int taco_reset_done(taco_env *env, int64_t *reset_buf, void *stream);
+
 /* PPOReplayBuffer.compute_returns_and_advantage (buffer_asymmetry.py:93-132) on DEVICE arrays laid out [horizon][num_envs]
  * (the reference's [H, N, 1]):  adv = GAE(gamma, lam), ret = adv + value, then (normalize != 0)
  * adv = (adv - mean(adv)) / (std(adv) + 1e-8) with the unbiased std.  ret and the un-normalised adv are bit-identical

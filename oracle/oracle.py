@@ -59,6 +59,8 @@ def lib():
         _lib.orc_set_difficulty.argtypes = [C.c_void_p, C.c_double]
         _lib.orc_set_threads.argtypes = [C.c_void_p, C.c_int]
         _lib.orc_set_world_rate_roundtrip.argtypes = [C.c_void_p, C.c_int]
+        _lib.orc_reset_done.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.orc_reset_done.restype = C.c_int
         _lib.orc_step.argtypes = [C.c_void_p] + [C.c_void_p] * 6
         _lib.orc_step.restype = C.c_int
         _lib.orc_get_state.argtypes = [C.c_void_p, C.c_void_p]
@@ -151,6 +153,12 @@ class OracleEnv:
         assert a.shape == (self.n, 4)
         lib().orc_step(self._h, _p(a), _p(self.obs_buf), _p(self.states_buf), _p(self.rew_buf), _p(self.reset_buf), _p(self.timeout_buf))
         return self.obs_buf, self.states_buf, self.rew_buf, self.reset_buf, self.timeout_buf
+
+    def reset_done(self):
+        """VecTask.reset_done (VT:363-375): the flagged envs are reset now; returns their ids"""
+        ids = np.nonzero(self.reset_buf)[0]
+        lib().orc_reset_done(self._h, _p(self.reset_buf))
+        return ids
 
     def get_state(self):
         blob = np.zeros((BLOB_ROWS, self.n), np.uint32)

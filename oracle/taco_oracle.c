@@ -923,6 +923,25 @@ static void step_env(const orc_env *e, int i, const float *actions, float *obs_b
     timeout_buf[i] = (uint8_t)((s->progress >= c->max_episode_length - 1) && (rs != 0)); /* VT:323 */
 }
 
+/* VecTask.reset_done (VT:363-375): reset_idx(done ids) outside a step -- the first lines of step_env's pre-physics part, on their own:
+ * FA:475-517 incl. reset_command_condition's progress == 500 envs (:500-503); reset_buf / progress_buf cleared (:510-511); the step
+ * counter does not move (the draws are keyed by the index of the step that follows). */
+int orc_reset_done(orc_env *e, int64_t *reset_buf) {
+    const orc_cfg *c = &e->cfg;
+    for (int i = 0; i < c->num_envs; ++i) {
+        env_state *s = &e->s[i];
+        const int gid = c->env_offset + i;
+        const int grp = task_group(e, gid);
+        draw_ctx D = {c->seed, (uint32_t)gid, (uint32_t)e->step_count, 0, 0, {0, 0, 0, 0}, 0};
+        const int is_reset = reset_buf[i] != 0;
+        const int at_time = s->progress == 500;
+        if (is_reset) reset_env(e, s, grp, &D);
+        if (is_reset || at_time) reset_command(e, s, grp, is_reset, at_time, &D);
+        if (is_reset) { reset_buf[i] = 0; s->progress = 0; }
+    }
+    return 0;
+}
+
 int orc_step(orc_env *e, const float *actions, float *obs_buf, float *states_buf, float *rew_buf, int64_t *reset_buf,
              uint8_t *timeout_buf) {
     const int n = e->cfg.num_envs;

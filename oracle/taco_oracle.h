@@ -99,6 +99,7 @@ void orc_set_world_rate_roundtrip(orc_env *e, int on); /* 1: body rates go throu
 /* One VecTask.step() (vec_task_asymmetry.py:290-334).  obs/states are the PERSISTENT frame stacks
  * [num_envs][len][26] (shifted in place, newest frame last, unclamped -- the caller clamps like the reference's
  * torch.clamp at :331-332); reset_buf is int64 in/out (ones before the first step, :246-247). */
+int orc_reset_done(orc_env *e, int64_t *reset_buf);   /* VecTask.reset_done, VT:363-375 */
 int orc_step(orc_env *e, const float *actions, float *obs_buf, float *states_buf, float *rew_buf, int64_t *reset_buf,
              uint8_t *timeout_buf);
 void orc_get_state(const orc_env *e, uint32_t *blob);

@@ -211,7 +211,8 @@ __global__ void export_state_kernel(const float *S, const float *hist, const flo
     if (row == TACO_S_DELAY_LEN) {
         val = __builtin_bit_cast(float, L);
     } else if (row >= TACO_S_ACT && row < TACO_S_ACT + 4) {            // actions = the action of the last step
-        val = hist[taco::tile_word(taco::HIST_ROWS, (hh - 1) & (taco::HIST_ROWS - 1), i) + (row - TACO_S_ACT)];
+        // (0 while no step has run since the env's reset: only taco_reset_done leaves an env there, FA:572)
+        val = taco::pw_progress(pw) == 0 ? 0.0f : hist[taco::tile_word(taco::HIST_ROWS, (hh - 1) & (taco::HIST_ROWS - 1), i) + (row - TACO_S_ACT)];
     } else if (row >= TACO_S_ACT_OLD && row < TACO_S_ACT_OLD + 4) {    // actions_old = the one before, 0 right after a reset (FA:572-573)
         const int progress = taco::pw_progress(pw);
         val = (progress <= 1) ? 0.0f : hist[taco::tile_word(taco::HIST_ROWS, (hh - 2) & (taco::HIST_ROWS - 1), i) + (row - TACO_S_ACT_OLD)];
@@ -427,6 +428,25 @@ int taco_step(taco_env *e, const float *actions, float *obs_buf, float *states_b
     io.actions = actions; io.obs_next = obs_buf; io.states_next = states_buf; io.rew = rew_buf;
     io.reset_buf = reset_buf; io.timeout_buf = timeout_buf;
     return launch_step(e, &io, stream);
+}
+
+int taco_reset_done(taco_env *e, int64_t *reset_buf, void *stream) {
+    if (!e) return fail(TACO_ERR_INVALID_ARG, "env is null");
+    if (!reset_buf) return fail(TACO_ERR_INVALID_ARG, "taco_reset_done: reset_buf is null");
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (stream != nullptr && hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) e->clock_on_device = 1;
+    taco::StepParams P = e->P;
+    P.S = e->S; P.ring = e->ring; P.hist = e->hist;
+    P.reset = (long long *)reset_buf;
+    P.ctl = e->ctl; P.use_ctl = e->clock_on_device;
+    P.step = (uint32_t)e->step_count; P.head = e->head; P.hh = e->hh;   // the clock of the NEXT step: it does not advance here
+    P.stamps = nullptr;
+    void *args[] = {&P};
+    const void *fn = (const void *)taco::taco_step_kernel<64, 1, false, false, false, true>;
+    hipError_t he = hipLaunchKernel(fn, dim3((unsigned)((e->cfg.num_envs + 63) / 64)), dim3(64), args, 0, (hipStream_t)stream);
+    if (he == hipSuccess) he = hipGetLastError();
+    if (he != hipSuccess) return hip_fail(he, "taco_reset_done launch");
+    return TACO_OK;
 }
 
 int taco_step_rollout(taco_env *e, const taco_rollout_io *io, void *stream) {

@@ -634,8 +634,11 @@ constexpr int CARRY_WORDS = 32;  // 30 used
 // OUT: the instantiation that also writes the clamped copies VecTask.step returns (obs_out / states_out).  A template parameter, not a
 // run-time switch: the copy code sits in the role wavefronts' post-phase, the critical path of the 4 096-env launch, where its mere
 // presence cost 0.75 us of 13.8 (SGPR spills, skipped branches) -- profiles/r02_d_ab_out_copy_paths.txt.
-template <int BLOCK, int LPE, bool SPLIT = false, bool CAP = false, bool OUT = false>
+// RESET_ONLY (<64, 1> only; taco_reset_done = VecTask.reset_done, VT:363-375): the kernel stops after reset_idx / reset_command_idx, stores what
+// they changed, clears the flags of the envs it reset and returns -- no action is pushed, no substep runs, the clock does not advance.
+template <int BLOCK, int LPE, bool SPLIT = false, bool CAP = false, bool OUT = false, bool RESET_ONLY = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT || CAP) ? 4 : 1, CAP ? 4 : 8))) void taco_step_kernel(const StepParams P) {
+    static_assert(!RESET_ONLY || (BLOCK == 64 && LPE == 1 && !SPLIT && !CAP && !OUT), "RESET_ONLY exists in the plain one-lane form only");
     static_assert(!SPLIT || BLOCK == 256, "SPLIT is the four-role form: one step wavefront + three role wavefronts per workgroup");
     static_assert(!CAP || (BLOCK == 64 && LPE == 1 && !SPLIT), "CAP is the one-wavefront-per-workgroup throughput form");
     // Per-wavefront LDS scratch, used for two things one after the other:
@@ -652,7 +655,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
     const uint32_t c_step = ctl_c[kCtlStep], c_head = ctl_c[kCtlHead], c_hh = ctl_c[kCtlHh];
     const bool from_ctl = P.use_ctl != 0;
     const struct { uint32_t step; int head, hh; } clk{from_ctl ? c_step : P.step, from_ctl ? (int)c_head : P.head, from_ctl ? (int)c_hh : P.hh};
-    if (!from_ctl && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (!RESET_ONLY && !from_ctl && blockIdx.x == 0 && threadIdx.x == 0) {
         P.ctl[kCtlStep] = P.step + 1u; P.ctl[kCtlHead] = (uint32_t)((P.head + 10) % TACO_RING_SLOTS); P.ctl[kCtlHh] = (uint32_t)((P.hh + 1) % HIST_ROWS);
     }
     constexpr int EPW = 64 / LPE;  // envs per wavefront
@@ -779,7 +782,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
     // Every load the step needs is issued up front, before the reset flag is known: the flag, the action, the 13 state
     // chunks and the 10 ring slots of this step are independent, so they share ONE memory round trip.
     const bool is_reset = P.reset[i] != 0;
-    const float4 a_in = reinterpret_cast<const float4 *>(P.act_in)[i];
+    const float4 a_in = RESET_ONLY ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : reinterpret_cast<const float4 *>(P.act_in)[i];
     float4 c_pos = CLD(C_POS), c_quat = CLD(C_QUAT), c_lin = CLD(C_LINVEL), c_ang = CLD(C_ANGVEL);
     float4 c_pp = CLD(C_PID_PREV), c_pi = CLD(C_PID_INT), c_om = CLD(C_OMEGA), c_misc = CLD(C_MISC);
     // rotor / aero parameters: per env only if something randomises them (launch-uniform switch, see kUniformParams)
@@ -880,6 +883,20 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
                 cmd0 = -1.0f;
             }
         }
+    }
+    if constexpr (RESET_ONLY) {
+        // reset_done (VT:363-375) = reset_idx on the flagged envs, outside a step: the fresh state (reset_env above) and the command go to
+        // the env's chunks, reset_buf / progress_buf are cleared (FA:510-511); reset_command_condition's progress == 500 envs get their
+        // command re-drawn as well (FA:500-503) -- and again, with the same draw, in the next step, whose pre_physics_step calls reset_idx too
+        if (active && (is_reset || at_time)) {
+            if (is_reset) {
+                CST(C_POS, c_pos); CST(C_QUAT, c_quat); CST(C_LINVEL, c_lin); CST(C_ANGVEL, c_ang);
+                CST(C_PID_PREV, c_pp); CST(C_PID_INT, c_pi); CST(C_OMEGA, c_om);
+                P.reset[i] = 0;
+            }
+            CST(C_MISC, make_float4(bat_t, cmd0, cmd1, flip_radian));
+        }
+        return;
     }
     act[0] = clampf(a_in.x, -P.clip_act, P.clip_act);  // VT:304; actions_old <- actions <- a (FA:321-322) is implicit in hist
     act[1] = clampf(a_in.y, -P.clip_act, P.clip_act);

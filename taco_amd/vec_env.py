@@ -215,8 +215,10 @@ class FpvBase:
         self.reset_buf[env_ids] = 1
 
     def reset_done(self):
-        """vec_task_asymmetry.py:363-375 (reset itself is deferred to the next step, see reset_idx)."""
+        """vec_task_asymmetry.py:363-375: reset_idx on the flagged envs NOW (taco_reset_done: fresh state and command, reset_buf and
+        progress_buf cleared), then the observation dict as it is -- like the reference, nothing recomputes the frames -- and the ids."""
         done_env_ids = self.reset_buf.nonzero(as_tuple=False).flatten()
+        _lib.check(self.lib.taco_reset_done(self._h, self.reset_buf.data_ptr(), _stream_ptr(self.device).value))
         return self._outputs(), done_env_ids
 
     def zero_actions(self):

@@ -259,3 +259,26 @@ def test_invalid_configurations_are_rejected():
     for bad in (dict(control_freq_inv=5), dict(num_envs=0), dict(substeps=0), dict(delay_time=95), dict(len_obs=0)):
         with pytest.raises(ValueError):
             O.OracleEnv(dict(flat, **bad))
+
+
+def test_reset_done_is_an_immediate_reset_idx():
+    """VT:363-375: reset_done() resets the flagged envs now (FA:475-517), clears reset_buf / progress_buf and leaves the step counter alone;
+    the following step sees no reset flag for them, so -- unlike an in-step reset (FA:629-630) -- it applies thrust."""
+    from oracle import oracle as O
+    from taco_amd import config
+    cfg = config.default_cfg("pos", 32, env_maxEpisodeLength=12, seed=4)
+    a, b = O.OracleEnv(config.flat_cfg(cfg)), O.OracleEnv(config.flat_cfg(cfg))
+    rng = np.random.default_rng(0)
+    acts = np.clip(0.3 * rng.standard_normal((13, 32, 4)) + np.array([0.6, 0, 0, 0]), -1, 1).astype(np.float32)
+    for t in range(11):
+        a.step(acts[t]); b.step(acts[t])
+    assert a.reset_buf.all()                                  # every env timed out (progress 11 >= maxEpisodeLength - 1)
+    ids = a.reset_done()
+    assert len(ids) == 32 and not a.reset_buf.any() and a.step_count == b.step_count == 11
+    sa = a.get_state().view(np.float32)
+    v0 = sa[7:10].copy()
+    assert (a.get_state()[65] == 0).all() and np.abs(sa[7:10]).max() < 4.0          # progress 0; fresh (randomised) velocities
+    a.step(acts[12]); b.step(acts[12])                        # a: plain step of the fresh state; b: reset inside the step, no force
+    sa, sb = a.get_state().view(np.float32), b.get_state().view(np.float32)
+    assert np.allclose(sb[7:10], v0 + np.array([[0.0], [0.0], [-9.81 * 0.01]]), atol=2e-5)   # b: the same reset state, ten substeps of free fall
+    assert (np.linalg.norm(sa[7:10] - sb[7:10], axis=0) > 5e-3).all()                        # a: thrust and drag were applied

@@ -295,3 +295,55 @@ def test_loop_forms_hand_over_on_rare_forms_and_nonfinite_inputs(form):
         gb, ob = env.get_state().cpu().numpy(), orc.get_state().view(np.float32)
         assert_bits_equal(gb[:20], ob[:20], what + " state 0..19")
         assert_bits_equal(gb[26:65], ob[26:65], what + " state 26..64")
+
+
+def test_reset_done_resets_now_like_the_reference():
+    """VecTask.reset_done (VT:363-375) = reset_idx on the flagged envs outside a step: fresh state and command, reset_buf / progress_buf
+    cleared, the step clock unchanged -- and the step that follows applies thrust to those envs (it sees no reset flag).  HIP vs oracle,
+    every state word, through several episodes' worth of interleaved step() / reset_done() calls; the progress == 500 command re-draw
+    of reset_command_condition (FA:500-503) is exercised by planting progress 500 through the state blob."""
+    from oracle import oracle as O
+    from taco_amd.vec_env import FpvBase
+    cfg = config.baseline_config(4, num_envs=777)            # mix, every randomisation on, 5 state frames
+    cfg["env"]["maxEpisodeLength"] = 37
+    flat = config.flat_cfg(cfg)
+    n = flat["num_envs"]
+    env, orc = FpvBase(cfg, copy_outputs=False), O.OracleEnv(flat, threads=8)
+    acts = action_stream(n, 160, 3)
+    acts_d = torch.from_numpy(acts).cuda()
+
+    def same(what):
+        gb, ob = env.get_state().cpu().numpy(), orc.get_state().view(np.float32)
+        flip_envs = np.arange(n) >= int(n / 3 * 2)
+        assert_bits_equal(gb[:20], ob[:20], what + " state fields 0..19")
+        assert_bits_equal(gb[26:67], ob[26:67], what + " state fields 26..66")
+        assert_bits_equal(gb[20:26][:, flip_envs], ob[20:26][:, flip_envs], what + " rpy of the flip envs")
+        assert_bits_equal(gb[67:], ob[67:], what + " delay line")
+        assert_bits_equal(env.reset_buf.cpu().numpy(), orc.reset_buf, what + " reset_buf")
+
+    resets = 0
+    for t in range(160):
+        env.step_raw(acts_d[t]); orc.step(acts[t])
+        if t % 7 == 3:                                       # every few steps: reset the done envs NOW instead of inside the next step
+            if t == 80:                                      # plant progress 500 in some envs that are not resetting
+                for side in (env, orc):
+                    b = side.get_state()
+                    b = b.clone() if torch.is_tensor(b) else b.copy()
+                    v = b.view(torch.int32) if torch.is_tensor(b) else b.view(np.int32)
+                    v[65, 600:700] = 500
+                    side.set_state(b)
+            pending = int(orc.reset_buf.sum())
+            _, ids = env.reset_done()
+            oids = orc.reset_done()
+            assert np.array_equal(ids.cpu().numpy(), oids) and len(oids) == pending
+            assert int(env.reset_buf.sum()) == 0 and int(orc.reset_buf.sum()) == 0
+            assert env.step_count == t + 1                   # the clock did not move
+            same(f"after reset_done at step {t}")
+            prog = env.progress_buf.cpu().numpy()
+            assert (prog[oids] == 0).all()
+            resets += pending
+        if t % 5 == 0:
+            same(f"step {t}")
+            assert_bits_equal(env.obs_buf.cpu().numpy(), orc.obs_buf, f"step {t} obs")
+            assert_bits_equal(env.rew_buf.cpu().numpy(), orc.rew_buf, f"step {t} rew")
+    assert resets > 50

@@ -124,7 +124,7 @@ def census(prog, lo, hi):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--kernel", default="_ZN4taco16taco_step_kernelILi256ELi1ELb0EEEvNS_10StepParamsE")
+    ap.add_argument("--kernel", default="_ZN4taco16taco_step_kernelILi64ELi1ELb0ELb1ELb0EEEvNS_10StepParamsE")
     ap.add_argument("--asm", default=None, help="use this assembly file instead of compiling")
     ap.add_argument("--out", default=None)
     ap.add_argument("--min-valu", type=int, default=150, help="only report loops with at least this many VALU instructions")
