@@ -238,7 +238,9 @@ int taco_critic_values(const taco_policy_cfg *cfg, const float *blob, int64_t ro
  * rew[t] += gamma * value[t] where an env was truncated (:314-324; the value of the pre-step state IS value_buf[t]).
  * Per step only the ACTOR runs (nothing before GAE consumes `value`): the critic is evaluated afterwards for all horizon + 1 slots in one
  * batched launch (taco_critic_values' kernel), same bits as a per-step act().  2 * horizon + 2 launches, no host work between the steps;
- * the policy's noise counter runs call0 .. call0 + horizon (the last number is reserved for the final state's act(), which draws nothing).
+ * the policy's noise counter runs call0 .. call0 + horizon - 1 (the critic draws nothing).  Capturable: on a capturing stream the env's
+ * clock and the actor's noise counter are read from the device-resident step word, so every replay of the graph is the NEXT rollout
+ * (fresh noise, continuing episodes), bit-identical to the same number of eager calls.
  * All arrays are DEVICE memory in the replay-buffer layout (taco_amd/rollout.py::RolloutBuffer.run). */
 typedef struct taco_rollout_bufs {
     float *obs_store;     /* [horizon + 1][num_envs][len_obs][26]    slot 0 = the stacks to start from */

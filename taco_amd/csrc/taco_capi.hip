@@ -640,8 +640,10 @@ size_t taco_policy_blob_floats(const taco_policy_cfg *c) {
 
 static int launch_policy(const taco_policy_cfg *c, const float *blob, int n, const float *obs, const float *states, uint64_t seed, uint32_t call,
                          int deterministic, int action_only, float *action, float *logp, float *value, float *mu, float *sigma,
-                         float *action_env, float act_lo, float act_hi, void *stream, uint64_t *stamps = nullptr) {
+                         float *action_env, float act_lo, float act_hi, void *stream, uint64_t *stamps = nullptr, const uint32_t *clock = nullptr,
+                         uint32_t call_delta = 0) {
     taco::PolicyParams P{};
+    P.clock = clock; P.call_delta = call_delta;
     P.obs_len = c->obs_len; P.obs_dim = c->obs_dim; P.states_len = c->states_len; P.states_dim = c->states_dim; P.act_dim = c->act_dim;
     P.n_actor_hidden = c->n_actor_hidden; P.lstm_hidden = c->lstm_hidden; P.n_critic_hidden = c->n_critic_hidden;
     for (int l = 0; l < 4; ++l) { P.actor_hidden[l] = c->actor_hidden[l]; P.critic_hidden[l] = c->critic_hidden[l]; }
@@ -756,11 +758,20 @@ int taco_rollout_run(taco_env *e, const taco_policy_cfg *c, const float *blob, c
         return fail(TACO_ERR_INVALID_ARG, "taco_rollout_run: policy and env geometry differ");
     const size_t n = (size_t)ec.num_envs;
     const size_t obs_slot = n * ec.len_obs * 26, st_slot = n * ec.len_states * 26;
+    // On a capturing stream the env's clock lives on the device (launch_step); the actor then takes its noise counter from it too:
+    // counter of step t = call0 + t = (device step word) + (call0 - step count at the start of the rollout), whatever replay this is.
+    {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (stream != nullptr && hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) e->clock_on_device = 1;
+        else if ((rc = refresh_clock(e)) != TACO_OK) return rc;   // eager, after replays: the host's clock is made current first (blocking, once)
+    }
+    const uint32_t *clock = e->clock_on_device ? e->ctl + taco::kCtlStep : nullptr;
+    const uint32_t call_delta = call0 - (uint32_t)e->step_count;
     for (int t = 0; t < horizon; ++t) {
         float *act_t = b->act_buf + (size_t)t * n * 4;
         rc = launch_policy(c, blob, (int)n, b->obs_store + (size_t)t * obs_slot, nullptr, seed, call0 + (uint32_t)t, 0, 1,
                            act_t, b->logp_buf + (size_t)t * n, nullptr, b->mu_buf + (size_t)t * n * 4, b->sigma_buf + (size_t)t * n * 4,
-                           b->act_env, (float)act_lo, (float)act_hi, stream);
+                           b->act_env, (float)act_lo, (float)act_hi, stream, nullptr, clock, call_delta);
         if (rc != TACO_OK) return rc;
         taco_rollout_io io{};
         io.actions = b->act_env;

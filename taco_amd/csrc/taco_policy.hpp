@@ -40,6 +40,8 @@ struct PolicyParams {
     float *value_tail;  // batched critic: rows >= value_split write value_tail[row - value_split] (the rollout's last_value)
     int value_split;
     float *hT;          // batched critic: workspace [n][128], the LSTM's h_T between the two kernels
+    const uint32_t *clock;  // optional: the env's device-resident step word (taco_step.hpp, kCtlStep).  Non-NULL: the noise counter is
+    uint32_t call_delta;    // *clock + call_delta instead of `call` -- what makes a captured rollout draw fresh noise at every replay
 };
 
 typedef float pf32x4 __attribute__((ext_vector_type(4)));
@@ -180,6 +182,7 @@ template <int NW>
 TD void actor_body(const PolicyParams &P, float *bufA, float *bufB) {
     constexpr int ROLE = 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t call = P.clock ? P.clock[0] + P.call_delta : P.call;
     POL_STAMP(0);
     const int row0 = blockIdx.x * POL_ROWS;
     const float *w = P.blob;
@@ -220,7 +223,7 @@ TD void actor_body(const PolicyParams &P, float *bufA, float *bufB) {
                 const float scale = e * e;
                 float act = mean;
                 if (!P.deterministic) {
-                    const U4 rnd = philox(P.seed_lo, P.seed_hi, (uint32_t)env, P.call, STREAM_POLICY, 0u);
+                    const U4 rnd = philox(P.seed_lo, P.seed_hi, (uint32_t)env, call, STREAM_POLICY, 0u);
                     const uint32_t ba = (a & 2) ? rnd.z : rnd.x, bb = (a & 2) ? rnd.w : rnd.y;
                     const float ua = 1.0f - uniform(ba), ub = uniform(bb);
                     const float rad = __builtin_sqrtf(-2.0f * log(ua));
@@ -257,7 +260,7 @@ TD void actor_body(const PolicyParams &P, float *bufA, float *bufB) {
                 const float scale = e * e;
                 float act = mean;
                 if (!P.deterministic) {
-                    if ((a & 3) == 0) rnd = philox(P.seed_lo, P.seed_hi, (uint32_t)env, P.call, STREAM_POLICY, (uint32_t)(a >> 2));
+                    if ((a & 3) == 0) rnd = philox(P.seed_lo, P.seed_hi, (uint32_t)env, call, STREAM_POLICY, (uint32_t)(a >> 2));
                     // two Box-Muller pairs per Philox block, as the env's observation noise draws them
                     const uint32_t ba = (a & 2) ? rnd.z : rnd.x, bb = (a & 2) ? rnd.w : rnd.y;
                     const float ua = 1.0f - uniform(ba), ub = uniform(bb);
@@ -445,7 +448,7 @@ constexpr int CR_MLP_ROWS = 64;
 // pad16(lstm_hidden) == 128, states_len <= POL_MAXT, critic MLP = two hidden layers padded to 128
 __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_kernel(const PolicyParams P) {
     __shared__ __attribute__((aligned(16))) float xs[2][POL_MAXT * CR_ROWS * 32];   // the block's state stacks as they lie in memory: [row][t][sd]
-    __shared__ __attribute__((aligned(16))) float hb[2][CR_ROWS * CR_LD];
+    __shared__ __attribute__((aligned(16))) float hb[3][CR_ROWS * CR_LD];   // h_t double buffer + [2] = h_T on its way to the workspace
     constexpr int KSX = 2, KSH = 8, hp = 128, ip = 32, RT = CR_ROWS / 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
@@ -589,19 +592,20 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_kernel(const Pol
                 lstm_cell(acc[rt][0][i], acc[rt][1][i], acc[rt][2][i], acc[rt][3][i], first ? 0.0f : cst[rt][i], cn, hv[rt][i]);
                 cst[rt][i] = cn;
             }
-        if (t + 1 < T) {
-            float *hout = hb[t & 1] + (4 * g) * CR_LD + col;
+        float *hout = hb[t + 1 < T ? (t & 1) : 2] + (4 * g) * CR_LD + col;   // (the last timestep's h goes out through hb[2], see flush_hT)
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) hout[(16 * rt + i) * CR_LD] = hv[rt][i];
-        } else {
-            const size_t row = (size_t)blk * CR_ROWS + 4 * g;
+            for (int i = 0; i < 4; ++i) hout[(16 * rt + i) * CR_LD] = hv[rt][i];
+    };
+    // h_T of block `blk` (complete in hb[2] after the barrier of its last timestep) -> workspace rows, 16 bytes per lane, coalesced; hb[2] is
+    // not written again before the last timestep of the next block, many barriers later
+    auto flush_hT = [&](int blk) {
+        const size_t row0 = (size_t)blk * CR_ROWS;
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (row + 16 * rt + i < (size_t)P.n) P.hT[(row + 16 * rt + i) * hp + col] = hv[rt][i];
+        for (int j = 0; j < CR_ROWS * (hp / 4) / (64 * POL_NW); ++j) {   // 32 rows x 32 float4 = 2 per thread
+            const int e = tid + 64 * POL_NW * j, row = e >> 5, k4 = e & 31;
+            if (row0 + row < (size_t)P.n) *reinterpret_cast<float4 *>(P.hT + (row0 + row) * hp + 4 * k4) = *reinterpret_cast<const float4 *>(hb[2] + row * CR_LD + 4 * k4);
         }
     };
     // profiling (P.stamps): workgroup 0, wavefronts 0 and 4: shader clock at the start of a timestep, after its MFMAs, after its cells, for the
@@ -615,6 +619,7 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_kernel(const Pol
         // the next block's stacks: the DMA lands during timestep 0 (the barrier that ends it waits for it; xs[(k + 1) & 1] was last read
         // in block k - 1)
         if (k + 1 < nb) stage(blk + (int)gridDim.x, (k + 1) & 1);
+        if (k > 0) flush_hT(blk - (int)gridDim.x);
         // ---- timestep 0: the x chain only (+ the sign rule)
         if (stamping && step < 21) P.stamps[(wave >> 2) * 64 + 3 * step] = __builtin_readcyclecounter();
         mfma_x(xh, 0);
@@ -643,6 +648,7 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_kernel(const Pol
             __syncthreads();
         }
     }
+    flush_hT((int)blockIdx.x + (nb - 1) * (int)gridDim.x);
     if (stamping && wave == 0) { P.stamps[257] = wall_clock64(); P.stamps[258] = __builtin_readcyclecounter(); }
 }
 

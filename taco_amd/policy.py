@@ -128,7 +128,7 @@ class ActorCritic:
             raise _lib.TacoError("the policy kernel runs on an MI355X; device must be a cuda:N (HIP) device")
         self.cfg = cfg_from_state_dict(state_dict, obs_len, states_len, obs_dim, states_dim)
         self.seed = int(seed)
-        self.calls = 0  # Philox counter of the action noise: (seed, env index, call number)
+        self.calls = 0  # Philox counter of the action noise: (seed, env index, call number); advanced by every SAMPLING call
         self.reuse_outputs = False  # True: act() returns the same five tensors every call (no allocations on the hot loop)
         self.stamps = None          # profiling: a [16] int64 device tensor that workgroup 0 of every act() launch fills with shader-clock stamps
         self._out = None
@@ -169,7 +169,8 @@ class ActorCritic:
                                                     C.c_uint64(self.seed), C.c_uint32(self.calls), 1 if deterministic else 0, 1 if action_only else 0,
                                                     action.data_ptr(), logp.data_ptr(), value.data_ptr(), mu.data_ptr(), sigma.data_ptr(),
                                                     self.stamps.data_ptr() if self.stamps is not None else None, s))
-        self.calls += 1
+        if not deterministic:
+            self.calls += 1     # (a deterministic call draws nothing)
         return action, logp, value, mu, sigma
 
     def act(self, actor_input, critic_input, deterministic=False, action_only=False):

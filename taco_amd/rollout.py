@@ -139,7 +139,7 @@ class RolloutBuffer:
         _lib.check(self.lib.taco_rollout_run(env._h, C.byref(policy.cfg), policy._blob.data_ptr(), C.byref(b), H, C.c_uint64(policy.seed),
                                              C.c_uint32(policy.calls), float(self.gamma), float(act_low), float(act_high),
                                              env.reset_buf.data_ptr(), s))
-        policy.calls += H + 1
+        policy.calls += H
         self.step = H
         return self._last_value
 

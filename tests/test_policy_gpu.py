@@ -32,18 +32,18 @@ def test_act_matches_reference_golden():
     assert torch.equal(pol.forward(obs), mu) and torch.equal(pol.act(obs, None, deterministic=True, action_only=True), mu)
 
 
-def _random_policy(rng, obs_len, states_len, actor_hidden, lstm, critic_hidden):
+def _random_policy(rng, obs_len, states_len, actor_hidden, lstm, critic_hidden, states_dim=26):
     sd = {"log_std": rng.uniform(-1, 0.5, 4).astype(np.float32)}
     dims = [obs_len * 26] + actor_hidden + [4]
     for i in range(len(dims) - 1):
         sd[f"actor_mlp.layers.{2 * i}.weight"] = (rng.standard_normal((dims[i + 1], dims[i])) * (1.5 / np.sqrt(dims[i]))).astype(np.float32)
         sd[f"actor_mlp.layers.{2 * i}.bias"] = (rng.standard_normal(dims[i + 1]) * 0.1).astype(np.float32)
     if lstm:
-        sd["critic_encoder.layers.weight_ih_l0"] = (rng.standard_normal((4 * lstm, 26)) * 0.3).astype(np.float32)
+        sd["critic_encoder.layers.weight_ih_l0"] = (rng.standard_normal((4 * lstm, states_dim)) * 0.3).astype(np.float32)
         sd["critic_encoder.layers.weight_hh_l0"] = (rng.standard_normal((4 * lstm, lstm)) * (1.0 / np.sqrt(lstm))).astype(np.float32)
         sd["critic_encoder.layers.bias_ih_l0"] = (rng.standard_normal(4 * lstm) * 0.1).astype(np.float32)
         sd["critic_encoder.layers.bias_hh_l0"] = (rng.standard_normal(4 * lstm) * 0.1).astype(np.float32)
-    dims = [lstm if lstm else states_len * 26] + critic_hidden + [1]
+    dims = [lstm if lstm else states_len * states_dim] + critic_hidden + [1]
     for i in range(len(dims) - 1):
         sd[f"critic_mlp.layers.{2 * i}.weight"] = (rng.standard_normal((dims[i + 1], dims[i])) * (1.5 / np.sqrt(dims[i]))).astype(np.float32)
         sd[f"critic_mlp.layers.{2 * i}.bias"] = (rng.standard_normal(dims[i + 1]) * 0.1).astype(np.float32)
@@ -67,7 +67,7 @@ def test_act_equals_oracle_bitwise(n, obs_len, states_len, actor_hidden, lstm, c
     obs = rng.standard_normal((n, obs_len, 26)).astype(np.float32)
     st = rng.standard_normal((n, states_len, 26)).astype(np.float32)
     obs[0, 0, :3] = [1e4, -1e4, 0.0]           # saturate a few units
-    for call, det in ((0, True), (1, False), (2, False)):
+    for call, det in ((0, True), (0, False), (1, False)):     # a deterministic call does not consume a noise counter
         assert pol.calls == call
         got = pol.act(torch.from_numpy(obs).cuda(), torch.from_numpy(st).cuda(), deterministic=det)
         eps = None if det else O.policy_noise(77, call, n)
@@ -177,3 +177,23 @@ def test_batched_critic_first_timestep_shortcut_keeps_the_sign_of_zero():
     std = torch.from_numpy(st).cuda()
     ref = pol.act(torch.zeros(96, 1, 26, device="cuda"), std, deterministic=True)[2]
     assert_bits_equal(pol.values(std).cpu().numpy(), ref.cpu().numpy(), "batched critic vs act(), zero-sign case")
+
+
+@pytest.mark.parametrize("states_dim", [17, 19, 30, 32])
+def test_batched_critic_other_state_widths(states_dim):
+    """The batched LSTM kernel copies the state stacks into LDS as they lie in memory and addresses [row][t][states_dim] in its fragment
+    reads: odd widths take the 4-byte read path, even ones the 8-byte path, 32 has no padding columns to zero."""
+    from oracle import oracle as O
+    from taco_amd import policy as P
+    rng = np.random.default_rng(states_dim)
+    sd = _random_policy(rng, 1, 4, [32], 128, [128, 128], states_dim=states_dim)
+    pol = P.ActorCritic(sd, 1, 4, seed=3, states_dim=states_dim)
+    rows = 1000 + states_dim
+    st = rng.standard_normal((rows, 4, states_dim)).astype(np.float32)
+    std = torch.from_numpy(st).cuda()
+    got = pol.values(std)
+    ref = pol.act(torch.zeros(rows, 1, 26, device="cuda"), std, deterministic=True)[2]
+    assert_bits_equal(got.cpu().numpy(), ref.cpu().numpy(), "batched critic vs act()")
+    oc = O.policy_cfg(1, 4, [32], 128, [128, 128], states_dim=states_dim)
+    exp = O.policy_act(oc, P.pack_state_dict(pol.cfg, sd), np.zeros((64, 1, 26), np.float32), st[-64:], deterministic=True)[2]
+    assert_bits_equal(got.cpu().numpy()[-64:].reshape(exp.shape), exp, "batched critic vs oracle")

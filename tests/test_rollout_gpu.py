@@ -149,3 +149,56 @@ def test_rollout_run_equals_the_python_loop(n, task, len_states, arch):
             assert_bits_equal(a.cpu().numpy(), b.cpu().numpy(), k)
         else:
             assert torch.equal(a, b), k
+
+
+def test_rollout_run_is_graph_capturable_and_replays_are_the_next_rollouts():
+    """taco_rollout_run captured into ONE HIP graph (2 H + 3 kernels + the clock advances): the env's clock and the actor's noise counter
+    come from the device-resident step word, so replay k is rollout k -- fresh action noise, episodes continuing -- bit-identical to k eager
+    calls (every replay-buffer array, the env's whole state)."""
+    from taco_amd import policy as P
+    from taco_amd.vec_env import FpvBase
+    import test_policy_gpu as TP
+    n, H, T = 333, 9, 5
+    rng = np.random.default_rng(11)
+    sd = TP._random_policy(rng, 1, T, [128, 128, 128], 128, [128, 128])
+    cfg = config.default_cfg("mix", n, env_lenStates=T, env_maxEpisodeLength=23, seed=8, observation_noise=True, rotor_noise=True)
+    keys = ("obs_buf", "states_buf", "act_buf", "rew_buf", "done_buf", "value_buf", "logp_buf", "mu_buf", "sigma_buf")
+
+    def snapshot(buf, env, last):
+        return {k: getattr(buf, k).clone() for k in keys} | {"last": last.clone(), "tmo": buf.time_outs.clone()}
+
+    # eager: three rollouts (the buffer carries the final stacks of one into slot 0 of the next, as PPO.run does)
+    env, pol, buf = FpvBase(cfg, copy_outputs=False), P.ActorCritic(sd, 1, T, seed=5), _buffer(n, H, 1, T)
+    eager = []
+    for k in range(3):
+        buf.reset()
+        eager.append(snapshot(buf, env, buf.run(env, pol)))
+    eager_state = env.get_state().view(torch.int32).clone()
+
+    # captured: rollout 0 eagerly on a side stream (allocations, warm-up), then rollout 1 captured and replayed twice = rollouts 1 and 2
+    env, pol, buf = FpvBase(cfg, copy_outputs=False), P.ActorCritic(sd, 1, T, seed=5), _buffer(n, H, 1, T)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        buf.reset()
+        got0 = snapshot(buf, env, buf.run(env, pol))
+        s.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            buf.reset()
+            last = buf.run(env, pol)
+    for k in (1, 2):
+        g.replay()
+        torch.cuda.synchronize()
+        got = snapshot(buf, env, last)
+        for name in got:
+            a, b = got[name], eager[k][name]
+            if a.dtype == torch.float32:
+                assert_bits_equal(a.cpu().numpy(), b.cpu().numpy(), f"replay {k} {name}")
+            else:
+                assert torch.equal(a, b), f"replay {k} {name}"
+    for name in got0:
+        assert torch.equal(got0[name].view(torch.int32) if got0[name].dtype == torch.float32 else got0[name],
+                           eager[0][name].view(torch.int32) if eager[0][name].dtype == torch.float32 else eager[0][name]), name
+    assert torch.equal(env.get_state().view(torch.int32), eager_state)
+    assert env.step_count == 3 * H
+    env.check()
