@@ -119,6 +119,37 @@ def test_full_size_parity_on_random_slices(idx, steps):
     assert (prog >= 1).all() and (prog <= flat["max_episode_length"]).all()
 
 
+@pytest.mark.parametrize("idx,n,steps,form", [(2, 16384, 60, "quad"), (3, 16384, 60, "quad"), (4, 32768, 40, "lane_roles"), (1, 65536, 25, "lane_throughput")])
+def test_whole_batch_parity_at_the_per_rank_shapes(idx, n, steps, form):
+    """SURVEY 8(d)'s configs 3 / 4 / 5 at their per-GPU shapes (rotate 16 384, flip 16 384, mix 32 768 with every flag and 5 state frames)
+    and the first throughput-form size, in the kernel form the product picks there: EVERY env against the oracle (all host threads),
+    outputs each few steps and the whole state at the end, bit for bit."""
+    from oracle import oracle as O
+    from taco_amd.vec_env import FpvBase
+    cfg = config.baseline_config(idx, num_envs=n)
+    flat = config.flat_cfg(cfg)
+    env = FpvBase(cfg, copy_outputs=False)
+    assert env.kernel_form == form
+    orc = O.OracleEnv(flat, threads=min(32, os.cpu_count() or 8))
+    g = torch.Generator().manual_seed(40 + idx)
+    for t in range(steps):
+        a = (0.3 * torch.randn((n, 4), generator=g)).clamp(-1, 1)
+        a[:, 0] = (a[:, 0] - 0.3).clamp(-1, 1)
+        env.step_raw(a.cuda())
+        orc.step(a.numpy())
+        if t % 8 == 7 or t == steps - 1:
+            what = f"config {idx + 1} step {t}"
+            assert_bits_equal(env.obs_buf.cpu().numpy(), orc.obs_buf, what + " obs")
+            assert_bits_equal(env.states_buf.cpu().numpy(), orc.states_buf, what + " states")
+            assert_bits_equal(env.rew_buf.cpu().numpy(), orc.rew_buf, what + " rew")
+            assert_bits_equal(env.reset_buf.cpu().numpy(), orc.reset_buf, what + " done")
+    gb, ob = env.get_state().cpu().numpy(), orc.get_state().view(np.float32)
+    flip = (np.arange(n) >= int(n / 3 * 2)) if flat["task_mode"] == "mix" else np.full(n, flat["task_mode"] == "flip")
+    assert_bits_equal(gb[:20], ob[:20], "state fields 0..19")
+    assert_bits_equal(gb[26:], ob[26:], "state fields 26.. and the delay line")
+    assert_bits_equal(gb[20:26][:, flip], ob[20:26][:, flip], "rpy of the flip envs")
+
+
 def test_maximum_size_two_million_envs_with_stacked_states():
     """The largest launch taco_create accepts (2 000 000 envs), with the documented 5-frame state stack: slices at the first, a middle
     and the last envs are re-simulated by the oracle and compared bit for bit; the stack of every env shifts by one frame."""
