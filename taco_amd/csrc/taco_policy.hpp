@@ -524,6 +524,7 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_kernel(const Pol
         m &= (uint32_t)__shfl_xor((int)m, 32, 64);
         allneg[q] = m != 0;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the first block's stacks (LDS-DMA) have landed
     __syncthreads();
 
     pf32x4 acc[RT][4];  // [row tile][gate], rows 16 rt + 4 g + i, column col
@@ -636,6 +637,7 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_kernel(const Pol
         cells(0, blk, true);
         if (stamping && step < 21) P.stamps[(wave >> 2) * 64 + 3 * step + 2] = __builtin_readcyclecounter();
         ++step;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next block's stacks have landed (the DMA was issued a whole timestep ago)
         __syncthreads();
         for (int t = 1; t < T; ++t) {
             if (stamping && step < 21) P.stamps[(wave >> 2) * 64 + 3 * step] = __builtin_readcyclecounter();
