@@ -481,9 +481,45 @@ def gen_policy():
          action_s=npy(action_s), logp_s=npy(logp_s), actor_hidden=np.array([64, 40]), critic_hidden=np.array([48]), lstm_hidden=np.array(24), **sd)
 
 
+def gen_policy_documented():
+    """The same module at the DOCUMENTED widths (README.md:60-66: actor MLP 26-128-128-128-4, critic LSTM 26 -> 128 over 5 frames + MLP
+    128-128-128-1) -- the architecture the batched critic kernels (taco_critic_lstm_kernel / taco_critic_mlp_kernel) are specialised for."""
+    import torch.nn as nn
+    NETS = _load("nets_asymmetry", REF / "IsaacGymEnvs/algorithms/nets_asymmetry.py")
+    torch.manual_seed(1400)
+    para = {
+        "actor_critic_mlp_dict": {"actor_input_dim": 26, "actor_output_dim": 4, "critic_input_dim": 26 * 5, "critic_output_dim": 1,
+                                  "actor_hidden_sizes": [128, 128, 128], "critic_hidden_sizes": [128, 128], "activation": nn.ReLU},
+        "use_actor_encoder": False, "use_critic_encoder": True, "share_encoder": False, "critic_encoder_type": "LSTM",
+        "critic_encoder_dict": {"encoder_type": "LSTM", "input_size": 26, "output_size": 128, "num_layers": 1, "bidirectional": False},
+    }
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        agent = NETS.PPO_ActorCritic(para)
+    with torch.no_grad():
+        agent.log_std.copy_(torch.tensor([-0.4, -0.1, 0.0, 0.2]))
+        for p_ in agent.parameters():
+            if p_.dim() >= 2:
+                p_.mul_(4.0)
+    g = torch.Generator().manual_seed(1401)
+    N = 100
+    obs = torch.randn(N, 1, 26, generator=g)
+    states = torch.randn(N, 5, 26, generator=g)
+    states[7] = 0.0                      # an all-zero stack
+    states[11, :3] = 0.0                 # a stack whose first frames are zero (a freshly reset env)
+    with torch.no_grad():
+        action, logp_det, value, mu, sigma = agent.act(obs, states, deterministic=True)
+    sd = {"sd." + k: npy(v) for k, v in agent.state_dict().items()}
+    save("policy_documented", obs=npy(obs), states=npy(states), mu=npy(mu), value=npy(value[:, 0]), sigma=npy(sigma), logp_det=npy(logp_det), **sd)
+
+
 if __name__ == "__main__":
+    if "--only-policy-documented" in sys.argv:
+        gen_policy_documented()
+        sys.exit(0)
     gen_gae()
     gen_policy()
+    gen_policy_documented()
     if "--only-gae" in sys.argv or "--only-next" in sys.argv:
         sys.exit(0)
     gen_quat(); gen_pid(); gen_alloc(); gen_battery(); gen_rotor(); gen_aero(); gen_reward(); gen_chain(); gen_obs(); gen_reset()

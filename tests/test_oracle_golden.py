@@ -214,6 +214,22 @@ def test_policy_forward_vs_reference_module(golden):
     np.testing.assert_allclose(lp, g["logp_s"], rtol=1e-6, atol=1e-5)
 
 
+def test_policy_forward_vs_reference_module_documented_widths(golden):
+    """The same at the documented widths (policy_documented.npz: actor 26-128-128-128-4, critic LSTM 26->128 over 5 frames + 128-128-128-1),
+    the architecture the batched critic kernels are specialised for; incl. an all-zero stack and a stack with zero leading frames."""
+    from taco_amd import policy as P
+    g = golden("policy_documented")
+    sd = {k[3:]: g[k] for k in g if k.startswith("sd.")}
+    cfg = P.cfg_from_state_dict(sd, 1, 5)
+    assert (list(cfg.actor_hidden)[:cfg.n_actor_hidden], cfg.lstm_hidden, list(cfg.critic_hidden)[:cfg.n_critic_hidden]) == ([128, 128, 128], 128, [128, 128])
+    oc = O.policy_cfg(1, 5, [128, 128, 128], 128, [128, 128])
+    a, lp, v, mu, sg = O.policy_act(oc, P.pack_state_dict(cfg, sd), g["obs"], g["states"], deterministic=True)
+    np.testing.assert_allclose(mu, g["mu"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(v, g["value"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(lp, g["logp_det"], rtol=0, atol=1e-5)
+    assert np.abs(g["value"]).max() > 0.05 and np.abs(g["mu"]).max() > 0.3     # the fixture is not degenerate
+
+
 def test_policy_transcendentals_and_noise():
     x = np.linspace(-30, 30, 6001).astype(np.float32)
     xd = x.astype(np.float64)

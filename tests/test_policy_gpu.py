@@ -32,6 +32,23 @@ def test_act_matches_reference_golden():
     assert torch.equal(pol.forward(obs), mu) and torch.equal(pol.act(obs, None, deterministic=True, action_only=True), mu)
 
 
+def test_documented_architecture_matches_reference_golden():
+    """policy_documented.npz (the reference's own module at the documented widths): act() and the batched critic against the reference's
+    numbers (1e-5), and against each other bit for bit."""
+    from taco_amd import policy as P
+    g = np.load(os.path.join(GOLD, "policy_documented.npz"))
+    sd = {k[3:]: g[k] for k in g.files if k.startswith("sd.")}
+    pol = P.ActorCritic(sd, 1, 5, seed=9)
+    obs, st = torch.from_numpy(g["obs"]).cuda(), torch.from_numpy(g["states"]).cuda()
+    action, logp, value, mu, sigma = pol.act(obs, st, deterministic=True)
+    np.testing.assert_allclose(mu.cpu().numpy(), g["mu"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(value.cpu().numpy()[:, 0], g["value"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(logp.cpu().numpy(), g["logp_det"], rtol=0, atol=1e-5)
+    batched = pol.values(st)
+    np.testing.assert_allclose(batched.cpu().numpy()[:, 0], g["value"], rtol=0, atol=1e-5)
+    assert_bits_equal(batched.cpu().numpy(), value.cpu().numpy(), "batched critic vs act()")
+
+
 def _random_policy(rng, obs_len, states_len, actor_hidden, lstm, critic_hidden, states_dim=26):
     sd = {"log_std": rng.uniform(-1, 0.5, 4).astype(np.float32)}
     dims = [obs_len * 26] + actor_hidden + [4]
