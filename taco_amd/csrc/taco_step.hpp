@@ -222,6 +222,14 @@ TD V3 euler_xyz_v1(Q4 q) {
     return e;
 }
 // TU:199-213 quat_from_euler_xyz
+TD Q4 quat_from_sincos(float sr, float cr, float sp, float cp, float sy, float cy) {
+    Q4 q;
+    q.w = cy * cr * cp + sy * sr * sp;
+    q.x = cy * sr * cp - sy * cr * sp;
+    q.y = cy * cr * sp + sy * sr * cp;
+    q.z = sy * cr * cp - cy * sr * sp;
+    return q;
+}
 TD Q4 quat_from_euler(float roll, float pitch, float yaw) {
     float cy, sy, cr, sr, cp, sp;
     sincos(yaw * 0.5f, sy, cy);
@@ -455,20 +463,50 @@ TD bool integrate_quad(const StepParams &P, uint32_t k3, float &pq, float &qq, f
 // from 10 Philox blocks of STREAM_RESET; a block whose consumers are all switched off (launch-uniform flags) is not generated.
 #define CST(c, val) buf_st4(rS, (val), voff, (uint32_t)(c) * row_bytes)
 #define CLD(c) buf_ld4(rS, voff, (uint32_t)(c) * row_bytes)
-TD void reset_env(const StepParams &P, uint32_t step, rsrc_t rS, uint32_t voff, uint32_t row_bytes, int gid, int grp, bool mix, bool store, float4 &c_pos,
-                  float4 &c_quat, float4 &c_lin, float4 &c_ang, float4 &c_pp, float4 &c_pi, float4 &c_om, float4 &c_misc, float4 &c_tau,
+// LPE == 4 (quad layout: the four lanes of an env run this redundantly): the Philox blocks are SHARED OUT -- lane `sub` evaluates blocks
+// sub, 4 + sub, 8 + sub (three Philox evaluations per lane instead of up to ten) and the quad reads each block's four uniforms from the
+// lane that made them (DPP quad_perm broadcasts).  Same numbers, ~200 instructions fewer on the path of every wavefront that holds a
+// resetting env -- at 4 096 envs that is some wavefront of nearly every launch, i.e. the launch time.
+template <int LPE>
+TD void reset_env(const StepParams &P, uint32_t step, rsrc_t rS, uint32_t voff, uint32_t row_bytes, int gid, int grp, bool mix, bool store, int sub,
+                  float4 &c_pos, float4 &c_quat, float4 &c_lin, float4 &c_ang, float4 &c_pp, float4 &c_pi, float4 &c_om, float4 &c_misc, float4 &c_tau,
                   float4 &c_op, float4 &c_a0, float4 &c_a1) {
     const uint32_t fl = P.flags;
-    auto block = [&](bool wanted, uint32_t b, float &u0, float &u1, float &u2, float &u3) {
-        u0 = u1 = u2 = u3 = 0.0f;
-        if (wanted) {  // (launch-uniform)
-            U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, step, STREAM_RESET, b);
-            u0 = uniform(r.x); u1 = uniform(r.y); u2 = uniform(r.z); u3 = uniform(r.w);
-        }
-    };
     const bool rc = (fl & TACO_F_RANDOM_ROTORDYNAMIC_COE) != 0, ra = (fl & TACO_F_RANDOM_AERODYNAMIC_COE) != 0;
     const bool rtau = (fl & TACO_F_ROTOR_RESPONSE) && (fl & TACO_F_RANDOM_ROTOR_RESPONSE), rspd = (fl & TACO_F_RANDOM_ROTOR_SPEED) != 0;
     const bool rpos = (fl & TACO_F_RANDOM_COPTER_POS) != 0, rquat = (fl & TACO_F_RANDOM_COPTER_QUAT) != 0, rvel = (fl & TACO_F_RANDOM_COPTER_VEL) != 0;
+    // which blocks this configuration draws from (launch-uniform), as a bit mask
+    const uint32_t want = 1u | ((rquat || rvel) ? 2u : 0u) | (rvel ? 4u : 0u) | ((rvel || (fl & TACO_F_RANDOM_TARGET_POS)) ? 8u : 0u) |
+                          (((fl & (TACO_F_RANDOM_TARGET_YAW | TACO_F_RANDOM_VOLTAGE)) || rc) ? 16u : 0u) | ((rc || rtau) ? 32u : 0u) |
+                          ((rtau || rspd) ? 64u : 0u) | ((rspd || ra) ? 128u : 0u) | (ra ? 256u : 0u) | ((fl & TACO_F_RANDOM_DELAY_TIME) ? 512u : 0u);
+    float qu[3][4] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};  // LPE == 4: this lane's uniforms of blocks sub, 4 + sub, 8 + sub
+    if constexpr (LPE == 4) {
+#pragma unroll
+        for (int rnd = 0; rnd < 3; ++rnd) {
+            if ((want >> (4 * rnd)) & 15u) {  // (launch-uniform: some lane's block of this round is drawn from)
+                const U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, step, STREAM_RESET, (uint32_t)(4 * rnd + sub));
+                qu[rnd][0] = uniform(r.x); qu[rnd][1] = uniform(r.y); qu[rnd][2] = uniform(r.z); qu[rnd][3] = uniform(r.w);
+            }
+        }
+    }
+    auto from_lane = [](float v, int k) {  // the value lane k of this quad holds
+        const int iv = __builtin_bit_cast(int, v);
+        const int o = k == 0 ? __builtin_amdgcn_update_dpp(0, iv, 0x00, 0xf, 0xf, true) : k == 1 ? __builtin_amdgcn_update_dpp(0, iv, 0x55, 0xf, 0xf, true)
+                    : k == 2 ? __builtin_amdgcn_update_dpp(0, iv, 0xaa, 0xf, 0xf, true) : __builtin_amdgcn_update_dpp(0, iv, 0xff, 0xf, 0xf, true);
+        return __builtin_bit_cast(float, o);
+    };
+    auto block = [&](bool wanted, uint32_t b, float &u0, float &u1, float &u2, float &u3) {
+        u0 = u1 = u2 = u3 = 0.0f;
+        if (wanted) {  // (launch-uniform)
+            if constexpr (LPE == 4) {
+                const int rnd = (int)(b >> 2), k = (int)(b & 3u);
+                u0 = from_lane(qu[rnd][0], k); u1 = from_lane(qu[rnd][1], k); u2 = from_lane(qu[rnd][2], k); u3 = from_lane(qu[rnd][3], k);
+            } else {
+                U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, step, STREAM_RESET, b);
+                u0 = uniform(r.x); u1 = uniform(r.y); u2 = uniform(r.z); u3 = uniform(r.w);
+            }
+        }
+    };
     float u0, u1, u2, u3, u4, u5, u6, u7;
     const float pi_sc = (float)(3.14159265358979323846 - (-3.14159265358979323846)), pi_lo = (float)(-3.14159265358979323846);
     // ---- reset_copter_idx: FA:725-756 pos, :783-812 rotate, :850-884 flip, :981-1056 mix (pos-style ranges for all groups)
@@ -498,25 +536,52 @@ TD void reset_env(const StepParams &P, uint32_t step, rsrc_t rS, uint32_t voff, 
         p.x = 0.0f; p.y = 0.0f; p.z = 2.5f;
     }
     c_pos = make_float4(p.x, p.y, p.z, as_f((int)make_pw(0, 0)));  // progress <- 0 (FA:510-511), no runs queued
-    Q4 q{0.0f, 0.0f, 0.0f, 1.0f};
-    if (rquat) {  // rand_quat FA:698-704 (flip: limits (pi, 0, 0))
+    float c0, c1, c2, c3;
+    block((fl & (TACO_F_RANDOM_TARGET_YAW | TACO_F_RANDOM_VOLTAGE)) || rc, 4, c0, c1, c2, c3);  // uniforms 16..19: target yaw, battery E, omega_para 0 1
+    const float tgt_yaw = (fl & TACO_F_RANDOM_TARGET_YAW) ? pi_sc * c0 + pi_lo : 0.0f;   // reset_target_idx FA:523-548
+    Q4 q{0.0f, 0.0f, 0.0f, 1.0f}, qt;
+    V3 rpy0;
+    if constexpr (LPE == 4) {
+        // the quad shares out the transcendental functions as well: lane j takes the sine / cosine of half of angle j (roll, pitch, yaw of
+        // rand_quat, and the target's yaw in lane 3), and of get_euler_xyz_v1 lane 0 the roll atan2, lane 2 the yaw atan2, lane 1 the pitch
+        // asin (every lane runs one atan2 and one asin on its own operands).  Same functions on the same arguments: same bits.
         const float l_sc = (grp == TACO_TASK_FLIP) ? 0.0f : pi_sc;
         const float l_lo = (grp == TACO_TASK_FLIP) ? -0.0f : pi_lo;
-        q = quat_from_euler(pi_sc * u3 + pi_lo, l_sc * u4 + l_lo, l_sc * u5 + l_lo);
+        const float a_r = pi_sc * u3 + pi_lo, a_p = l_sc * u4 + l_lo, a_y = l_sc * u5 + l_lo;
+        const float ang = sub == 0 ? a_r : (sub == 1 ? a_p : (sub == 2 ? a_y : tgt_yaw));
+        float sn, cs;
+        sincos(ang * 0.5f, sn, cs);
+        if (rquat)  // rand_quat FA:698-704 (flip: limits (pi, 0, 0))
+            q = quat_from_sincos(from_lane(sn, 0), from_lane(cs, 0), from_lane(sn, 1), from_lane(cs, 1), from_lane(sn, 2), from_lane(cs, 2));
+        float s0, c0_;
+        sincos(0.0f * 0.5f, s0, c0_);  // (constant-folded) what quat_from_euler(0, 0, yaw) takes for its roll and pitch
+        qt = quat_from_sincos(s0, c0_, s0, c0_, from_lane(sn, 3), from_lane(cs, 3));
+        const float n0 = 2.0f * (q.w * q.x + q.y * q.z), d0 = q.w * q.w - q.x * q.x - q.y * q.y + q.z * q.z;
+        const float sinp = 2.0f * (q.w * q.y - q.z * q.x);
+        const float n2 = 2.0f * (q.w * q.z + q.x * q.y), d2 = q.w * q.w + q.x * q.x - q.y * q.y - q.z * q.z;
+        const float at = atan2(sub == 2 ? n2 : n0, sub == 2 ? d2 : d0);
+        float pit;
+        if (absf(sinp) >= 1.0f) pit = kHalfPi * (sinp > 0.0f ? 1.0f : (sinp < 0.0f ? -1.0f : 0.0f));
+        else pit = asin(sinp);
+        rpy0 = V3{from_lane(at, 0), from_lane(pit, 1), from_lane(at, 2)};  // FA:752-754
+    } else {
+        if (rquat) {  // rand_quat FA:698-704 (flip: limits (pi, 0, 0))
+            const float l_sc = (grp == TACO_TASK_FLIP) ? 0.0f : pi_sc;
+            const float l_lo = (grp == TACO_TASK_FLIP) ? -0.0f : pi_lo;
+            q = quat_from_euler(pi_sc * u3 + pi_lo, l_sc * u4 + l_lo, l_sc * u5 + l_lo);
+        }
+        qt = quat_from_euler(0.0f, 0.0f, tgt_yaw);
+        rpy0 = euler_xyz_v1(q);  // FA:752-754
     }
     c_quat = make_float4(q.x, q.y, q.z, q.w);
-    {
-        const V3 e0 = euler_xyz_v1(q);  // FA:752-754
-        if (store) {
-            CST(C_RPY_OLD, make_float4(e0.x, e0.y, e0.z, 0.0f));
-            CST(C_RPY_CONT, make_float4(e0.x, e0.y, e0.z, 0.0f));
-        }
+    if (store) {
+        CST(C_RPY_OLD, make_float4(rpy0.x, rpy0.y, rpy0.z, 0.0f));
+        CST(C_RPY_CONT, make_float4(rpy0.x, rpy0.y, rpy0.z, 0.0f));
     }
     float a0, a1, a2, a3, b0, b1, b2, b3;
     block(rvel, 2, a0, a1, a2, a3);                                          // uniforms 8..11: linvel z, angvel x y z
     block(rvel || (fl & TACO_F_RANDOM_TARGET_POS), 3, b0, b1, b2, b3);       // uniforms 12..15: flip sign, target x y z
-    float c0, c1, c2, c3, d0, d1, d2, d3;
-    block((fl & (TACO_F_RANDOM_TARGET_YAW | TACO_F_RANDOM_VOLTAGE)) || rc, 4, c0, c1, c2, c3);  // uniforms 16..19: target yaw, battery E, omega_para 0 1
+    float d0, d1, d2, d3;
     block(rc || rtau, 5, d0, d1, d2, d3);                                    // uniforms 20..23: omega_para 2 3 4, tau 0
     float h0, h1, h2, h3;
     block((fl & TACO_F_RANDOM_DELAY_TIME) != 0, 9, h0, h1, h2, h3);          // uniform 36: delay length
@@ -549,11 +614,7 @@ TD void reset_env(const StepParams &P, uint32_t step, rsrc_t rS, uint32_t voff, 
         if (fl & TACO_F_RANDOM_TARGET_POS) CST(C_TGT_POS, make_float4(P.df * (4.0f * b1 + -2.0f), P.df * (4.0f * b2 + -2.0f), 3.0f + P.df * (4.0f * b3 + -2.0f), 0.0f));
         else CST(C_TGT_POS, make_float4(0.0f, 0.0f, 3.0f, 0.0f));
     }
-    {
-        const float yaw = (fl & TACO_F_RANDOM_TARGET_YAW) ? pi_sc * c0 + pi_lo : 0.0f;
-        const Q4 qt = quat_from_euler(0.0f, 0.0f, yaw);
-        if (store) CST(C_TGT_QUAT, make_float4(qt.x, qt.y, qt.z, qt.w));
-    }
+    if (store) CST(C_TGT_QUAT, make_float4(qt.x, qt.y, qt.z, qt.w));
     // ---- reset_controller_idx FA:550-558
     c_pp = make_float4(0.0f, 0.0f, 0.0f, (fl & TACO_F_RANDOM_VOLTAGE) ? (float)2.2 * c1 + 0.0f : 0.0f);  // + battery E_c
     c_pi = make_float4(0.0f, 0.0f, 0.0f, 0.0f);                                                          // + battery u_1
@@ -807,7 +868,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
     // reset_idx (FA:475-517): the lanes that reset get their fresh state in the registers the up-front loads filled (see reset_env)
     const bool wave_has_reset = __builtin_amdgcn_ballot_w64(is_reset) != 0;
     if (wave_has_reset) {
-        if (is_reset) reset_env(P, clk.step, rS, voff, row_bytes, gid, grp, mix, active, c_pos, c_quat, c_lin, c_ang, c_pp, c_pi, c_om, c_misc, c_tau, c_op, c_a0, c_a1);
+        if (is_reset) reset_env<LPE>(P, clk.step, rS, voff, row_bytes, gid, grp, mix, active, sub, c_pos, c_quat, c_lin, c_ang, c_pp, c_pi, c_om, c_misc, c_tau, c_op, c_a0, c_a1);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // (the target pose and the unwrapped angles it stored are loaded further down)
     }
     if (P.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TACO_STAMP(1); }  // all up-front loads have landed
