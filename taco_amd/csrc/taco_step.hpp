@@ -1747,6 +1747,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
     }
     }
     TACO_STAMP(5);
+    if (SPLIT && P.stamps && blockIdx.x == 0 && lane == 0) P.stamps[5 + wv] = __builtin_readcyclecounter();  // [6..8]: the role wavefronts' ends
 #undef TACO_STAMP
 #undef MB_WAIT
 #undef MB_POST

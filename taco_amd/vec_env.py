@@ -255,7 +255,8 @@ class FpvBase:
         """Profiling aid: run `steps` steps with the phase stamps bound and return the mean shader-clock ticks between the
         phase boundaries of workgroup 0 (entry->loads, ->pre-phase, ->substeps, ->stores+frames, ->end).  back_to_back: launch the steps
         without host synchronisation in between and read the LAST launch's stamps (warm instruction cache, as in a rollout)."""
-        st = torch.zeros(8, dtype=torch.int64, device=self.device)
+        st = torch.zeros(16, dtype=torch.int64, device=self.device)
+        self._last_stamps = st
         _lib.check(self.lib.taco_bind_phase_stamps(self._h, st.data_ptr()))
         acc = torch.zeros(5, dtype=torch.float64)
         try:
