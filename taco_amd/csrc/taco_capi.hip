@@ -638,6 +638,16 @@ size_t taco_policy_blob_floats(const taco_policy_cfg *c) {
     return n;
 }
 
+static int device_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        else return 256;
+    }
+    return cus;
+}
+
 static int launch_policy(const taco_policy_cfg *c, const float *blob, int n, const float *obs, const float *states, uint64_t seed, uint32_t call,
                          int deterministic, int action_only, float *action, float *logp, float *value, float *mu, float *sigma,
                          float *action_env, float act_lo, float act_hi, void *stream, uint64_t *stamps = nullptr, const uint32_t *clock = nullptr,
@@ -653,9 +663,19 @@ static int launch_policy(const taco_policy_cfg *c, const float *blob, int n, con
     P.n = n; P.deterministic = deterministic ? 1 : 0;
     P.seed_lo = (uint32_t)seed; P.seed_hi = (uint32_t)(seed >> 32); P.call = call;
     P.role0 = 0; P.value_tail = nullptr; P.value_split = INT_MAX;
-    hipLaunchKernelGGL(taco::taco_policy_kernel, dim3((n + taco::POL_ROWS - 1) / taco::POL_ROWS, action_only ? 1 : 2), dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
+    // the actor alone above 8 192 rows, documented architecture: the throughput form (weights resident, 64 rows per pass); otherwise the
+    // 16-rows-per-workgroup form, which is the faster one while its workgroups fit the chip in two rounds
+    auto p16 = [](int x) { return (x + 15) / 16 * 16; };
+    const bool actor_throughput = action_only && n > 8192 && !stamps && c->act_dim == 4 && p16(c->obs_len * c->obs_dim) == 32 && c->n_actor_hidden == 3 &&
+                                  p16(c->actor_hidden[0]) == 128 && p16(c->actor_hidden[1]) == 128 && p16(c->actor_hidden[2]) == 128;
+    if (actor_throughput) {
+        const int npass = (n + taco::CR_MLP_ROWS - 1) / taco::CR_MLP_ROWS, cap = 2 * device_cus();
+        hipLaunchKernelGGL(taco::taco_actor_kernel, dim3((unsigned)(npass < cap ? npass : cap)), dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
+    } else {
+        hipLaunchKernelGGL(taco::taco_policy_kernel, dim3((n + taco::POL_ROWS - 1) / taco::POL_ROWS, action_only ? 1 : 2), dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
+    }
     hipError_t he = hipGetLastError();
-    if (he != hipSuccess) return hip_fail(he, "taco_policy_kernel launch");
+    if (he != hipSuccess) return hip_fail(he, "policy kernel launch");
     return TACO_OK;
 }
 
@@ -665,15 +685,6 @@ static bool critic_batched_form(const taco_policy_cfg *c) {
     auto p16 = [](int x) { return (x + 15) / 16 * 16; };
     return c->lstm_hidden > 0 && p16(c->lstm_hidden) == 128 && p16(c->states_dim) == 32 && c->states_len <= taco::POL_MAXT && c->n_critic_hidden == 2 &&
            p16(c->critic_hidden[0]) == 128 && p16(c->critic_hidden[1]) == 128;
-}
-static int device_cus() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-        else return 256;
-    }
-    return cus;
 }
 // cu_limit > 0: the persistent LSTM kernel uses at most that many workgroups (a stream that owns fewer CUs than the device has)
 static int launch_critic(const taco_policy_cfg *c, const float *blob, size_t rows, const float *states, float *value, float *value_tail, size_t split,

@@ -175,6 +175,44 @@ TD void lstm_resident(const float *Wih, const float *Whh, const float *bs, int h
     }
 }
 
+// distribution (:333-345) for act_dim == 4: thread (er, a) owns action component a of row er of the workgroup's tile (whole quads: the
+// log-prob's two sums run over the quad by DPP, in component order)
+TD void sample4(const PolicyParams &P, const float *x, int ld, int row0, int er, int a, const float *log_std, uint32_t call) {
+    const int env = row0 + er;
+    const bool live = env < P.n;
+    const float mean = x[er * ld + a];
+    const float e = expf_own(log_std[a]);
+    const float scale = e * e;
+    float act = mean;
+    if (!P.deterministic) {
+        const U4 rnd = philox(P.seed_lo, P.seed_hi, (uint32_t)env, call, STREAM_POLICY, 0u);
+        const uint32_t ba = (a & 2) ? rnd.z : rnd.x, bb = (a & 2) ? rnd.w : rnd.y;
+        const float ua = 1.0f - uniform(ba), ub = uniform(bb);
+        const float rad = __builtin_sqrtf(-2.0f * log(ua));
+        float sn, cs;
+        sincos(kTwoPi * ub, sn, cs);
+        const float eps = (a & 1) ? rad * sn : rad * cs;
+        act = mean + scale * eps;
+    }
+    const float zz = (act - mean) / scale;
+    const float z2 = zz * zz, ls = log(scale);
+    auto bcq = [](float v, int k) {
+        const int iv = __builtin_bit_cast(int, v);
+        const int o = k == 0 ? __builtin_amdgcn_update_dpp(0, iv, 0x00, 0xf, 0xf, true) : k == 1 ? __builtin_amdgcn_update_dpp(0, iv, 0x55, 0xf, 0xf, true)
+                    : k == 2 ? __builtin_amdgcn_update_dpp(0, iv, 0xaa, 0xf, 0xf, true) : __builtin_amdgcn_update_dpp(0, iv, 0xff, 0xf, 0xf, true);
+        return __builtin_bit_cast(float, o);
+    };
+    float lp = 0.0f + bcq(z2, 0); lp = lp + bcq(z2, 1); lp = lp + bcq(z2, 2); lp = lp + bcq(z2, 3);
+    float hld = 0.0f + bcq(ls, 0); hld = hld + bcq(ls, 1); hld = hld + bcq(ls, 2); hld = hld + bcq(ls, 3);
+    if (live) {
+        P.action[(size_t)env * 4 + a] = act;
+        if (P.action_env) P.action_env[(size_t)env * 4 + a] = clampf(act, P.act_lo, P.act_hi);
+        P.mu[(size_t)env * 4 + a] = mean;
+        P.sigma[(size_t)env * 4 + a] = log_std[a];
+        if (a == 0) P.logp[env] = -0.5f * (4.0f * 1.8378770664093453f + lp) - hld;
+    }
+}
+
 #define POL_STAMP(k) do { if (P.stamps && blockIdx.x == 0 && tid == 0) P.stamps[(k) + 8 * ROLE] = __builtin_readcyclecounter(); } while (0)
 
 // ---- the actor: MLP + tanh head + action sampling / log-prob (nets_asymmetry.py:331-345) for the 16 envs of workgroup blockIdx.x
@@ -214,42 +252,7 @@ TD void actor_body(const PolicyParams &P, float *bufA, float *bufB) {
         // ---- distribution (:333-345): scale_tril = diag(exp(log_std) * exp(log_std)).  One thread per (env, action component) when
         // act_dim == 4 (the log-prob's two sums run over the quad by DPP, in component order); one thread per env otherwise.
         if (P.act_dim == 4) {
-            if (tid < 4 * POL_ROWS) {
-                const int er = tid >> 2, a = tid & 3;
-                const int env = row0 + er;
-                const bool live = env < P.n;
-                const float mean = x[er * POL_LD + a];
-                const float e = expf_own(log_std[a]);
-                const float scale = e * e;
-                float act = mean;
-                if (!P.deterministic) {
-                    const U4 rnd = philox(P.seed_lo, P.seed_hi, (uint32_t)env, call, STREAM_POLICY, 0u);
-                    const uint32_t ba = (a & 2) ? rnd.z : rnd.x, bb = (a & 2) ? rnd.w : rnd.y;
-                    const float ua = 1.0f - uniform(ba), ub = uniform(bb);
-                    const float rad = __builtin_sqrtf(-2.0f * log(ua));
-                    float sn, cs;
-                    sincos(kTwoPi * ub, sn, cs);
-                    const float eps = (a & 1) ? rad * sn : rad * cs;
-                    act = mean + scale * eps;
-                }
-                const float zz = (act - mean) / scale;
-                const float z2 = zz * zz, ls = log(scale);
-                auto bcq = [](float v, int k) {
-                    const int iv = __builtin_bit_cast(int, v);
-                    const int o = k == 0 ? __builtin_amdgcn_update_dpp(0, iv, 0x00, 0xf, 0xf, true) : k == 1 ? __builtin_amdgcn_update_dpp(0, iv, 0x55, 0xf, 0xf, true)
-                                : k == 2 ? __builtin_amdgcn_update_dpp(0, iv, 0xaa, 0xf, 0xf, true) : __builtin_amdgcn_update_dpp(0, iv, 0xff, 0xf, 0xf, true);
-                    return __builtin_bit_cast(float, o);
-                };
-                float lp = 0.0f + bcq(z2, 0); lp = lp + bcq(z2, 1); lp = lp + bcq(z2, 2); lp = lp + bcq(z2, 3);
-                float hld = 0.0f + bcq(ls, 0); hld = hld + bcq(ls, 1); hld = hld + bcq(ls, 2); hld = hld + bcq(ls, 3);
-                if (live) {
-                    P.action[(size_t)env * 4 + a] = act;
-                    if (P.action_env) P.action_env[(size_t)env * 4 + a] = clampf(act, P.act_lo, P.act_hi);
-                    P.mu[(size_t)env * 4 + a] = mean;
-                    P.sigma[(size_t)env * 4 + a] = log_std[a];
-                    if (a == 0) P.logp[env] = -0.5f * (4.0f * 1.8378770664093453f + lp) - hld;
-                }
-            }
+            if (tid < 4 * POL_ROWS) sample4(P, x, POL_LD, row0, tid >> 2, tid & 3, log_std, call);
         } else if (tid < POL_ROWS && row0 + tid < P.n) {
             const int env = row0 + tid;
             float lp = 0.0f, half_log_det = 0.0f;
@@ -734,6 +737,86 @@ __global__ __launch_bounds__(64 * POL_NW, 4) void taco_critic_mlp_kernel(const P
             }
         }
         __syncthreads();
+    }
+}
+
+
+// The actor alone at LARGE N (taco_policy_act / taco_rollout_run above 8 192 envs): the 16-row form above is built for latency (256
+// workgroups at 4 096 envs, one per CU: 9.6 us) and runs at 25 % of the f32 MFMA peak from 16 384 envs on; this form keeps the weight
+// fragments of all four layers in registers (tile = wave; 8 + 32 + 32 + 32 float4), takes 64 rows per pass (four 16-row MFMA tiles per
+// weight fragment) and walks passes b, b + grid, ...  Same chains in the same k order as dense_tile: same bits.
+// requirements (host): the documented actor -- pad16(obs_len * obs_dim) == 32, three hidden layers padded to 128, act_dim == 4
+__global__ __launch_bounds__(64 * POL_NW) void taco_actor_kernel(const PolicyParams P) {
+    __shared__ __attribute__((aligned(16))) float xb[CR_MLP_ROWS * CR_LD];
+    __shared__ __attribute__((aligned(16))) float yb[CR_MLP_ROWS * CR_LD];
+    constexpr int hp = 128, ip = 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const uint32_t call = P.clock ? P.clock[0] + P.call_delta : P.call;
+    const float *W0 = P.blob, *b0 = W0 + hp * ip, *W1 = b0 + hp, *b1 = W1 + hp * hp, *W2 = b1 + hp, *b2 = W2 + hp * hp, *W3 = b2 + hp, *b3 = W3 + 16 * hp;
+    const float *log_std = b3 + 16;
+    const int col = wave * 16 + r;
+    float4 w0[2], w1[8], w2[8], w3[8];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) w0[s] = *reinterpret_cast<const float4 *>(W0 + ((size_t)(wave * 2 + s) * 64 + lane) * 4);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        w1[s] = *reinterpret_cast<const float4 *>(W1 + ((size_t)(wave * 8 + s) * 64 + lane) * 4);
+        w2[s] = *reinterpret_cast<const float4 *>(W2 + ((size_t)(wave * 8 + s) * 64 + lane) * 4);
+        w3[s] = *reinterpret_cast<const float4 *>(W3 + ((size_t)s * 64 + lane) * 4);
+    }
+    const float c0 = b0[col], c1 = b1[col], c2 = b2[col], c3 = b3[r];
+    auto layer = [&](const float *in, float *out, const float4 *wf, int ks, float bias) {
+#pragma unroll
+        for (int rt = 0; rt < CR_MLP_ROWS / 16; ++rt) {
+            const float *arow = in + (16 * rt + r) * CR_LD + 4 * g;
+            pf32x4 acc = {bias, bias, bias, bias};
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                if (s < ks) {
+                    const float4 a4 = *reinterpret_cast<const float4 *>(arow + 16 * s);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, wf[s].x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, wf[s].y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, wf[s].z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wf[s].w, acc, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) out[(16 * rt + 4 * g + i) * CR_LD + col] = acc[i] < 0.0f ? 0.0f : acc[i];
+        }
+    };
+    const int kin = P.obs_len * P.obs_dim;
+    const int npass = (P.n + CR_MLP_ROWS - 1) / CR_MLP_ROWS;
+    for (int c = blockIdx.x; c < npass; c += gridDim.x) {
+        const int row0 = c * CR_MLP_ROWS;
+        for (int e = tid; e < CR_MLP_ROWS * ip; e += 64 * POL_NW) {  // obs [row][kin] -> xb[row][32], zero beyond kin and beyond the last row
+            const int row = e >> 5, k = e & 31;
+            xb[row * CR_LD + k] = (row0 + row < P.n && k < kin) ? P.obs[(size_t)(row0 + row) * kin + k] : 0.0f;
+        }
+        __syncthreads();
+        layer(xb, yb, w0, 2, c0);
+        __syncthreads();
+        layer(yb, xb, w1, 8, c1);
+        __syncthreads();
+        layer(xb, yb, w2, 8, c2);
+        __syncthreads();
+        if (wave < CR_MLP_ROWS / 16) {  // the 128 -> 4 head (one 16-column tile) with its tanh: wavefront w takes row tile w
+            const float *arow = yb + (16 * wave + r) * CR_LD + 4 * g;
+            pf32x4 acc = {c3, c3, c3, c3};
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const float4 a4 = *reinterpret_cast<const float4 *>(arow + 16 * s);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, w3[s].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, w3[s].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, w3[s].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, w3[s].w, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xb[(16 * wave + 4 * g + i) * CR_LD + r] = tanh_own(acc[i]);
+        }
+        __syncthreads();
+        if (tid < 4 * CR_MLP_ROWS) sample4(P, xb, CR_LD, row0, tid >> 2, tid & 3, log_std, call);
+        __syncthreads();  // xb is staged again by the next pass
     }
 }
 

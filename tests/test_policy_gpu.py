@@ -214,3 +214,31 @@ def test_batched_critic_other_state_widths(states_dim):
     oc = O.policy_cfg(1, 4, [32], 128, [128, 128], states_dim=states_dim)
     exp = O.policy_act(oc, P.pack_state_dict(pol.cfg, sd), np.zeros((64, 1, 26), np.float32), st[-64:], deterministic=True)[2]
     assert_bits_equal(got.cpu().numpy()[-64:].reshape(exp.shape), exp, "batched critic vs oracle")
+
+
+@pytest.mark.parametrize("n", [8193, 20000, 65536 + 3])
+def test_actor_throughput_form_equals_the_latency_form_and_oracle(n):
+    """Above 8 192 rows act(action_only=True) runs taco_actor_kernel (weights resident, 64 rows per pass): same actions, log-probs, means as
+    the 16-row form (which a full act() still uses) and as the oracle, bit for bit, sampled and deterministic."""
+    from oracle import oracle as O
+    from taco_amd import policy as P
+    rng = np.random.default_rng(n)
+    sd = _random_policy(rng, 1, 5, [128, 128, 128], 128, [128, 128])
+    pol = P.ActorCritic(sd, 1, 5, seed=13)
+    obs = rng.standard_normal((n, 1, 26)).astype(np.float32)
+    obs[5, 0, :3] = [1e4, -1e4, 0.0]
+    st = rng.standard_normal((n, 5, 26)).astype(np.float32)
+    obs_d, st_d = torch.from_numpy(obs).cuda(), torch.from_numpy(st).cuda()
+    for det in (True, False):
+        call = pol.calls
+        full = pol.act(obs_d, st_d, deterministic=det)              # the 16-row kernel (actor + critic roles)
+        pol.calls = call
+        fast = pol._run(obs_d, None, det, True)                      # the throughput actor
+        for name, k in (("action", 0), ("logp", 1), ("mu", 3), ("sigma", 4)):
+            assert_bits_equal(fast[k].cpu().numpy(), full[k].cpu().numpy(), f"det={det} {name}")
+        pick = np.r_[0:40, n - 40:n]
+        oc = O.policy_cfg(1, 5, [128, 128, 128], 128, [128, 128])
+        eps = None if det else O.policy_noise(13, call, n)[pick]
+        exp = O.policy_act(oc, P.pack_state_dict(pol.cfg, sd), obs[pick], st[pick], eps=eps, deterministic=det)
+        assert_bits_equal(fast[0].cpu().numpy()[pick], exp[0], f"det={det} action vs oracle")
+        assert_bits_equal(fast[1].cpu().numpy()[pick], exp[1], f"det={det} logp vs oracle")
