@@ -123,3 +123,50 @@ def test_policy_packing_matches_the_layout_both_sides_read():
     F = P._frag(W).reshape(2, 3, 64, 4)                      # [tile][k block][lane = 16 g + r][t]
     for tile, s, g, r, t in ((0, 0, 0, 0, 0), (1, 2, 3, 15, 3), (0, 1, 2, 5, 1)):
         assert F[tile, s, 16 * g + r, t] == W[16 * tile + r, 16 * s + 4 * g + t]
+
+
+def test_checkpoint_merge_and_slice_by_global_env_id():
+    """taco_amd/checkpoint.py on stand-in envs (no GPU): merge() joins adjoining shards in env order and refuses gaps or mixed runs;
+    load_state_dict() hands an env exactly the columns / rows of its [env_offset, env_offset + num_envs) range."""
+    import torch
+    from taco_amd import checkpoint, _lib
+
+    class Env:
+        def __init__(self, lo, n, total):
+            self._flat = {"num_envs": n, "env_offset": lo, "num_envs_global": total, "task_mode": "mix", "len_obs": 1, "len_states": 2, "seed": 3}
+            self.device = torch.device("cpu")
+            self.difficulty, self.step_count = 0.0, 0
+            self.blob = None
+            self.obs_buf, self.states_buf = torch.zeros(n, 1, 26), torch.zeros(n, 2, 26)
+            self.rew_buf, self.reset_buf, self.timeout_buf = torch.zeros(n), torch.zeros(n, dtype=torch.long), torch.zeros(n, dtype=torch.bool)
+
+        def get_state(self):
+            return self.blob
+
+        def set_state(self, b):
+            self.blob = b.clone()
+
+    def filled(lo, n, total, step=17):
+        e = Env(lo, n, total)
+        ids = torch.arange(lo, lo + n, dtype=torch.float32)
+        e.blob = ids.repeat(_lib.BLOB_ROWS, 1) + torch.arange(_lib.BLOB_ROWS, dtype=torch.float32)[:, None] * 1000
+        e.obs_buf += ids[:, None, None]; e.states_buf += ids[:, None, None]; e.rew_buf += ids; e.reset_buf += ids.long()
+        e.difficulty, e.step_count = 0.4, step
+        return e
+
+    parts = [filled(0, 5, 12), filled(5, 4, 12), filled(9, 3, 12)]
+    merged = checkpoint.merge([checkpoint.state_dict(p) for p in (parts[2], parts[0], parts[1])])
+    assert merged["flat_cfg"]["num_envs"] == 12 and merged["flat_cfg"]["env_offset"] == 0 and merged["blob"].shape == (_lib.BLOB_ROWS, 12)
+    assert torch.equal(merged["blob"][0], torch.arange(12, dtype=torch.float32)) and torch.equal(merged["rew_buf"], torch.arange(12, dtype=torch.float32))
+    tgt = Env(3, 6, 12)
+    checkpoint.load_state_dict(tgt, merged)
+    assert tgt.step_count == 17 and tgt.difficulty == 0.4
+    assert torch.equal(tgt.blob[0], torch.arange(3, 9, dtype=torch.float32)) and torch.equal(tgt.obs_buf[:, 0, 0], torch.arange(3, 9, dtype=torch.float32))
+    with pytest.raises(ValueError, match="adjoin"):
+        checkpoint.merge([checkpoint.state_dict(parts[0]), checkpoint.state_dict(parts[2])])
+    with pytest.raises(ValueError, match="step_count"):
+        checkpoint.merge([checkpoint.state_dict(parts[0]), checkpoint.state_dict(filled(5, 4, 12, step=18))])
+    with pytest.raises(ValueError, match="merge"):
+        checkpoint.load_state_dict(Env(3, 6, 12), checkpoint.state_dict(parts[0]))
+    with pytest.raises(ValueError, match="num_envs_global"):
+        checkpoint.load_state_dict(Env(0, 5, 13), merged)
