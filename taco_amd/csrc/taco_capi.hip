@@ -278,8 +278,12 @@ template <bool OUT> const void *kernel_of(int form) {
     }
 }
 // `out`: the instantiation that also writes the clamped obs / states copies (taco_rollout_io.obs_out / states_out)
-FormInfo form_info(int form, bool out = false) {
+// `wide`: the two-wavefronts-per-SIMD build of the four-role quad form (taco_step.hpp, WIDE), see wide_form()
+FormInfo form_info(int form, bool out = false, bool wide = false) {
     const void *fn = out ? kernel_of<true>(form) : kernel_of<false>(form);
+    if (wide && form == TACO_FORM_QUAD_ROLES)
+        fn = out ? (const void *)taco::taco_step_kernel<kBlockLarge, 4, true, false, true, false, true>
+                 : (const void *)taco::taco_step_kernel<kBlockLarge, 4, true, false, false, false, true>;
     switch (form) {
         case TACO_FORM_QUAD_ROLES: return {4, kBlockLarge, 1, fn};
         case TACO_FORM_LANE_ROLES: return {1, kBlockLarge, 1, fn};
@@ -287,6 +291,8 @@ FormInfo form_info(int form, bool out = false) {
         default: return {1, kBlockSmall, 0, fn};
     }
 }
+// every wavefront of the launch has a SIMD to itself (256 workgroups of 4) and no stack history to move: the register cap buys nothing
+bool wide_form(const taco_cfg &c) { return c.num_envs <= 4096 && c.len_obs == 1 && c.len_states == 1; }
 int choose_form(const taco_cfg &c) {
     const bool stacks = c.len_obs > 1 || c.len_states > 1;
     if (c.num_envs <= kQuadMaxEnvs) {
@@ -406,7 +412,8 @@ int launch_step(taco_env *e, const taco_rollout_io *io, void *stream) {
     int grid, block;
     grid_of(e, &grid, &block);
     void *args[] = {&P};
-    hipError_t he = hipLaunchKernel(form_info(e->form, P.obs_out != nullptr || P.states_out != nullptr).fn, dim3(grid), dim3(block), args, 0, (hipStream_t)stream);
+    hipError_t he = hipLaunchKernel(form_info(e->form, P.obs_out != nullptr || P.states_out != nullptr, wide_form(e->cfg)).fn, dim3(grid), dim3(block), args, 0,
+                                    (hipStream_t)stream);
     if (he == hipSuccess) he = hipGetLastError();
     if (he != hipSuccess) return hip_fail(he, "taco_step_kernel launch");
     if (e->clock_on_device) {
@@ -832,7 +839,7 @@ int taco_bind_phase_stamps(taco_env *e, uint64_t *stamps) {
 
 int taco_occupancy(const taco_env *e, int *resident_blocks_per_cu, int *lds_bytes_per_block) {
     if (!e || !resident_blocks_per_cu || !lds_bytes_per_block) return fail(TACO_ERR_INVALID_ARG, "taco_occupancy: null argument");
-    const FormInfo f = form_info(e->form);
+    const FormInfo f = form_info(e->form, false, wide_form(e->cfg));
     hipFuncAttributes at;
     hipError_t he = hipFuncGetAttributes(&at, f.fn);
     if (he != hipSuccess) return hip_fail(he, "hipFuncGetAttributes");

@@ -697,8 +697,12 @@ constexpr int CARRY_WORDS = 32;  // 30 used
 // presence cost 0.75 us of 13.8 (SGPR spills, skipped branches) -- profiles/r02_d_ab_out_copy_paths.txt.
 // RESET_ONLY (<64, 1> only; taco_reset_done = VecTask.reset_done, VT:363-375): the kernel stops after reset_idx / reset_command_idx, stores what
 // they changed, clears the flags of the envs it reset and returns -- no action is pushed, no substep runs, the clock does not advance.
-template <int BLOCK, int LPE, bool SPLIT = false, bool CAP = false, bool OUT = false, bool RESET_ONLY = false>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT || CAP) ? 4 : 1, CAP ? 4 : 8))) void taco_step_kernel(const StepParams P) {
+// WIDE (<256, 4, true> only): the same four-role quad form compiled for two wavefronts per SIMD instead of four (up to 256 VGPRs): used
+// while every wavefront of the launch has a SIMD to itself anyway (<= 4 096 envs, no frame stacks), where the 128-register cap of the
+// general form buys nothing and costs 2 % (12.90 vs 13.19 us at 4 096 envs; with stacks or from 8 192 envs on the capped form is faster).
+template <int BLOCK, int LPE, bool SPLIT = false, bool CAP = false, bool OUT = false, bool RESET_ONLY = false, bool WIDE = false>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT || CAP) ? (WIDE ? 2 : 4) : 1, CAP ? 4 : 8))) void taco_step_kernel(const StepParams P) {
+    static_assert(!WIDE || (BLOCK == 256 && LPE == 4 && SPLIT && !RESET_ONLY), "WIDE is a variant of the four-role quad form");
     static_assert(!RESET_ONLY || (BLOCK == 64 && LPE == 1 && !SPLIT && !CAP && !OUT), "RESET_ONLY exists in the plain one-lane form only");
     static_assert(!SPLIT || BLOCK == 256, "SPLIT is the four-role form: one step wavefront + three role wavefronts per workgroup");
     static_assert(!CAP || (BLOCK == 64 && LPE == 1 && !SPLIT), "CAP is the one-wavefront-per-workgroup throughput form");
