@@ -17,7 +17,7 @@ FLAG_BITS = {
     "random_target_yaw": 4, "battery_consumption": 5, "random_voltage": 6, "rotor_noise": 7, "rotor_delay": 8,
     "rotor_response": 9, "random_rotordynamic_coe": 10, "random_rotor_delay": 11, "random_rotor_response": 12,
     "random_rotor_speed": 13, "random_aerodynamic_coe": 14, "ramdom_delay_time": 15, "ramdom_deploy_time": 16,
-    "random_command": 17, "observation_noise": 18,
+    "random_command": 17, "observation_noise": 18, "world_rate_roundtrip": 19,
 }
 NUM_FIELDS = 67
 BLOB_ROWS = 67 + 400
@@ -159,6 +159,13 @@ class OracleEnv:
         ids = np.nonzero(self.reset_buf)[0]
         lib().orc_reset_done(self._h, _p(self.reset_buf))
         return ids
+
+    def reset_idx(self, ids):
+        """FpvBase.reset_idx(env_ids) (FA:475-517) called directly: those envs are re-initialised now, their reset_buf / progress_buf cleared"""
+        mask = np.zeros(self.n, np.int64)
+        mask[np.asarray(ids, np.int64)] = 1
+        lib().orc_reset_done(self._h, _p(mask))
+        self.reset_buf[np.asarray(ids, np.int64)] = 0
 
     def get_state(self):
         blob = np.zeros((BLOB_ROWS, self.n), np.uint32)

@@ -849,7 +849,7 @@ static void step_env(const orc_env *e, int i, const float *actions, float *obs_b
             tq[2] = (ts[0] + ts[1]) + (ts[2] + ts[3]);
         }
         integrate_substep(&e->ip, s->p, s->q, s->v, wb, F, tq); /* gym.simulate VT:313 */
-        if (e->world_rate_roundtrip) { quat_sandwich(s->q, wb, s->w); rotate_inv(s->q, s->w, wb); }
+        if (e->world_rate_roundtrip || (fl & ORC_F_WORLD_RATE_ROUNDTRIP)) { quat_sandwich(s->q, wb, s->w); rotate_inv(s->q, s->w, wb); }
     }
 
     quat_sandwich(s->q, wb, s->w); /* root state: world-frame angular velocity */

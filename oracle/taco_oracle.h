@@ -50,7 +50,8 @@ enum {
     ORC_F_RANDOM_DELAY_TIME = 1u << 15,  /* cfg key "ramdom_delay_time" (sic) */
     ORC_F_RANDOM_DEPLOY_TIME = 1u << 16, /* cfg key "ramdom_deploy_time" (sic) */
     ORC_F_RANDOM_COMMAND = 1u << 17,
-    ORC_F_OBSERVATION_NOISE = 1u << 18
+    ORC_F_OBSERVATION_NOISE = 1u << 18,
+    ORC_F_WORLD_RATE_ROUNDTRIP = 1u << 19 /* same as orc_set_world_rate_roundtrip(e, 1) */
 };
 
 /* Same field order and types as struct taco_cfg in include/taco_env.h (declared independently). */

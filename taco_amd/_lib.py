@@ -4,9 +4,10 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("TACO_ENV_LIB", os.path.join(HERE, "libtaco_env.so"))  # override = A/B builds of the same ABI
+LIB_PATH = os.environ.get("TACO_ENV_LIB", os.path.join(HERE, "libtaco_env.so"))  # override = A/B builds of the same ABI (taken as it is, never rebuilt)
+SKIP_ABI_CHECK = os.environ.get("TACO_ENV_LIB_SKIP_ABI", "") == "1"   # explicit opt-out for A/B runs ACROSS ABI revisions (missing symbols are stubbed)
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 NUM_FIELDS = 67
 RING_SLOTS = 100
 BLOB_ROWS = NUM_FIELDS + 4 * RING_SLOTS
@@ -18,12 +19,12 @@ FLAG_BITS = {
     "random_target_yaw": 4, "battery_consumption": 5, "random_voltage": 6, "rotor_noise": 7, "rotor_delay": 8,
     "rotor_response": 9, "random_rotordynamic_coe": 10, "random_rotor_delay": 11, "random_rotor_response": 12,
     "random_rotor_speed": 13, "random_aerodynamic_coe": 14, "ramdom_delay_time": 15, "ramdom_deploy_time": 16,
-    "random_command": 17, "observation_noise": 18,
+    "random_command": 17, "observation_noise": 18, "world_rate_roundtrip": 19, "record_flag": 20,
 }
 # every symbol include/taco_env.h declares
 EXPORTS = ["taco_abi_version", "taco_source_hash", "taco_last_error", "taco_workspace_bytes", "taco_create", "taco_destroy", "taco_step",
            "taco_gather_row_floats", "taco_bind_gather_block", "taco_set_difficulty", "taco_get_step_count", "taco_set_step_count", "taco_get_state", "taco_set_state",
-           "taco_step_kernel_name", "taco_launch_geometry", "taco_set_kernel_form", "taco_get_kernel_form", "taco_check", "taco_get_field", "taco_step_rollout", "taco_reset_done", "taco_gae_workspace_bytes", "taco_gae", "taco_occupancy", "taco_bind_phase_stamps", "taco_policy_blob_floats", "taco_policy_act", "taco_rollout_run", "taco_policy_act_stamped", "taco_critic_values", "taco_critic_workspace_bytes"]
+           "taco_step_kernel_name", "taco_launch_geometry", "taco_set_kernel_form", "taco_get_kernel_form", "taco_check", "taco_get_field", "taco_step_rollout", "taco_reset_done", "taco_gae_workspace_bytes", "taco_gae", "taco_occupancy", "taco_bind_phase_stamps", "taco_policy_blob_floats", "taco_policy_act", "taco_rollout_run", "taco_policy_act_stamped", "taco_critic_values", "taco_critic_workspace_bytes", "taco_peek_step_count"]
 
 
 class TacoCfg(C.Structure):
@@ -64,7 +65,8 @@ class _Missing:
 
 
 def _declare(lib, ab_build=False):
-    """prototypes of every entry point of include/taco_env.h"""
+    """prototypes of every entry point of include/taco_env.h.  ab_build (TACO_ENV_LIB override AND TACO_ENV_LIB_SKIP_ABI=1): the library may be of
+    another ABI revision -- missing symbols are stubbed and the version check is skipped; an override alone is held to this binding's ABI."""
     if ab_build:  # A/B comparisons across ABI revisions: tolerate missing newer symbols, skip the version check
         for name in EXPORTS:
             if not hasattr(lib, name):
@@ -89,6 +91,8 @@ def _declare(lib, ab_build=False):
     lib.taco_set_difficulty.restype = C.c_int
     lib.taco_get_step_count.argtypes = [C.c_void_p]
     lib.taco_get_step_count.restype = C.c_int64
+    lib.taco_peek_step_count.argtypes = [C.c_void_p]
+    lib.taco_peek_step_count.restype = C.c_int64
     lib.taco_set_step_count.argtypes = [C.c_void_p, C.c_int64]
     lib.taco_set_step_count.restype = C.c_int
     lib.taco_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -142,13 +146,17 @@ def _open(path, test_hooks=False):
     TACO_ENV_LIB override (A/B builds of the same ABI) is taken as it is."""
     overridden = not test_hooks and "TACO_ENV_LIB" in os.environ
     if not overridden:
-        from . import build as _build
-        if _build.needs_build(path):
-            try:
+        try:
+            from . import build as _build
+            if _build.needs_build(path):
                 _build.build(test_hooks=test_hooks)
-            except Exception as e:  # noqa: BLE001 -- report the build failure, never fall back to anything else
-                raise TacoError(f"{path} is missing or stale (built from other sources than csrc/) and building it failed ({e}); run "
+        except FileNotFoundError as e:
+            if not os.path.exists(path):   # a deployment without csrc/ next to the package: the binary is taken as it is, if there is one
+                raise TacoError(f"{path} is missing and its sources are not next to the package ({e}); build it from a source checkout with "
                                 "`python -m taco_amd.build` (hipcc, gfx950).  There is no CPU fallback for the step path.") from e
+        except Exception as e:  # noqa: BLE001 -- report the build failure, never fall back to anything else
+            raise TacoError(f"{path} is missing or stale (built from other sources than csrc/) and building it failed ({e}); run "
+                            "`python -m taco_amd.build` (hipcc, gfx950).  There is no CPU fallback for the step path.") from e
     if not os.path.exists(path):
         raise TacoError(f"{path} is missing: build it with `python -m taco_amd.build` (hipcc, gfx950). "
                         "There is no CPU fallback for the step path.")
@@ -156,7 +164,7 @@ def _open(path, test_hooks=False):
     # the one torch's other bundled libraries were built against: load torch first, so that libtaco_env.so binds to the runtime already
     # in the process.  (The other order leaves torch on /opt/rocm's runtime and HIP reports "no ROCm-capable device".)
     import torch  # noqa: F401
-    return _declare(C.CDLL(path), ab_build=overridden)
+    return _declare(C.CDLL(path), ab_build=overridden and SKIP_ABI_CHECK)
 
 
 def load():

@@ -39,6 +39,16 @@ def composite_body(asset="without_duct"):
     return m, tuple(J)
 
 
+def airframe(asset="without_duct"):
+    """cfg overrides selecting one of the reference's two MJCF airframes (assets/xml/fpv_without_duct.xml, fpv_with_duct.xml:6: 0.570 kg,
+    J = (1.09e-3, 1.47e-3, 1.226e-3)): `default_cfg(..., **airframe("with_duct"))`.  The composite mass / inertia (chassis + 8 welded arm /
+    rotor bodies) follow from `composite_body`."""
+    if asset not in _CHASSIS:
+        raise ValueError(f"unknown airframe {asset!r}: one of {sorted(_CHASSIS)}")
+    m, J = composite_body(asset)
+    return {"asset": asset, "mass": m, "inertia": J}
+
+
 _TASK_FLAGS_TRAIN = dict(
     random_copter_pos=True, random_copter_quat=True, random_copter_vel=True, random_target_pos=True, random_target_yaw=True,
     battery_consumption=True, random_voltage=True,
@@ -108,6 +118,8 @@ def flat_cfg(cfg, env_offset=0, num_envs_local=None):
               "random_rotor_delay", "random_rotor_response", "random_rotor_speed", "random_aerodynamic_coe", "ramdom_delay_time",
               "ramdom_deploy_time", "random_command", "observation_noise"):
         d[k] = bool(cfg[k])
+    d["world_rate_roundtrip"] = bool(cfg.get("world_rate_roundtrip", False))  # the reference's literal data flow of the angular rate (taco_env.h)
+    d["record_flag"] = bool(cfg.get("record_flag", False))                    # all envs track copter_rpy_continuous (fpv_asymmetry.py:113, :339-347)
     if int(cfg.get("delay_time_max", 100)) != 100:
         raise ValueError("delay_time_max must be 100 (hard-coded in the reference, fpv_asymmetry.py:329)")
     return d

@@ -52,6 +52,7 @@ struct taco_env {
     uint32_t *ctl;        // control block (last 256 bytes of the workspace): device-resident step clock + sticky status word
     int clock_on_device;  // a launch was captured into a HIP graph: replays advance the device clock only, the fields above may be stale
                           // (taco_get_step_count re-reads them); until then every launch reads the device clock
+    void *capture_stream; // the stream a launch of this handle was last seen CAPTURING on (refresh_clock refuses to synchronise while it still is)
     int params_imported;  // taco_set_state has been called: rotor / aero parameters may differ per env from now on (see kUniformParams)
     float *gather;  // optional per-rank all-gather block, see taco_bind_gather_block
     unsigned long long *stamps;  // optional phase stamps, see taco_bind_phase_stamps
@@ -61,6 +62,15 @@ struct taco_env {
 namespace {
 
 int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+bool is_capturing(void *stream) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    return stream != nullptr && hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+}
+// a launch of this handle is being captured into a HIP graph: from now on the step clock is the device-resident one (see launch_step)
+void note_capture(taco_env *e, void *stream) {
+    if (is_capturing(stream)) { e->clock_on_device = 1; e->capture_stream = stream; }
+}
 
 // x / c via q = x * RN(1/c) + one fma correction (taco_math.hpp div_const) is used for the run-time divisor dt only if it is
 // bit-identical to the IEEE quotient for this dt: checked exhaustively over one binade of x, both signs (the three
@@ -196,6 +206,13 @@ __global__ void init_state_kernel(float *S, float *hist, float *ring, uint32_t *
     word(S, npad, i, TACO_S_PROGRESS) = __builtin_bit_cast(float, (int)taco::make_pw(0, 0));
 }
 
+// `actions` (blob rows 40..43) = the action of the last step: row hh - 1 of the action history; 0 while no step has run since the env's reset
+// (only taco_reset_done / reset_idx leave an env there, FA:572).  Shared by the blob export and the one-row export.
+__device__ __forceinline__ float last_action(float *S, const float *hist, int npad, int i, int hh, int k) {
+    const uint32_t pw = __builtin_bit_cast(uint32_t, word(S, npad, i, TACO_S_PROGRESS));
+    return taco::pw_progress(pw) == 0 ? 0.0f : hist[taco::tile_word(taco::HIST_ROWS, (hh - 1) & (taco::HIST_ROWS - 1), i) + k];
+}
+
 // blob (include/taco_env.h layout: field-major words, logical dense delay line) <-> workspace (float4 chunks; pending
 // actions as run queue over the action history, or as the physical slot ring once DENSE)
 __global__ void export_state_kernel(const float *S, const float *hist, const float *ring, uint32_t *blob, int n, int npad, int head, int hh) {
@@ -211,8 +228,7 @@ __global__ void export_state_kernel(const float *S, const float *hist, const flo
     if (row == TACO_S_DELAY_LEN) {
         val = __builtin_bit_cast(float, L);
     } else if (row >= TACO_S_ACT && row < TACO_S_ACT + 4) {            // actions = the action of the last step
-        // (0 while no step has run since the env's reset: only taco_reset_done leaves an env there, FA:572)
-        val = taco::pw_progress(pw) == 0 ? 0.0f : hist[taco::tile_word(taco::HIST_ROWS, (hh - 1) & (taco::HIST_ROWS - 1), i) + (row - TACO_S_ACT)];
+        val = last_action(Sm, hist, npad, i, hh, row - TACO_S_ACT);
     } else if (row >= TACO_S_ACT_OLD && row < TACO_S_ACT_OLD + 4) {    // actions_old = the one before, 0 right after a reset (FA:572-573)
         const int progress = taco::pw_progress(pw);
         val = (progress <= 1) ? 0.0f : hist[taco::tile_word(taco::HIST_ROWS, (hh - 2) & (taco::HIST_ROWS - 1), i) + (row - TACO_S_ACT_OLD)];
@@ -353,6 +369,7 @@ int taco_create(const taco_cfg *cfg, int device, void *workspace, size_t workspa
     e->ring = e->hist + (size_t)taco::HIST_ROWS * e->npad * 4;
     e->ctl = (uint32_t *)(e->ring + (size_t)TACO_RING_SLOTS * e->npad * 4);
     e->clock_on_device = 0;
+    e->capture_stream = nullptr;
     e->step_count = 0;
     e->head = 0;
     e->hh = 0;
@@ -382,10 +399,7 @@ int launch_step(taco_env *e, const taco_rollout_io *io, void *stream) {
     // instead (every eager launch leaves the next values there) and is followed by a one-thread kernel that advances it.  Once a capture
     // has happened the host's copy may be stale (replays advance the device clock only): every launch then takes the device path until
     // taco_get_step_count has re-read it.
-    {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (stream != nullptr && hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) e->clock_on_device = 1;
-    }
+    note_capture(e, stream);
     const size_t n_envs = (size_t)e->cfg.num_envs;
     taco::StepParams P = e->P;
     P.S = e->S; P.ring = e->ring; P.hist = e->hist;
@@ -440,8 +454,7 @@ int taco_step(taco_env *e, const float *actions, float *obs_buf, float *states_b
 int taco_reset_done(taco_env *e, int64_t *reset_buf, void *stream) {
     if (!e) return fail(TACO_ERR_INVALID_ARG, "env is null");
     if (!reset_buf) return fail(TACO_ERR_INVALID_ARG, "taco_reset_done: reset_buf is null");
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (stream != nullptr && hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) e->clock_on_device = 1;
+    note_capture(e, stream);
     taco::StepParams P = e->P;
     P.S = e->S; P.ring = e->ring; P.hist = e->hist;
     P.reset = (long long *)reset_buf;
@@ -506,12 +519,27 @@ int taco_bind_gather_block(taco_env *e, float *block) {
 }
 
 namespace {
-// re-read the clock the graph replays advanced (blocking): afterwards the host's copy is current again and launches go back to the eager path
-int refresh_clock(taco_env *e) {
+// re-read the clock the graph replays advanced (blocking): afterwards the host's copy is current again and launches go back to the eager path.
+// `stream` non-NULL: the read is ordered on the caller's stream (the entry points that take one export / import state in that stream's
+// order anyway) and only that stream is waited for; NULL: the whole device is (taco_get_step_count / taco_set_step_count have no stream).
+// Synchronising while a stream is capturing is illegal (it would invalidate the capture): TACO_ERR_STATE instead.
+int refresh_clock(taco_env *e, void *stream = nullptr) {
+    if (e->capture_stream != nullptr) {
+        if (is_capturing(e->capture_stream) || is_capturing(stream))
+            return fail(TACO_ERR_STATE, "the step clock cannot be read back while a stream is capturing launches of this handle: end the capture first "
+                                        "(taco_get_step_count / taco_set_step_count / taco_get_state / taco_set_state / taco_get_field / an eager taco_rollout_run synchronise)");
+        e->capture_stream = nullptr;
+    }
     if (!e->clock_on_device) return TACO_OK;
     uint32_t c[3];
-    hipError_t he = hipDeviceSynchronize();
-    if (he == hipSuccess) he = hipMemcpy(c, e->ctl, sizeof(c), hipMemcpyDeviceToHost);
+    hipError_t he;
+    if (stream != nullptr) {
+        he = hipMemcpyAsync(c, e->ctl, sizeof(c), hipMemcpyDeviceToHost, (hipStream_t)stream);
+        if (he == hipSuccess) he = hipStreamSynchronize((hipStream_t)stream);
+    } else {
+        he = hipDeviceSynchronize();
+        if (he == hipSuccess) he = hipMemcpy(c, e->ctl, sizeof(c), hipMemcpyDeviceToHost);
+    }
     if (he != hipSuccess) return hip_fail(he, "reading the device-resident step clock");
     e->step_count = (e->step_count & ~(int64_t)0xffffffff) | c[taco::kCtlStep];  // (the kernel's Philox counter is the low 32 bits)
     e->head = (int)c[taco::kCtlHead];
@@ -526,10 +554,18 @@ int64_t taco_get_step_count(taco_env *e) {
     if (refresh_clock(e) != TACO_OK) return -1;
     return e->step_count;
 }
+int64_t taco_peek_step_count(const taco_env *e) { return e ? e->step_count : -1; }
+// The device-resident copy of the clock is set as well: a capture may be the very next launch (checkpoint restore -> capture -> replay), and a
+// captured step reads its Philox counter from there.  (Ring head and history row are not part of a checkpoint -- the blob is in logical
+// order -- and their device copies already equal the host's: every eager launch mirrors them.)
 int taco_set_step_count(taco_env *e, int64_t n) {
     if (!e || n < 0) return fail(TACO_ERR_INVALID_ARG, "taco_set_step_count: bad argument");
     const int rc = refresh_clock(e);
     if (rc != TACO_OK) return rc;
+    const uint32_t word = (uint32_t)n;
+    hipError_t he = hipDeviceSynchronize();   // an eager step still in flight would overwrite the word with ITS successor
+    if (he == hipSuccess) he = hipMemcpy(e->ctl + taco::kCtlStep, &word, sizeof(word), hipMemcpyHostToDevice);
+    if (he != hipSuccess) return hip_fail(he, "writing the device-resident step clock");
     e->step_count = n;
     return TACO_OK;
 }
@@ -554,7 +590,7 @@ __global__ void export_field_kernel(const float *S, const float *hist, uint32_t 
     float val;
     if (field == TACO_S_PROGRESS) val = __builtin_bit_cast(float, taco::pw_progress(__builtin_bit_cast(uint32_t, word(Sm, npad, i, TACO_S_PROGRESS))));
     else if (field == TACO_S_DELAY_LEN) val = __builtin_bit_cast(float, taco::dw_L(__builtin_bit_cast(uint32_t, word(Sm, npad, i, TACO_S_DELAY_LEN))));
-    else if (field >= TACO_S_ACT && field < TACO_S_ACT + 4) val = hist[taco::tile_word(taco::HIST_ROWS, (hh - 1) & (taco::HIST_ROWS - 1), i) + (field - TACO_S_ACT)];
+    else if (field >= TACO_S_ACT && field < TACO_S_ACT + 4) val = last_action(Sm, hist, npad, i, hh, field - TACO_S_ACT);
     else val = word(Sm, npad, i, field);
     out[i] = __builtin_bit_cast(uint32_t, val);
 }
@@ -564,7 +600,7 @@ int taco_get_field(taco_env *e, int field, uint32_t *out, void *stream) {
     if (!e || !out) return fail(TACO_ERR_INVALID_ARG, "taco_get_field: null argument");
     if (field < 0 || field >= TACO_NUM_FIELDS || (field >= TACO_S_ACT_OLD && field < TACO_S_ACT_OLD + 4))
         return fail(TACO_ERR_INVALID_ARG, "taco_get_field: field must be a TACO_S_* row other than actions_old (use taco_get_state for that)");
-    const int rc = refresh_clock(e);
+    const int rc = refresh_clock(e, stream);
     if (rc != TACO_OK) return rc;
     const int n = e->cfg.num_envs;
     hipLaunchKernelGGL(export_field_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->S, e->hist, out, field, n, e->npad, e->hh);
@@ -574,7 +610,7 @@ int taco_get_field(taco_env *e, int field, uint32_t *out, void *stream) {
 
 int taco_get_state(taco_env *e, uint32_t *blob, void *stream) {
     if (!e || !blob) return fail(TACO_ERR_INVALID_ARG, "taco_get_state: null argument");
-    if (refresh_clock(e) != TACO_OK) return TACO_ERR_HIP;
+    { const int rc = refresh_clock(e, stream); if (rc != TACO_OK) return rc; }
     const int n = e->cfg.num_envs;
     hipLaunchKernelGGL(export_state_kernel, dim3((n + 255) / 256, TACO_BLOB_ROWS), dim3(256), 0, (hipStream_t)stream, e->S, e->hist, e->ring, blob, n,
                        e->npad, e->head, e->hh);
@@ -584,7 +620,7 @@ int taco_get_state(taco_env *e, uint32_t *blob, void *stream) {
 
 int taco_set_state(taco_env *e, const uint32_t *blob, void *stream) {
     if (!e || !blob) return fail(TACO_ERR_INVALID_ARG, "taco_set_state: null argument");
-    if (refresh_clock(e) != TACO_OK) return TACO_ERR_HIP;
+    { const int rc = refresh_clock(e, stream); if (rc != TACO_OK) return rc; }
     const int n = e->cfg.num_envs;
     hipLaunchKernelGGL(import_state_kernel, dim3((n + 255) / 256, TACO_BLOB_ROWS), dim3(256), 0, (hipStream_t)stream, e->S, e->hist, e->ring, blob, n,
                        e->npad, e->head, e->hh);
@@ -778,11 +814,8 @@ int taco_rollout_run(taco_env *e, const taco_policy_cfg *c, const float *blob, c
     const size_t obs_slot = n * ec.len_obs * 26, st_slot = n * ec.len_states * 26;
     // On a capturing stream the env's clock lives on the device (launch_step); the actor then takes its noise counter from it too:
     // counter of step t = call0 + t = (device step word) + (call0 - step count at the start of the rollout), whatever replay this is.
-    {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (stream != nullptr && hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) e->clock_on_device = 1;
-        else if ((rc = refresh_clock(e)) != TACO_OK) return rc;   // eager, after replays: the host's clock is made current first (blocking, once)
-    }
+    if (is_capturing(stream)) note_capture(e, stream);
+    else if ((rc = refresh_clock(e, stream)) != TACO_OK) return rc;   // eager, after replays: the host's clock is made current first (blocking, once)
     const uint32_t *clock = e->clock_on_device ? e->ctl + taco::kCtlStep : nullptr;
     const uint32_t call_delta = call0 - (uint32_t)e->step_count;
     for (int t = 0; t < horizon; ++t) {

@@ -1,12 +1,14 @@
 // taco_step.hpp -- the fused VecTask.step() kernel for gfx950 (MI355X).
 //
-// One lane = one env.  All persistent per-env state lives in HBM as a structure of arrays (field-major,
-// stride npad = num_envs rounded up to 64), so every state load/store of a wavefront is one fully coalesced 256-byte
-// access.  One launch performs, for every env: reset + domain randomisation (if its reset flag is set), the
-// pending-action delay line, 10 x [euler unwrap, body rates, rate PID, allocator, battery sag, rotor first-order
-// lag, aero, rigid-body integrate], then the relative state, the 26-D observation / state frames (transposed through a
-// per-wavefront LDS tile so the [env][frame][26] rows are written with coalesced stores), the task reward and the
-// done / time-out flags.  No MFMA: this is element-wise ODE integration, the largest contraction is 4x4 . 4.
+// All persistent per-env state lives in HBM as 16 float4 CHUNKS per env, TILE-major (tiles of 64 consecutive envs: chunk c of env i at
+// byte (((i >> 6) * 16 + c) * 64 + (i & 63)) * 16, see "workspace layout" below), so every state load / store of a wavefront is ONE
+// fully coalesced 16-byte-per-lane access and everything a wavefront touches of an array is one contiguous block.  One lane = one env
+// in the throughput forms, four lanes = one env ("quad layout") in the latency forms (see the instantiation table above the kernel).
+// One launch performs, for every env: reset + domain randomisation (if its reset flag is set), the pending-action delay line,
+// 10 x [euler unwrap, body rates, rate PID, allocator, battery sag, rotor first-order lag, aero, rigid-body integrate], then the relative
+// state, the 26-D observation / state frames (transposed through a per-wavefront LDS tile so the [env][frame][26] rows are written with
+// coalesced stores), the task reward and the done / time-out flags.  No MFMA: this is element-wise ODE integration, the largest
+// contraction is 4x4 . 4.
 //
 // Reference lines restated by each block are cited inline (FA = isaacgymenvs/tasks/fpv_asymmetry.py,
 // VT = tasks/base/vec_task_asymmetry.py, CTRL = tasks/control/, TU = python/isaacgym/torch_utils.py,
@@ -15,6 +17,10 @@
 #include <type_traits>
 #include "taco_math.hpp"
 #include "../../include/taco_env.h"
+
+#ifndef TACO_AB_RT
+#define TACO_AB_RT 0  // A/B builds only: 1 = the PLAIN loop forms do the world-rate round trip as well (cost measurement, profiles/r03_a_*)
+#endif
 
 namespace taco {
 
@@ -815,7 +821,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
                     : (gid < P.mix_n1 ? TACO_TASK_POS : (gid < P.mix_n2 ? TACO_TASK_ROTATE : TACO_TASK_FLIP));
     const bool mix = P.task_mode == TACO_TASK_MIX;
     // copter_rpy_continuous is consumed only by the flip command (FA:831, :930); other envs keep their reset-time value
-    const bool track_rpy = grp == TACO_TASK_FLIP;
+    const bool track_rpy = grp == TACO_TASK_FLIP || (fl & TACO_F_TRACK_RPY) != 0;  // (record_flag: every env, as the reference does)
     // wave-uniform form of the same predicate: the euler/unwrap block runs for a whole wavefront or not at all (lanes of
     // other tasks then compute values nobody reads), which keeps the substep loop free of divergent control flow
     const bool wave_tracks_rpy = __builtin_amdgcn_ballot_w64(track_rpy) != 0;
@@ -1112,7 +1118,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
     // wave-uniform euler/unwrap switch (flip envs) the PLAIN forms of the loop have these decided at compile time (no branches over the unused blocks, integrator
     // unrolled; a lone wavefront pays ~10 issue slots for every taken branch)
     const Consts Crt{P.dt, P.rdt, P.h, P.half_h, P.inv_m, P.g, P.J0, P.J1, P.J2, P.hJi0, P.hJi1, P.hJi2, P.arm_x, P.arm_y};
-    const bool plain1 = !(fl & TACO_F_ROTOR_NOISE) && P.substeps == 2 && (fl & TACO_F_BATTERY_CONSUMPTION) != 0;  // (+ bit 3 of the form: euler/unwrap on or off)
+    const bool plain1 = !(fl & (TACO_F_ROTOR_NOISE | TACO_F_WORLD_RATE_ROUNDTRIP)) && P.substeps == 2 && (fl & TACO_F_BATTERY_CONSUMPTION) != 0;  // (+ bit 3 of the form: euler/unwrap on or off)
     // one lane per env: the PLAIN forms also carry the default airframe's constants as literals (kPlainConsts: the handle has exactly those)
     const bool plain = plain1 && (LPE != 1 || (fl & kPlainConsts) != 0);
     if constexpr (LPE == 1) {
@@ -1225,7 +1231,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
             if (wave_has_reset) {  // (wave-uniform: normally skipped)
                 if (is_reset) { F = V3{0.0f, 0.0f, 0.0f}; tq = V3{0.0f, 0.0f, 0.0f}; }  // FA:629-630: no force during the reset step
             }
-            return integrate<PLAIN ? 2 : 0>(C, P.substeps, p, q, v, wb, F, tq);
+            const bool rare = integrate<PLAIN ? 2 : 0>(C, P.substeps, p, q, v, wb, F, tq);
+            if ((!PLAIN && (fl & TACO_F_WORLD_RATE_ROUNDTRIP)) || (PLAIN && TACO_AB_RT)) {  // the reference's data flow (FA:350): the rates pass through the root state
+                const V3 ww = quat_sandwich(q, wb);
+                wb = quat_rotate(conj(q), ww);
+            }
+            return rare;
         };
         // the FIN form of the loop runs while `fin` holds (normally all ten substeps), the exact form takes over at the first rare form
         int ks = 0;
@@ -1393,7 +1404,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
                 Fq = from_bits(bits(selm(k2, Fz, dragq * vbq)) & keep);
                 tqq = from_bits(bits(selm(k2, tz, txy)) & keep);
             }
-            return integrate_quad<PLAIN ? 2 : 0>(P, k3, pq, qq, vq, bq, Fq, tqq, Jq, hJiq, gzq, sm3);
+            const bool rare = integrate_quad<PLAIN ? 2 : 0>(P, k3, pq, qq, vq, bq, Fq, tqq, Jq, hJiq, gzq, sm3);
+            if ((!PLAIN && (fl & TACO_F_WORLD_RATE_ROUNDTRIP)) || (PLAIN && TACO_AB_RT)) {  // FA:350 literally: w = R(q) b (quat_sandwich), b = quat_rotate(conj(q), w), lane j = component j
+                const float ww = bc3(qq), q1 = rot1(qq), q2 = rot2(qq);
+                float t = fma(q1, rot2(bq), -(q2 * rot1(bq)));
+                t = t + t;
+                const float wq = fma(q1, rot2(t), fma(-q2, rot1(t), fma(ww, t, bq)));
+                bq = from_bits(bits(quad_rotate(-qq, ww, wq)) & ~k3);  // (lane 3 holds no rate component: kept at +0)
+            }
+            return rare;
         };
         int ks = 0;
         auto run_form = [&](auto form) {

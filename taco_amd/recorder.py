@@ -41,6 +41,10 @@ class EpisodeRecorder:
     def record(self, env, env_index=0):
         """one row of env `env_index` at the RL rate, with the reference's key names (fpv_asymmetry.py:657-696) for
         everything the kernel keeps; call after env.step().  Starts a new file set when the env was just reset."""
+        if not env.tracks_rpy(env_index):
+            raise _lib.TacoError("EpisodeRecorder.record: copter_rpy_continuous of this env is not kept up to date -- the step kernel maintains it for "
+                                 "flip envs only unless the env was created with cfg['record_flag'] = True (as the reference's test mode does, "
+                                 "fpv_asymmetry.py:113-117, train_fpv_asymmetry_ppo.py:349-352)")
         blob = env.get_state()[:_lib.NUM_FIELDS, env_index].cpu().numpy()
         progress = int(blob[65:66].view(np.int32)[0])
         if progress == 1 and self.episode_dict:     # fpv_asymmetry.py:514-517: dump + reset when env 0 is reset

@@ -135,6 +135,13 @@ class RolloutBuffer:
                              self.rew_buf.data_ptr(), self.done_buf.data_ptr(), self.value_buf.data_ptr(), self.logp_buf.data_ptr(),
                              self.mu_buf.data_ptr(), self.sigma_buf.data_ptr(), self._timeouts.data_ptr(), self._last_value.data_ptr(),
                              policy.critic_workspace((H + 1) * N).data_ptr())
+        # The actor's noise counter is (env step word) + call_delta on a capturing stream (taco_rollout_run), so replays of a captured rollout
+        # consume counters the Python-side policy.calls never sees: the first EAGER run() after replays re-derives it from the env's clock.
+        if torch.cuda.is_current_stream_capturing():
+            self._captured = True
+        elif getattr(self, "_captured", False):
+            self.sync_policy_counter(env, policy)
+        self._call_delta = (policy.calls - self.lib.taco_peek_step_count(env._h)) & 0xffffffff   # == the C side's call_delta for this call
         s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(self.lib.taco_rollout_run(env._h, C.byref(policy.cfg), policy._blob.data_ptr(), C.byref(b), H, C.c_uint64(policy.seed),
                                              C.c_uint32(policy.calls), float(self.gamma), float(act_low), float(act_high),
@@ -142,6 +149,14 @@ class RolloutBuffer:
         policy.calls += H
         self.step = H
         return self._last_value
+
+    def sync_policy_counter(self, env, policy):
+        """After replays of a captured run(): set policy.calls to the counter the NEXT rollout step will use (env step count + the offset the
+        captured rollout was recorded with), so that eager policy.act() / run() calls draw fresh noise instead of repeating the streams the
+        replays consumed.  run() does this by itself; call it before going back to policy.act() by hand.  Blocks (re-reads the device clock)."""
+        if getattr(self, "_call_delta", None) is not None:
+            policy.calls = (env.step_count + self._call_delta) & 0xffffffff
+        self._captured = False
 
     @property
     def time_outs(self):

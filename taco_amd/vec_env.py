@@ -137,6 +137,20 @@ class FpvBase:
         _lib.check(self.lib.taco_get_field(self._h, _lib.NUM_FIELDS - 2, self._progress.data_ptr(), _stream_ptr(self.device).value), self.lib)
         return self._progress.to(torch.long)
 
+    @property
+    def randomize_buf(self):
+        """vec_task_asymmetry.py:252 / fpv_asymmetry.py:376: incremented by one per step() for every env and never cleared on this path
+        (its only consumer, apply_randomizations, is never called by the task) -- i.e. the number of steps taken"""
+        return torch.full((self.num_envs,), int(self.step_count), device=self.device, dtype=torch.long)
+
+    def tracks_rpy(self, env_index=0):
+        """is copter_rpy_old / copter_rpy_continuous (blob rows 20..25) of this env kept up to date?  (flip envs always; every env with
+        cfg['record_flag'], TACO_F_TRACK_RPY)"""
+        if self._flat.get("record_flag", False):
+            return True
+        mode, gid = self._flat["task_mode"], self.env_offset + int(env_index)
+        return mode == "flip" or (mode == "mix" and gid >= int(self.num_envs_global / 3 * 2))
+
     def check(self):
         """raise if any step kernel recorded a sticky error since the env was created (blocks on the current stream)"""
         _lib.check(self.lib.taco_check(self._h, _stream_ptr(self.device).value), self.lib)
@@ -192,7 +206,12 @@ class FpvBase:
         _lib.check(self.lib.taco_step_rollout(self._h, C.byref(io), _stream_ptr(self.device)))
 
     def step(self, actions):
-        """vec_task_asymmetry.py:290-334: ONE kernel launch (the clamped obs / states copies are written by the step kernel)."""
+        """vec_task_asymmetry.py:290-334: ONE kernel launch (the clamped obs / states copies are written by the step kernel).
+
+        ALIASING CONTRACT (differs from the reference, which returns freshly allocated clamped tensors): the returned obs / states tensors
+        are two persistent buffer pairs used alternately -- what step t returned is overwritten by step t + 2; rew / done / time_outs are
+        the env's own buffers, overwritten by step t + 1.  The PPO loop copies them into its replay buffer straight away
+        (ppo_asymmetry.py:326-329), which is the intended use; a caller that keeps observations across more than one step must clone()."""
         if not self._want_out:
             self.step_raw(actions)
             self.obs_dict["obs"], self.obs_dict["states"] = self.obs_buf.to(self.rl_device), self.states_buf.to(self.rl_device)
@@ -211,8 +230,19 @@ class FpvBase:
         return self.obs_dict, self.rew_buf.to(self.rl_device), self.reset_buf.to(self.rl_device), self.extras
 
     def reset_idx(self, env_ids):
-        """Mark envs for reset; like the reference, the re-initialisation itself runs at the start of the next step()."""
-        self.reset_buf[env_ids] = 1
+        """fpv_asymmetry.py:475-517: re-initialise the envs `env_ids` NOW (fresh state, controller memory, delay line, target; command
+        re-drawn for them and for envs at progress 500; progress_buf and reset_buf of `env_ids` cleared, :510-511) -- one launch of the
+        RESET_ONLY instantiation on a scratch mask, the step clock does not advance.  Inside step() the same reset is fused into the step
+        kernel, driven by reset_buf; to only MARK envs for the next step() write env.reset_buf[ids] = 1, as the reference's callers do."""
+        ids = torch.as_tensor(env_ids, device=self.device, dtype=torch.long).flatten()
+        if ids.numel() == 0:
+            return
+        if not hasattr(self, "_reset_mask"):
+            self._reset_mask = torch.zeros(self.num_envs, device=self.device, dtype=torch.long)
+        self._reset_mask.zero_()
+        self._reset_mask[ids] = 1
+        _lib.check(self.lib.taco_reset_done(self._h, self._reset_mask.data_ptr(), _stream_ptr(self.device).value), self.lib)
+        self.reset_buf[ids] = 0
 
     def reset_done(self):
         """vec_task_asymmetry.py:363-375: reset_idx on the flagged envs NOW (taco_reset_done: fresh state and command, reset_buf and
@@ -239,7 +269,10 @@ class FpvBase:
 
     @property
     def step_count(self):
-        return self.lib.taco_get_step_count(self._h)
+        n = self.lib.taco_get_step_count(self._h)
+        if n < 0:
+            raise _lib.TacoError(f"libtaco_env: taco_get_step_count failed: {self.lib.taco_last_error().decode()}")
+        return n
 
     @step_count.setter
     def step_count(self, n):

@@ -43,12 +43,19 @@ def test_vectask_surface_matches_the_reference_contract():
         prog = env.progress_buf
         assert (prog[done != 0] >= 1).all() and (prog <= 50).all()
     assert saw_timeout
-    # reset_idx marks envs; the reset happens inside the next step
-    env.reset_idx(torch.tensor([3, 5], device="cuda"))
+    # writing reset_buf marks envs for the next step (or for reset_done()); reset_idx(ids) re-initialises NOW, like the reference's (FA:475-517)
+    env.reset_buf[[3, 5]] = 1
     obs, ids = env.reset_done()
     assert {3, 5} <= set(ids.tolist())
     env.step(a)
     assert (env.progress_buf[[3, 5]] == 1).all()
+    before, n0 = env.get_state()[:13, 7].clone(), env.step_count
+    env.reset_buf[9] = 1
+    env.reset_idx(torch.tensor([7, 9], device="cuda"))
+    assert (env.progress_buf[[7, 9]] == 0).all() and not env.reset_buf[[7, 9]].any() and not torch.equal(env.get_state()[:13, 7], before)
+    assert env.step_count == n0 == 63 and torch.equal(env.randomize_buf, torch.full((128,), 63, device="cuda"))   # (VT:252, FA:376: += 1 per step)
+    env.step(a)
+    assert (env.progress_buf[[7, 9]] == 1).all()
     # difficulty is writable and read back (ppo_asymmetry.py:173-175)
     env.difficulty = 0.25
     assert env.difficulty == 0.25 and cfg["difficulty"] == 0.25
@@ -206,6 +213,30 @@ def test_checkpoint_file_roundtrip_and_recorder(tmp_path):
     assert pos.ndim == 2 and pos.shape[1] == 3
 
 
+def test_recorder_logs_the_live_rpy_continuous_of_a_pos_env(tmp_path):
+    """FA:346, :662: the reference logs the LIVE copter_rpy_continuous of env 0 whatever the task.  The kernel maintains it for flip envs
+    only unless cfg['record_flag'] is set: the recorder refuses an env that does not keep it, and with the flag its rows equal the oracle's."""
+    from oracle import oracle as O
+    from taco_amd._lib import TacoError
+    from taco_amd.recorder import EpisodeRecorder
+    from taco_amd.vec_env import FpvPos
+    with pytest.raises(TacoError, match="record_flag"):
+        EpisodeRecorder(str(tmp_path / "x")).record(FpvPos(config.default_cfg("pos", 64), copy_outputs=False))
+    cfg = config.default_cfg("pos", 64, record_flag=True, record_path=str(tmp_path / "rec"), env_maxEpisodeLength=60)
+    env, orc = FpvPos(cfg, copy_outputs=False), O.OracleEnv(config.flat_cfg(cfg))
+    rec = EpisodeRecorder(cfg["record_path"])
+    g = torch.Generator().manual_seed(1)
+    exp = []
+    for t in range(100):
+        a = (0.5 * torch.randn(64, 4, generator=g)).clamp(-1, 1)
+        a[:, 0] -= 0.2
+        env.step_raw(a.cuda()); orc.step(a.numpy()); rec.record(env)
+        exp.append(orc.get_state().view(np.float32)[23:26, 0].copy())
+    rec.dump_buffer()
+    got = np.concatenate([np.load(tmp_path / "rec" / f"copter_rpy_continuous{k}.npy") for k in range(rec.dump_index)])
+    assert np.array_equal(got, np.array(exp)) and np.ptp(got, axis=0).max() > 0.5, "rows 23..25 of a pos env must be live, not the reset-time value"
+
+
 def test_checkpoint_restores_across_shardings():
     """A checkpoint of one 600-env run restores two shards of it (250 + 350 envs, as two ranks would hold them), and the two shards'
     checkpoints merge()d restore a 600-env run again -- everything continues bit-identically (every per-env word is a blob column and
@@ -308,6 +339,54 @@ def test_step_is_graph_capturable_and_replays_continue_the_run():
     assert torch.equal(a_env.get_state().view(torch.int32), b_env.get_state().view(torch.int32))
     assert_bits_equal(a_env.obs_buf.cpu().numpy(), b_env.obs_buf.cpu().numpy(), "eager steps after the replays")
     a_env.check(); b_env.check()
+
+
+def test_capture_as_the_first_launch_after_a_checkpoint_restore():
+    """A restored env whose FIRST launch is a capture: taco_set_step_count (checkpoint.load_state_dict) must have put the step count into
+    the device-resident clock too, or every replay would draw from the Philox counters of step 0.  Replays vs the eager twin, bit for bit.
+    Also: reading the clock back while the capture is in progress is refused (TACO_ERR_STATE) instead of invalidating the capture."""
+    from taco_amd import checkpoint
+    from taco_amd._lib import TacoError
+    from taco_amd.vec_env import FpvBase
+    n = 500
+    kw = dict(env_maxEpisodeLength=30, env_lenStates=2, seed=9, ramdom_deploy_time=True, observation_noise=True, rotor_noise=True)
+    twin = FpvBase(config.default_cfg("mix", n, **kw), copy_outputs=False)
+    g = torch.Generator().manual_seed(4)
+    acts = (0.3 * torch.randn((8, n, 4), generator=g)).clamp(-1, 1).cuda()
+    for t in range(21):
+        twin.step_raw(acts[t % 8])
+    sd = checkpoint.state_dict(twin)
+    env = FpvBase(config.default_cfg("mix", n, **kw), copy_outputs=False)      # fresh handle: its device clock reads step 0
+    checkpoint.load_state_dict(env, sd)
+    act = torch.zeros((n, 4), device="cuda")
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        graph.capture_begin()
+        env.step_raw(act)
+        with pytest.raises(TacoError, match="capturing"):
+            env.get_state()
+        with pytest.raises(TacoError, match="capturing"):
+            env.step_count
+        graph.capture_end()
+    torch.cuda.current_stream().wait_stream(s)
+    for t in range(21, 70):
+        act.copy_(acts[t % 8])
+        graph.replay()
+        twin.step_raw(acts[t % 8])
+        if t % 8 == 0 or t == 69:
+            for name in ("obs_buf", "states_buf", "rew_buf", "reset_buf", "timeout_buf"):
+                assert_bits_equal(getattr(env, name).cpu().numpy(), getattr(twin, name).cpu().numpy(), f"replay {t} {name}")
+    assert env.step_count == twin.step_count == 70
+    assert torch.equal(env.get_state().view(torch.int32), twin.get_state().view(torch.int32))
+    # the one-row export agrees with the blob on the `actions` row of an env that has not stepped since its reset (FA:572: zeros)
+    env.reset_idx(torch.tensor([3], device="cuda"))
+    out = torch.empty(n, device="cuda")
+    from taco_amd import _lib
+    _lib.check(env.lib.taco_get_field(env._h, 40, out.data_ptr(), None), env.lib)
+    assert out[3] == 0 and torch.equal(out, env.get_state()[40])
 
 
 @pytest.mark.parametrize("n,len_states,form", [(300, 1, "auto"), (300, 5, "auto"), (70000, 1, "auto"), (20000, 5, "auto"), (300, 3, "lane"), (300, 3, "quad")])

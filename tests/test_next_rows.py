@@ -79,6 +79,22 @@ def test_schedules_match_the_reference_formulas():
     assert all(a[0] >= b[0] - 1e-18 and a[1] >= b[1] - 1e-12 and a[2] <= b[2] + 1e-12 for a, b in zip(vals, vals[1:]))  # (the ramp overshoots its end value by 1 ulp at the knot, as the reference's does)
 
 
+def test_schedules_equal_the_references_update_preamble():
+    """Row N3 pinned by fixture: tests/golden/schedules.npz holds what the reference's OWN `PPO.update(epoch)` preamble (ppo_asymmetry.py:142-175,
+    executed on a stub self by tests/golden/make_schedules_golden.py) yields for every epoch -- constructor defaults, two other knot sets and all
+    schedules off.  `Schedules.at(epoch)` must return the same three doubles, bit for bit."""
+    import ast
+    from taco_amd.train_utils import Schedules
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "schedules.npz"))
+    for case in ("defaults", "long", "short", "off"):
+        s = Schedules(**dict(ast.literal_eval(str(g[case + "_kw"]))))
+        ref = g[case]
+        assert ref.shape == (s.epochs + 1, 3)
+        got = np.array([s.at(e) for e in range(s.epochs + 1)], np.float64)
+        assert np.array_equal(got, ref), f"{case}: first difference at epoch {np.argwhere(got != ref)[0]}"
+    assert np.allclose(g["defaults"][250], [1.5e-4, 3.25, 0.55], rtol=1e-12)
+
+
 def test_spectral_clamp_and_torchscript_export(tmp_path):
     """Row N3: spectral_normalize_actors (:398-404) and save_actor_as_pt (:458-468) on the golden policy's actor."""
     import torch

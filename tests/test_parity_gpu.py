@@ -38,6 +38,8 @@ def run_pair(cfg, steps, seed=0, check_every=1, hover_bias=False, form="auto", l
         flip_envs = gids >= int(n / 3 * 2)
     else:
         flip_envs = np.full(n, flat["task_mode"] == "flip")
+    if flat.get("record_flag", False):
+        flip_envs = np.full(n, True)   # record_flag: the kernel keeps copter_rpy_continuous current for every env (TACO_F_TRACK_RPY)
     acts = action_stream(n, steps, seed)
     if hover_bias:
         acts[:, :, 0] = np.clip(acts[:, :, 0] + 0.25, -1, 1)
@@ -347,3 +349,89 @@ def test_reset_done_resets_now_like_the_reference():
             assert_bits_equal(env.obs_buf.cpu().numpy(), orc.obs_buf, f"step {t} obs")
             assert_bits_equal(env.rew_buf.cpu().numpy(), orc.rew_buf, f"step {t} rew")
     assert resets > 50
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# The chain HIP kernel -> the reference's own VecTask.step(), closed directly: the glue fixtures (tests/golden/glue_*.npz, traces of
+# fpv_asymmetry.py + vec_task_asymmetry.py running on CPU, tests/golden/make_glue_golden.py) replayed through the HIP env -- same cfg,
+# seed and actions -- and compared with what the REFERENCE held after every recorded step, with no oracle in between.  EXACT: flags,
+# progress, delay length, the whole 400-word pending-action line, actions, parameters, pos / rotate commands; continuous state within the
+# tolerances of tests/util.py::GLUE_TOL.  Both arithmetic modes of the angular rate (see tests/test_oracle_golden.py): the product's
+# default ("carried") and the reference's literal data flow ("roundtrip", cfg["world_rate_roundtrip"] = True), the latter also bit for
+# bit against the oracle in the same mode.  Measured maxima, HIP vs the reference's run (identical to the oracle's, as they must be):
+#   carried  : root state 1.6e-3, obs / states 5.2e-4, reward 1.4e-6        roundtrip: 3.8e-4, 1.3e-4, 6.5e-7
+# ---------------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["carried", "roundtrip"])
+@pytest.mark.parametrize("case", ["pos", "overflow", "deploy", "rotate", "flip", "mix"])
+def test_hip_kernel_equals_the_references_own_step(case, mode, golden):
+    from taco_amd.vec_env import FpvBase
+    from util import check_against_glue_fixture, check_glue_trace_content, glue_case
+    g = golden("glue_" + case)
+    cfg, acts, rec_steps = glue_case(g)
+    cfg["world_rate_roundtrip"] = mode == "roundtrip"
+    cfg["record_flag"] = True   # rows 20..25 (copter_rpy_old / _continuous) of every env are compared, as the reference maintains them
+    env = FpvBase(cfg, copy_outputs=False)
+    acts_d = torch.from_numpy(acts).cuda()
+    seen, maxima = {}, {}
+    for t in range(acts.shape[0]):
+        env.step_raw(acts_d[t])
+        if t in rec_steps:
+            check_against_glue_fixture(g, rec_steps[t], f"HIP glue_{case} [{mode}] step {t}", env.get_state().cpu().numpy(), env.obs_buf.cpu().numpy(),
+                                       env.states_buf.cpu().numpy(), env.rew_buf.cpu().numpy(), env.reset_buf.cpu().numpy(),
+                                       env.timeout_buf.cpu().numpy(), maxima, seen)
+    check_glue_trace_content(case, seen)
+    env.check()
+    print(f"HIP glue_{case} [{mode}] maxima: " + ", ".join(f"{k} {v:.2e}" for k, v in maxima.items()))
+
+
+@pytest.mark.parametrize("form", ["quad_roles", "quad", "lane", "lane_roles", "lane_throughput"])
+def test_world_rate_roundtrip_mode_equals_the_oracle_bitwise(form):
+    """the reference's literal data flow of the angular rate (TACO_F_WORLD_RATE_ROUNDTRIP): every instantiation against the oracle in the same mode"""
+    cfg = config.baseline_config(4, num_envs=600)   # mix, every randomisation on, 5 state frames
+    cfg["world_rate_roundtrip"] = True
+    run_pair(cfg, steps=120, check_every=10, hover_bias=True, form=form)
+    cfg = config.baseline_config(1, num_envs=300)
+    cfg["world_rate_roundtrip"] = True
+    run_pair(cfg, steps=150, check_every=10, form=form)
+
+
+@pytest.mark.parametrize("task", ["pos", "rotate", "mix"])
+def test_record_flag_tracks_rpy_continuous_for_every_env(task):
+    """record_flag (fpv_asymmetry.py:113): rows 20..25 are live for pos / rotate envs too, as in the reference (FA:339-347) -- what the
+    episode recorder logs (FA:662).  run_pair compares them for every env when the flag is set."""
+    cfg = config.default_cfg(task, 500, record_flag=True, env_maxEpisodeLength=200)
+    for form in ("auto", "lane"):
+        run_pair(cfg, steps=260, check_every=20, hover_bias=True, form=form)
+
+
+def test_reset_idx_resets_the_given_envs_now():
+    """FpvBase.reset_idx(env_ids) (FA:475-517) called from outside a step: those envs get their fresh state at once (taco_reset_done on an id
+    mask), reset_buf / progress_buf of them cleared, nothing else touched; HIP vs oracle word for word, then 30 more steps."""
+    from oracle import oracle as O
+    from taco_amd.vec_env import FpvBase
+    cfg = config.baseline_config(4, num_envs=300)
+    flat = config.flat_cfg(cfg)
+    env, orc = FpvBase(cfg, copy_outputs=False), O.OracleEnv(flat, threads=4)
+    acts = action_stream(300, 60, 5)
+    acts_d = torch.from_numpy(acts).cuda()
+    flip_envs = np.arange(300) >= 200
+    for t in range(60):
+        env.step_raw(acts_d[t]); orc.step(acts[t])
+        if t in (10, 11, 29):
+            ids = np.array([0, 17, 150, 299] if t != 11 else [17, 201])
+            env.reset_idx(torch.from_numpy(ids).cuda()); orc.reset_idx(ids)
+            assert env.step_count == t + 1
+        gb, ob = env.get_state().cpu().numpy(), orc.get_state().view(np.float32)
+        assert_bits_equal(gb[:20], ob[:20], f"step {t} state fields 0..19")
+        assert_bits_equal(gb[26:], ob[26:], f"step {t} state fields 26.. + delay line")
+        assert_bits_equal(gb[20:26][:, flip_envs], ob[20:26][:, flip_envs], f"step {t} rpy of the flip envs")
+        assert_bits_equal(env.reset_buf.cpu().numpy(), orc.reset_buf, f"step {t} reset_buf")
+        assert_bits_equal(env.obs_buf.cpu().numpy(), orc.obs_buf, f"step {t} obs")
+
+
+def test_ducted_airframe_preset():
+    """assets/xml/fpv_with_duct.xml:6 (0.570 kg, J = (1.09e-3, 1.47e-3, 1.226e-3)) through config.airframe(): the general (non-literal) constants"""
+    cfg = config.default_cfg("pos", 500, **config.airframe("with_duct"))
+    assert abs(config.flat_cfg(cfg)["mass"] - 0.5700008) < 1e-9
+    for form in ("auto", "lane", "lane_throughput"):
+        run_pair(cfg, steps=150, check_every=10, form=form)

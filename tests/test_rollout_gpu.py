@@ -167,13 +167,14 @@ def test_rollout_run_is_graph_capturable_and_replays_are_the_next_rollouts():
     def snapshot(buf, env, last):
         return {k: getattr(buf, k).clone() for k in keys} | {"last": last.clone(), "tmo": buf.time_outs.clone()}
 
-    # eager: three rollouts (the buffer carries the final stacks of one into slot 0 of the next, as PPO.run does)
+    # eager: four rollouts (the buffer carries the final stacks of one into slot 0 of the next, as PPO.run does)
     env, pol, buf = FpvBase(cfg, copy_outputs=False), P.ActorCritic(sd, 1, T, seed=5), _buffer(n, H, 1, T)
     eager = []
-    for k in range(3):
+    for k in range(4):
         buf.reset()
         eager.append(snapshot(buf, env, buf.run(env, pol)))
-    eager_state = env.get_state().view(torch.int32).clone()
+        if k == 2:
+            eager_state = env.get_state().view(torch.int32).clone()
 
     # captured: rollout 0 eagerly on a side stream (allocations, warm-up), then rollout 1 captured and replayed twice = rollouts 1 and 2
     env, pol, buf = FpvBase(cfg, copy_outputs=False), P.ActorCritic(sd, 1, T, seed=5), _buffer(n, H, 1, T)
@@ -201,4 +202,13 @@ def test_rollout_run_is_graph_capturable_and_replays_are_the_next_rollouts():
                            eager[0][name].view(torch.int32) if eager[0][name].dtype == torch.float32 else eager[0][name]), name
     assert torch.equal(env.get_state().view(torch.int32), eager_state)
     assert env.step_count == 3 * H
+    # ... and back to EAGER sampling after the replays: the Python-side noise counter (policy.calls) never saw the 2 H counters the replays
+    # consumed; run() re-derives it from the env's clock, so rollout 3 draws fresh noise = the eager twin's rollout 3
+    assert pol.calls == 2 * H
+    buf.reset()
+    got3 = snapshot(buf, env, buf.run(env, pol))
+    assert pol.calls == 4 * H
+    for name in got3:
+        a, b = got3[name], eager[3][name]
+        assert torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a, b.view(torch.int32) if b.dtype == torch.float32 else b), f"eager rollout after replays: {name}"
     env.check()
