@@ -314,16 +314,16 @@ def rollout_entry(n, horizon, dev, torch):
         ts.append((time.perf_counter() - t0) / 4)
     ts.sort()
     rows, T, hd2 = (horizon + 1) * n, env.len_states, hd
-    st = buf._states_store.view(rows, T, 26)
+    st = buf._frames   # the replay store's frame ring [horizon + T][n][26]: what taco_rollout_run's critic pass reads
     for _ in range(3):
-        pol.values(st)
+        pol.values_ring(st)
     torch.cuda.synchronize()
     cs = []
     for _ in range(5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(4):
-            pol.values(st)
+            pol.values_ring(st)
         e1.record()
         torch.cuda.synchronize()
         cs.append(e0.elapsed_time(e1) * 1e-3 / 4)

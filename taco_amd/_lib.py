@@ -24,7 +24,7 @@ FLAG_BITS = {
 # every symbol include/taco_env.h declares
 EXPORTS = ["taco_abi_version", "taco_source_hash", "taco_last_error", "taco_workspace_bytes", "taco_create", "taco_destroy", "taco_step",
            "taco_gather_row_floats", "taco_bind_gather_block", "taco_set_difficulty", "taco_get_step_count", "taco_set_step_count", "taco_get_state", "taco_set_state",
-           "taco_step_kernel_name", "taco_launch_geometry", "taco_set_kernel_form", "taco_get_kernel_form", "taco_check", "taco_get_field", "taco_step_rollout", "taco_reset_done", "taco_gae_workspace_bytes", "taco_gae", "taco_occupancy", "taco_bind_phase_stamps", "taco_policy_blob_floats", "taco_policy_act", "taco_rollout_run", "taco_policy_act_stamped", "taco_critic_values", "taco_critic_workspace_bytes", "taco_peek_step_count"]
+           "taco_step_kernel_name", "taco_launch_geometry", "taco_set_kernel_form", "taco_get_kernel_form", "taco_check", "taco_get_field", "taco_step_rollout", "taco_reset_done", "taco_gae_workspace_bytes", "taco_gae", "taco_occupancy", "taco_bind_phase_stamps", "taco_policy_blob_floats", "taco_policy_act", "taco_rollout_run", "taco_policy_act_stamped", "taco_critic_values", "taco_critic_workspace_bytes", "taco_peek_step_count", "taco_critic_values_ring"]
 
 
 class TacoCfg(C.Structure):
@@ -42,7 +42,7 @@ class RolloutIO(C.Structure):
     """struct taco_rollout_io (include/taco_env.h)"""
     _fields_ = [("actions", C.c_void_p), ("obs_prev", C.c_void_p), ("obs_next", C.c_void_p), ("states_prev", C.c_void_p),
                 ("states_next", C.c_void_p), ("rew", C.c_void_p), ("reset_buf", C.c_void_p), ("timeout_buf", C.c_void_p),
-                ("done_f32", C.c_void_p), ("obs_out", C.c_void_p), ("states_out", C.c_void_p)]
+                ("done_f32", C.c_void_p), ("obs_out", C.c_void_p), ("states_out", C.c_void_p), ("states_newest_only", C.c_int32)]
 
 
 class RolloutBufs(C.Structure):
@@ -119,6 +119,8 @@ def _declare(lib, ab_build=False):
     lib.taco_policy_act_stamped.restype = C.c_int
     lib.taco_critic_values.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.taco_critic_values.restype = C.c_int
+    lib.taco_critic_values_ring.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.taco_critic_values_ring.restype = C.c_int
     lib.taco_critic_workspace_bytes.argtypes = [C.c_void_p, C.c_int64]
     lib.taco_critic_workspace_bytes.restype = C.c_size_t
     lib.taco_rollout_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(RolloutBufs), C.c_int, C.c_uint64, C.c_uint32, C.c_double,

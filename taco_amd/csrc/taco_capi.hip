@@ -49,6 +49,8 @@ struct taco_env {
     int slow_server;
 #endif
     int form;  // TACO_FORM_* the step launches (never TACO_FORM_AUTO here: resolved by choose_form)
+    int form_ring;    // ... and the form of a launch that writes only the newest states frame (taco_rollout_io.states_newest_only)
+    int form_pinned;  // taco_set_kernel_form chose `form`: every launch uses it
     uint32_t *ctl;        // control block (last 256 bytes of the workspace): device-resident step clock + sticky status word
     int clock_on_device;  // a launch was captured into a HIP graph: replays advance the device clock only, the fields above may be stale
                           // (taco_get_step_count re-reads them); until then every launch reads the device clock
@@ -322,11 +324,12 @@ int choose_form(const taco_cfg &c) {
     if (stacks && c.num_envs <= kSplitLaneMaxEnvs) return TACO_FORM_LANE_ROLES;
     return c.num_envs >= kThroughputMinEnvs ? TACO_FORM_LANE_THROUGHPUT : TACO_FORM_LANE;
 }
-void grid_of(const taco_env *e, int *grid, int *block) {
-    const FormInfo f = form_info(e->form);
+void grid_of_form(const taco_env *e, int form, int *grid, int *block) {
+    const FormInfo f = form_info(form);
     *block = f.block;
     *grid = f.split ? (e->cfg.num_envs * f.lpe + 63) / 64 : (e->cfg.num_envs * f.lpe + f.block - 1) / f.block;
 }
+void grid_of(const taco_env *e, int *grid, int *block) { grid_of_form(e, e->form, grid, block); }
 
 }  // namespace
 
@@ -377,6 +380,8 @@ int taco_create(const taco_cfg *cfg, int device, void *workspace, size_t workspa
     e->stamps = nullptr;
     e->params_imported = 0;
     e->form = choose_form(e->cfg);
+    { taco_cfg one = e->cfg; one.len_states = 1; e->form_ring = choose_form(one); }
+    e->form_pinned = 0;
     std::memset(&e->P, 0, sizeof(e->P));
     derive(e);
     hipLaunchKernelGGL(init_state_kernel, dim3((e->npad + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->S, e->hist, e->ring, e->ctl, e->npad,
@@ -419,14 +424,26 @@ int launch_step(taco_env *e, const taco_rollout_io *io, void *stream) {
     P.step = (uint32_t)e->step_count;
     P.obs_bytes = (uint32_t)((size_t)n_envs * e->cfg.len_obs * 26 * sizeof(float));
     P.states_bytes = (uint32_t)((size_t)n_envs * e->cfg.len_states * 26 * sizeof(float));
+    // states_newest_only: `states_next` is ONE frame per env ([num_envs][26], a row of the replay store's frame ring): the launch runs as a
+    // len_states = 1 step -- nothing is shifted, nothing of an older stack is read
+    const bool newest_only = io->states_newest_only != 0 && e->cfg.len_states > 1;
+    if (newest_only) {
+        if (io->states_out) return fail(TACO_ERR_INVALID_ARG, "states_newest_only writes no stack: states_out must be NULL");
+        P.len_states = 1; P.states_bytes = (uint32_t)(n_envs * 26 * sizeof(float)); P.states_prev = P.states;
+    }
     P.gather_row = (uint32_t)taco_gather_row_floats(e->cfg.len_obs);
     P.gather_bytes = (uint32_t)((size_t)n_envs * P.gather_row * sizeof(float));
     P.head = e->head;
     P.hh = e->hh;
     int grid, block;
-    grid_of(e, &grid, &block);
     void *args[] = {&P};
-    hipError_t he = hipLaunchKernel(form_info(e->form, P.obs_out != nullptr || P.states_out != nullptr, wide_form(e->cfg)).fn, dim3(grid), dim3(block), args, 0,
+    // (a handle created with a state stack launches the form chosen for stacks; the newest-frame-only launch of the same handle takes the
+    // form its env count would get WITHOUT one -- the role wavefronts have no history to move -- unless the caller pinned a form)
+    const int form = newest_only && !e->form_pinned ? e->form_ring : e->form;
+    grid_of_form(e, form, &grid, &block);
+    taco_cfg eff = e->cfg;
+    if (newest_only) eff.len_states = 1;
+    hipError_t he = hipLaunchKernel(form_info(form, P.obs_out != nullptr || P.states_out != nullptr, wide_form(eff)).fn, dim3(grid), dim3(block), args, 0,
                                     (hipStream_t)stream);
     if (he == hipSuccess) he = hipGetLastError();
     if (he != hipSuccess) return hip_fail(he, "taco_step_kernel launch");
@@ -730,8 +747,9 @@ static bool critic_batched_form(const taco_policy_cfg *c) {
            p16(c->critic_hidden[0]) == 128 && p16(c->critic_hidden[1]) == 128;
 }
 // cu_limit > 0: the persistent LSTM kernel uses at most that many workgroups (a stream that owns fewer CUs than the device has)
+// ring_n > 0: `states` is a frame ring [slots + states_len - 1][ring_n][states_dim] and row = slot * ring_n + env (taco_policy.hpp, PolicyParams.ring_n)
 static int launch_critic(const taco_policy_cfg *c, const float *blob, size_t rows, const float *states, float *value, float *value_tail, size_t split,
-                         float *workspace, int cu_limit, void *stream, uint64_t *stamps = nullptr) {
+                         float *workspace, int cu_limit, void *stream, uint64_t *stamps = nullptr, int ring_n = 0) {
     if (rows > (size_t)INT_MAX - 64) return fail(TACO_ERR_INVALID_ARG, "critic: too many rows for one launch");
     taco::PolicyParams P{};
     P.obs_len = c->obs_len; P.obs_dim = c->obs_dim; P.states_len = c->states_len; P.states_dim = c->states_dim; P.act_dim = c->act_dim;
@@ -739,7 +757,7 @@ static int launch_critic(const taco_policy_cfg *c, const float *blob, size_t row
     for (int l = 0; l < 4; ++l) { P.actor_hidden[l] = c->actor_hidden[l]; P.critic_hidden[l] = c->critic_hidden[l]; }
     P.blob = blob; P.states = states; P.value = value; P.value_tail = value_tail;
     P.value_split = split > rows ? INT_MAX : (int)split;
-    P.n = (int)rows; P.role0 = 1; P.hT = workspace; P.stamps = (unsigned long long *)stamps;
+    P.n = (int)rows; P.role0 = 1; P.hT = workspace; P.stamps = (unsigned long long *)stamps; P.ring_n = ring_n;
     if (critic_batched_form(c)) {
         if (!workspace || ((uintptr_t)workspace & 15u) != 0) return fail(TACO_ERR_INVALID_ARG, "critic: the batched form needs a 16-byte aligned workspace (taco_critic_workspace_bytes)");
         if (((uintptr_t)states & 15u) != 0) return fail(TACO_ERR_INVALID_ARG, "critic: the batched form needs 16-byte aligned state stacks");
@@ -778,6 +796,17 @@ int taco_critic_values(const taco_policy_cfg *c, const float *blob, int64_t rows
     return launch_critic(c, blob, (size_t)rows, states, value, nullptr, (size_t)rows + 1, (float *)workspace, 0, stream, stamps);
 }
 
+int taco_critic_values_ring(const taco_policy_cfg *c, const float *blob, int64_t slots, int num_envs, const float *frames, float *value, void *workspace,
+                            void *stream) {
+    const int rc = policy_cfg_ok(c);
+    if (rc != TACO_OK) return rc;
+    if (!blob || !frames || !value) return fail(TACO_ERR_INVALID_ARG, "taco_critic_values_ring: null buffer pointer");
+    if (slots < 1 || num_envs < 1) return fail(TACO_ERR_INVALID_ARG, "taco_critic_values_ring: slots and num_envs must be >= 1");
+    if (((uintptr_t)blob & 15u) != 0) return fail(TACO_ERR_INVALID_ARG, "taco_critic_values_ring: the weight blob must be 16-byte aligned");
+    const size_t rows = (size_t)slots * (size_t)num_envs;
+    return launch_critic(c, blob, rows, frames, value, nullptr, rows + 1, (float *)workspace, 0, stream, nullptr, num_envs);
+}
+
 int taco_policy_act_stamped(const taco_policy_cfg *c, const float *blob, int n, const float *obs, const float *states, uint64_t seed, uint32_t call,
                             int deterministic, int action_only, float *action, float *logp, float *value, float *mu, float *sigma, uint64_t *stamps,
                             void *stream) {
@@ -811,7 +840,7 @@ int taco_rollout_run(taco_env *e, const taco_policy_cfg *c, const float *blob, c
     if (c->obs_len != ec.len_obs || c->states_len != ec.len_states || c->obs_dim != 26 || c->states_dim != 26 || c->act_dim != 4)
         return fail(TACO_ERR_INVALID_ARG, "taco_rollout_run: policy and env geometry differ");
     const size_t n = (size_t)ec.num_envs;
-    const size_t obs_slot = n * ec.len_obs * 26, st_slot = n * ec.len_states * 26;
+    const size_t obs_slot = n * ec.len_obs * 26, frame = n * 26;   // states_store is a frame ring: [horizon + len_states][n][26]
     // On a capturing stream the env's clock lives on the device (launch_step); the actor then takes its noise counter from it too:
     // counter of step t = call0 + t = (device step word) + (call0 - step count at the start of the rollout), whatever replay this is.
     if (is_capturing(stream)) note_capture(e, stream);
@@ -827,7 +856,8 @@ int taco_rollout_run(taco_env *e, const taco_policy_cfg *c, const float *blob, c
         taco_rollout_io io{};
         io.actions = b->act_env;
         io.obs_prev = b->obs_store + (size_t)t * obs_slot; io.obs_next = b->obs_store + (size_t)(t + 1) * obs_slot;
-        io.states_prev = b->states_store + (size_t)t * st_slot; io.states_next = b->states_store + (size_t)(t + 1) * st_slot;
+        io.states_prev = nullptr; io.states_next = b->states_store + (size_t)(t + ec.len_states) * frame;   // the newest frame of slot t + 1
+        io.states_newest_only = 1;
         io.rew = b->rew_buf + (size_t)t * n; io.reset_buf = reset_buf; io.timeout_buf = b->timeout_buf + (size_t)t * n;
         io.done_f32 = b->done_buf + (size_t)t * n;
         rc = launch_step(e, &io, stream);
@@ -835,7 +865,7 @@ int taco_rollout_run(taco_env *e, const taco_policy_cfg *c, const float *blob, c
     }
     // the values of all H + 1 state stacks (:311 value of slot t, :341 of the final state) in one launch: slots 0..H-1 -> value_buf, H -> last_value
     const size_t count = (size_t)horizon * n;
-    rc = launch_critic(c, blob, count + n, b->states_store, b->value_buf, b->last_value, count, b->critic_ws, 0, stream);
+    rc = launch_critic(c, blob, count + n, b->states_store, b->value_buf, b->last_value, count, b->critic_ws, 0, stream, nullptr, ec.len_states > 1 ? (int)n : 0);
     if (rc != TACO_OK) return rc;
     hipLaunchKernelGGL(taco::timeout_bootstrap_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, b->rew_buf, b->value_buf, b->done_buf,
                        b->timeout_buf, count, (float)gamma);
@@ -848,6 +878,7 @@ int taco_set_kernel_form(taco_env *e, int form) {
     if (!e) return fail(TACO_ERR_INVALID_ARG, "env is null");
     if (form < TACO_FORM_AUTO || form > TACO_FORM_LANE_THROUGHPUT) return fail(TACO_ERR_INVALID_ARG, "taco_set_kernel_form: unknown form");
     e->form = form == TACO_FORM_AUTO ? choose_form(e->cfg) : form;
+    e->form_pinned = form != TACO_FORM_AUTO;
     return TACO_OK;
 }
 int taco_get_kernel_form(const taco_env *e) { return e ? e->form : TACO_ERR_INVALID_ARG; }

@@ -40,6 +40,9 @@ struct PolicyParams {
     float *value_tail;  // batched critic: rows >= value_split write value_tail[row - value_split] (the rollout's last_value)
     int value_split;
     float *hT;          // batched critic: workspace [n][128], the LSTM's h_T between the two kernels
+    int ring_n;         // critic input layout.  0: state stacks [row][states_len][states_dim].  N > 0: a frame RING [slot + k][N][states_dim] -- row
+                        // = slot * N + env, its frame k is ring row `row + k * N` (the replay store of taco_rollout_run: one frame per step
+                        // instead of a shifted stack per slot; include/taco_env.h taco_rollout_bufs)
     const uint32_t *clock;  // optional: the env's device-resident step word (taco_step.hpp, kCtlStep).  Non-NULL: the noise counter is
     uint32_t call_delta;    // *clock + call_delta instead of `call` -- what makes a captured rollout draw fresh noise at every replay
 };
@@ -314,7 +317,8 @@ TD void critic_body(const PolicyParams &P, float *bufA, float *bufB, float *xs) 
         for (int e = tid; e < T * POL_ROWS * ip; e += 64 * NW) {
             const int t = e / (POL_ROWS * ip), rem = e - t * POL_ROWS * ip, r = rem / ip, k = rem - r * ip;
             const int env = row0 + r;
-            xs[(t * POL_ROWS + r) * POL_XLD + k] = (env < P.n && k < P.states_dim) ? P.states[((size_t)env * T + t) * P.states_dim + k] : 0.0f;
+            const size_t src = P.ring_n > 0 ? ((size_t)env + (size_t)t * (size_t)P.ring_n) * P.states_dim + k : ((size_t)env * T + t) * P.states_dim + k;
+            xs[(t * POL_ROWS + r) * POL_XLD + k] = (env < P.n && k < P.states_dim) ? P.states[src] : 0.0f;
         }
         for (int e = tid; e < POL_ROWS * hp; e += 64 * NW) x[(e / hp) * POL_LD + (e % hp)] = 0.0f;
         __syncthreads();
@@ -392,7 +396,9 @@ TD void critic_body(const PolicyParams &P, float *bufA, float *bufB, float *xs) 
         for (int e = tid; e < POL_ROWS * in; e += 64 * NW) {
             const int r = e / in, k = e - r * in;
             const int env = row0 + r;
-            x[r * POL_LD + k] = (env < P.n && k < kin) ? P.states[(size_t)env * kin + k] : 0.0f;
+            size_t src = (size_t)env * kin + k;
+            if (P.ring_n > 0) { const int t = k / P.states_dim; src = ((size_t)env + (size_t)t * (size_t)P.ring_n) * P.states_dim + (k - t * P.states_dim); }
+            x[r * POL_LD + k] = (env < P.n && k < kin) ? P.states[src] : 0.0f;
         }
         __syncthreads();
     }
@@ -486,11 +492,34 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_kernel(const Pol
     // ---- staging of one block's state stacks: the block's bytes are contiguous in memory (32 rows x T x sd floats), and they are copied
     // AS THEY LIE into xs[half] by LDS-DMA (global_load_lds_dwordx4: no registers -- this kernel has none to spare -- 1 KiB per wavefront
     // instruction); the fragment reads below do the [row][t][sd] addressing and zero the columns beyond sd.
+    // Ring input (P.ring_n = N > 0): frame k of row `row` is ring row `row + k N`, so the 32 rows' frames of ONE timestep are contiguous
+    // (32 x sd floats) whatever slot boundaries the block straddles: T pieces per block, xs[half] = [t][row][sd] instead of [row][t][sd].
+    const bool ring = P.ring_n > 0;
     const size_t total_bytes = (size_t)P.n * T * sd * sizeof(float);
     const int block_bytes = CR_ROWS * T * sd * (int)sizeof(float);
+    const int piece_bytes = CR_ROWS * sd * (int)sizeof(float);   // ring: one timestep of the block
+    const bool ring_dma_ok = ring && (((size_t)P.ring_n * sd * sizeof(float)) & 15u) == 0 && (piece_bytes & 15) == 0;   // 16-byte aligned pieces
     auto stage = [&](int blk, int half) {
         const size_t base = (size_t)blk * block_bytes;
-        if (base + block_bytes <= total_bytes) {  // wave-uniform
+        if (ring) {
+            const size_t row0 = (size_t)blk * CR_ROWS;
+            if (ring_dma_ok && row0 + CR_ROWS <= (size_t)P.n) {  // wave-uniform
+                const int per_piece = (piece_bytes / 16 + 63) / 64;   // wavefront instructions per timestep piece (sd = 26: 208 x 16 B = 4)
+                for (int j = wave; j < T * per_piece; j += POL_NW) {  // (wave-uniform trip count)
+                    const int k = j / per_piece, off = ((j - k * per_piece) * 64 + lane) * 16;
+                    const char *src = reinterpret_cast<const char *>(P.states) + (row0 + (size_t)k * (size_t)P.ring_n) * sd * sizeof(float);
+                    if (off < piece_bytes)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off),
+                                                         (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(xs[half]) + k * piece_bytes + (j - k * per_piece) * 1024), 16, 0, 0);
+                }
+            } else {  // the last, partial block, or pieces that are not 16-byte aligned (odd N): plain loads, zeros for the missing rows
+#pragma unroll 1
+                for (int e = tid; e < T * CR_ROWS * sd; e += 64 * POL_NW) {
+                    const int k = e / (CR_ROWS * sd), rem = e - k * CR_ROWS * sd, row = rem / sd;
+                    xs[half][e] = row0 + row < (size_t)P.n ? P.states[(row0 + (size_t)k * (size_t)P.ring_n) * sd + rem] : 0.0f;
+                }
+            }
+        } else if (base + block_bytes <= total_bytes) {  // wave-uniform
             const char *src = reinterpret_cast<const char *>(P.states) + base;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {  // 32 rows x 8 frames x 32 floats = 2048 pieces of 16 B at most = 4 per thread
@@ -537,12 +566,13 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_kernel(const Pol
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[rt][q] = pf32x4{bq[q], bq[q], bq[q], bq[q]};
-        const float *xt = xh + (r * T + t) * sd + 4 * g;
+        const float *xt = xh + (ring ? (t * CR_ROWS + r) * sd : (r * T + t) * sd) + 4 * g;
+        const int tile_stride = ring ? 16 * sd : 16 * T * sd;   // floats between the two 16-row tiles of the block
 #pragma unroll
         for (int s = 0; s < KSX; ++s) {
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                const float *at = xt + 16 * rt * T * sd + 16 * s;
+                const float *at = xt + rt * tile_stride + 16 * s;
                 float4 a4;
                 if (sd_even) {  // frames start 8-byte aligned
                     const float2 lo = *reinterpret_cast<const float2 *>(at), hi = *reinterpret_cast<const float2 *>(at + 2);

@@ -197,6 +197,22 @@ class ActorCritic:
                                                stamps.data_ptr() if stamps is not None else None, s))
         return out.view(*lead, 1)
 
+    def values_ring(self, frames):
+        """The critic over a FRAME RING [slots + states_len - 1, N, states_dim] (the replay store's layout, taco_amd/rollout.py): value
+        [slots, N, 1] of the stacks frames[slot : slot + states_len, env].  Same kernels, same bits as values() on the materialised stacks."""
+        T = self.cfg.states_len
+        if frames.dim() != 3 or frames.shape[0] < T or frames.shape[2] != self.cfg.states_dim:
+            raise ValueError(f"frame ring of shape {tuple(frames.shape)} does not match the critic ([slots + {T - 1}, N, {self.cfg.states_dim}])")
+        fr = frames
+        if fr.dtype != torch.float32 or not fr.is_contiguous() or fr.device != self.device:
+            fr = fr.to(device=self.device, dtype=torch.float32).contiguous()
+        slots, n = fr.shape[0] - T + 1, fr.shape[1]
+        out = torch.empty(slots * n, device=self.device)
+        ws = self.critic_workspace(slots * n)
+        s = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(self.lib.taco_critic_values_ring(C.byref(self.cfg), self._blob.data_ptr(), slots, n, fr.data_ptr(), out.data_ptr(), ws.data_ptr(), s), self.lib)
+        return out.view(slots, n, 1)
+
     def critic_workspace(self, rows):
         """the batched critic's workspace for `rows` state stacks (kept and reused while it is large enough)"""
         need = int(self.lib.taco_critic_workspace_bytes(C.byref(self.cfg), rows))

@@ -5,11 +5,18 @@ and shapes (`obs_buf [H,N,L,D]`, `states_buf`, `act_buf`, `rew_buf [H,N,1]`, `do
 `adv_buf`, `mu_buf`, `sigma_buf`, `logp_buf`, `step`), same `store / reset / compute_returns_and_advantage /
 batch_idx_generator`, so `PPO.update()` (ppo_asymmetry.py:178-194) can index it unchanged.
 
-Two things are done the MI355X way:
-* `collect(env, actions)` lets the step kernel write slot t+1 of the obs / states storage, `rew_buf[t]` and `done_buf[t]`
-  itself (taco_step_rollout), replacing five of the nine per-step torch copies of `store` and the two `obs.copy_(next_obs)`
-  of the rollout loop (ppo_asymmetry.py:326-329).  The storage has H+1 slots; `obs_buf` / `states_buf` are views of the
-  first H, `next_obs` / `next_states` views of slot `step`.
+Three things are done the MI355X way:
+* `collect(env, actions)` lets the step kernel write slot t+1 of the obs storage, the newest states frame, `rew_buf[t]` and
+  `done_buf[t]` itself (taco_step_rollout), replacing five of the nine per-step torch copies of `store` and the two
+  `obs.copy_(next_obs)` of the rollout loop (ppo_asymmetry.py:326-329).  The obs storage has H+1 slots; `obs_buf` is a view of
+  the first H, `next_obs` a view of slot `step`.
+* The STATE STACKS are kept as a FRAME RING `[H + T][N][D]` (T = states_len): the reference's frame stacks are shifted by one frame
+  per step and never cleared, not even by a reset (fpv_asymmetry.py:392, :413), so the stack of slot t is exactly ring rows
+  t .. t+T-1.  One frame (104 B) is written per env-step instead of a shifted T-frame stack, and the batched critic reads every frame
+  once per block instead of T times.  `states_buf [H,N,T,D]` and `next_states [N,T,D]` are OVERLAPPING STRIDED VIEWS of the ring
+  (`torch.as_strided`): index / gather them freely (`PPO.update`'s minibatch indexing), `.contiguous()` materialises; never write
+  through them.  `store()` (the generic copying path) therefore keeps only the newest frame of the stack it is given (all T at slot
+  0) -- exact for stacks that evolve as the reference's do (`check_shift=True` verifies it).
 * `compute_returns_and_advantage` is three kernel launches (taco_gae) instead of ~9 H torch launches.
 PyTorch only owns the memory.  There is no torch fallback for the arithmetic.
 """
@@ -33,9 +40,10 @@ class RolloutBuffer:
         self.lib = _lib.load()
         H, N, dev = horizon_len, num_envs, self.device
         self._obs_store = torch.zeros(H + 1, N, obs_len, obs_dim, dtype=torch.float32, device=dev)
-        self._states_store = torch.zeros(H + 1, N, states_len, states_dim, dtype=torch.float32, device=dev)
+        self._frames = torch.zeros(H + states_len, N, states_dim, dtype=torch.float32, device=dev)   # the states frame ring
         self.obs_buf = self._obs_store[:H]
-        self.states_buf = self._states_store[:H]
+        self.states_buf = self._stack_view(0, H)
+        self.check_shift = False   # store(): verify that the stacks handed in are shifts of each other (debugging aid; one sync per call)
         self._gae_ws = torch.empty(self.lib.taco_gae_workspace_bytes(), dtype=torch.uint8, device=dev)
         self._alloc_small()
         self.step = 0
@@ -48,14 +56,25 @@ class RolloutBuffer:
         self.ret_buf, self.value_buf, self.adv_buf = z(H, N, 1), z(H, N, 1), z(H, N, 1)
         self.mu_buf, self.sigma_buf, self.logp_buf = z(H, N, self.act_dim), z(H, N, self.act_dim), z(H, N, 1)
 
+    def _stack_view(self, slot0, slots):
+        """[slots, N, T, D] view of the ring: stack (slot, env) = ring rows slot .. slot + T - 1 of that env (overlapping, read-only)"""
+        N, T, D = self.num_envs, self.states_len, self.states_dim
+        return torch.as_strided(self._frames, (slots, N, T, D), (N * D, D, N * D, 1), storage_offset=self._frames.storage_offset() + slot0 * N * D)
+
     # ---- the reference's API -------------------------------------------------------------------------------------------
     def store(self, obs, states, act, rew, log_prob, done, value, mu, sigma):
         """buffer_asymmetry.py:49-68, the generic (copying) path; usable with any env."""
         if self.step >= self.horizon_len:
             raise AssertionError("Rollout buffer overflow")
-        t = self.step
+        t, T = self.step, self.states_len
         self.obs_buf[t].copy_(obs)
-        self.states_buf[t].copy_(states)
+        states = states.view(self.num_envs, T, self.states_dim)
+        if t == 0:
+            self._frames[:T].copy_(states.transpose(0, 1))
+        else:
+            if self.check_shift and not torch.equal(states[:, :-1], self._stack_view(t, 1)[0][:, :-1]):
+                raise AssertionError("store(): the state stack is not the previous one shifted by a frame: the frame-ring replay store cannot hold it")
+            self._frames[t + T - 1].copy_(states[:, -1])
         self.rew_buf[t].copy_(rew.view(-1, 1))
         self.done_buf[t].copy_(done.view(-1, 1))
         self._store_policy(t, act, log_prob, value, mu, sigma)
@@ -66,7 +85,8 @@ class RolloutBuffer:
         the stacks the env last wrote (slot `step`) become slot 0 of the next rollout."""
         if self.step > 0:
             self._obs_store[0].copy_(self._obs_store[self.step])
-            self._states_store[0].copy_(self._states_store[self.step])
+            self._frames[:self.states_len].copy_(self._frames[self.step:self.step + self.states_len].clone() if self.step < self.states_len
+                                                 else self._frames[self.step:self.step + self.states_len])
         for t in (self.act_buf, self.rew_buf, self.done_buf, self.ret_buf, self.value_buf, self.adv_buf, self.mu_buf, self.sigma_buf, self.logp_buf):
             t.zero_()  # in place: the pointers stay valid for captured graphs
         self.step = 0
@@ -95,7 +115,8 @@ class RolloutBuffer:
 
     @property
     def next_states(self):
-        return self._states_store[self.step]
+        """[N, T, D] strided view of the ring: the state stacks of slot `step`"""
+        return self._stack_view(self.step, 1)[0]
 
     def collect(self, env, actions, log_prob=None, value=None, mu=None, sigma=None, act=None):
         """env.step(actions) + store(...) of ppo_asymmetry.py:311-329 with the env writing this step's slots in place.
@@ -108,8 +129,8 @@ class RolloutBuffer:
         if (env.num_envs, env.len_obs, env.num_obs, env.len_states, env.num_states) != (self.num_envs, self.obs_len, self.obs_dim, self.states_len, self.states_dim):
             raise ValueError("env and buffer geometry differ")
         t = self.step
-        env.step_into(actions, self._obs_store[t], self._obs_store[t + 1], self._states_store[t], self._states_store[t + 1],
-                      self.rew_buf[t], self.done_buf[t])
+        env.step_into(actions, self._obs_store[t], self._obs_store[t + 1], None, None, self.rew_buf[t], self.done_buf[t],
+                      states_newest=self._frames[t + self.states_len])
         self._store_policy(t, actions if act is None else act, log_prob, value, mu, sigma)
         self.step += 1
         return self.rew_buf[t].view(-1), env.reset_buf, env.timeout_buf
@@ -131,7 +152,7 @@ class RolloutBuffer:
             self._timeouts = torch.zeros(H, N, dtype=torch.uint8, device=dev)
             self._last_value = torch.empty(N, 1, device=dev)
             self._run_scratch = True
-        b = _lib.RolloutBufs(self._obs_store.data_ptr(), self._states_store.data_ptr(), self.act_buf.data_ptr(), self._act_env.data_ptr(),
+        b = _lib.RolloutBufs(self._obs_store.data_ptr(), self._frames.data_ptr(), self.act_buf.data_ptr(), self._act_env.data_ptr(),
                              self.rew_buf.data_ptr(), self.done_buf.data_ptr(), self.value_buf.data_ptr(), self.logp_buf.data_ptr(),
                              self.mu_buf.data_ptr(), self.sigma_buf.data_ptr(), self._timeouts.data_ptr(), self._last_value.data_ptr(),
                              policy.critic_workspace((H + 1) * N).data_ptr())
@@ -170,7 +191,7 @@ class RolloutBuffer:
     def seed_stacks(self, env):
         """Adopt the env's current frame stacks as slot `step` (e.g. when attaching to an env that already stepped)."""
         self._obs_store[self.step].copy_(env.obs_buf)
-        self._states_store[self.step].copy_(env.states_buf)
+        self._frames[self.step:self.step + self.states_len].copy_(env.states_buf.transpose(0, 1))
 
     def _store_policy(self, t, act, log_prob, value, mu, sigma):
         self.act_buf[t].copy_(act)

@@ -183,16 +183,21 @@ class FpvBase:
                                 self.reset_buf.data_ptr(), self.timeout_buf.data_ptr(), _stream_ptr(self.device).value)
         _lib.check(rc)
 
-    def step_into(self, actions, obs_prev, obs_next, states_prev, states_next, rew, done_f32=None):
+    def step_into(self, actions, obs_prev, obs_next, states_prev, states_next, rew, done_f32=None, states_newest=None):
         """taco_step_rollout: like step_raw, but the frame stacks are read from `*_prev` and written to `*_next` (replay-buffer
         slots, see taco_amd/rollout.py), the reward goes to `rew` and the new done flags also to `done_f32` (fp32).
+        `states_newest` ([num_envs, 26], instead of states_prev / states_next): only the newest states frame is written, into that row of
+        a frame ring (taco_rollout_io.states_newest_only) -- no stack is shifted.
         reset_buf / timeout_buf stay the env's own.  Tensors must be contiguous fp32 on the env's device."""
         if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.device != self.device:
             actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
         if actions.shape != (self.num_envs, self.num_acts):
             raise ValueError(f"actions must be [{self.num_envs}, {self.num_acts}], got {tuple(actions.shape)}")
+        if (states_newest is None) == (states_next is None):
+            raise ValueError("step_into: give either states_prev / states_next (stacks) or states_newest (one frame per env)")
+        frame_shape = (self.num_envs, self.num_states)
         shapes = ((obs_prev, self.obs_buf.shape), (obs_next, self.obs_buf.shape), (states_prev, self.states_buf.shape),
-                  (states_next, self.states_buf.shape), (rew, None), (done_f32, None))
+                  (states_next, self.states_buf.shape), (states_newest, frame_shape), (rew, None), (done_f32, None))
         for t, shp in shapes:
             if t is None:
                 continue
@@ -200,10 +205,15 @@ class FpvBase:
                 raise ValueError("step_into: buffers must be contiguous fp32 tensors on the env's device")
             if (shp is not None and tuple(t.shape) != tuple(shp)) or (shp is None and t.numel() != self.num_envs):
                 raise ValueError(f"step_into: buffer of shape {tuple(t.shape)} does not match the env")
-        io = _lib.RolloutIO(actions.data_ptr(), obs_prev.data_ptr(), obs_next.data_ptr(), states_prev.data_ptr(), states_next.data_ptr(),
-                            rew.data_ptr(), self.reset_buf.data_ptr(), self.timeout_buf.data_ptr(),
-                            done_f32.data_ptr() if done_f32 is not None else None)
-        _lib.check(self.lib.taco_step_rollout(self._h, C.byref(io), _stream_ptr(self.device)))
+        if states_newest is not None:
+            io = _lib.RolloutIO(actions.data_ptr(), obs_prev.data_ptr(), obs_next.data_ptr(), None, states_newest.data_ptr(),
+                                rew.data_ptr(), self.reset_buf.data_ptr(), self.timeout_buf.data_ptr(),
+                                done_f32.data_ptr() if done_f32 is not None else None, None, None, 1)
+        else:
+            io = _lib.RolloutIO(actions.data_ptr(), obs_prev.data_ptr(), obs_next.data_ptr(), states_prev.data_ptr(), states_next.data_ptr(),
+                                rew.data_ptr(), self.reset_buf.data_ptr(), self.timeout_buf.data_ptr(),
+                                done_f32.data_ptr() if done_f32 is not None else None)
+        _lib.check(self.lib.taco_step_rollout(self._h, C.byref(io), _stream_ptr(self.device)), self.lib)
 
     def step(self, actions):
         """vec_task_asymmetry.py:290-334: ONE kernel launch (the clamped obs / states copies are written by the step kernel).

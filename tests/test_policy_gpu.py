@@ -173,6 +173,29 @@ def test_batched_critic_equals_act_and_oracle_bitwise(rows, states_len, lstm, cr
         assert torch.equal(pol.values(std.view(3, rows // 3, states_len, 26)), got.view(3, rows // 3, 1))
 
 
+@pytest.mark.parametrize("slots,n,states_len,lstm,critic_hidden", [
+    (33, 4096, 5, 128, [128, 128]),   # the rollout's shape: H + 1 slots, the batched form, 16-byte aligned pieces (LDS-DMA)
+    (7, 333, 5, 128, [128, 128]),     # odd N: pieces only 8-byte aligned (plain-load staging), blocks straddle slot boundaries
+    (5, 70, 3, 128, [128, 128]),      # ragged last block
+    (4, 96, 1, 128, [128, 128]),      # one frame per stack
+    (6, 100, 4, 64, [128, 128]),      # narrower LSTM: the policy kernel's critic role on a ring
+    (6, 100, 2, 0, [256, 32]),        # no encoder: the flattened stack gathered from the ring
+])
+def test_critic_on_a_frame_ring_equals_the_materialised_stacks(slots, n, states_len, lstm, critic_hidden):
+    """taco_critic_values_ring: frames [slots + T - 1][N][26], row (slot, env) = frames[slot : slot + T, env] -- the replay store's layout
+    (one frame per step instead of a shifted stack per slot).  Bit-identical to the critic on the materialised stacks."""
+    from taco_amd import policy as P
+    rng = np.random.default_rng(slots * 1000 + n)
+    sd = _random_policy(rng, 1, states_len, [32], lstm, critic_hidden)
+    pol = P.ActorCritic(sd, 1, states_len, seed=3)
+    frames = torch.from_numpy(rng.standard_normal((slots + states_len - 1, n, 26)).astype(np.float32)).cuda()
+    frames[1, n // 2] = 0.0
+    stacks = torch.as_strided(frames, (slots, n, states_len, 26), (n * 26, 26, n * 26, 1)).contiguous()
+    got = pol.values_ring(frames)
+    assert got.shape == (slots, n, 1)
+    assert_bits_equal(got.cpu().numpy(), pol.values(stacks).cpu().numpy(), "critic on the ring vs on the stacks")
+
+
 def test_batched_critic_first_timestep_shortcut_keeps_the_sign_of_zero():
     """The batched LSTM skips the W_hh h_{-1} chain of the first timestep (h_{-1} = +0).  fma(+0, w, acc) changes acc only when acc is a
     zero: -0 survives iff every weight of the column is negative.  Build exactly that: zero input rows, biases of -0.0, one gate column

@@ -41,11 +41,14 @@ def timed(fn):
     return (time.perf_counter() - t0) / a.reps
 
 
+ref_states = torch.zeros(H, N, buf.states_len, 26, device="cuda")
+
+
 def loop_copy():
     buf.step = 0
     for t in range(H):
         env.step_raw(acts[t])
-        buf.obs_buf[t].copy_(obs); buf.states_buf[t].copy_(states)
+        buf.obs_buf[t].copy_(obs); ref_states[t].copy_(states)   # (the reference's [H,N,T,26] store: the product keeps a frame ring instead)
         buf.rew_buf[t].copy_(env.rew_buf.view(-1, 1)); buf.done_buf[t].copy_(env.reset_buf.view(-1, 1))
         obs.copy_(env.obs_buf); states.copy_(env.states_buf)
 
@@ -54,7 +57,7 @@ def loop_fused():
     buf.step = 0
     for t in range(H):
         buf.collect(env, acts[t])
-    buf._obs_store[0].copy_(buf._obs_store[H]); buf._states_store[0].copy_(buf._states_store[H])
+    buf._obs_store[0].copy_(buf._obs_store[H]); buf._frames[:buf.states_len].copy_(buf._frames[H:H + buf.states_len])
 
 
 def gae_torch():
