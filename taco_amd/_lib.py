@@ -24,7 +24,7 @@ FLAG_BITS = {
 # every symbol include/taco_env.h declares
 EXPORTS = ["taco_abi_version", "taco_source_hash", "taco_last_error", "taco_workspace_bytes", "taco_create", "taco_destroy", "taco_step",
            "taco_gather_row_floats", "taco_bind_gather_block", "taco_set_difficulty", "taco_get_step_count", "taco_set_step_count", "taco_get_state", "taco_set_state",
-           "taco_step_kernel_name", "taco_launch_geometry", "taco_set_kernel_form", "taco_get_kernel_form", "taco_check", "taco_get_field", "taco_step_rollout", "taco_reset_done", "taco_gae_workspace_bytes", "taco_gae", "taco_occupancy", "taco_bind_phase_stamps", "taco_policy_blob_floats", "taco_policy_act", "taco_rollout_run", "taco_policy_act_stamped", "taco_critic_values", "taco_critic_workspace_bytes", "taco_peek_step_count", "taco_critic_values_ring"]
+           "taco_step_kernel_name", "taco_launch_geometry", "taco_set_kernel_form", "taco_get_kernel_form", "taco_check", "taco_get_field", "taco_step_rollout", "taco_reset_done", "taco_gae_workspace_bytes", "taco_gae", "taco_occupancy", "taco_bind_phase_stamps", "taco_policy_blob_floats", "taco_policy_act", "taco_rollout_run", "taco_policy_act_stamped", "taco_critic_values", "taco_critic_workspace_bytes", "taco_peek_step_count", "taco_critic_values_ring", "taco_set_rollout_fusion", "taco_bind_rollout_stamps"]
 
 
 class TacoCfg(C.Structure):
@@ -126,6 +126,10 @@ def _declare(lib, ab_build=False):
     lib.taco_rollout_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(RolloutBufs), C.c_int, C.c_uint64, C.c_uint32, C.c_double,
                                      C.c_double, C.c_double, C.c_void_p, C.c_void_p]
     lib.taco_rollout_run.restype = C.c_int
+    lib.taco_set_rollout_fusion.argtypes = [C.c_void_p, C.c_int]
+    lib.taco_set_rollout_fusion.restype = C.c_int
+    lib.taco_bind_rollout_stamps.argtypes = [C.c_void_p, C.c_void_p]
+    lib.taco_bind_rollout_stamps.restype = C.c_int
     lib.taco_bind_phase_stamps.argtypes = [C.c_void_p, C.c_void_p]
     lib.taco_bind_phase_stamps.restype = C.c_int
     lib.taco_occupancy.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]

@@ -16,6 +16,7 @@
 #include "taco_step.hpp"
 #include "taco_rollout.hpp"
 #include "taco_policy.hpp"
+#include "taco_fused.hpp"
 
 namespace {
 
@@ -51,6 +52,8 @@ struct taco_env {
     int form;  // TACO_FORM_* the step launches (never TACO_FORM_AUTO here: resolved by choose_form)
     int form_ring;    // ... and the form of a launch that writes only the newest states frame (taco_rollout_io.states_newest_only)
     int form_pinned;  // taco_set_kernel_form chose `form`: every launch uses it
+    int fusion_off;   // taco_set_rollout_fusion(env, 0): taco_rollout_run launches the actor and the step per step even where the persistent kernel applies
+    unsigned long long *rollout_stamps;  // optional profiling buffer of the persistent rollout kernel (taco_bind_rollout_stamps)
     uint32_t *ctl;        // control block (last 256 bytes of the workspace): device-resident step clock + sticky status word
     int clock_on_device;  // a launch was captured into a HIP graph: replays advance the device clock only, the fields above may be stale
                           // (taco_get_step_count re-reads them); until then every launch reads the device clock
@@ -177,10 +180,10 @@ __device__ __forceinline__ float &word(float *S, int npad, int i, int field) {
     const int sl = taco::field_slot(field);
     return S[taco::tile_word(taco::NUM_CHUNKS, sl >> 2, i) + (sl & 3)];
 }
-__global__ void advance_clock_kernel(uint32_t *ctl) {  // behind every step that took its clock from the control block (graph replays)
-    ctl[taco::kCtlStep] += 1u;
-    ctl[taco::kCtlHead] = (ctl[taco::kCtlHead] + 10u) % TACO_RING_SLOTS;
-    ctl[taco::kCtlHh] = (ctl[taco::kCtlHh] + 1u) % taco::HIST_ROWS;
+__global__ void advance_clock_kernel(uint32_t *ctl, uint32_t steps) {  // behind every launch that took its clock from the control block (graph replays)
+    ctl[taco::kCtlStep] += steps;
+    ctl[taco::kCtlHead] = (ctl[taco::kCtlHead] + 10u * steps) % TACO_RING_SLOTS;
+    ctl[taco::kCtlHh] = (ctl[taco::kCtlHh] + steps) % taco::HIST_ROWS;
 }
 __global__ void init_state_kernel(float *S, float *hist, float *ring, uint32_t *ctl, int npad, float tau0, int delay_time) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -382,6 +385,8 @@ int taco_create(const taco_cfg *cfg, int device, void *workspace, size_t workspa
     e->form = choose_form(e->cfg);
     { taco_cfg one = e->cfg; one.len_states = 1; e->form_ring = choose_form(one); }
     e->form_pinned = 0;
+    e->fusion_off = 0;
+    e->rollout_stamps = nullptr;
     std::memset(&e->P, 0, sizeof(e->P));
     derive(e);
     hipLaunchKernelGGL(init_state_kernel, dim3((e->npad + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->S, e->hist, e->ring, e->ctl, e->npad,
@@ -448,7 +453,7 @@ int launch_step(taco_env *e, const taco_rollout_io *io, void *stream) {
     if (he == hipSuccess) he = hipGetLastError();
     if (he != hipSuccess) return hip_fail(he, "taco_step_kernel launch");
     if (e->clock_on_device) {
-        hipLaunchKernelGGL(advance_clock_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, e->ctl);
+        hipLaunchKernelGGL(advance_clock_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, e->ctl, 1u);
         he = hipGetLastError();
         if (he != hipSuccess) return hip_fail(he, "advance_clock_kernel launch");
     }
@@ -766,7 +771,8 @@ static int launch_critic(const taco_policy_cfg *c, const float *blob, size_t row
         const size_t nblocks = (rows + taco::CR_ROWS - 1) / taco::CR_ROWS;
         const size_t walk = (nblocks + cus - 1) / cus;
         const unsigned grid = (unsigned)((nblocks + walk - 1) / walk);
-        hipLaunchKernelGGL(taco::taco_critic_lstm_kernel, dim3(grid), dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
+        if (ring_n > 0) hipLaunchKernelGGL(taco::taco_critic_lstm_kernel<true>, dim3(grid), dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
+        else hipLaunchKernelGGL(taco::taco_critic_lstm_kernel<false>, dim3(grid), dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
         hipError_t he = hipGetLastError();
         if (he != hipSuccess) return hip_fail(he, "taco_critic_lstm_kernel launch");
         const size_t nchunks = (rows + taco::CR_MLP_ROWS - 1) / taco::CR_MLP_ROWS;
@@ -824,6 +830,17 @@ int taco_policy_act(const taco_policy_cfg *c, const float *blob, int n, const fl
     return taco_policy_act_stamped(c, blob, n, obs, states, seed, call, deterministic, action_only, action, logp, value, mu, sigma, nullptr, stream);
 }
 
+// The persistent actor + step kernel (taco_fused.hpp) covers the documented rollout: one observation frame per step (len_obs = 1), the actor MLP
+// 26-128-128-128-4 (widths padded to 32 / 128 / 16), launches of at most kFusedMaxEnvs envs (16 envs per workgroup, one workgroup per CU at a
+// time: 512 workgroups are two rounds of the chip).  Anything else runs the launch-per-step path, same results.
+constexpr int kFusedMaxEnvs = 8192;
+static bool fused_rollout_ok(const taco_env *e, const taco_policy_cfg *c) {
+    auto p16 = [](int x) { return (x + 15) / 16 * 16; };
+    return !e->fusion_off && !e->form_pinned && e->gather == nullptr && e->cfg.num_envs <= kFusedMaxEnvs && e->cfg.len_obs == 1 && c->obs_len == 1 &&
+           c->obs_dim == 26 && c->act_dim == 4 && c->n_actor_hidden == 3 && p16(c->actor_hidden[0]) == 128 && p16(c->actor_hidden[1]) == 128 &&
+           p16(c->actor_hidden[2]) == 128;
+}
+
 // ---- a whole PPO rollout (ppo_asymmetry.py:308-342) enqueued from C: 2 H + 2 launches, no host work between the steps
 int taco_rollout_run(taco_env *e, const taco_policy_cfg *c, const float *blob, const taco_rollout_bufs *b, int horizon, uint64_t seed, uint32_t call0,
                      double gamma, double act_lo, double act_hi, int64_t *reset_buf, void *stream) {
@@ -847,7 +864,31 @@ int taco_rollout_run(taco_env *e, const taco_policy_cfg *c, const float *blob, c
     else if ((rc = refresh_clock(e, stream)) != TACO_OK) return rc;   // eager, after replays: the host's clock is made current first (blocking, once)
     const uint32_t *clock = e->clock_on_device ? e->ctl + taco::kCtlStep : nullptr;
     const uint32_t call_delta = call0 - (uint32_t)e->step_count;
-    for (int t = 0; t < horizon; ++t) {
+    const bool fused = fused_rollout_ok(e, c);
+    if (fused) {
+        // the whole per-step chain as ONE persistent launch (taco_fused.hpp): a workgroup owns 16 envs for all `horizon` steps
+        taco::RolloutParams R{};
+        R.S = e->P;
+        R.S.S = e->S; R.S.ring = e->ring; R.S.hist = e->hist; R.S.reset = (long long *)reset_buf; R.S.ctl = e->ctl; R.S.use_ctl = e->clock_on_device;
+        R.S.step = (uint32_t)e->step_count; R.S.head = e->head; R.S.hh = e->hh; R.S.gather_row = (uint32_t)taco_gather_row_floats(1); R.S.gather_bytes = 0;
+        R.blob = blob; R.pseed_lo = (uint32_t)seed; R.pseed_hi = (uint32_t)(seed >> 32); R.call0 = call0; R.clock = clock; R.call_delta = call_delta;
+        R.act_lo = (float)act_lo; R.act_hi = (float)act_hi;
+        R.obs_store = b->obs_store; R.frames = b->states_store; R.act_buf = b->act_buf; R.mu_buf = b->mu_buf; R.sigma_buf = b->sigma_buf;
+        R.logp_buf = b->logp_buf; R.rew_buf = b->rew_buf; R.done_buf = b->done_buf; R.timeout_buf = b->timeout_buf;
+        R.horizon = horizon; R.len_states = ec.len_states; R.stamps = e->rollout_stamps;
+        hipLaunchKernelGGL(taco::taco_rollout_kernel, dim3((unsigned)((n + taco::POL_ROWS - 1) / taco::POL_ROWS)), dim3(taco::FU_THREADS), 0, (hipStream_t)stream, R);
+        hipError_t he = hipGetLastError();
+        if (he != hipSuccess) return hip_fail(he, "taco_rollout_kernel launch");
+        if (e->clock_on_device) {
+            hipLaunchKernelGGL(advance_clock_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, e->ctl, (uint32_t)horizon);
+            he = hipGetLastError();
+            if (he != hipSuccess) return hip_fail(he, "advance_clock_kernel launch");
+        }
+        e->step_count += horizon;
+        e->head = (e->head + 10 * horizon) % TACO_RING_SLOTS;
+        e->hh = (e->hh + horizon) % taco::HIST_ROWS;
+    }
+    for (int t = 0; !fused && t < horizon; ++t) {
         float *act_t = b->act_buf + (size_t)t * n * 4;
         rc = launch_policy(c, blob, (int)n, b->obs_store + (size_t)t * obs_slot, nullptr, seed, call0 + (uint32_t)t, 0, 1,
                            act_t, b->logp_buf + (size_t)t * n, nullptr, b->mu_buf + (size_t)t * n * 4, b->sigma_buf + (size_t)t * n * 4,
@@ -893,6 +934,18 @@ int taco_test_slow_battery_server(taco_env *e, int on) {
     return TACO_OK;
 }
 #endif
+
+int taco_set_rollout_fusion(taco_env *e, int on) {
+    if (!e) return fail(TACO_ERR_INVALID_ARG, "env is null");
+    e->fusion_off = on ? 0 : 1;
+    return TACO_OK;
+}
+int taco_bind_rollout_stamps(taco_env *e, uint64_t *stamps) {
+    if (!e) return fail(TACO_ERR_INVALID_ARG, "env is null");
+    if (stamps && ((uintptr_t)stamps & 7u) != 0) return fail(TACO_ERR_INVALID_ARG, "stamps must be 8-byte aligned");
+    e->rollout_stamps = (unsigned long long *)stamps;
+    return TACO_OK;
+}
 
 int taco_bind_phase_stamps(taco_env *e, uint64_t *stamps) {
     if (!e) return fail(TACO_ERR_INVALID_ARG, "env is null");

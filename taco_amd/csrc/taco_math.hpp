@@ -12,6 +12,9 @@
 namespace taco {
 
 #define TD __device__ __forceinline__
+// LDS pointers that stay LDS pointers when passed around (through a generic pointer the accesses become flat loads)
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(3))) int lds_i32;
 
 constexpr float kPi = 3.14159265358979323846f;
 constexpr float kTwoPi = 6.28318530717958647692f;

@@ -180,7 +180,8 @@ TD void lstm_resident(const float *Wih, const float *Whh, const float *bs, int h
 
 // distribution (:333-345) for act_dim == 4: thread (er, a) owns action component a of row er of the workgroup's tile (whole quads: the
 // log-prob's two sums run over the quad by DPP, in component order)
-TD void sample4(const PolicyParams &P, const float *x, int ld, int row0, int er, int a, const float *log_std, uint32_t call) {
+// env_lds (optional, the fused rollout kernel): [rows][4] in LDS, receives the action clipped to [act_lo, act_hi] for EVERY row of the tile
+TD void sample4(const PolicyParams &P, const float *x, int ld, int row0, int er, int a, const float *log_std, uint32_t call, lds_f32 *env_lds = nullptr) {
     const int env = row0 + er;
     const bool live = env < P.n;
     const float mean = x[er * ld + a];
@@ -207,6 +208,7 @@ TD void sample4(const PolicyParams &P, const float *x, int ld, int row0, int er,
     };
     float lp = 0.0f + bcq(z2, 0); lp = lp + bcq(z2, 1); lp = lp + bcq(z2, 2); lp = lp + bcq(z2, 3);
     float hld = 0.0f + bcq(ls, 0); hld = hld + bcq(ls, 1); hld = hld + bcq(ls, 2); hld = hld + bcq(ls, 3);
+    if (env_lds) env_lds[er * 4 + a] = clampf(act, P.act_lo, P.act_hi);
     if (live) {
         P.action[(size_t)env * 4 + a] = act;
         if (P.action_env) P.action_env[(size_t)env * 4 + a] = clampf(act, P.act_lo, P.act_hi);
@@ -455,6 +457,9 @@ constexpr int CR_MLP_ROWS = 64;
 
 // requirements (checked by the host, which falls back to taco_policy_kernel's critic role otherwise): pad16(states_dim) == 32,
 // pad16(lstm_hidden) == 128, states_len <= POL_MAXT, critic MLP = two hidden layers padded to 128
+// RING: the input is a frame ring (PolicyParams.ring_n) instead of materialised stacks -- a template parameter so that the fragment
+// addressing of either layout is compile-time arithmetic (as a run-time switch it cost 23 SGPR spills and 4 more VGPR spills)
+template <bool RING>
 __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_kernel(const PolicyParams P) {
     __shared__ __attribute__((aligned(16))) float xs[2][POL_MAXT * CR_ROWS * 32];   // the block's state stacks as they lie in memory: [row][t][sd]
     __shared__ __attribute__((aligned(16))) float hb[3][CR_ROWS * CR_LD];   // h_t double buffer + [2] = h_T on its way to the workspace
@@ -494,14 +499,14 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_kernel(const Pol
     // instruction); the fragment reads below do the [row][t][sd] addressing and zero the columns beyond sd.
     // Ring input (P.ring_n = N > 0): frame k of row `row` is ring row `row + k N`, so the 32 rows' frames of ONE timestep are contiguous
     // (32 x sd floats) whatever slot boundaries the block straddles: T pieces per block, xs[half] = [t][row][sd] instead of [row][t][sd].
-    const bool ring = P.ring_n > 0;
+    constexpr bool ring = RING;
     const size_t total_bytes = (size_t)P.n * T * sd * sizeof(float);
     const int block_bytes = CR_ROWS * T * sd * (int)sizeof(float);
     const int piece_bytes = CR_ROWS * sd * (int)sizeof(float);   // ring: one timestep of the block
     const bool ring_dma_ok = ring && (((size_t)P.ring_n * sd * sizeof(float)) & 15u) == 0 && (piece_bytes & 15) == 0;   // 16-byte aligned pieces
     auto stage = [&](int blk, int half) {
         const size_t base = (size_t)blk * block_bytes;
-        if (ring) {
+        if constexpr (ring) {
             const size_t row0 = (size_t)blk * CR_ROWS;
             if (ring_dma_ok && row0 + CR_ROWS <= (size_t)P.n) {  // wave-uniform
                 const int per_piece = (piece_bytes / 16 + 63) / 64;   // wavefront instructions per timestep piece (sd = 26: 208 x 16 B = 4)
@@ -519,7 +524,7 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_kernel(const Pol
                     xs[half][e] = row0 + row < (size_t)P.n ? P.states[(row0 + (size_t)k * (size_t)P.ring_n) * sd + rem] : 0.0f;
                 }
             }
-        } else if (base + block_bytes <= total_bytes) {  // wave-uniform
+        } else if (base + block_bytes <= total_bytes) {  // (materialised stacks) wave-uniform
             const char *src = reinterpret_cast<const char *>(P.states) + base;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {  // 32 rows x 8 frames x 32 floats = 2048 pieces of 16 B at most = 4 per thread

@@ -706,8 +706,25 @@ constexpr int CARRY_WORDS = 32;  // 30 used
 // WIDE (<256, 4, true> only): the same four-role quad form compiled for two wavefronts per SIMD instead of four (up to 256 VGPRs): used
 // while every wavefront of the launch has a SIMD to itself anyway (<= 4 096 envs, no frame stacks), where the 128-register cap of the
 // general form buys nothing and costs 2 % (12.90 vs 13.19 us at 4 096 envs; with stacks or from 8 192 envs on the capped form is faster).
-template <int BLOCK, int LPE, bool SPLIT = false, bool CAP = false, bool OUT = false, bool RESET_ONLY = false, bool WIDE = false>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT || CAP) ? (WIDE ? 2 : 4) : 1, CAP ? 4 : 8))) void taco_step_kernel(const StepParams P) {
+// FUSED (taco_rollout.hpp, taco_rollout_kernel): the same step as the body of a PERSISTENT kernel whose workgroup (16 envs, quad layout, the
+// four roles) also holds the actor -- four more wavefronts that compute this step's action from the previous step's observation WHILE the
+// step wavefront runs the substeps: with at least ten pending slots the ten slots a step consumes are older actions (delay_time >= 10 ms), so
+// the step only needs its own action for the bookkeeping after the loop (history row, frame words 19..22).  FusedCtx carries what the
+// enclosing kernel provides instead of the launch: the role of this wavefront, the step clock, the actor's action mailbox and the LDS
+// buffer the next observation goes to.  Everything else -- every arithmetic operation -- is the code of the launch-per-step forms.
+struct FusedCtx {
+    int role;            // 0 step wavefront, 1 battery server + reward, 2 obs frame, 3 states frame (what `threadIdx.x >> 6` is in the SPLIT forms)
+    uint32_t step;       // the clock of this step
+    int head, hh;
+    lds_f32 *act_lds;    // [16][4]: the action the actor sampled for this step, clipped to the policy's limits (ppo_asymmetry.py:310)
+    lds_i32 *act_seq;    // >= act_want once act_lds holds this step's action
+    int act_want;
+    lds_f32 *xin;        // [16][xin_ld]: the actor's input rows; the obs role leaves the new (noised) frame there
+    int xin_ld;
+};
+template <int BLOCK, int LPE, bool SPLIT, bool CAP, bool OUT, bool RESET_ONLY, bool WIDE, bool FUSED>
+TD void step_core(const StepParams &P, const FusedCtx &FX) {
+    static_assert(!FUSED || (BLOCK == 256 && LPE == 4 && SPLIT && !OUT && !RESET_ONLY && !CAP), "FUSED is the four-role quad form inside the rollout kernel");
     static_assert(!WIDE || (BLOCK == 256 && LPE == 4 && SPLIT && !RESET_ONLY), "WIDE is a variant of the four-role quad form");
     static_assert(!RESET_ONLY || (BLOCK == 64 && LPE == 1 && !SPLIT && !CAP && !OUT), "RESET_ONLY exists in the plain one-lane form only");
     static_assert(!SPLIT || BLOCK == 256, "SPLIT is the four-role form: one step wavefront + three role wavefronts per workgroup");
@@ -725,8 +742,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
     const __attribute__((address_space(4))) uint32_t *ctl_c = (const __attribute__((address_space(4))) uint32_t *)P.ctl;
     const uint32_t c_step = ctl_c[kCtlStep], c_head = ctl_c[kCtlHead], c_hh = ctl_c[kCtlHh];
     const bool from_ctl = P.use_ctl != 0;
-    const struct { uint32_t step; int head, hh; } clk{from_ctl ? c_step : P.step, from_ctl ? (int)c_head : P.head, from_ctl ? (int)c_hh : P.hh};
-    if (!RESET_ONLY && !from_ctl && blockIdx.x == 0 && threadIdx.x == 0) {
+    const struct { uint32_t step; int head, hh; } clk{FUSED ? FX.step : (from_ctl ? c_step : P.step), FUSED ? FX.head : (from_ctl ? (int)c_head : P.head),
+                                                      FUSED ? FX.hh : (from_ctl ? (int)c_hh : P.hh)};
+    if (!FUSED && !RESET_ONLY && !from_ctl && blockIdx.x == 0 && threadIdx.x == 0) {
         P.ctl[kCtlStep] = P.step + 1u; P.ctl[kCtlHead] = (uint32_t)((P.head + 10) % TACO_RING_SLOTS); P.ctl[kCtlHh] = (uint32_t)((P.hh + 1) % HIST_ROWS);
     }
     constexpr int EPW = 64 / LPE;  // envs per wavefront
@@ -738,7 +756,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
     constexpr int LDS_WORDS = SPLIT ? WAVE_LDS_WORDS + 2 * TILE_WORDS : (BLOCK / 64) * WAVE_LDS_WORDS;
     __shared__ __attribute__((aligned(16))) float lds_all[LDS_WORDS];
     const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
+    const int wv = FUSED ? FX.role : (int)(threadIdx.x >> 6);
     float *tile = SPLIT ? lds_all + (wv == 0 ? 0 : WAVE_LDS_WORDS + (wv == 3 ? TILE_WORDS : 0)) : lds_all + wv * WAVE_LDS_WORDS;
     float4 *slots = reinterpret_cast<float4 *>(tile);  // (wavefront 0 / non-SPLIT only)
     const int sub = lane & (LPE - 1);  // lane inside the env's quad (0 when LPE == 1)
@@ -806,7 +824,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
                                  __hip_atomic_store(&mb_seq[idx], (value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
     // (only while every wavefront of the launch has a SIMD to itself -- 1 024 on the MI355X -- or the server would take issue slots
     // from another workgroup's wavefront 0: 19.0 vs 18.4 us at 8 192 envs)
-    const bool bat_served = SPLIT && LPE == 4 && (P.flags & TACO_F_BATTERY_CONSUMPTION) != 0 && gridDim.x * 4u <= 1024u;
+    const bool bat_served = SPLIT && LPE == 4 && (P.flags & TACO_F_BATTERY_CONSUMPTION) != 0 && (FUSED || gridDim.x * 4u <= 1024u);   // (FUSED: one workgroup per CU)
     Carry K;
     const int i = in_range ? i_raw : P.n - 1;  // tail lanes shadow the last env and store nothing
     const int gid = P.env_offset + i;
@@ -853,7 +871,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
     // Every load the step needs is issued up front, before the reset flag is known: the flag, the action, the 13 state
     // chunks and the 10 ring slots of this step are independent, so they share ONE memory round trip.
     const bool is_reset = P.reset[i] != 0;
-    const float4 a_in = RESET_ONLY ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : reinterpret_cast<const float4 *>(P.act_in)[i];
+    float4 a_in = (RESET_ONLY || FUSED) ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : reinterpret_cast<const float4 *>(P.act_in)[i];
     float4 c_pos = CLD(C_POS), c_quat = CLD(C_QUAT), c_lin = CLD(C_LINVEL), c_ang = CLD(C_ANGVEL);
     float4 c_pp = CLD(C_PID_PREV), c_pi = CLD(C_PID_INT), c_om = CLD(C_OMEGA), c_misc = CLD(C_MISC);
     // rotor / aero parameters: per env only if something randomises them (launch-uniform switch, see kUniformParams)
@@ -969,18 +987,35 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
         }
         return;
     }
-    act[0] = clampf(a_in.x, -P.clip_act, P.clip_act);  // VT:304; actions_old <- actions <- a (FA:321-322) is implicit in hist
-    act[1] = clampf(a_in.y, -P.clip_act, P.clip_act);
-    act[2] = clampf(a_in.z, -P.clip_act, P.clip_act);
-    act[3] = clampf(a_in.w, -P.clip_act, P.clip_act);
-    const float4 act4 = make_float4(act[0], act[1], act[2], act[3]);
-    const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (active) buf_st4(rH, act4, voff, (uint32_t)(clk.hh & (HIST_ROWS - 1)) * row_bytes);  // this step's action, row hh
     int T = 10;
     if (fl & TACO_F_RANDOM_DEPLOY_TIME) {
         U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, clk.step, STREAM_DEPLOY, 0u);
         T = 10 - rounded_normal(uniform(r.x), 1);
     }
+    // FUSED: this step's action is being computed by the actor wavefronts right now.  The ten slots this step consumes hold it only if an
+    // env has fewer than ten pending slots, or keeps the literal slot ring (DENSE: the ring is written ahead of the substeps); then -- wave-
+    // uniformly, rarely: delay_time < 10 ms or the overflow regime -- the step waits for the actor here.  Otherwise the action is picked up
+    // after the substeps (`have_act` false: the zeros standing in for it below are never selected into a slot).
+    bool have_act = !FUSED;
+    auto fetch_action = [&]() {   // (FUSED) wait for the actor's mailbox, take this env's clipped action
+        int spins_ = 0;
+        while (__hip_atomic_load(FX.act_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < FX.act_want && ++spins_ < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (spins_ >= (1 << 22)) mb_timeout = true;
+        a_in = make_float4(FX.act_lds[el * 4 + 0], FX.act_lds[el * 4 + 1], FX.act_lds[el * 4 + 2], FX.act_lds[el * 4 + 3]);
+        have_act = true;
+    };
+    if constexpr (FUSED) {
+        const bool early = dense || dlen + T > TACO_RING_SLOTS - 10 || dlen < 10;
+        if (__builtin_amdgcn_ballot_w64(early) != 0) fetch_action();
+    }
+    act[0] = clampf(a_in.x, -P.clip_act, P.clip_act);  // VT:304; actions_old <- actions <- a (FA:321-322) is implicit in hist
+    act[1] = clampf(a_in.y, -P.clip_act, P.clip_act);
+    act[2] = clampf(a_in.z, -P.clip_act, P.clip_act);
+    act[3] = clampf(a_in.w, -P.clip_act, P.clip_act);
+    float4 act4 = make_float4(act[0], act[1], act[2], act[3]);
+    const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (have_act && active) buf_st4(rH, act4, voff, (uint32_t)(clk.hh & (HIST_ROWS - 1)) * row_bytes);  // this step's action, row hh
     // value of queued run j (0 = oldest) BEFORE this step's push: the action of (m - j) steps ago
     auto run_value = [&](int j) -> float4 {
         const uint32_t row = (uint32_t)((clk.hh - (q_m - j)) & (HIST_ROWS - 1));
@@ -1459,6 +1494,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
     }
 
     TACO_STAMP(3);  // substeps done
+    if (FUSED && !bat_served && __builtin_expect(mb_timeout, 0)) {  // (the wait for the actor's action gave up; with the battery served this is reported above)
+        if (lane == 0) atomicOr(&P.ctl[kCtlStatus], kStatusMailboxTimeout);
+        bat_V = nanf32();
+    }
     w = quat_sandwich(q, wb);  // root state: world-frame angular velocity
 
     // ------------------------------------------------------------------ post_physics_step FA:374-388
@@ -1480,6 +1519,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
         h4[5] = make_float4(flip_radian, as_f(progress), 0.0f, 0.0f); h4[6] = c_tp; h4[7] = c_tq;
     }
     if (SPLIT) __syncthreads();  // barrier 2 of 2 (every wavefront executes exactly the same two)
+    if constexpr (FUSED) {
+        if (!have_act) {  // (wave-uniform) the common case: the actor finished under the substeps -- barrier 2 is its completion too
+            fetch_action();
+            act4 = make_float4(clampf(a_in.x, -P.clip_act, P.clip_act), clampf(a_in.y, -P.clip_act, P.clip_act), clampf(a_in.z, -P.clip_act, P.clip_act),
+                               clampf(a_in.w, -P.clip_act, P.clip_act));
+            if (active) buf_st4(rH, act4, voff, (uint32_t)(clk.hh & (HIST_ROWS - 1)) * row_bytes);  // this step's action, row hh
+        }
+    }
     if (active) {
         // Everything the substep loop evolved goes back to its SoA row NOW, so the registers are free for the
         // observation / reward code below.
@@ -1547,6 +1594,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
         const float4 a0 = h4[0], a1 = h4[1], a2 = h4[2], a3 = h4[3], a4 = h4[4], a5 = h4[5];
         K.p = V3{a0.x, a0.y, a0.z}; K.bat_V = a0.w; K.v = V3{a1.x, a1.y, a1.z}; K.cmd0 = a1.w; K.w = V3{a2.x, a2.y, a2.z}; K.cmd1 = a2.w;
         K.q = Q4{a3.x, a3.y, a3.z, a3.w}; K.act[0] = a4.x; K.act[1] = a4.y; K.act[2] = a4.z; K.act[3] = a4.w;
+        if constexpr (FUSED) {  // the step wavefront may not have had the action when it wrote the Carry: the roles take it from the actor's mailbox
+#pragma unroll
+            for (int k = 0; k < 4; ++k) K.act[k] = clampf(FX.act_lds[el * 4 + k], -P.clip_act, P.clip_act);
+        }
         K.flip_radian = a5.x; K.progress = as_i(a5.y); K.c_tp = h4[6]; K.c_tq = h4[7];
     }
     // ------------------------------------------------------------------ post-phase: works on the Carry only
@@ -1688,6 +1739,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
         fr[23] = fr[23] + P.df * (nrm[10] * (float)(0.06 / 3 / 3) + 0.0f);
     }
     if (roleO) put_frame(P.obs, P.obs_prev, P.obs_bytes, P.len_obs, fr, SPLIT || (fl & TACO_F_OBSERVATION_NOISE) != 0, OUT ? P.obs_out : nullptr, P.clip_obs);
+    if constexpr (FUSED) {
+        if (roleO && sub == 0) {  // ... and into the actor's input rows: the observation the next step's action is computed from never leaves the CU
+#pragma unroll
+            for (int k = 0; k < 26; ++k) FX.xin[el * FX.xin_ld + k] = fr[k];
+        }
+    }
     // Optional all-gather block, one 128-byte-aligned row per env: [obs stack | reward | done | time-out | pad].  The obs part is written by
     // the wavefront that holds the obs frame (the newest frame from registers, older frames re-read from this env's just-written obs row),
     // the three tail words by the reward wavefront below.
@@ -1775,6 +1832,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT ||
 #undef MB_WAIT
 #undef MB_POST
 #undef MB_SEQ
+}
+
+// the launch-per-step forms: one step_core per launch
+template <int BLOCK, int LPE, bool SPLIT = false, bool CAP = false, bool OUT = false, bool RESET_ONLY = false, bool WIDE = false>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT || CAP) ? (WIDE ? 2 : 4) : 1, CAP ? 4 : 8))) void taco_step_kernel(const StepParams P) {
+    step_core<BLOCK, LPE, SPLIT, CAP, OUT, RESET_ONLY, WIDE, false>(P, FusedCtx{});
 }
 
 }  // namespace taco

@@ -107,6 +107,15 @@ class FpvBase:
         """pin one of the five instantiations of the step kernel (`_lib.FORMS`; "auto" = the library's choice for this env count)"""
         _lib.check(self.lib.taco_set_kernel_form(self._h, _lib.FORMS[name]), self.lib)
 
+    def set_rollout_fusion(self, on=True):
+        """taco_rollout_run's persistent actor + step kernel (taco_fused.hpp) on / off for this env (on by default where it applies)"""
+        _lib.check(self.lib.taco_set_rollout_fusion(self._h, 1 if on else 0), self.lib)
+
+    def bind_rollout_stamps(self, stamps):
+        """profiling: a [136] int64 device tensor workgroup 0 of the persistent rollout kernel fills (SIMD of its 8 wavefronts, per-step clocks); None unbinds"""
+        self._rollout_stamps = stamps
+        _lib.check(self.lib.taco_bind_rollout_stamps(self._h, stamps.data_ptr() if stamps is not None else None), self.lib)
+
     @property
     def kernel_form(self):
         f = self.lib.taco_get_kernel_form(self._h)

@@ -212,3 +212,57 @@ def test_rollout_run_is_graph_capturable_and_replays_are_the_next_rollouts():
         a, b = got3[name], eager[3][name]
         assert torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a, b.view(torch.int32) if b.dtype == torch.float32 else b), f"eager rollout after replays: {name}"
     env.check()
+
+
+@pytest.mark.parametrize("n,task,len_states,kw", [
+    (4096, "mix", 5, dict(observation_noise=True, rotor_noise=True, ramdom_delay_time=True, ramdom_deploy_time=True, random_rotordynamic_coe=True)),  # config 5's flags
+    (333, "pos", 1, dict()),                                  # ragged last workgroup, one frame
+    (1000, "flip", 3, dict(delay_time=5)),                    # fewer than ten pending slots: the step waits for the actor (early path)
+    (500, "rotate", 2, dict(delay_time=85, ramdom_deploy_time=True)),   # the delay line's overflow regime: DENSE envs take the early path
+    (600, "mix", 5, dict(battery_consumption=False)),         # no battery server
+])
+def test_persistent_rollout_kernel_equals_the_launch_per_step_path(n, task, len_states, kw):
+    """taco_rollout_run with the persistent actor + step kernel (one workgroup owns 16 envs for the whole horizon, the actor's MFMAs run
+    under the substeps) against the same call with fusion switched off (2 H launches): every replay-buffer array, the env's whole state and
+    reset_buf bit for bit, over three rollouts with episode ends; and the hardware really places the eight wavefronts two per SIMD in
+    launch order, which is what keeps the actor off the step wavefront's SIMD."""
+    from taco_amd import policy as P
+    from taco_amd.vec_env import FpvBase
+    import test_policy_gpu as TP
+    H = 16
+    rng = np.random.default_rng(7)
+    sd = TP._random_policy(rng, 1, len_states, [128, 128, 128], 128, [128, 128])
+    cfg = config.default_cfg(task, n, env_lenStates=len_states, env_maxEpisodeLength=21, seed=4, **kw)
+    keys = ("obs_buf", "states_buf", "act_buf", "rew_buf", "done_buf", "value_buf", "logp_buf", "mu_buf", "sigma_buf", "ret_buf", "adv_buf")
+    outs = []
+    for fused in (True, False):
+        env = FpvBase(cfg, copy_outputs=False)
+        env.set_rollout_fusion(fused)
+        stamps = torch.zeros(136, dtype=torch.int64, device="cuda")
+        env.bind_rollout_stamps(stamps)
+        pol = P.ActorCritic(sd, 1, len_states, seed=21)
+        buf = _buffer(n, H, 1, len_states)
+        snaps = []
+        for epoch in range(3):
+            buf.reset()
+            last = buf.run(env, pol)
+            buf.compute_returns_and_advantage(last)
+            snaps.append({k: getattr(buf, k).clone() for k in keys} | {"last": last.clone(), "tmo": buf.time_outs.clone(), "reset": env.reset_buf.clone(),
+                                                                         "state": env.get_state().view(torch.int32).clone()})
+        env.check()
+        assert env.step_count == 3 * H and pol.calls == 3 * H
+        if fused:
+            simd = stamps[:8].cpu().tolist()
+            assert simd[0] == simd[4] and simd[1] == simd[5] and simd[2] == simd[6] and simd[3] == simd[7] and len(set(simd[:4])) == 4, f"wavefront -> SIMD placement {simd}"
+            assert stamps[8:8 + 2 * H].min() > 0, "the persistent kernel did not run"
+        else:
+            assert stamps.abs().sum() == 0, "fusion was switched off, yet the persistent kernel ran"
+        outs.append(snaps)
+    assert sum(float(s["done_buf"].sum()) for s in outs[0]) > 0 and sum(int(s["tmo"].sum()) for s in outs[0]) > 0
+    for epoch in range(3):
+        for k in outs[0][epoch]:
+            a, b = outs[0][epoch][k], outs[1][epoch][k]
+            if a.dtype == torch.float32:
+                assert_bits_equal(a.cpu().numpy(), b.cpu().numpy(), f"rollout {epoch} {k}")
+            else:
+                assert torch.equal(a, b), f"rollout {epoch} {k}"
