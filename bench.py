@@ -268,20 +268,9 @@ def graph_entry(n, acts, dev, torch, steps_in_graph=64):
             "what": "taco_step captured into a HIP graph (2 kernel nodes per step: step + clock advance), 20 replays per window"}
 
 
-def rollout_entry(n, horizon, dev, torch):
-    """config 5's 'LSTM-critic rollout': one taco_rollout_run call = horizon x (actor forward -> clipped action -> env step writing the next
-    replay slot), then the critic over all horizon + 1 slots in one batched pass + time-out bootstrap, then GAE.  Random-init weights of the
-    documented architecture (actor MLP 26-128-128-128-4, critic LSTM 26->128 over 5 frames + MLP 128-128-128-1).  The critic is timed alone
-    as well (taco_critic_values over the same (horizon + 1) x n state stacks) and priced against the f32 MFMA peak."""
+def documented_policy(rng, hd=128):
+    """random-init weights of the documented architecture (README.md:60-66): actor MLP 26-128-128-128-4, critic LSTM 26 -> 128 + MLP 128-128-128-1"""
     import numpy as np
-    from taco_amd import config, policy as P
-    from taco_amd.rollout import RolloutBuffer
-    from taco_amd.vec_env import FpvBase
-    cfg = config.baseline_config(4, num_envs=n)
-    env = FpvBase(cfg, sim_device=str(dev), rl_device=str(dev), copy_outputs=False)
-    buf = RolloutBuffer(n, 26, 1, 26, env.len_states, 4, horizon, 4, 0.99, 0.95, str(dev))
-    rng = np.random.default_rng(0)
-    hd = 128
     sd = {"log_std": np.zeros(4, np.float32)}
     dims = [26, hd, hd, hd, 4]
     for i in range(4):
@@ -295,6 +284,23 @@ def rollout_entry(n, horizon, dev, torch):
     for i in range(3):
         sd[f"critic_mlp.layers.{2 * i}.weight"] = (rng.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32)
         sd[f"critic_mlp.layers.{2 * i}.bias"] = np.zeros(dims[i + 1], np.float32)
+    return sd
+
+
+def rollout_entry(n, horizon, dev, torch):
+    """config 5's 'LSTM-critic rollout': one taco_rollout_run call = horizon x (actor forward -> clipped action -> env step writing the next
+    replay slot), then the critic over all horizon + 1 slots in one batched pass + time-out bootstrap, then GAE.  Random-init weights of the
+    documented architecture (actor MLP 26-128-128-128-4, critic LSTM 26->128 over 5 frames + MLP 128-128-128-1).  The critic is timed alone
+    as well (taco_critic_values over the same (horizon + 1) x n state stacks) and priced against the f32 MFMA peak."""
+    import numpy as np
+    from taco_amd import config, policy as P
+    from taco_amd.rollout import RolloutBuffer
+    from taco_amd.vec_env import FpvBase
+    cfg = config.baseline_config(4, num_envs=n)
+    env = FpvBase(cfg, sim_device=str(dev), rl_device=str(dev), copy_outputs=False)
+    buf = RolloutBuffer(n, 26, 1, 26, env.len_states, 4, horizon, 4, 0.99, 0.95, str(dev))
+    hd = 128
+    sd = documented_policy(np.random.default_rng(0))
     pol = P.ActorCritic(sd, 1, env.len_states)
 
     def run():
@@ -313,6 +319,19 @@ def rollout_entry(n, horizon, dev, torch):
         torch.cuda.synchronize()
         ts.append((time.perf_counter() - t0) / 4)
     ts.sort()
+    fused_ms = ts[2] * 1e3
+    env.set_rollout_fusion(False)   # the launch-per-step path of the same call (2 x horizon + 3 launches), for comparison
+    run()
+    torch.cuda.synchronize()
+    us = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(4):
+            run()
+        torch.cuda.synchronize()
+        us.append((time.perf_counter() - t0) / 4)
+    us.sort()
+    env.set_rollout_fusion(True)
     rows, T, hd2 = (horizon + 1) * n, env.len_states, hd
     st = buf._frames   # the replay store's frame ring [horizon + T][n][26]: what taco_rollout_run's critic pass reads
     for _ in range(3):
@@ -330,9 +349,91 @@ def rollout_entry(n, horizon, dev, torch):
     cs.sort()
     flops = 2 * rows * (T * 4 * hd2 * (26 + hd2) + 2 * hd2 * hd2 + hd2)
     return {"config": 5, "what": "taco_rollout_run (actor forward + env step per step, replay store fused; critic batched over all slots afterwards) + GAE",
-            "envs": n, "horizon": horizon, "len_states": T, "ms_per_rollout": ts[2] * 1e3, "env_steps_per_s": n * horizon / ts[2],
+            "envs": n, "horizon": horizon, "len_states": T, "ms_per_rollout": fused_ms, "env_steps_per_s": n * horizon / ts[2],
+            "per_step_chain": ("ONE persistent kernel (a workgroup owns 16 envs for the whole horizon; the actor's MFMAs run under the substeps): 4 launches per rollout"
+                               if n <= 8192 else "actor launch + step launch per step (above 8 192 envs)"),
+            "ms_per_rollout_launch_per_step": us[1] * 1e3,
             "critic": {"rows": rows, "ms": cs[2] * 1e3, "tflops": flops / cs[2] / 1e12, "frac_of_f32_mfma_peak": flops / cs[2] / 157.3e12,
                        "note": "model flops 2 rows (T 4 H (26 + H) + 2 H H + H) over the LSTM + MLP kernels' time; peak 157.3 TFLOP/s (MI355X_MICROARCH.md)"}}
+
+
+def shader_clock_mhz():
+    """peak shader clock of the GPU from sysfs (pp_dpm_sclk's highest level); 2400 (MI355X_MICROARCH.md) if it cannot be read"""
+    import glob
+    import re
+    best = 0
+    for f in glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"):
+        try:
+            for line in open(f):
+                m = re.search(r"(\d+)\s*Mhz", line, re.I)
+                if m:
+                    best = max(best, int(m.group(1)))
+        except OSError:
+            pass
+    return (best, "sysfs pp_dpm_sclk") if best > 0 else (2400, "MI355X_MICROARCH.md peak engine clock (sysfs not readable)")
+
+
+def latency_floor(env, acts, kernel_avg_us, torch):
+    """What bounds the 4 096-env launch: not bytes but the instruction stream of its SLOWEST wavefront (every step wavefront has a SIMD to
+    itself and issues one instruction per ~5 clocks whatever the dependencies: tools/ubench/valu_single).  Measured, not modelled: the
+    kernel's own shader-clock stamps (taco_bind_phase_stamps) of workgroup 0 give the critical path in clocks -- step wavefront entry -> its
+    last store, and the latest role wavefront's end; at the GPU's peak shader clock that is the floor the launch cannot beat without
+    shortening the stream.  instr_per_step_wavefront comes from the committed PMC summary of the same build when there is one."""
+    ph = env.phase_stamps(acts[0], steps=200, back_to_back=True)
+    st = env._last_stamps.cpu().tolist()
+    wave0 = st[5] - st[0]
+    roles_end = max(st[6:9]) - st[0] if max(st[6:9]) > 0 else wave0
+    mhz, src = shader_clock_mhz()
+    ticks = max(wave0, roles_end)
+    out = {"critical_path_clocks": ticks, "step_wavefront_clocks": wave0, "phases_clocks": {"loads": ph[0], "pre_phase": ph[1], "ten_substeps": ph[2],
+           "state_stores_and_frames": ph[3], "tail": ph[4]}, "shader_clock_mhz": mhz, "clock_source": src, "us": ticks / mhz,
+           "frac_of_kernel_avg": ticks / mhz / kernel_avg_us,
+           "note": "kernel_avg_us - us = dispatch of 256 workgroups x 4 wavefronts + the drain of the last stores (GPU-side launch boundary)"}
+    try:
+        import glob
+        from taco_amd import build
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+        d = json.load(open(files[-1])) if files else {}
+        if d.get("source_hash") == build.source_hash() and "instr_per_step_wavefront_4096" in d.get("derived", {}):
+            n_i = d["derived"]["instr_per_step_wavefront_4096"]
+            out["instr_per_step_wavefront"] = n_i
+            out["clocks_per_instr"] = wave0 / n_i
+    except Exception:  # noqa: BLE001
+        pass
+    return out
+
+
+def init_dist(world, rank, dev, backend, torch):
+    """-> (torch.distributed or None, backend in use, error text or None).  The requested backend first ("nccl" = RCCL); if its
+    initialisation fails, gloo (the timed region holds no data-path collective: only the barriers and the max-over-ranks reduction need
+    a process group); if that fails too the ranks run unsynchronised and the line says so."""
+    if world == 1:
+        return None, None, None
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    err = None
+    for b in ([backend, "gloo"] if backend != "gloo" else ["gloo"]):
+        try:
+            if b == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            else:
+                dist.init_process_group(b, rank=rank, world_size=world)
+            probe = torch.ones(1, device=dev if b == "nccl" else "cpu")
+            dist.all_reduce(probe)
+            if int(probe.item()) != world:
+                raise RuntimeError(f"all_reduce over {world} ranks returned {probe.item()}")
+            return dist, b, err
+        except Exception as e:  # noqa: BLE001
+            err = (err + " | " if err else "") + f"{b}: {repr(e)[:240]}"
+            try:
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+            except Exception:  # noqa: BLE001
+                pass
+    return None, None, err
+
+
+BASELINE_TOTALS = {2: ("pos", 1, None), 3: ("rotate", 2, 16384), 4: ("flip", 3, 65536), 5: ("mix", 4, 262144)}   # BASELINE.json configs[1..4] (1-based numbers)
 
 
 def main():
@@ -341,6 +442,9 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU (BASELINE configs[1]: 4096)")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
+                    help="which BASELINE.json config (1-based) the MAIN timed leg runs: 2 = pos, 4 096 envs per GPU (weak scaling, the metric's config); "
+                         "3 = rotate 16 384 / 4 = flip 65 536 / 5 = mix 262 144 envs IN TOTAL, sharded over the N ranks (strong scaling)")
     ap.add_argument("--gather", action="store_true", help="N > 1: put the per-step RCCL all-gather inside the main timed region "
                     "(default: the sharded path alone is timed, the gathered variants are timed separately and reported as with_allgather)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -367,27 +471,45 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+    dist, backend_used, dist_error = init_dist(world, rank, dev, backend, torch)
+    solo = world > 1 and dist is None    # no process group could be formed: every rank measures alone, rank 0 reports its own rate x N
 
-    n_local = args.envs
-    n_global = n_local * world
-    cfg = config.baseline_config(1, num_envs=n_global)
+    task, cfg_idx, total = BASELINE_TOTALS[args.config]
+    weak = args.config == 2
+    n_global = args.envs * world if weak else total
+    cfg = config.baseline_config(cfg_idx, num_envs=n_global)
     if world > 1:
         from taco_amd.dist import ShardedEnv
-        env = ShardedEnv(cfg, rank=rank, world_size=world, device=dev, gather=args.gather)
+        env = ShardedEnv(cfg, rank=rank, world_size=world, device=dev, gather=args.gather and not solo)
         step = env.step_gathered
+        n_local = env.hi - env.lo
     else:
-        env = FpvBase(cfg, sim_device=str(dev), rl_device=str(dev), copy_outputs=False)
-        step = env.step_raw
-    n_act = 64
+        env = FpvBase(cfg, sim_device=str(dev), rl_device=str(dev))   # copy_outputs=True: VecTask.step() as the PPO loop calls it
+        step = env.step
+        n_local = n_global
+    n_act = 64 if n_local <= 65536 else 8
     acts = make_actions(n_local, n_act, 1000 + rank, dev)
+
+    def sync_ranks():
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if not dist:
+            return x
+        t = torch.tensor([x], device=dev if backend_used == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather_floats(x):
+        if not dist:
+            return [x]
+        t = torch.tensor([x], device=dev if backend_used == "nccl" else "cpu", dtype=torch.float64)
+        outs = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(outs, t)
+        return [float(o.item()) for o in outs]
 
     def timed(step_fn, a, steps, warmup, finish=None):
         """W untimed steps, then exactly K steps bracketed by barrier + synchronize; max over ranks"""
@@ -396,37 +518,49 @@ def main():
             step_fn(a[t % na])
         if finish:
             finish()
-        torch.cuda.synchronize()
-        if dist:
-            dist.barrier()
-        torch.cuda.synchronize()
+        sync_ranks()
         t0 = time.perf_counter()
         for t in range(steps):
             step_fn(a[t % na])
         if finish:
             finish()
-        torch.cuda.synchronize()
-        if dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        if dist:
-            tmax = torch.tensor([el], device=dev, dtype=torch.float64)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            el = float(tmax.item())
-        return el
+        sync_ranks()
+        return max_over_ranks(time.perf_counter() - t0)
 
-    elapsed = timed(step, acts, args.steps, args.warmup)
-    value = n_global * args.steps / elapsed
+    # ---- the main timed leg.  It holds no data-path collective (envs are independent); a failure inside it still yields a line.
+    main_error = None
+    try:
+        elapsed = timed(step, acts, args.steps, args.warmup)
+    except Exception as e:  # noqa: BLE001
+        main_error = repr(e)[:300]
+        dist = None
+        solo = world > 1
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(args.steps):
+            (env.env.step_raw if world > 1 else env.step_raw)(acts[t % n_act])
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    value = (n_local * world if solo else n_global) * args.steps / elapsed
 
+    base = env.env if world > 1 else env
+    k_avg_us, k_med_us = time_kernel_launches(base, acts, min(args.steps, 500), torch)
     multi = None
+    if world > 1:
+        multi = {"backend": backend_used, "kernel_us_per_rank": gather_floats(k_avg_us), "envs_per_rank": gather_floats(float(n_local))}
+        if dist_error:
+            multi["collective_init_error"] = dist_error
+        if solo:
+            multi["error"] = "no process group: the ranks ran unsynchronised; value = rank 0's own rate x N (" + (dist_error or main_error or "") + ")"
+            multi["ranks_seen"] = [rank]
+        if main_error:
+            multi["main_leg_error"] = main_error
     if dist:
-        multi = {}
         # which ranks the collective library actually connected (one all-gather of rank ids)
-        ids = torch.full((world,), -1, device=dev, dtype=torch.int64)
-        dist.all_gather_into_tensor(ids, torch.tensor([rank], device=dev, dtype=torch.int64))
-        multi["ranks_seen"] = sorted(int(x) for x in ids.tolist())
-        multi["backend"] = backend
+        ids_dev = dev if backend_used == "nccl" else "cpu"
+        ids = [torch.zeros(1, dtype=torch.int64, device=ids_dev) for _ in range(world)]
+        dist.all_gather(ids, torch.tensor([rank], device=ids_dev, dtype=torch.int64))
+        multi["ranks_seen"] = sorted(int(x.item()) for x in ids)
         if not args.gather:
             # The same K steps with the north-star's single all-gather of [obs|rew|done|timeout] per step (one learner sees all envs).
             # The headline above is already measured: a failure of this optional leg is reported, it does not cost the result line.
@@ -455,57 +589,98 @@ def main():
             except Exception as e:  # noqa: BLE001
                 multi["with_allgather"] = {"error": repr(e)[:300]}
             env.gather = False
-        # strong scaling: BASELINE's "4 096 envs" spread over the N GPUs (512-2 048 envs per rank: the latency regime, expected to lose)
-        try:
-            from taco_amd.dist import ShardedEnv
-            n_s = 4096
-            senv = ShardedEnv(config.baseline_config(1, num_envs=n_s), rank=rank, world_size=world, device=dev, gather=False)
-            sacts = make_actions(senv.hi - senv.lo, n_act, 2000 + rank, dev)
-            el_s = timed(senv.step_gathered, sacts, args.steps, min(args.warmup, 50))
-            senv.gather = True
-            el_sg = timed(senv.step_gathered, sacts, args.steps, min(args.warmup, 50))
-            multi["strong_scaling"] = {"envs_total": n_s, "envs_per_rank": senv.hi - senv.lo, "value": n_s * args.steps / el_s, "unit": "env-steps/s",
-                                       "ms_per_step": el_s / args.steps * 1e3, "with_allgather_value": n_s * args.steps / el_sg,
-                                       "with_allgather_ms_per_step": el_sg / args.steps * 1e3}
-            del senv
-        except Exception as e:  # noqa: BLE001
-            multi["strong_scaling"] = {"error": repr(e)[:300]}
+        short = max(50, min(args.steps, 300))
+        if weak:
+            # strong scaling: BASELINE's "4 096 envs" spread over the N GPUs (512-2 048 envs per rank: the latency regime, expected to lose)
+            try:
+                from taco_amd.dist import ShardedEnv
+                n_s = 4096
+                senv = ShardedEnv(config.baseline_config(1, num_envs=n_s), rank=rank, world_size=world, device=dev, gather=False)
+                sacts = make_actions(senv.hi - senv.lo, n_act, 2000 + rank, dev)
+                el_s = timed(senv.step_gathered, sacts, args.steps, min(args.warmup, 50))
+                senv.gather = True
+                el_sg = timed(senv.step_gathered, sacts, args.steps, min(args.warmup, 50))
+                multi["strong_scaling"] = {"envs_total": n_s, "envs_per_rank": senv.hi - senv.lo, "value": n_s * args.steps / el_s, "unit": "env-steps/s",
+                                           "ms_per_step": el_s / args.steps * 1e3, "with_allgather_value": n_s * args.steps / el_sg,
+                                           "with_allgather_ms_per_step": el_sg / args.steps * 1e3}
+                del senv
+            except Exception as e:  # noqa: BLE001
+                multi["strong_scaling"] = {"error": repr(e)[:300]}
+
+    # BASELINE.json's configs 3, 4 and 5 at their REAL shapes: the total env count sharded over the N ranks of this run (rotate 16 384; flip
+    # 65 536; mix 262 144 with every flag, 5 state frames and the policy rollout), each leg wrapped: a failure costs only its own entry
+    baseline_legs = None
+    if not args.no_configs and not solo:
+        short = max(50, min(args.steps, 300))
+        baseline_legs = [sharded_config_leg(number, rank, world, dev, torch, timed, gather_floats, short) for number in (3, 4, 5) if number != args.config]
+        baseline_legs.append(sharded_rollout_leg(262144, 16, rank, world, dev, torch, sync_ranks, max_over_ranks))
+        if dist:
+            # ... and rank 0 alone on configs[1] while the others wait: the N = 1 number of THIS run, for agreement with the 1-GPU record
+            try:
+                sync_ranks()
+                if rank == 0:
+                    e1 = FpvBase(config.baseline_config(1, num_envs=args.envs), sim_device=str(dev), rl_device=str(dev))
+                    a1 = make_actions(args.envs, 64, 1000, dev)
+                    med1, _, _ = steady_windows(e1.step, a1, torch, 0.05, 3, 1000)
+                    multi["n1_on_rank0"] = {"us_per_step": med1, "value": args.envs / (med1 * 1e-6), "what": "VecTask.step() at 4 096 envs on rank 0's GPU alone"}
+                    del e1
+                sync_ranks()
+            except Exception as e:  # noqa: BLE001
+                multi["n1_on_rank0"] = {"error": repr(e)[:300]}
 
     out = None
     if rank == 0:
-        base = env.env if world > 1 else env
-        k_avg_us, k_med_us = time_kernel_launches(base, acts, min(args.steps, 500), torch)
-        achieved = ALGO_BYTES_PER_ENV_STEP * n_local / (k_avg_us * 1e-6) / 1e9
+        nbytes = algo_bytes(base.len_states)
+        achieved = nbytes * n_local / (k_avg_us * 1e-6) / 1e9
         grid, block = base.launch_geometry()
         traffic, traffic_src = pmc_traffic(n_local)
+        what = {2: "task_mode=pos, 4096 envs per GPU, rotor_response_time=0.017, delay_time=20, dt=0.001 x 10 substeps, PhysX-substeps=2, random pose/vel/target, battery on",
+                3: "task_mode=rotate, 16 384 envs in total, delay_time=20, random_command", 4: "task_mode=flip, 65 536 envs in total",
+                5: "task_mode=mix, 262 144 envs in total, every random_* flag, observation / rotor noise, random delay + deploy time, 5 state frames"}[args.config]
         out = {
-            "metric": "env-steps/s at 4096 envs per GPU, fpv_asymmetry.step() hot path (task_mode=pos); one taco_step launch per step",
+            "metric": ("env-steps/s at 4096 envs per GPU, fpv_asymmetry.step() hot path (task_mode=pos); VecTask.step() = one taco_step launch per step"
+                       if weak else f"env-steps/s of BASELINE configs[{args.config - 1}] ({task}, {n_global} envs in total) sharded over the GPUs; one taco_step launch per step and rank"),
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: task_mode=pos, 4096 envs per GPU, rotor_response_time=0.017, delay_time=20, "
-                                   "dt=0.001 x 10 substeps, PhysX-substeps=2, random pose/vel/target, battery on",
+            "config": {"workload": f"BASELINE configs[{args.config - 1}]: " + what,
                        "envs_per_gpu": n_local, "envs_total": n_global, "parallelism": f"env-sharded x{world}",
+                       "api": "VecTask.step() (taco_amd.vec_env: returns the reference's (obs dict, rew, done, extras))" if world == 1 else "ShardedEnv.step_gathered() (taco_step on this rank's slice)",
                        "collective": ("1 RCCL all-gather of [obs|rew|done|timeout] per step" if (world > 1 and args.gather) else
                                       "none in the timed region: envs are independent, each rank steps its own slice"),
                        "kernel": base.lib.taco_step_kernel_name().decode(), "kernel_form": base.kernel_form, "grid": grid, "block": block},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel_avg_us": k_avg_us, "kernel_bracketed_median_us": k_med_us,
-                         "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
-                         "note": "4096 envs = 256 step wavefronts (4 lanes per env, one per CU) + 3 post-phase role wavefronts each: instruction-latency "
-                                 "regime (SURVEY 8d); the throughput regime is large_n"},
+                         "traffic": traffic, "traffic_frac": (traffic / (k_avg_us * 1e-6) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                         "traffic_source": traffic_src, "kernel_avg_us": k_avg_us, "kernel_bracketed_median_us": k_med_us,
+                         "algorithmic_bytes_per_env_step": nbytes,
+                         "note": "frac = ALGORITHMIC bytes (SURVEY 8d) / kernel time / 8 TB/s; traffic_frac = counter-measured HBM bytes / kernel time / 8 TB/s. "
+                                 "4096 envs = 256 step wavefronts (4 lanes per env, one per CU) + 3 post-phase role wavefronts each: instruction-latency "
+                                 "regime (SURVEY 8d), see latency_floor; the throughput regime is large_n"},
         }
         if multi:
             out.update(multi)
-        if world == 1:
-            med, ws, _ = steady_windows(env.step_raw, acts, torch, 0.05, 5, 2000)
-            out["steady_state"] = {"us_per_step": med, "env_steps_per_s": n_local / (med * 1e-6), "windows_us": ws,
+        if baseline_legs is not None:
+            out["baseline_configs"] = baseline_legs
+        if world == 1 and weak:
+            try:
+                out["latency_floor"] = latency_floor(base, acts, k_avg_us, torch)
+            except Exception as e:  # noqa: BLE001
+                out["latency_floor"] = {"error": repr(e)[:300]}
+            med, ws, _ = steady_windows(env.step, acts, torch, 0.05, 5, 2000)
+            out["steady_state"] = {"us_per_step": med, "env_steps_per_s": n_local / (med * 1e-6), "windows_us": ws, "api": "VecTask.step()",
                                    "protocol": "median of 5 event-bracketed windows of 2000 back-to-back steps after 50 ms of warm-up"}
-            aenv = FpvBase(config.baseline_config(1, num_envs=n_local), sim_device=str(dev), rl_device=str(dev))   # copy_outputs=True: the reference's contract
-            amed, aws, _ = steady_windows(aenv.step, acts, torch, 0.05, 5, 1000)
-            out["step_api"] = {"us_per_step": amed, "env_steps_per_s": n_local / (amed * 1e-6),
-                               "what": "VecTask.step(): the same launch also writes the clamped obs / states copies it returns (no torch op, no allocation)"}
-            del aenv
+            rmed, rws, _ = steady_windows(env.step_raw, acts, torch, 0.05, 5, 2000)
+            out["step_raw"] = {"us_per_step": rmed, "env_steps_per_s": n_local / (rmed * 1e-6), "windows_us": rws,
+                               "what": "taco_step in place on the current buffers (no return values built): the same kernel launch without VecTask.step()'s host-side dict"}
+            out["step_api"] = {"us_per_step": med, "env_steps_per_s": n_local / (med * 1e-6),
+                               "what": "VecTask.step() = the headline (ping-pong buffer pairs: the launch step_raw makes, no copy, no torch op)"}
+            try:
+                cenv = FpvBase(config.default_cfg("pos", n_local, env_clipObservations=5.0, env_clipStates=5.0), sim_device=str(dev), rl_device=str(dev))
+                cmed, _, _ = steady_windows(cenv.step, acts, torch, 0.05, 5, 1000)
+                out["step_api_finite_clip"] = {"us_per_step": cmed, "what": "VecTask.step() with finite clipObservations / clipStates: the kernel's OUT instantiation also writes the clamped copies"}
+                del cenv
+            except Exception as e:  # noqa: BLE001
+                out["step_api_finite_clip"] = {"error": repr(e)[:300]}
             try:
                 out["graph_replay"] = graph_entry(n_local, acts, dev, torch)
             except Exception as e:  # noqa: BLE001
@@ -528,12 +703,13 @@ def main():
                     bacts = make_actions(big_n, 4, 7, dev)
                     b_med, b_ws, b_first = steady_windows(benv.step_raw, bacts, torch, 0.25, 5, 200)
                     bg, bb = benv.launch_geometry()
-                    nbytes = algo_bytes(ls)
-                    ach = nbytes * big_n / (b_med * 1e-6) / 1e9
+                    nb = algo_bytes(ls)
+                    ach = nb * big_n / (b_med * 1e-6) / 1e9
                     tr, _ = pmc_traffic(big_n) if ls == 1 else (None, None)
                     out["large_n"].append({"envs": big_n, "len_states": ls, "kernel_avg_us": b_med, "env_steps_per_s": big_n / (b_med * 1e-6),
-                                           "algorithmic_bytes_per_env_step": nbytes, "achieved_GBps": ach, "frac_of_hbm_peak": ach / HBM_PEAK_GBPS,
-                                           "traffic": tr, "kernel_form": benv.kernel_form, "grid": bg, "block": bb, "windows_us": b_ws,
+                                           "algorithmic_bytes_per_env_step": nb, "achieved_GBps": ach, "frac_of_hbm_peak": ach / HBM_PEAK_GBPS,
+                                           "traffic": tr, "traffic_frac_of_hbm_peak": (tr / (b_med * 1e-6) / 1e9 / HBM_PEAK_GBPS) if tr else None,
+                                           "kernel_form": benv.kernel_form, "grid": bg, "block": bb, "windows_us": b_ws,
                                            "first_100_launches_us": b_first,
                                            "protocol": "median of 5 windows of 200 back-to-back launches after 0.25 s of warm-up launches"})
                     del benv, bacts
@@ -549,6 +725,69 @@ def main():
             dist.destroy_process_group()
         except Exception:  # noqa: BLE001 -- the result line is out; a failing teardown must not turn the run into an error
             pass
+
+
+def sharded_config_leg(number, rank, world, dev, torch, timed, gather_floats, steps):
+    """one BASELINE config at its real total env count, sharded over the ranks of this run: the sharded path alone, then with the per-step all-gather"""
+    from taco_amd import config
+    from taco_amd.dist import ShardedEnv
+    task, idx, total = BASELINE_TOTALS[number]
+    try:
+        senv = ShardedEnv(config.baseline_config(idx, num_envs=total), rank=rank, world_size=world, device=dev, gather=False)
+        n_local = senv.hi - senv.lo
+        sacts = make_actions(n_local, 8, 3000 + rank, dev)
+        el = timed(senv.step_gathered, sacts, steps, 30)
+        k_us, _ = time_kernel_launches(senv.env, sacts, min(steps, 200), torch)
+        entry = {"config": number, "task_mode": task, "envs_total": total, "envs_per_rank": n_local, "len_states": senv.env.len_states, "steps": steps,
+                 "value": total * steps / el, "unit": "env-steps/s", "ms_per_step": el / steps * 1e3, "kernel_us_per_rank": gather_floats(k_us),
+                 "kernel_form": senv.env.kernel_form, "frac_of_hbm_peak_per_gpu": algo_bytes(senv.env.len_states) * n_local / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBPS}
+        try:
+            senv.gather = True
+            el_g = timed(senv.step_gathered, sacts, steps, 10)
+            entry["with_allgather"] = {"value": total * steps / el_g, "ms_per_step": el_g / steps * 1e3, "bytes_per_rank": int(senv.block.numel() * 4)}
+        except Exception as e:  # noqa: BLE001
+            entry["with_allgather"] = {"error": repr(e)[:300]}
+        del senv
+        torch.cuda.empty_cache()
+        return entry
+    except Exception as e:  # noqa: BLE001
+        return {"config": number, "envs_total": total, "error": repr(e)[:300]}
+
+
+def sharded_rollout_leg(total, horizon, rank, world, dev, torch, sync_ranks, max_over_ranks):
+    """BASELINE configs[4]'s "LSTM-critic rollout" at its real shape: every rank rolls out its slice of the 262 144 envs (actor + env step per
+    step, critic batched afterwards, GAE) -- data-parallel, no collective inside; value = total env-steps / max-over-ranks time."""
+    import numpy as np
+    from taco_amd import config, policy as P
+    from taco_amd.dist import shard_bounds
+    from taco_amd.rollout import RolloutBuffer
+    from taco_amd.vec_env import FpvBase
+    try:
+        lo, hi = shard_bounds(total, world, rank)
+        n = hi - lo
+        env = FpvBase(config.baseline_config(4, num_envs=total), sim_device=str(dev), rl_device=str(dev), copy_outputs=False, env_offset=lo, num_envs_local=n)
+        buf = RolloutBuffer(n, 26, 1, 26, env.len_states, 4, horizon, 4, 0.99, 0.95, str(dev))
+        pol = P.ActorCritic(documented_policy(np.random.default_rng(0)), 1, env.len_states, device=str(dev))
+
+        def run():
+            buf.reset()
+            buf.compute_returns_and_advantage(buf.run(env, pol))
+
+        for _ in range(2):
+            run()
+        sync_ranks()
+        t0 = time.perf_counter()
+        reps = 4
+        for _ in range(reps):
+            run()
+        sync_ranks()
+        el = max_over_ranks(time.perf_counter() - t0) / reps
+        del buf, env, pol
+        torch.cuda.empty_cache()
+        return {"config": 5, "what": "taco_rollout_run + GAE on every rank's slice (policy forward included), data-parallel", "envs_total": total, "envs_per_rank": n,
+                "horizon": horizon, "ms_per_rollout": el * 1e3, "value": total * horizon / el, "unit": "env-steps/s"}
+    except Exception as e:  # noqa: BLE001
+        return {"config": 5, "what": "rollout", "envs_total": total, "error": repr(e)[:300]}
 
 
 if __name__ == "__main__":

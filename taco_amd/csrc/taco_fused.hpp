@@ -42,8 +42,8 @@ struct RolloutParams {
     float *logp_buf, *rew_buf, *done_buf;  // [horizon][n]
     uint8_t *timeout_buf;                  // [horizon][n]
     int horizon, len_states;
-    unsigned long long *stamps;  // optional [8 + 2 * 64]: workgroup 0: [w] = SIMD of wavefront w; [8 + 2 t], [9 + 2 t] = shader clock of the step wavefront
-                                 // at the start / end of step t (t < 64)
+    unsigned long long *stamps;  // optional [8 + 2 * 64 + workgroups]: workgroup 0: [w] = SIMD of wavefront w; [8 + 2 t], [9 + 2 t] = shader clock of the step
+                                 // wavefront at the start / end of step t (t < 64); [136 + b] = clocks workgroup b's step wavefront spent in its loop
 };
 
 __global__ __launch_bounds__(FU_THREADS) void taco_rollout_kernel(const RolloutParams R) {
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(FU_THREADS) void taco_rollout_kernel(const RolloutP
     __shared__ __attribute__((aligned(16))) float xa[POL_ROWS * FU_LD];
     __shared__ __attribute__((aligned(16))) float xb[POL_ROWS * FU_LD];
     __shared__ float act_lds[POL_ROWS * 4];
-    __shared__ int act_seq, a_cnt;
+    __shared__ int act_seq, a_cnt, reset_seq, reset_lds[POL_ROWS];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = R.S.n, row0 = blockIdx.x * POL_ROWS;
     if (row0 >= n) return;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(FU_THREADS) void taco_rollout_kernel(const RolloutP
         const int r = e >> 5, k = e & 31;
         xin[r * FU_XLD + k] = (row0 + r < n && k < 26) ? R.obs_store[(size_t)(row0 + r) * 26 + k] : 0.0f;
     }
-    if (tid == 0) { act_seq = 0; a_cnt = 0; }
+    if (tid == 0) { act_seq = 0; a_cnt = 0; reset_seq = 0; }
     __syncthreads();
 
     if (actor >= 0) {
@@ -176,6 +176,7 @@ __global__ __launch_bounds__(FU_THREADS) void taco_rollout_kernel(const RolloutP
         Q.len_obs = 1; Q.len_states = 1;   // one frame per step and stack: the replay store keeps the stacks as a frame ring
         Q.obs_bytes = Q.states_bytes = (uint32_t)(frame * sizeof(float));
         Q.gather = nullptr; Q.stamps = nullptr; Q.obs_out = nullptr; Q.states_out = nullptr; Q.act_in = nullptr;
+        const unsigned long long loop_t0 = __builtin_readcyclecounter();
 #pragma unroll 1
         for (int t = 0; t < H; ++t) {
             if (R.stamps && blockIdx.x == 0 && tid == 0 && t < 64) R.stamps[8 + 2 * t] = __builtin_readcyclecounter();
@@ -185,9 +186,11 @@ __global__ __launch_bounds__(FU_THREADS) void taco_rollout_kernel(const RolloutP
             FusedCtx FX;
             FX.role = role; FX.step = step0 + (uint32_t)t; FX.head = (head0 + 10 * t) % TACO_RING_SLOTS; FX.hh = (hh0 + t) % HIST_ROWS;
             FX.act_lds = (lds_f32 *)act_lds; FX.act_seq = (lds_i32 *)&act_seq; FX.act_want = t + 1; FX.xin = (lds_f32 *)xin; FX.xin_ld = FU_XLD;
+            FX.reset_lds = (lds_i32 *)reset_lds; FX.reset_seq = (lds_i32 *)&reset_seq; FX.reset_want = t;
             step_core<256, 4, true, false, false, false, false, true>(Q, FX);   // (its two barriers are the step's two)
             if (R.stamps && blockIdx.x == 0 && tid == 0 && t < 64) R.stamps[9 + 2 * t] = __builtin_readcyclecounter();
         }
+        if (R.stamps && tid == 0) R.stamps[136 + blockIdx.x] = __builtin_readcyclecounter() - loop_t0;
     }
     // eager launch: leave the clock after `horizon` steps in the control block, as every step launch does (a captured launch is followed by
     // advance_clock_kernel instead: nothing may write the clock while other workgroups still read it)

@@ -721,6 +721,9 @@ struct FusedCtx {
     int act_want;
     lds_f32 *xin;        // [16][xin_ld]: the actor's input rows; the obs role leaves the new (noised) frame there
     int xin_ld;
+    lds_i32 *reset_lds;  // [16]: the done flags the reward role computed in the PREVIOUS step of this kernel (the step wavefront starts the next
+    lds_i32 *reset_seq;  //   step while the roles are still in their post-phase: reset_buf in memory may not have been written yet);
+    int reset_want;      //   valid once *reset_seq >= reset_want.  reset_want == 0 (first step of the kernel): the flags are read from reset_buf.
 };
 template <int BLOCK, int LPE, bool SPLIT, bool CAP, bool OUT, bool RESET_ONLY, bool WIDE, bool FUSED>
 TD void step_core(const StepParams &P, const FusedCtx &FX) {
@@ -811,6 +814,14 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     // mb_om: rotor speeds (wave 0 -> 1), mb_v: voltage (1 -> 0), mb_bs: battery state E u1 t (0 -> 1 before, 1 -> 0 after), mb_seq: counters
     __shared__ float mb_om[SPLIT ? 64 : 4], mb_v[SPLIT ? 16 : 4], mb_bs[SPLIT ? 64 : 4];
     __shared__ int mb_seq[4];
+    // Rotor noise (CTRL/thrust_dynamics.py:68-78: every substep multiplies each rotor speed by a fresh uniform factor) SERVED by the obs role
+    // wavefront in the four-role quad forms: the 10 x EPW Philox blocks of a step depend on counters only, so that wavefront draws them all
+    // into this table right after barrier 1 (~3 blocks per lane) while wavefront 0 is still in its pre-phase, and a substep costs wavefront 0
+    // one LDS read and the multiply instead of a Philox block evaluated redundantly in the four lanes of every env (~1 000 instructions of a
+    // config-5 step's critical path).  Same draws, same expression for the factor: same bits.
+    constexpr bool NOISE_TAB = SPLIT && LPE == 4;
+    __shared__ float rn_tab[NOISE_TAB ? 10 * (64 / LPE) * 4 : 4];
+    const bool noise_served = NOISE_TAB && (P.flags & TACO_F_ROTOR_NOISE) != 0;
     // The arrays are named directly at every use (macros, not lambdas or pointer parameters) so that the accesses stay LDS instructions;
     // through a generic pointer they become flat loads.  MB_WAIT is bounded, so a protocol bug can never hang the GPU; a wait that gives up
     // sets kStatusMailboxTimeout in the workspace's sticky status word (taco_check reports TACO_ERR_STATE) and poisons the voltage with NaN.
@@ -870,7 +881,13 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     // ------------------------------------------------------------------ pre_physics_step FA:317-332
     // Every load the step needs is issued up front, before the reset flag is known: the flag, the action, the 13 state
     // chunks and the 10 ring slots of this step are independent, so they share ONE memory round trip.
-    const bool is_reset = P.reset[i] != 0;
+    bool is_reset;
+    if constexpr (FUSED) {
+        if (FX.reset_want > 0) is_reset = false;   // (comes from the reward role's mailbox, below: the loads are issued first)
+        else is_reset = P.reset[i] != 0;
+    } else {
+        is_reset = P.reset[i] != 0;
+    }
     float4 a_in = (RESET_ONLY || FUSED) ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : reinterpret_cast<const float4 *>(P.act_in)[i];
     float4 c_pos = CLD(C_POS), c_quat = CLD(C_QUAT), c_lin = CLD(C_LINVEL), c_ang = CLD(C_ANGVEL);
     float4 c_pp = CLD(C_PID_PREV), c_pi = CLD(C_PID_INT), c_om = CLD(C_OMEGA), c_misc = CLD(C_MISC);
@@ -892,6 +909,15 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     for (int k = 0; k < 4; ++k) {  // (rows this configuration's queue never reaches are not fetched: P.hw_rows)
         hwin[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (k < P.hw_rows) hwin[k] = buf_ld4(rH, voff, (uint32_t)((clk.hh - 1 - k) & (HIST_ROWS - 1)) * row_bytes);
+    }
+    if constexpr (FUSED) {
+        if (FX.reset_want > 0) {   // the previous step's done flags: posted by the reward role, ~a load round trip after this wavefront got here
+            int spins_ = 0;
+            while (__hip_atomic_load(FX.reset_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < FX.reset_want && ++spins_ < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (spins_ >= (1 << 22)) mb_timeout = true;
+            is_reset = FX.reset_lds[el] != 0;
+        }
     }
     // reset_idx (FA:475-517): the lanes that reset get their fresh state in the registers the up-front loads filled (see reset_env)
     const bool wave_has_reset = __builtin_amdgcn_ballot_w64(is_reset) != 0;
@@ -1153,7 +1179,8 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     // wave-uniform euler/unwrap switch (flip envs) the PLAIN forms of the loop have these decided at compile time (no branches over the unused blocks, integrator
     // unrolled; a lone wavefront pays ~10 issue slots for every taken branch)
     const Consts Crt{P.dt, P.rdt, P.h, P.half_h, P.inv_m, P.g, P.J0, P.J1, P.J2, P.hJi0, P.hJi1, P.hJi2, P.arm_x, P.arm_y};
-    const bool plain1 = !(fl & (TACO_F_ROTOR_NOISE | TACO_F_WORLD_RATE_ROUNDTRIP)) && P.substeps == 2 && (fl & TACO_F_BATTERY_CONSUMPTION) != 0;  // (+ bit 3 of the form: euler/unwrap on or off)
+    // (rotor noise: PLAIN forms exist for it where the noise table is served -- bit 4 of the form; + bit 3: euler/unwrap on or off)
+    const bool plain1 = (!(fl & TACO_F_ROTOR_NOISE) || noise_served) && !(fl & TACO_F_WORLD_RATE_ROUNDTRIP) && P.substeps == 2 && (fl & TACO_F_BATTERY_CONSUMPTION) != 0;
     // one lane per env: the PLAIN forms also carry the default airframe's constants as literals (kPlainConsts: the handle has exactly those)
     const bool plain = plain1 && (LPE != 1 || (fl & kPlainConsts) != 0);
     if constexpr (LPE == 1) {
@@ -1329,7 +1356,7 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
             // loop forms: 0 exact, 1 FIN, 2 FIN + PLAIN (battery computed here), 6 FIN + PLAIN + battery served by wavefront 1; + 8: with
             // euler/unwrap (wavefronts that hold flip envs)
             constexpr int MODE = decltype(fin_c)::value;
-            constexpr bool FIN = (MODE & 1) != 0 || MODE >= 2, PLAIN = (MODE & 2) != 0;
+            constexpr bool FIN = (MODE & 1) != 0 || MODE >= 2, PLAIN = (MODE & 2) != 0, NOISY = (MODE & 16) != 0;   // NOISY: PLAIN + served rotor noise
             const bool served = PLAIN ? (MODE & 4) != 0 : bat_served;
             if (PLAIN ? (MODE & 8) != 0 : wave_tracks_rpy) {
                 // refresh_state FA:339-347, get_euler_xyz_v1 TU:175-196 with lane j evaluating angle j: roll and yaw are the same atan2 on
@@ -1409,11 +1436,17 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
                 const float target = (opara[0] * 1.0f + opara[1] * x + opara[2] * y + opara[3] * (x * x) + opara[4] * x * y) * 100.0f;
                 omq = omq + itq * (target - omq);
             }
-            if (!PLAIN && (fl & TACO_F_ROTOR_NOISE)) {  // CTRL/thrust_dynamics.py:68-78
-                U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, clk.step, STREAM_ROTOR, (uint32_t)ks);
-                const float n_sc = (float)((1 + 10.0 / 700) - (1 - 10.0 / 700)), n_lo = (float)(1 - 10.0 / 700);
-                const uint32_t rk = sub == 0 ? r.x : (sub == 1 ? r.y : (sub == 2 ? r.z : r.w));
-                omq = omq * (n_sc * uniform(rk) + n_lo);
+            if constexpr (NOISY) {
+                omq = omq * rn_tab[(ks * EPW + el) * 4 + sub];   // CTRL/thrust_dynamics.py:68-78, the factor drawn by the obs role wavefront
+            } else if (!PLAIN && (fl & TACO_F_ROTOR_NOISE)) {  // CTRL/thrust_dynamics.py:68-78
+                if (noise_served) {
+                    omq = omq * rn_tab[(ks * EPW + el) * 4 + sub];
+                } else {
+                    U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, clk.step, STREAM_ROTOR, (uint32_t)ks);
+                    const float n_sc = (float)((1 + 10.0 / 700) - (1 - 10.0 / 700)), n_lo = (float)(1 - 10.0 / 700);
+                    const uint32_t rk = sub == 0 ? r.x : (sub == 1 ? r.y : (sub == 2 ? r.z : r.w));
+                    omq = omq * (n_sc * uniform(rk) + n_lo);
+                }
             }
             if (served) {  // the rotor speeds the NEXT substep's battery step starts from
                 mb_om[lane] = omq;
@@ -1458,7 +1491,20 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
                 if (rare) break;
             }
         };
-        if (SPLIT && fin && plain && bat_served) {
+        if (noise_served) {   // the noise table is complete before the first substep reads it (posted ~a pre-phase ago: normally no wait)
+            MB_WAIT(2, 1);
+        }
+        if (NOISE_TAB && fin && plain && noise_served) {   // (the PLAIN forms with the served rotor noise compiled in)
+            if constexpr (NOISE_TAB) {
+                if (bat_served) {
+                    if (!wave_tracks_rpy) run_form(std::integral_constant<int, 22>{});
+                    else run_form(std::integral_constant<int, 30>{});
+                } else {
+                    if (!wave_tracks_rpy) run_form(std::integral_constant<int, 18>{});
+                    else run_form(std::integral_constant<int, 26>{});
+                }
+            }
+        } else if (SPLIT && fin && plain && bat_served) {
             if (!wave_tracks_rpy) run_form(std::integral_constant<int, 6>{});
             else run_form(std::integral_constant<int, 14>{});
         } else if (fin && plain) {
@@ -1565,6 +1611,20 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     } else {
         if (wv == 1 && lane < 4) mb_seq[lane] = 0;
         __syncthreads();  // barrier 1 of 2
+        if constexpr (NOISE_TAB) {
+            if (wv == 2 && noise_served) {   // the step's 10 x EPW rotor-noise blocks -> rn_tab (first: wavefront 0 needs them at its first substep)
+                const float n_sc = (float)((1 + 10.0 / 700) - (1 - 10.0 / 700)), n_lo = (float)(1 - 10.0 / 700);
+#pragma unroll 1
+                for (int b = lane; b < 10 * EPW; b += 64) {
+                    const int ks = b / EPW, e = b - ks * EPW;
+                    const int ie = (int)wave_env0 + e < P.n ? (int)wave_env0 + e : P.n - 1;   // (tail slots shadow the last env, as wavefront 0's lanes do)
+                    const U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)(P.env_offset + ie), clk.step, STREAM_ROTOR, (uint32_t)ks);
+                    rn_tab[b * 4 + 0] = n_sc * uniform(r.x) + n_lo; rn_tab[b * 4 + 1] = n_sc * uniform(r.y) + n_lo;
+                    rn_tab[b * 4 + 2] = n_sc * uniform(r.z) + n_lo; rn_tab[b * 4 + 3] = n_sc * uniform(r.w) + n_lo;
+                }
+                MB_POST(2, 1);
+            }
+        }
         if (wv == 3 && P.len_states > 1) shift_history(P.states, P.states_prev, P.states_bytes, P.len_states, OUT ? P.states_out : nullptr, P.clip_states);
         if (wv == 2 && P.len_obs > 1) shift_history(P.obs, P.obs_prev, P.obs_bytes, P.len_obs, OUT ? P.obs_out : nullptr, P.clip_obs);
         if (wv == 2 && (fl & TACO_F_OBSERVATION_NOISE)) { gen_obs_noise(); noise_ready = true; }
@@ -1766,9 +1826,27 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     TACO_STAMP(4);  // state stores + frames done
     if (roleR) {
     // ------------------------------------------------------------------ compute_reward CTRL/task_reward.py
+    // the done flag first (all it needs is the task's position error, the height and the progress counter): in the persistent rollout
+    // kernel the step wavefront is already at the top of the NEXT step, waiting for exactly this flag
     float rew, pos_dist;
-    if (grp == TACO_TASK_POS) {  // :20-47
+    if (grp == TACO_TASK_ROTATE) {
+        const float hori = norm2(rel_pos.x, rel_pos.y) - 1.2f, vert = absf(rel_pos.z);
+        pos_dist = __builtin_sqrtf(hori * hori + vert * vert);
+    } else {
         pos_dist = norm3(rel_pos_b.x, rel_pos_b.y, rel_pos_b.z);
+    }
+    long long die = 0;
+    if (p.z < 0.1f) die = 1;
+    if (pos_dist > 10.0f) die = 1;
+    const float max_len_f = (float)P.max_len;
+    const long long rs = ((float)progress >= max_len_f - 1.0f) ? 1 : die;
+    const bool tmo = (progress >= P.max_len - 1) && (rs != 0);  // VT:323
+    if constexpr (FUSED) {   // the next step of this kernel takes its reset flags from here (tail lanes shadow env n - 1, as the step wavefront's do)
+        if (sub == 0) FX.reset_lds[el] = (int)rs;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (lane == 0) __hip_atomic_store(FX.reset_seq, FX.reset_want + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (grp == TACO_TASK_POS) {  // :20-47
         float pr = 1.0f / (1.0f + pos_dist * pos_dist) + 1.0f / (1.0f + 10.0f * pos_dist * pos_dist);
         Q4 mq = quat_mul(q, conj(qt));  // quat_diff_rad TJ:145-164
         float nn = norm3(mq.x, mq.y, mq.z);
@@ -1783,9 +1861,6 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
         float ny0 = cross_term(0.0f, nx2, 1.0f, nx1), ny1 = cross_term(1.0f, nx0, 0.0f, nx2), ny2 = cross_term(0.0f, nx1, 0.0f, nx0);
         float yn = norm3(ny0, ny1, ny2) + 1e-8f;
         ny0 = ny0 / yn; ny1 = ny1 / yn; ny2 = ny2 / yn;
-        float hori = norm2(rel_pos.x, rel_pos.y) - 1.2f;
-        float vert = absf(rel_pos.z);
-        pos_dist = __builtin_sqrtf(hori * hori + vert * vert);
         float pr = 1.0f / (1.0f + pos_dist * pos_dist) + 1.0f / (1.0f + 10.0f * pos_dist * pos_dist);
         float normal = (rel_v.x * nx0 + rel_v.y * nx1) + rel_v.z * nx2;
         float tang = (rel_v.x * ny0 + rel_v.y * ny1) + rel_v.z * ny2;
@@ -1797,19 +1872,12 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
         float dr = 1.0f / (1.0f + ddir * ddir) + 1.0f / (1.0f + 10.0f * ddir * ddir);
         rew = TACO_DIVC(pr * lr * dr, 100.0f);
     } else {  // :107-143
-        pos_dist = norm3(rel_pos_b.x, rel_pos_b.y, rel_pos_b.z);
         float pr = 1.0f / (1.0f + 1.0f * pos_dist) + 1.0f / (1.0f + 10.0f * pos_dist);
         float xr = 1.0f / (1.0f + 10.0f * (1.0f - tilt00));
         float cd = TACO_DIVC(cmd1 / 2.0f, kPi);
         float cr = 1.0f / (1.0f + cd * cd) + 1.0f / (1.0f + 10.0f * cd * cd);
         rew = TACO_DIVC(pr * xr * cr, 100.0f);
     }
-    long long die = 0;
-    if (p.z < 0.1f) die = 1;
-    if (pos_dist > 10.0f) die = 1;
-    const float max_len_f = (float)P.max_len;
-    const long long rs = ((float)progress >= max_len_f - 1.0f) ? 1 : die;
-    const bool tmo = (progress >= P.max_len - 1) && (rs != 0);  // VT:323
 
     // ------------------------------------------------------------------ store
     if (active) {

@@ -49,12 +49,14 @@ class RolloutBuffer:
         self.step = 0
 
     def _alloc_small(self):
-        H, N, dev = self.horizon_len, self.num_envs, self.device
-        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)  # noqa: E731
-        self.act_buf = z(H, N, self.act_dim)
-        self.rew_buf, self.done_buf = z(H, N, 1), z(H, N, 1)
-        self.ret_buf, self.value_buf, self.adv_buf = z(H, N, 1), z(H, N, 1), z(H, N, 1)
-        self.mu_buf, self.sigma_buf, self.logp_buf = z(H, N, self.act_dim), z(H, N, self.act_dim), z(H, N, 1)
+        """the nine per-step arrays of buffer_asymmetry.py:24-47 as views of ONE allocation: reset() clears them with a single launch"""
+        H, N, dev, A = self.horizon_len, self.num_envs, self.device, self.act_dim
+        widths = (("act_buf", A), ("rew_buf", 1), ("done_buf", 1), ("ret_buf", 1), ("value_buf", 1), ("adv_buf", 1), ("mu_buf", A), ("sigma_buf", A), ("logp_buf", 1))
+        self._small = torch.zeros(sum(w for _, w in widths) * H * N, dtype=torch.float32, device=dev)
+        off = 0
+        for name, w in widths:
+            setattr(self, name, self._small[off:off + H * N * w].view(H, N, w))
+            off += H * N * w
 
     def _stack_view(self, slot0, slots):
         """[slots, N, T, D] view of the ring: stack (slot, env) = ring rows slot .. slot + T - 1 of that env (overlapping, read-only)"""
@@ -87,8 +89,7 @@ class RolloutBuffer:
             self._obs_store[0].copy_(self._obs_store[self.step])
             self._frames[:self.states_len].copy_(self._frames[self.step:self.step + self.states_len].clone() if self.step < self.states_len
                                                  else self._frames[self.step:self.step + self.states_len])
-        for t in (self.act_buf, self.rew_buf, self.done_buf, self.ret_buf, self.value_buf, self.adv_buf, self.mu_buf, self.sigma_buf, self.logp_buf):
-            t.zero_()  # in place: the pointers stay valid for captured graphs
+        self._small.zero_()  # all nine per-step arrays, in place (one launch): the pointers stay valid for captured graphs
         self.step = 0
 
     def compute_returns_and_advantage(self, last_values, normalize=True):

@@ -78,19 +78,27 @@ class FpvBase:
 
         # allocate_buffers, vec_task_asymmetry.py:231-254
         dev = self.device
-        self.obs_buf = torch.zeros((self.num_envs, self.len_obs, self.num_obs), device=dev, dtype=torch.float32)
-        self.states_buf = torch.zeros((self.num_envs, self.len_states, self.num_states), device=dev, dtype=torch.float32)
+        # obs_buf / states_buf: with copy_outputs (the default) TWO buffers each, used alternately -- step() reads the frame stacks from the
+        # current pair and writes the next one (taco_step_rollout's prev / next), so what a step() returned stays untouched by the next
+        # step() without any copy: the reference returns a clamped COPY of its buffers (vec_task_asymmetry.py:331-332), and with the
+        # default clip of +inf that copy is the buffer's content.  `env.obs_buf` / `env.states_buf` are always the current pair.
+        self._want_pp = bool(copy_outputs)
+        self._finite_clip = bool(math.isfinite(self.clip_obs) or math.isfinite(self.clip_states))
+        npp = 2 if self._want_pp else 1
+        self._obs_pp = [torch.zeros((self.num_envs, self.len_obs, self.num_obs), device=dev, dtype=torch.float32) for _ in range(npp)]
+        self._states_pp = [torch.zeros((self.num_envs, self.len_states, self.num_states), device=dev, dtype=torch.float32) for _ in range(npp)]
+        self._pp = 0
         self.rew_buf = torch.zeros(self.num_envs, device=dev, dtype=torch.float32)
         self.reset_buf = torch.ones(self.num_envs, device=dev, dtype=torch.long)
         self.timeout_buf = torch.zeros(self.num_envs, device=dev, dtype=torch.bool)
         self.extras = {}
         self.obs_dict = {}
-        # What step() returns as obs / states (vec_task_asymmetry.py:331-332: a clamped COPY of the buffers) is written by the step kernel
-        # itself into these buffers -- no torch.clamp launch, no allocation per step.  Two pairs alternate, so a tensor returned by one
-        # step() stays untouched by the next (the reference returns a fresh tensor every time; the PPO loop copies it straight away).
-        self._want_out = bool(copy_outputs or math.isfinite(self.clip_obs) or math.isfinite(self.clip_states))
-        self._out = [(torch.zeros_like(self.obs_buf), torch.zeros_like(self.states_buf)) for _ in range(2)] if self._want_out else None
+        # finite clipObservations / clipStates: the clamped copies step() returns are written by the step kernel itself (its OUT
+        # instantiation) into two alternating pairs -- no torch.clamp launch, no allocation per step
+        self._out = [(torch.zeros_like(self._obs_pp[0]), torch.zeros_like(self._states_pp[0])) for _ in range(2)] if self._finite_clip else None
         self._out_k = 0
+        self._step_io = {}
+        self._same_device = self.rl_device == self.device
         self._progress = torch.zeros(self.num_envs, device=dev, dtype=torch.int32)
 
         nbytes = self.lib.taco_workspace_bytes(C.byref(self._c))
@@ -112,7 +120,7 @@ class FpvBase:
         _lib.check(self.lib.taco_set_rollout_fusion(self._h, 1 if on else 0), self.lib)
 
     def bind_rollout_stamps(self, stamps):
-        """profiling: a [136] int64 device tensor workgroup 0 of the persistent rollout kernel fills (SIMD of its 8 wavefronts, per-step clocks); None unbinds"""
+        """profiling: a [136 + ceil(num_envs / 16)] int64 device tensor workgroup 0 of the persistent rollout kernel fills (SIMD of its 8 wavefronts, per-step clocks); None unbinds"""
         self._rollout_stamps = stamps
         _lib.check(self.lib.taco_bind_rollout_stamps(self._h, stamps.data_ptr() if stamps is not None else None), self.lib)
 
@@ -139,6 +147,15 @@ class FpvBase:
         self._difficulty = float(value)
         self.cfg["difficulty"] = self._difficulty
         _lib.check(self.lib.taco_set_difficulty(self._h, self._difficulty))
+
+    @property
+    def obs_buf(self):
+        """[num_envs, len_obs, 26] frame stacks, newest frame last, unclamped (fpv_asymmetry.py:392): the CURRENT buffer of the alternating pair"""
+        return self._obs_pp[self._pp]
+
+    @property
+    def states_buf(self):
+        return self._states_pp[self._pp]
 
     @property
     def progress_buf(self):
@@ -225,26 +242,45 @@ class FpvBase:
         _lib.check(self.lib.taco_step_rollout(self._h, C.byref(io), _stream_ptr(self.device)), self.lib)
 
     def step(self, actions):
-        """vec_task_asymmetry.py:290-334: ONE kernel launch (the clamped obs / states copies are written by the step kernel).
+        """vec_task_asymmetry.py:290-334: ONE kernel launch, nothing else on the device.
 
-        ALIASING CONTRACT (differs from the reference, which returns freshly allocated clamped tensors): the returned obs / states tensors
-        are two persistent buffer pairs used alternately -- what step t returned is overwritten by step t + 2; rew / done / time_outs are
-        the env's own buffers, overwritten by step t + 1.  The PPO loop copies them into its replay buffer straight away
-        (ppo_asymmetry.py:326-329), which is the intended use; a caller that keeps observations across more than one step must clone()."""
-        if not self._want_out:
-            self.step_raw(actions)
-            self.obs_dict["obs"], self.obs_dict["states"] = self.obs_buf.to(self.rl_device), self.states_buf.to(self.rl_device)
-        else:
-            if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.device != self.device:
-                actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
-            if actions.shape != (self.num_envs, self.num_acts):
-                raise ValueError(f"actions must be [{self.num_envs}, {self.num_acts}], got {tuple(actions.shape)}")
-            obs_out, states_out = self._out[self._out_k]
+        What is returned as obs / states: the reference returns clamp(obs_buf, +-clipObservations) -- a fresh tensor.  Here, with the default
+        clip of +inf, step() reads the frame stacks from the current buffer pair and writes the OTHER pair, which becomes `env.obs_buf` /
+        `env.states_buf` and is returned as it is (no copy exists anywhere; the launch is the one step_raw() makes); with a finite clip the
+        same launch also writes the clamped copies (the kernel's OUT instantiation) into two alternating output pairs.
+        ALIASING CONTRACT (differs from the reference's freshly allocated tensors): the obs / states tensors of step t are overwritten by
+        step t + 2; rew / done / time_outs are the env's own buffers, overwritten by step t + 1.  The PPO loop copies them into its replay
+        buffer straight away (ppo_asymmetry.py:326-329), which is the intended use; a caller that keeps observations across more than one
+        step must clone().  copy_outputs=False: everything in place, the returned tensors ARE the buffers."""
+        if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.device != self.device:
+            actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
+        if actions.shape != (self.num_envs, self.num_acts):
+            raise ValueError(f"actions must be [{self.num_envs}, {self.num_acts}], got {tuple(actions.shape)}")
+        cur = self._pp
+        nxt = cur ^ 1 if (self._want_pp and not self._finite_clip) else cur   # (finite clip: the clamped copies are what survives)
+        k = self._out_k if self._finite_clip else 0
+        io = self._step_io.get((cur, k))
+        if io is None:   # the argument block of this (buffer pair, output pair) combination: built once, only the action pointer changes
+            obs_out, states_out = self._out[k] if self._finite_clip else (None, None)
+            io = _lib.RolloutIO(None, self._obs_pp[cur].data_ptr() if nxt != cur else None, self._obs_pp[nxt].data_ptr(),
+                                self._states_pp[cur].data_ptr() if nxt != cur else None, self._states_pp[nxt].data_ptr(), self.rew_buf.data_ptr(),
+                                self.reset_buf.data_ptr(), self.timeout_buf.data_ptr(), None,
+                                obs_out.data_ptr() if obs_out is not None else None, states_out.data_ptr() if states_out is not None else None)
+            self._step_io[(cur, k)] = io
+        io.actions = actions.data_ptr()
+        rc = self.lib.taco_step_rollout(self._h, C.byref(io), _stream_ptr(self.device))
+        if rc != 0:
+            _lib.check(rc, self.lib)
+        self._pp = nxt
+        if self._finite_clip:
             self._out_k ^= 1
-            io = _lib.RolloutIO(actions.data_ptr(), None, self.obs_buf.data_ptr(), None, self.states_buf.data_ptr(), self.rew_buf.data_ptr(),
-                                self.reset_buf.data_ptr(), self.timeout_buf.data_ptr(), None, obs_out.data_ptr(), states_out.data_ptr())
-            _lib.check(self.lib.taco_step_rollout(self._h, C.byref(io), _stream_ptr(self.device)), self.lib)
-            self.obs_dict["obs"], self.obs_dict["states"] = obs_out.to(self.rl_device), states_out.to(self.rl_device)
+            obs, st = self._out[k]
+        else:
+            obs, st = self._obs_pp[nxt], self._states_pp[nxt]
+        if self._same_device:
+            self.obs_dict["obs"], self.obs_dict["states"], self.extras["time_outs"] = obs, st, self.timeout_buf
+            return self.obs_dict, self.rew_buf, self.reset_buf, self.extras
+        self.obs_dict["obs"], self.obs_dict["states"] = obs.to(self.rl_device), st.to(self.rl_device)
         self.extras["time_outs"] = self.timeout_buf.to(self.rl_device)
         return self.obs_dict, self.rew_buf.to(self.rl_device), self.reset_buf.to(self.rl_device), self.extras
 

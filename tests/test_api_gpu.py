@@ -417,6 +417,36 @@ def test_step_returns_kernel_written_clamped_copies(n, len_states, form):
     env.check()
 
 
+@pytest.mark.parametrize("n,len_obs,len_states,form", [(300, 1, 1, "auto"), (300, 2, 5, "auto"), (20000, 1, 5, "auto"), (70000, 1, 1, "auto"), (300, 3, 3, "lane"), (300, 1, 4, "quad")])
+def test_step_returns_the_other_buffer_pair_without_a_copy(n, len_obs, len_states, form):
+    """Default clip (+inf): step() is the launch step_raw() makes -- the frame stacks are read from the current buffer pair and written to the
+    other one (prev / next of taco_step_rollout), which is returned as it is.  Bit-identical to an env stepped in place, through every store
+    path; the tensors of step t survive step t + 1 and are reused by step t + 2; env.obs_buf / states_buf are always the current pair."""
+    from taco_amd.vec_env import FpvBase
+    kw = dict(env_lenStates=len_states, env_lenObservations=len_obs, env_maxEpisodeLength=30, observation_noise=True)
+    env = FpvBase(config.default_cfg("mix", n, **kw), kernel_form=form)
+    ref = FpvBase(config.default_cfg("mix", n, **kw), kernel_form=form, copy_outputs=False)
+    g = torch.Generator().manual_seed(1)
+    acts = (0.3 * torch.randn((6, n, 4), generator=g)).clamp(-1, 1).cuda()
+    held = []
+    for t in range(45):
+        d, rew, done, info = env.step(acts[t % 6])
+        ref.step_raw(acts[t % 6])
+        assert d["obs"].data_ptr() == env.obs_buf.data_ptr() and d["states"].data_ptr() == env.states_buf.data_ptr()
+        assert torch.equal(d["obs"].view(torch.int32), ref.obs_buf.view(torch.int32)) and torch.equal(d["states"].view(torch.int32), ref.states_buf.view(torch.int32)), t
+        assert torch.equal(rew.view(torch.int32), ref.rew_buf.view(torch.int32)) and torch.equal(done, ref.reset_buf)
+        if held:
+            assert torch.equal(held[-1][0].view(torch.int32), held[-1][1].view(torch.int32)), "the previous step's tensors must survive this step"
+            assert held[-1][0].data_ptr() != d["states"].data_ptr()
+        if len(held) > 1:
+            assert held[-2][0].data_ptr() == d["states"].data_ptr()          # two pairs alternate
+        held.append((d["states"], d["states"].clone()))
+    assert torch.equal(env.get_state().view(torch.int32), ref.get_state().view(torch.int32))
+    env.step_raw(acts[0]); ref.step_raw(acts[0])                              # in place on the current pair
+    assert torch.equal(env.states_buf.view(torch.int32), ref.states_buf.view(torch.int32))
+    env.check()
+
+
 def _run_bench(extra, env_extra=None, timeout=420):
     import json
     import subprocess
@@ -457,7 +487,20 @@ def test_bench_line_contract():
     assert [(x["config"], x.get("task_mode"), x["envs"]) for x in cfgs[:3]] == [(3, "rotate", 16384), (4, "flip", 16384), (5, "mix", 32768)]
     assert cfgs[2]["len_states"] == 5 and cfgs[2]["algorithmic_bytes_per_env_step"] == 1236.0 and "observation_noise" in cfgs[2]["flags_on"]
     assert cfgs[3]["config"] == 5 and cfgs[3]["env_steps_per_s"] > 0, cfgs[3]
-    assert d["step_api"]["us_per_step"] < 1.25 * d["steady_state"]["us_per_step"], "step() is one launch: it must cost about what step_raw costs"
+    # the headline IS VecTask.step(): ping-pong buffer pairs, the launch step_raw() makes (the host-side dict is all it adds)
+    assert "VecTask.step()" in d["metric"] and d["steady_state"]["api"] == "VecTask.step()"
+    assert d["steady_state"]["us_per_step"] < 1.12 * d["step_raw"]["us_per_step"], "step() is one launch: it must cost about what step_raw costs"
+    assert d["step_api_finite_clip"]["us_per_step"] < 1.3 * d["step_raw"]["us_per_step"]
+    r = d["roofline"]
+    assert "traffic_frac" in r and (r["traffic"] is None or abs(r["traffic_frac"] - r["traffic"] / (r["kernel_avg_us"] * 1e-6) / 1e9 / 8000.0) < 1e-9)
+    lf = d["latency_floor"]
+    assert 0.4 < lf["frac_of_kernel_avg"] < 1.0 and lf["critical_path_clocks"] >= lf["step_wavefront_clocks"] > 10000, lf
+    ro = cfgs[4]
+    assert ro["config"] == "5 at 4096 envs x 32 steps" and "persistent" in ro["per_step_chain"] and ro["ms_per_rollout"] < ro["ms_per_rollout_launch_per_step"]
+    # BASELINE configs 3-5 at their TOTAL env counts (here on one rank), the rollout of config 5 included
+    bc = d["baseline_configs"]
+    assert [(x["config"], x["envs_total"]) for x in bc] == [(3, 16384), (4, 65536), (5, 262144), (5, 262144)] and all("error" not in x for x in bc), bc
+    assert bc[2]["len_states"] == 5 and bc[3]["horizon"] == 16 and bc[3]["value"] > 0
 
 
 def test_bench_launches_its_own_ranks():
@@ -468,6 +511,19 @@ def test_bench_launches_its_own_ranks():
     assert abs(d["value"] - 8192 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     w = d["with_allgather"]
     assert "error" not in w and w["value"] > 0 and w["overlapped"]["value"] > 0 and w["bytes_per_rank"] == 4096 * 32 * 4
+    assert len(d["kernel_us_per_rank"]) == 2 and d["envs_per_rank"] == [4096.0, 4096.0] and d["n1_on_rank0"]["value"] > 0
+    bc = d["baseline_configs"]      # BASELINE configs 3-5 at their real totals, sharded over the two ranks; config 5 with its rollout
+    assert [(x["config"], x["envs_total"], x["envs_per_rank"]) for x in bc] == [(3, 16384, 8192), (4, 65536, 32768), (5, 262144, 131072), (5, 262144, 131072)], bc
+    assert all("error" not in x and x["value"] > 0 for x in bc) and all("error" not in x["with_allgather"] for x in bc[:3])
+
+
+def test_bench_main_leg_on_another_baseline_config_and_backend_fallback():
+    """`--config 4`: BASELINE configs[3] (flip, 65 536 envs in total) as the MAIN timed leg, sharded over two ranks; the process group is asked
+    for over a backend that cannot initialise here ("ucc"): the ranks fall back to gloo, the line is printed and says what happened."""
+    d = _run_bench(["--gpus", "2", "--steps", "40", "--warmup", "10", "--config", "4", "--no-configs"], {"TACO_BENCH_BACKEND": "ucc", "TACO_BENCH_ONE_DEVICE": "1"})
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["envs_total"] == 65536 and d["config"]["envs_per_gpu"] == 32768
+    assert "configs[3]" in d["metric"] and abs(d["value"] - 65536 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert d["backend"] == "gloo" and "ucc" in d["collective_init_error"] and d["ranks_seen"] == [0, 1]
     s = d["strong_scaling"]
     assert "error" not in s and s["envs_total"] == 4096 and s["envs_per_rank"] == 2048 and s["value"] > 0
 

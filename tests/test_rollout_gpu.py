@@ -238,7 +238,7 @@ def test_persistent_rollout_kernel_equals_the_launch_per_step_path(n, task, len_
     for fused in (True, False):
         env = FpvBase(cfg, copy_outputs=False)
         env.set_rollout_fusion(fused)
-        stamps = torch.zeros(136, dtype=torch.int64, device="cuda")
+        stamps = torch.zeros(136 + (n + 15) // 16, dtype=torch.int64, device="cuda")
         env.bind_rollout_stamps(stamps)
         pol = P.ActorCritic(sd, 1, len_states, seed=21)
         buf = _buffer(n, H, 1, len_states)
