@@ -515,6 +515,8 @@ def test_bench_launches_its_own_ranks():
     bc = d["baseline_configs"]      # BASELINE configs 3-5 at their real totals, sharded over the two ranks; config 5 with its rollout
     assert [(x["config"], x["envs_total"], x["envs_per_rank"]) for x in bc] == [(3, 16384, 8192), (4, 65536, 32768), (5, 262144, 131072), (5, 262144, 131072)], bc
     assert all("error" not in x and x["value"] > 0 for x in bc) and all("error" not in x["with_allgather"] for x in bc[:3])
+    s = d["strong_scaling"]
+    assert "error" not in s and s["envs_total"] == 4096 and s["envs_per_rank"] == 2048 and s["value"] > 0
 
 
 def test_bench_main_leg_on_another_baseline_config_and_backend_fallback():
@@ -524,8 +526,6 @@ def test_bench_main_leg_on_another_baseline_config_and_backend_fallback():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["envs_total"] == 65536 and d["config"]["envs_per_gpu"] == 32768
     assert "configs[3]" in d["metric"] and abs(d["value"] - 65536 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     assert d["backend"] == "gloo" and "ucc" in d["collective_init_error"] and d["ranks_seen"] == [0, 1]
-    s = d["strong_scaling"]
-    assert "error" not in s and s["envs_total"] == 4096 and s["envs_per_rank"] == 2048 and s["value"] > 0
 
 
 def test_yaml_launcher_equals_the_python_built_config(tmp_path):
