@@ -313,10 +313,18 @@ FormInfo form_info(int form, bool out = false, bool wide = false) {
     }
 }
 // every wavefront of the launch has a SIMD to itself (256 workgroups of 4) and no stack history to move: the register cap buys nothing
-bool wide_form(const taco_cfg &c) { return c.num_envs <= 4096 && c.len_obs == 1 && c.len_states == 1; }
+// ... and nothing for the served tables to do (the WIDE build carries neither the euler nor the rotor-noise server: flip envs, record_flag and
+// rotor noise take the general build, where those leave the step wavefront's instruction stream)
+bool wide_form(const taco_cfg &c) {
+    return c.num_envs <= 4096 && c.len_obs == 1 && c.len_states == 1 && (c.task_mode == TACO_TASK_POS || c.task_mode == TACO_TASK_ROTATE) &&
+           !(c.flags & (TACO_F_ROTOR_NOISE | TACO_F_TRACK_RPY));
+}
 int choose_form(const taco_cfg &c) {
     const bool stacks = c.len_obs > 1 || c.len_states > 1;
     if (c.num_envs <= kQuadMaxEnvs) {
+        // flip envs (the euler server) keep the role form up to the quad limit: 18.1 vs 19.1 us at 16 384 flip envs (profiles/r03_f_ab_step_servers.txt)
+        const bool euler_served = c.task_mode == TACO_TASK_FLIP || c.task_mode == TACO_TASK_MIX || (c.flags & TACO_F_TRACK_RPY) != 0;
+        if (euler_served) return TACO_FORM_QUAD_ROLES;
         // three helper wavefronts per 16 envs take over the post-phase: pays while every wavefront still has a SIMD to itself.  With
         // frame stacks the role wavefronts also move the stack history under the substeps, which pays up to the quad limit
         // (16 384 envs, 5 state frames: 19.2 us vs 22.1 us; 5 + 5 frames: 19.9 us vs 26.0 us; without stacks 18.0 us vs 17.5 us).

@@ -808,19 +808,32 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
             }
         }
     };
-    __shared__ __attribute__((aligned(16))) float hand[SPLIT ? (64 / LPE) * CARRY_WORDS : 4];
+    // (quad forms: 40 words per env instead of CARRY_WORDS -- the block doubles as the rotor-noise table, see rn_tab below)
+    __shared__ __attribute__((aligned(16))) float hand[SPLIT ? (64 / LPE) * (LPE == 4 ? 40 : CARRY_WORDS) : 4];
     // SPLIT: while wavefront 0 runs the substeps, wavefront 1 serves the battery model one substep AHEAD: the voltage of substep k
     // depends only on the rotor speeds left by substep k - 1, which are known ~2 000 clocks before the voltage is needed.
     // mb_om: rotor speeds (wave 0 -> 1), mb_v: voltage (1 -> 0), mb_bs: battery state E u1 t (0 -> 1 before, 1 -> 0 after), mb_seq: counters
     __shared__ float mb_om[SPLIT ? 64 : 4], mb_v[SPLIT ? 16 : 4], mb_bs[SPLIT ? 64 : 4];
-    __shared__ int mb_seq[4];
+    __shared__ int mb_seq[8];   // mailbox counters: 0 rotor speeds, 1 voltage, 2 rotor-noise table, 3 attitudes for the euler server, 4 its result
     // Rotor noise (CTRL/thrust_dynamics.py:68-78: every substep multiplies each rotor speed by a fresh uniform factor) SERVED by the obs role
     // wavefront in the four-role quad forms: the 10 x EPW Philox blocks of a step depend on counters only, so that wavefront draws them all
     // into this table right after barrier 1 (~3 blocks per lane) while wavefront 0 is still in its pre-phase, and a substep costs wavefront 0
     // one LDS read and the multiply instead of a Philox block evaluated redundantly in the four lanes of every env (~1 000 instructions of a
     // config-5 step's critical path).  Same draws, same expression for the factor: same bits.
-    constexpr bool NOISE_TAB = SPLIT && LPE == 4;
-    __shared__ float rn_tab[NOISE_TAB ? 10 * (64 / LPE) * 4 : 4];
+    // Euler angles + unwrap (FA:339-347: consumed only by the flip command, once per step) SERVED by the states role wavefront in the same
+    // forms: wavefront 0 leaves the attitude of every substep in eq_tab (one LDS write + the counter) and the server runs the eleven
+    // atan2 / asin / unwrap evaluations of the step behind it -- ~150 instructions per substep off the critical path of every wavefront
+    // that holds flip envs (flip at 4 096 envs: 17.9 -> us; the tail of a mixed-task rollout).  Same quad-layout code, same bits.
+    constexpr bool EULER_TAB = SPLIT && LPE == 4 && !WIDE;   // (WIDE = the headline form: launches without flip envs and rotor noise only, see wide_form)
+    // (eq_tab lives in the two role tiles, 2 x 16 x 26 words, which are idle until barrier 2 -- by then the server has read every attitude)
+    static_assert(!EULER_TAB || 2 * TILE_WORDS >= 11 * 64, "eq_tab must fit in the role wavefronts' frame tiles");
+    float *const eq_tab = lds_all + WAVE_LDS_WORDS;
+    __shared__ float eu_io[EULER_TAB ? 2 * 64 : 4];
+    constexpr bool NOISE_TAB = SPLIT && LPE == 4 && !WIDE;
+    // (rn_tab lives in `hand`: the table is read by the substeps, the Carry is written after the last one and read after barrier 2; the
+    // server writes the next table only after barrier 1 of the next step)
+    static_assert(!NOISE_TAB || (64 / LPE) * 40 >= 10 * (64 / LPE) * 4, "rn_tab must fit in the Carry block");
+    float *const rn_tab = hand;
     const bool noise_served = NOISE_TAB && (P.flags & TACO_F_ROTOR_NOISE) != 0;
     // The arrays are named directly at every use (macros, not lambdas or pointer parameters) so that the accesses stay LDS instructions;
     // through a generic pointer they become flat loads.  MB_WAIT is bounded, so a protocol bug can never hang the GPU; a wait that gives up
@@ -854,6 +867,7 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     // wave-uniform form of the same predicate: the euler/unwrap block runs for a whole wavefront or not at all (lanes of
     // other tasks then compute values nobody reads), which keeps the substep loop free of divergent control flow
     const bool wave_tracks_rpy = __builtin_amdgcn_ballot_w64(track_rpy) != 0;
+    const bool euler_served = EULER_TAB && wave_tracks_rpy;   // (the same for every wavefront of the workgroup: they hold the same envs)
 
     // Observation noise FA:402-410: 12 normals (Box-Muller on uniforms 4..15 of STREAM_OBS) and the small random rotation.  None of it
     // depends on the state, so the obs role wavefront of the SPLIT form draws it while the substeps run.
@@ -1358,7 +1372,10 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
             constexpr int MODE = decltype(fin_c)::value;
             constexpr bool FIN = (MODE & 1) != 0 || MODE >= 2, PLAIN = (MODE & 2) != 0, NOISY = (MODE & 16) != 0;   // NOISY: PLAIN + served rotor noise
             const bool served = PLAIN ? (MODE & 4) != 0 : bat_served;
-            if (PLAIN ? (MODE & 8) != 0 : wave_tracks_rpy) {
+            if (EULER_TAB && (PLAIN ? (MODE & 8) != 0 : wave_tracks_rpy)) {
+                eq_tab[ks * 64 + lane] = qq;   // the euler server (states role wavefront) takes it from here
+                MB_POST(3, ks + 1);
+            } else if (PLAIN ? (MODE & 8) != 0 : wave_tracks_rpy) {
                 // refresh_state FA:339-347, get_euler_xyz_v1 TU:175-196 with lane j evaluating angle j: roll and yaw are the same atan2 on
                 // different operands (lanes 0 and 2), pitch the asin form (lane 1) -- one atan2 and one asin per substep instead of two and
                 // one.  With c = this lane's quaternion component: numerator 2 (w c +- c' c'') (c', c'' the next two components; minus in
@@ -1482,6 +1499,7 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
             }
             return rare;
         };
+        if (euler_served) { eu_io[lane] = roq; eu_io[64 + lane] = rcq; }   // (published by the first MB_POST(3, ...))
         int ks = 0;
         auto run_form = [&](auto form) {
 #pragma unroll 1
@@ -1535,6 +1553,10 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
         pid_prev[0] = bc0(ppq); pid_prev[1] = bc1(ppq); pid_prev[2] = bc2(ppq);
         pid_int[0] = bc0(piq); pid_int[1] = bc1(piq); pid_int[2] = bc2(piq);
         omega[0] = bc0(omq); omega[1] = bc1(omq); omega[2] = bc2(omq); omega[3] = bc3(omq);
+        if (euler_served) {   // the attitude after the tenth substep (refresh_state of post_physics_step, FA:382), then the server's result
+            eq_tab[10 * 64 + lane] = qq;
+            MB_POST(3, 11);
+        }
         rpy_old[0] = bc0(roq); rpy_old[1] = bc1(roq); rpy_old[2] = bc2(roq);
         rpy_cont[0] = bc0(rcq); rpy_cont[1] = bc1(rcq); rpy_cont[2] = bc2(rcq);
     }
@@ -1548,7 +1570,18 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
 
     // ------------------------------------------------------------------ post_physics_step FA:374-388
     progress += 1;
-    if (wave_tracks_rpy) {  // refresh_state FA:382 (euler + unwrap part)
+    if (euler_served) {   // all eleven refreshes of the step were the server's
+        if constexpr (EULER_TAB) {
+            MB_WAIT(4, 1);
+            const float ro = eu_io[lane], rc = eu_io[64 + lane];
+            rpy_old[0] = bc0(ro); rpy_old[1] = bc1(ro); rpy_old[2] = bc2(ro);
+            rpy_cont[0] = bc0(rc); rpy_cont[1] = bc1(rc); rpy_cont[2] = bc2(rc);
+            if (__builtin_expect(mb_timeout, 0)) {
+                if (lane == 0) atomicOr(&P.ctl[kCtlStatus], kStatusMailboxTimeout);
+                rpy_cont[0] = nanf32();
+            }
+        }
+    } else if (wave_tracks_rpy) {  // refresh_state FA:382 (euler + unwrap part)
         V3 e = euler_xyz_v1(q);
         unwrap(e.x, rpy_old[0], rpy_cont[0]);
         unwrap(e.y, rpy_old[1], rpy_cont[1]);
@@ -1609,7 +1642,7 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     }
     if (SPLIT) { TACO_STAMP(4); TACO_STAMP(5); return; }  // wave 0 is done; the roles below belong to the other three wavefronts
     } else {
-        if (wv == 1 && lane < 4) mb_seq[lane] = 0;
+        if (wv == 1 && lane < 8) mb_seq[lane] = 0;
         __syncthreads();  // barrier 1 of 2
         if constexpr (NOISE_TAB) {
             if (wv == 2 && noise_served) {   // the step's 10 x EPW rotor-noise blocks -> rn_tab (first: wavefront 0 needs them at its first substep)
@@ -1627,6 +1660,30 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
         }
         if (wv == 3 && P.len_states > 1) shift_history(P.states, P.states_prev, P.states_bytes, P.len_states, OUT ? P.states_out : nullptr, P.clip_states);
         if (wv == 2 && P.len_obs > 1) shift_history(P.obs, P.obs_prev, P.obs_bytes, P.len_obs, OUT ? P.obs_out : nullptr, P.clip_obs);
+        if constexpr (EULER_TAB) {
+            if (wv == 3 && euler_served) {   // the euler server: eleven attitudes -> get_euler_xyz_v1 + unwrap, lane j of an env's quad = angle j
+                const uint32_t sgn = 0x80000000u;
+                const uint32_t m2_lane1 = (sub == 1) ? sgn : 0u, sgn_lane0 = (sub == 0) ? sgn : 0u, sgn_lane2 = (sub == 2) ? sgn : 0u;
+                MB_WAIT(3, 1);
+                float roq = eu_io[lane], rcq = eu_io[64 + lane];
+#pragma unroll 1
+                for (int k = 0; k < 11; ++k) {
+                    MB_WAIT(3, k + 1);
+                    const float qq = eq_tab[k * 64 + lane];
+                    const float wq = bc3(qq), sq = qq * qq;
+                    const float num = 2.0f * (wq * qq + xorf(rot1(qq) * rot2(qq), m2_lane1));
+                    const float den = ((bc3(sq) + xorf(bc0(sq), sgn_lane0)) - bc1(sq)) + xorf(bc2(sq), sgn_lane2);
+                    const float at = atan2(num, den);
+                    float pit;
+                    if (absf(num) >= 1.0f) pit = kHalfPi * (num > 0.0f ? 1.0f : (num < 0.0f ? -1.0f : 0.0f));
+                    else pit = asin(num);
+                    unwrap(sub == 1 ? pit : at, roq, rcq);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // (wavefront 0 is past its reads of eu_io: it posted counter 3 after them)
+                eu_io[lane] = roq; eu_io[64 + lane] = rcq;
+                MB_POST(4, 1);
+            }
+        }
         if (wv == 2 && (fl & TACO_F_OBSERVATION_NOISE)) { gen_obs_noise(); noise_ready = true; }
         if (bat_served && wv == 1) {  // battery server (the reward wavefront, idle until the post-phase): ten voltages, each one substep ahead of wavefront 0
             MB_WAIT(0, 1);
@@ -1826,27 +1883,35 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     TACO_STAMP(4);  // state stores + frames done
     if (roleR) {
     // ------------------------------------------------------------------ compute_reward CTRL/task_reward.py
-    // the done flag first (all it needs is the task's position error, the height and the progress counter): in the persistent rollout
-    // kernel the step wavefront is already at the top of the NEXT step, waiting for exactly this flag
-    float rew, pos_dist;
-    if (grp == TACO_TASK_ROTATE) {
-        const float hori = norm2(rel_pos.x, rel_pos.y) - 1.2f, vert = absf(rel_pos.z);
-        pos_dist = __builtin_sqrtf(hori * hori + vert * vert);
-    } else {
-        pos_dist = norm3(rel_pos_b.x, rel_pos_b.y, rel_pos_b.z);
-    }
-    long long die = 0;
-    if (p.z < 0.1f) die = 1;
-    if (pos_dist > 10.0f) die = 1;
-    const float max_len_f = (float)P.max_len;
-    const long long rs = ((float)progress >= max_len_f - 1.0f) ? 1 : die;
-    const bool tmo = (progress >= P.max_len - 1) && (rs != 0);  // VT:323
-    if constexpr (FUSED) {   // the next step of this kernel takes its reset flags from here (tail lanes shadow env n - 1, as the step wavefront's do)
+    // FUSED: the done flag FIRST (all it needs is the task's position error, the height and the progress counter): in the persistent rollout
+    // kernel the step wavefront is already at the top of the NEXT step, waiting for exactly this flag.  (The launch-per-step forms keep
+    // the reward's own order: the reordering costs their one-wavefront instantiations SGPR spills.)
+    float rew, pos_dist = 0.0f;
+    auto done_flags = [&](long long &rs_, bool &tmo_) {
+        long long die = 0;
+        if (p.z < 0.1f) die = 1;
+        if (pos_dist > 10.0f) die = 1;
+        const float max_len_f = (float)P.max_len;
+        rs_ = ((float)progress >= max_len_f - 1.0f) ? 1 : die;
+        tmo_ = (progress >= P.max_len - 1) && (rs_ != 0);  // VT:323
+    };
+    long long rs = 0;
+    bool tmo = false;
+    if constexpr (FUSED) {
+        if (grp == TACO_TASK_ROTATE) {
+            const float hori = norm2(rel_pos.x, rel_pos.y) - 1.2f, vert = absf(rel_pos.z);
+            pos_dist = __builtin_sqrtf(hori * hori + vert * vert);
+        } else {
+            pos_dist = norm3(rel_pos_b.x, rel_pos_b.y, rel_pos_b.z);
+        }
+        done_flags(rs, tmo);
+        // the next step of this kernel takes its reset flags from here (tail lanes shadow env n - 1, as the step wavefront's do)
         if (sub == 0) FX.reset_lds[el] = (int)rs;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         if (lane == 0) __hip_atomic_store(FX.reset_seq, FX.reset_want + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     if (grp == TACO_TASK_POS) {  // :20-47
+        if constexpr (!FUSED) pos_dist = norm3(rel_pos_b.x, rel_pos_b.y, rel_pos_b.z);
         float pr = 1.0f / (1.0f + pos_dist * pos_dist) + 1.0f / (1.0f + 10.0f * pos_dist * pos_dist);
         Q4 mq = quat_mul(q, conj(qt));  // quat_diff_rad TJ:145-164
         float nn = norm3(mq.x, mq.y, mq.z);
@@ -1861,6 +1926,11 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
         float ny0 = cross_term(0.0f, nx2, 1.0f, nx1), ny1 = cross_term(1.0f, nx0, 0.0f, nx2), ny2 = cross_term(0.0f, nx1, 0.0f, nx0);
         float yn = norm3(ny0, ny1, ny2) + 1e-8f;
         ny0 = ny0 / yn; ny1 = ny1 / yn; ny2 = ny2 / yn;
+        if constexpr (!FUSED) {
+            float hori = norm2(rel_pos.x, rel_pos.y) - 1.2f;
+            float vert = absf(rel_pos.z);
+            pos_dist = __builtin_sqrtf(hori * hori + vert * vert);
+        }
         float pr = 1.0f / (1.0f + pos_dist * pos_dist) + 1.0f / (1.0f + 10.0f * pos_dist * pos_dist);
         float normal = (rel_v.x * nx0 + rel_v.y * nx1) + rel_v.z * nx2;
         float tang = (rel_v.x * ny0 + rel_v.y * ny1) + rel_v.z * ny2;
@@ -1872,12 +1942,14 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
         float dr = 1.0f / (1.0f + ddir * ddir) + 1.0f / (1.0f + 10.0f * ddir * ddir);
         rew = TACO_DIVC(pr * lr * dr, 100.0f);
     } else {  // :107-143
+        if constexpr (!FUSED) pos_dist = norm3(rel_pos_b.x, rel_pos_b.y, rel_pos_b.z);
         float pr = 1.0f / (1.0f + 1.0f * pos_dist) + 1.0f / (1.0f + 10.0f * pos_dist);
         float xr = 1.0f / (1.0f + 10.0f * (1.0f - tilt00));
         float cd = TACO_DIVC(cmd1 / 2.0f, kPi);
         float cr = 1.0f / (1.0f + cd * cd) + 1.0f / (1.0f + 10.0f * cd * cd);
         rew = TACO_DIVC(pr * xr * cr, 100.0f);
     }
+    if constexpr (!FUSED) done_flags(rs, tmo);
 
     // ------------------------------------------------------------------ store
     if (active) {

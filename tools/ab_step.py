@@ -16,11 +16,12 @@ def child(case, roundtrip, record_flag):
     import bench
     from taco_amd import config
     from taco_amd.vec_env import FpvBase
-    idx, n = (int(x) for x in case.split(":"))
+    parts = case.split(":")     # config index : envs [: kernel form]
+    idx, n = int(parts[0]), int(parts[1])
     cfg = config.baseline_config(idx, num_envs=n)
     cfg["world_rate_roundtrip"] = bool(roundtrip)
     cfg["record_flag"] = bool(record_flag)
-    env = FpvBase(cfg, copy_outputs=False)
+    env = FpvBase(cfg, copy_outputs=False, kernel_form=parts[2] if len(parts) > 2 else "auto")
     acts = bench.make_actions(n, 8, 0, "cuda")
     med, ws, first = bench.steady_windows(env.step_raw, acts, torch, 0.25, 5, 2000 if n <= 16384 else (400 if n <= 131072 else 200))
     print(json.dumps({"us": med, "spread": (ws[-1] - ws[0]) / med, "form": env.kernel_form}))
@@ -47,8 +48,8 @@ if __name__ == "__main__":
                     continue
                 d = json.loads(out.stdout.strip().splitlines()[-1])
                 res.setdefault((lib, case), []).append(d["us"])
-                print(f"round {r} {lib:40s} {case:12s} {d['us']:8.2f} us  spread {d['spread']:.3f}  {d['form']}", flush=True)
+                print(f"round {r} {lib:40s} {case:24s} {d['us']:8.2f} us  spread {d['spread']:.3f}  {d['form']}", flush=True)
     print("---- median of rounds")
     for (lib, case), v in res.items():
         v.sort()
-        print(f"{lib:40s} {case:12s} {v[len(v) // 2]:8.2f} us   {v}")
+        print(f"{lib:40s} {case:24s} {v[len(v) // 2]:8.2f} us   {v}")
