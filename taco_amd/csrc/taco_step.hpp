@@ -1028,10 +1028,12 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
         return;
     }
     int T = 10;
-    if (fl & TACO_F_RANDOM_DEPLOY_TIME) {
-        U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, clk.step, STREAM_DEPLOY, 0u);
-        T = 10 - rounded_normal(uniform(r.x), 1);
-    }
+    auto draw_T = [&]() {
+        if (fl & TACO_F_RANDOM_DEPLOY_TIME) {
+            U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, clk.step, STREAM_DEPLOY, 0u);
+            T = 10 - rounded_normal(uniform(r.x), 1);
+        }
+    };
     // FUSED: this step's action is being computed by the actor wavefronts right now.  The ten slots this step consumes hold it only if an
     // env has fewer than ten pending slots, or keeps the literal slot ring (DENSE: the ring is written ahead of the substeps); then -- wave-
     // uniformly, rarely: delay_time < 10 ms or the overflow regime -- the step waits for the actor here.  Otherwise the action is picked up
@@ -1046,6 +1048,7 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
         have_act = true;
     };
     if constexpr (FUSED) {
+        draw_T();
         const bool early = dense || dlen + T > TACO_RING_SLOTS - 10 || dlen < 10;
         if (__builtin_amdgcn_ballot_w64(early) != 0) fetch_action();
     }
@@ -1056,6 +1059,7 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     float4 act4 = make_float4(act[0], act[1], act[2], act[3]);
     const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (have_act && active) buf_st4(rH, act4, voff, (uint32_t)(clk.hh & (HIST_ROWS - 1)) * row_bytes);  // this step's action, row hh
+    if constexpr (!FUSED) draw_T();
     // value of queued run j (0 = oldest) BEFORE this step's push: the action of (m - j) steps ago
     auto run_value = [&](int j) -> float4 {
         const uint32_t row = (uint32_t)((clk.hh - (q_m - j)) & (HIST_ROWS - 1));
