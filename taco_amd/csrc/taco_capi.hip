@@ -305,6 +305,9 @@ FormInfo form_info(int form, bool out = false, bool wide = false) {
     if (wide && form == TACO_FORM_QUAD_ROLES)
         fn = out ? (const void *)taco::taco_step_kernel<kBlockLarge, 4, true, false, true, false, true>
                  : (const void *)taco::taco_step_kernel<kBlockLarge, 4, true, false, false, false, true>;
+    if (wide && form == TACO_FORM_LANE_ROLES)
+        fn = out ? (const void *)taco::taco_step_kernel<kBlockLarge, 1, true, false, true, false, true>
+                 : (const void *)taco::taco_step_kernel<kBlockLarge, 1, true, false, false, false, true>;
     switch (form) {
         case TACO_FORM_QUAD_ROLES: return {4, kBlockLarge, 1, fn};
         case TACO_FORM_LANE_ROLES: return {1, kBlockLarge, 1, fn};
@@ -315,7 +318,9 @@ FormInfo form_info(int form, bool out = false, bool wide = false) {
 // every wavefront of the launch has a SIMD to itself (256 workgroups of 4) and no stack history to move: the register cap buys nothing
 // ... and nothing for the served tables to do (the WIDE build carries neither the euler nor the rotor-noise server: flip envs, record_flag and
 // rotor noise take the general build, where those leave the step wavefront's instruction stream)
-bool wide_form(const taco_cfg &c) {
+// The one-lane role form: its launch puts at most two wavefronts on a SIMD up to 32 768 envs (512 workgroups of four).
+bool wide_form(const taco_cfg &c, int form) {
+    if (form == TACO_FORM_LANE_ROLES) return c.num_envs <= 32768;
     return c.num_envs <= 4096 && c.len_obs == 1 && c.len_states == 1 && (c.task_mode == TACO_TASK_POS || c.task_mode == TACO_TASK_ROTATE) &&
            !(c.flags & (TACO_F_ROTOR_NOISE | TACO_F_TRACK_RPY));
 }
@@ -456,7 +461,7 @@ int launch_step(taco_env *e, const taco_rollout_io *io, void *stream) {
     grid_of_form(e, form, &grid, &block);
     taco_cfg eff = e->cfg;
     if (newest_only) eff.len_states = 1;
-    hipError_t he = hipLaunchKernel(form_info(form, P.obs_out != nullptr || P.states_out != nullptr, wide_form(eff)).fn, dim3(grid), dim3(block), args, 0,
+    hipError_t he = hipLaunchKernel(form_info(form, P.obs_out != nullptr || P.states_out != nullptr, wide_form(eff, form)).fn, dim3(grid), dim3(block), args, 0,
                                     (hipStream_t)stream);
     if (he == hipSuccess) he = hipGetLastError();
     if (he != hipSuccess) return hip_fail(he, "taco_step_kernel launch");
@@ -964,7 +969,7 @@ int taco_bind_phase_stamps(taco_env *e, uint64_t *stamps) {
 
 int taco_occupancy(const taco_env *e, int *resident_blocks_per_cu, int *lds_bytes_per_block) {
     if (!e || !resident_blocks_per_cu || !lds_bytes_per_block) return fail(TACO_ERR_INVALID_ARG, "taco_occupancy: null argument");
-    const FormInfo f = form_info(e->form, false, wide_form(e->cfg));
+    const FormInfo f = form_info(e->form, false, wide_form(e->cfg, e->form));
     hipFuncAttributes at;
     hipError_t he = hipFuncGetAttributes(&at, f.fn);
     if (he != hipSuccess) return hip_fail(he, "hipFuncGetAttributes");

@@ -703,7 +703,9 @@ constexpr int CARRY_WORDS = 32;  // 30 used
 // presence cost 0.75 us of 13.8 (SGPR spills, skipped branches) -- profiles/r02_d_ab_out_copy_paths.txt.
 // RESET_ONLY (<64, 1> only; taco_reset_done = VecTask.reset_done, VT:363-375): the kernel stops after reset_idx / reset_command_idx, stores what
 // they changed, clears the flags of the envs it reset and returns -- no action is pushed, no substep runs, the clock does not advance.
-// WIDE (<256, 4, true> only): the same four-role quad form compiled for two wavefronts per SIMD instead of four (up to 256 VGPRs): used
+// WIDE (<256, 1, true>): likewise for the one-lane role form while its launch puts at most two wavefronts on a SIMD (<= 32 768 envs): no register
+// cap, no spills (the capped build has 9 VGPR spills).
+// WIDE (<256, 4, true>): the same four-role quad form compiled for two wavefronts per SIMD instead of four (up to 256 VGPRs): used
 // while every wavefront of the launch has a SIMD to itself anyway (<= 4 096 envs, no frame stacks), where the 128-register cap of the
 // general form buys nothing and costs 2 % (12.90 vs 13.19 us at 4 096 envs; with stacks or from 8 192 envs on the capped form is faster).
 // FUSED (taco_rollout.hpp, taco_rollout_kernel): the same step as the body of a PERSISTENT kernel whose workgroup (16 envs, quad layout, the
@@ -728,7 +730,7 @@ struct FusedCtx {
 template <int BLOCK, int LPE, bool SPLIT, bool CAP, bool OUT, bool RESET_ONLY, bool WIDE, bool FUSED>
 TD void step_core(const StepParams &P, const FusedCtx &FX) {
     static_assert(!FUSED || (BLOCK == 256 && LPE == 4 && SPLIT && !OUT && !RESET_ONLY && !CAP), "FUSED is the four-role quad form inside the rollout kernel");
-    static_assert(!WIDE || (BLOCK == 256 && LPE == 4 && SPLIT && !RESET_ONLY), "WIDE is a variant of the four-role quad form");
+    static_assert(!WIDE || (BLOCK == 256 && SPLIT && !RESET_ONLY), "WIDE is a variant of the four-role forms");
     static_assert(!RESET_ONLY || (BLOCK == 64 && LPE == 1 && !SPLIT && !CAP && !OUT), "RESET_ONLY exists in the plain one-lane form only");
     static_assert(!SPLIT || BLOCK == 256, "SPLIT is the four-role form: one step wavefront + three role wavefronts per workgroup");
     static_assert(!CAP || (BLOCK == 64 && LPE == 1 && !SPLIT), "CAP is the one-wavefront-per-workgroup throughput form");
@@ -809,7 +811,7 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
         }
     };
     // (quad forms: 40 words per env instead of CARRY_WORDS -- the block doubles as the rotor-noise table, see rn_tab below)
-    __shared__ __attribute__((aligned(16))) float hand[SPLIT ? (64 / LPE) * (LPE == 4 ? 40 : CARRY_WORDS) : 4];
+    __shared__ __attribute__((aligned(16))) float hand[SPLIT ? (64 / LPE) * 40 : 4];
     // SPLIT: while wavefront 0 runs the substeps, wavefront 1 serves the battery model one substep AHEAD: the voltage of substep k
     // depends only on the rotor speeds left by substep k - 1, which are known ~2 000 clocks before the voltage is needed.
     // mb_om: rotor speeds (wave 0 -> 1), mb_v: voltage (1 -> 0), mb_bs: battery state E u1 t (0 -> 1 before, 1 -> 0 after), mb_seq: counters
@@ -824,12 +826,13 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     // forms: wavefront 0 leaves the attitude of every substep in eq_tab (one LDS write + the counter) and the server runs the eleven
     // atan2 / asin / unwrap evaluations of the step behind it -- ~150 instructions per substep off the critical path of every wavefront
     // that holds flip envs (flip at 4 096 envs: 17.9 -> us; the tail of a mixed-task rollout).  Same quad-layout code, same bits.
-    constexpr bool EULER_TAB = SPLIT && LPE == 4 && !WIDE;   // (WIDE = the headline form: launches without flip envs and rotor noise only, see wide_form)
+    constexpr bool EULER_TAB = SPLIT && !(WIDE && LPE == 4);   // (WIDE quad = the headline form: launches without flip envs and rotor noise only, see wide_form)
     // (eq_tab lives in the two role tiles, 2 x 16 x 26 words, which are idle until barrier 2 -- by then the server has read every attitude)
-    static_assert(!EULER_TAB || 2 * TILE_WORDS >= 11 * 64, "eq_tab must fit in the role wavefronts' frame tiles");
+    // (one lane per env: the attitude is a float4 per lane and substep, the unwrap memory six words per lane)
+    static_assert(!EULER_TAB || 2 * TILE_WORDS >= 11 * 64 * (LPE == 4 ? 1 : 4), "eq_tab must fit in the role wavefronts' frame tiles");
     float *const eq_tab = lds_all + WAVE_LDS_WORDS;
-    __shared__ float eu_io[EULER_TAB ? 2 * 64 : 4];
-    constexpr bool NOISE_TAB = SPLIT && LPE == 4 && !WIDE;
+    __shared__ float eu_io[EULER_TAB ? (LPE == 4 ? 2 : 6) * 64 : 4];
+    constexpr bool NOISE_TAB = SPLIT && !(WIDE && LPE == 4);
     // (rn_tab lives in `hand`: the table is read by the substeps, the Carry is written after the last one and read after barrier 2; the
     // server writes the next table only after barrier 1 of the next step)
     static_assert(!NOISE_TAB || (64 / LPE) * 40 >= 10 * (64 / LPE) * 4, "rn_tab must fit in the Carry block");
@@ -849,6 +852,8 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     // (only while every wavefront of the launch has a SIMD to itself -- 1 024 on the MI355X -- or the server would take issue slots
     // from another workgroup's wavefront 0: 19.0 vs 18.4 us at 8 192 envs)
     const bool bat_served = SPLIT && LPE == 4 && (P.flags & TACO_F_BATTERY_CONSUMPTION) != 0 && (FUSED || gridDim.x * 4u <= 1024u);   // (FUSED: one workgroup per CU)
+    const int euler_role = bat_served ? 3 : 1;   // which role wavefront serves the euler angles: the reward wavefront while it is idle (no battery to serve),
+                                                 // otherwise the states wavefront (which may first have a stack history to move)
     Carry K;
     const int i = in_range ? i_raw : P.n - 1;  // tail lanes shadow the last env and store nothing
     const int gid = P.env_offset + i;
@@ -1202,6 +1207,11 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     // one lane per env: the PLAIN forms also carry the default airframe's constants as literals (kPlainConsts: the handle has exactly those)
     const bool plain = plain1 && (LPE != 1 || (fl & kPlainConsts) != 0);
     if constexpr (LPE == 1) {
+        int noise_have = 0;   // highest rotor-noise counter value seen (NOISE_TAB)
+        if (euler_served) {   // the unwrap memory goes to the euler server (published by the first MB_POST(3, ...))
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { eu_io[k * 64 + lane] = rpy_old[k]; eu_io[(3 + k) * 64 + lane] = rpy_cont[k]; }
+        }
         // one substep; FIN: see `fin` above.  Returns whether the integrator took a rare form in some lane (wave-uniform).
         auto substep = [&](auto fin_c, const int ks) -> bool {
             // loop forms: 0 exact, 1 FIN, 2 FIN + PLAIN, 10 FIN + PLAIN with euler/unwrap (wavefronts that hold flip envs)
@@ -1210,7 +1220,10 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
             Consts C;  // PLAIN: the default airframe as literals; otherwise the handle's values (SGPR operands)
             if constexpr (PLAIN) C = kDefaultConsts; else C = Crt;
             // refresh_state, the part the inner loop consumes FA:339-350
-            if (PLAIN ? (MODE & 8) != 0 : wave_tracks_rpy) {
+            if (EULER_TAB && (PLAIN ? (MODE & 8) != 0 : wave_tracks_rpy)) {
+                reinterpret_cast<float4 *>(eq_tab)[ks * 64 + lane] = make_float4(q.x, q.y, q.z, q.w);   // the euler server takes it from here
+                MB_POST(3, ks + 1);
+            } else if (PLAIN ? (MODE & 8) != 0 : wave_tracks_rpy) {
                 V3 e = euler_xyz_v1(q);
                 unwrap(e.x, rpy_old[0], rpy_cont[0]);
                 unwrap(e.y, rpy_old[1], rpy_cont[1]);
@@ -1284,7 +1297,14 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
                     omega[k] = omega[k] + (1.0f / tau[k]) * 0.001f * (target - omega[k]);
                 }
             }
-            if (!PLAIN && (fl & TACO_F_ROTOR_NOISE)) {  // CTRL/thrust_dynamics.py:68-78
+            if (NOISE_TAB && noise_served) {  // CTRL/thrust_dynamics.py:68-78, the factors drawn by the obs role wavefront (wave-uniform switch)
+                if (noise_have < ks + 1) {   // (the server runs several substeps ahead: normally one read of the counter per step)
+                    MB_WAIT(2, ks + 1);
+                    noise_have = MB_SEQ(2);
+                }
+                const float4 f4 = reinterpret_cast<const float4 *>(rn_tab)[ks * EPW + el];
+                omega[0] = omega[0] * f4.x; omega[1] = omega[1] * f4.y; omega[2] = omega[2] * f4.z; omega[3] = omega[3] * f4.w;
+            } else if (!PLAIN && (fl & TACO_F_ROTOR_NOISE)) {  // CTRL/thrust_dynamics.py:68-78
                 U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, clk.step, STREAM_ROTOR, (uint32_t)ks);
                 const float n_sc = (float)((1 + 10.0 / 700) - (1 - 10.0 / 700)), n_lo = (float)(1 - 10.0 / 700);
                 omega[0] = omega[0] * (n_sc * uniform(r.x) + n_lo);
@@ -1344,6 +1364,10 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
         }
     #pragma unroll 1
         for (; ks < 10; ++ks) substep(std::integral_constant<int, 0>{}, ks);
+        if (euler_served) {   // the attitude after the tenth substep (refresh_state of post_physics_step, FA:382)
+            reinterpret_cast<float4 *>(eq_tab)[10 * 64 + lane] = make_float4(q.x, q.y, q.z, q.w);
+            MB_POST(3, 11);
+        }
 
     } else {
         // ---- quad layout: scatter (lane j keeps component j), run the ten substeps, gather back
@@ -1577,9 +1601,14 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     if (euler_served) {   // all eleven refreshes of the step were the server's
         if constexpr (EULER_TAB) {
             MB_WAIT(4, 1);
-            const float ro = eu_io[lane], rc = eu_io[64 + lane];
-            rpy_old[0] = bc0(ro); rpy_old[1] = bc1(ro); rpy_old[2] = bc2(ro);
-            rpy_cont[0] = bc0(rc); rpy_cont[1] = bc1(rc); rpy_cont[2] = bc2(rc);
+            if constexpr (LPE == 4) {
+                const float ro = eu_io[lane], rc = eu_io[64 + lane];
+                rpy_old[0] = bc0(ro); rpy_old[1] = bc1(ro); rpy_old[2] = bc2(ro);
+                rpy_cont[0] = bc0(rc); rpy_cont[1] = bc1(rc); rpy_cont[2] = bc2(rc);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { rpy_old[k] = eu_io[k * 64 + lane]; rpy_cont[k] = eu_io[(3 + k) * 64 + lane]; }
+            }
             if (__builtin_expect(mb_timeout, 0)) {
                 if (lane == 0) atomicOr(&P.ctl[kCtlStatus], kStatusMailboxTimeout);
                 rpy_cont[0] = nanf32();
@@ -1658,14 +1687,34 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
                     const U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)(P.env_offset + ie), clk.step, STREAM_ROTOR, (uint32_t)ks);
                     rn_tab[b * 4 + 0] = n_sc * uniform(r.x) + n_lo; rn_tab[b * 4 + 1] = n_sc * uniform(r.y) + n_lo;
                     rn_tab[b * 4 + 2] = n_sc * uniform(r.z) + n_lo; rn_tab[b * 4 + 3] = n_sc * uniform(r.w) + n_lo;
+                    if constexpr (LPE == 1) MB_POST(2, ks + 1);   // (one pass of the loop = one substep's blocks: published as they are drawn)
                 }
-                MB_POST(2, 1);
+                if constexpr (LPE == 4) MB_POST(2, 1);
             }
         }
         if (wv == 3 && P.len_states > 1) shift_history(P.states, P.states_prev, P.states_bytes, P.len_states, OUT ? P.states_out : nullptr, P.clip_states);
         if (wv == 2 && P.len_obs > 1) shift_history(P.obs, P.obs_prev, P.obs_bytes, P.len_obs, OUT ? P.obs_out : nullptr, P.clip_obs);
         if constexpr (EULER_TAB) {
-            if (wv == 3 && euler_served) {   // the euler server: eleven attitudes -> get_euler_xyz_v1 + unwrap, lane j of an env's quad = angle j
+            if (LPE == 1 && wv == euler_role && euler_served) {   // one lane per env: the scalar get_euler_xyz_v1 + three unwraps per attitude
+                MB_WAIT(3, 1);
+                float ro[3], rc[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { ro[k] = eu_io[k * 64 + lane]; rc[k] = eu_io[(3 + k) * 64 + lane]; }
+#pragma unroll 1
+                for (int k = 0; k < 11; ++k) {
+                    MB_WAIT(3, k + 1);
+                    const float4 q4 = reinterpret_cast<const float4 *>(eq_tab)[k * 64 + lane];
+                    const V3 e = euler_xyz_v1(Q4{q4.x, q4.y, q4.z, q4.w});
+                    unwrap(e.x, ro[0], rc[0]);
+                    unwrap(e.y, ro[1], rc[1]);
+                    unwrap(e.z, ro[2], rc[2]);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { eu_io[k * 64 + lane] = ro[k]; eu_io[(3 + k) * 64 + lane] = rc[k]; }
+                MB_POST(4, 1);
+            }
+            if (LPE == 4 && wv == euler_role && euler_served) {   // the euler server: eleven attitudes -> get_euler_xyz_v1 + unwrap, lane j of an env's quad = angle j
                 const uint32_t sgn = 0x80000000u;
                 const uint32_t m2_lane1 = (sub == 1) ? sgn : 0u, sgn_lane0 = (sub == 0) ? sgn : 0u, sgn_lane2 = (sub == 2) ? sgn : 0u;
                 MB_WAIT(3, 1);
