@@ -395,9 +395,8 @@ def latency_floor(env, acts, kernel_avg_us, torch):
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
         d = json.load(open(files[-1])) if files else {}
         if d.get("source_hash") == build.source_hash() and "instr_per_step_wavefront_4096" in d.get("derived", {}):
-            n_i = d["derived"]["instr_per_step_wavefront_4096"]
-            out["instr_per_step_wavefront"] = n_i
-            out["clocks_per_instr"] = wave0 / n_i
+            out["instr_per_whole_step_wavefront"] = d["derived"]["instr_per_step_wavefront_4096"]   # counters of the quad form WITHOUT role wavefronts: one
+            # wavefront runs the whole step (pre-phase, ten substeps, post-phase); the headline form's step wavefront hands the post-phase and the battery to its roles
     except Exception:  # noqa: BLE001
         pass
     return out

@@ -29,7 +29,7 @@ def counters(d):
     return out
 
 
-S = {"sq_262144": counters(f"{tag}_pmc_sq_262144")}
+S = {"sq_262144": counters(f"{tag}_pmc_sq_262144"), "sq_4096_quad": counters(f"{tag}_pmc_sq_4096_quad")}
 for n in (262144, 4096):
     S[f"fetch_{n}"] = counters(f"{tag}_pmc_FETCH_SIZE_{n}")
     S[f"write_{n}"] = counters(f"{tag}_pmc_WRITE_SIZE_{n}")
@@ -49,6 +49,11 @@ sq = S["sq_262144"]
 if "SQ_WAVES" in sq and sq["SQ_WAVES"]["mean_per_launch"]:
     w = sq["SQ_WAVES"]["mean_per_launch"]
     der["per_wave_262144"] = {k: v["mean_per_launch"] / w for k, v in sq.items() if k != "SQ_WAVES"}
+sq4 = S["sq_4096_quad"]
+if "SQ_WAVES" in sq4 and sq4["SQ_WAVES"]["mean_per_launch"]:
+    w = sq4["SQ_WAVES"]["mean_per_launch"]
+    der["per_wave_4096_quad"] = {k: v["mean_per_launch"] / w for k, v in sq4.items() if k != "SQ_WAVES"}
+    der["instr_per_step_wavefront_4096"] = sum(sq4[k]["mean_per_launch"] for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH") if k in sq4) / w
 S["derived"] = der
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from taco_amd import build as _build  # noqa: E402

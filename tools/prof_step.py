@@ -13,9 +13,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--envs", type=int, default=262144)
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--config", type=int, default=1)
+ap.add_argument("--form", default="auto", help="kernel form to pin (taco_amd._lib.FORMS)")
 ap.add_argument("--api", action="store_true", help="call VecTask.step() (clamped copies, dict outputs) instead of step_raw()")
 a = ap.parse_args()
-env = FpvBase(config.baseline_config(a.config, num_envs=a.envs), copy_outputs=a.api)
+env = FpvBase(config.baseline_config(a.config, num_envs=a.envs), copy_outputs=a.api, kernel_form=a.form)
 g = torch.Generator().manual_seed(0)
 acts = (0.3 * torch.randn((8, a.envs, 4), generator=g) + torch.tensor([-0.45, 0, 0, 0])).clamp(-1, 1).cuda()
 for t in range(a.steps):

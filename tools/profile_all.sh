@@ -5,6 +5,7 @@
 #   3. three separate --pmc passes (SQ set, FETCH_SIZE, WRITE_SIZE) at 262144 envs and FETCH/WRITE at 4096 envs
 #   4. tools/pmc_summary.py                            -> gpurun_out/<tag>_pmc_summary.json, <tag>_kernel_stats_bench_4096.csv
 #   5. kernel trace of VecTask.step() calls            -> gpurun_out/<tag>_step_api_kernel_stats.csv
+#   5b. kernel trace of taco_rollout_run                -> gpurun_out/<tag>_rollout_kernel_stats.csv
 #   6. bench.py --gpus 2 over gloo on this one GPU     -> gpurun_out/<tag>_bench_2ranks_gloo_one_gpu.json
 # --pmc is never combined with any trace domain other than --kernel-trace; python3 is the program right after `--`.
 set -eo pipefail
@@ -21,10 +22,16 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/${TAG}_pmc_${c}_262144" -- python3 "$R/tools/prof_step.py" --envs 262144 --steps 12 >> "$O/${TAG}_pmc.log" 2>&1
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/${TAG}_pmc_${c}_4096" -- python3 "$R/tools/prof_step.py" --envs 4096 --steps 40 >> "$O/${TAG}_pmc.log" 2>&1
 done
+# 3b. instructions of ONE wavefront that runs a whole step (the quad form without role wavefronts: every wavefront is a step wavefront) at 4 096 envs:
+#     the count behind bench.py's latency_floor
+rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d "$O/${TAG}_pmc_sq_4096_quad" -- python3 "$R/tools/prof_step.py" --envs 4096 --steps 40 --form quad >> "$O/${TAG}_pmc.log" 2>&1
 # 5. VecTask.step() issues ONE kernel per call: kernel trace of 200 step() calls at 4 096 envs (copy_outputs=True: clamped copies included)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${TAG}_step_api" -- python3 "$R/tools/prof_step.py" --api --envs 4096 --steps 200 >> "$O/${TAG}_pmc.log" 2>&1
+# 5b. one PPO rollout (config 5's flags, 4 096 envs x 32 steps): the persistent actor + step kernel, the batched critic, GAE
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${TAG}_rollout" -- python3 "$R/tools/prof_rollout.py" >> "$O/${TAG}_pmc.log" 2>&1
 cd "$R"
 python3 tools/pmc_summary.py "$TAG"
+cp "$O/${TAG}_rollout"/*/*kernel_stats.csv "$O/${TAG}_rollout_kernel_stats.csv"
 cp "$O/${TAG}_step_api"/*/*kernel_stats.csv "$O/${TAG}_step_api_kernel_stats.csv"
 # 6. the N > 1 code path end to end on this one GPU: 2 ranks over gloo (the driver runs the real thing over RCCL on 8 GPUs)
 TACO_BENCH_BACKEND=gloo TACO_BENCH_ONE_DEVICE=1 python3 bench.py --gpus 2 --steps 500 --warmup 100 --no-cpu-baseline --no-large-n --no-configs > "$O/${TAG}_bench_2ranks_gloo_one_gpu.json" 2> "$O/${TAG}_bench_2ranks.err" || true
