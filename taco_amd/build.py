@@ -26,7 +26,7 @@ LIB_HOOKS = os.path.join(HERE, "libtaco_env_testhooks.so")
 SOURCES = ["taco_capi.hip"]
 DEPS = ["taco_capi.hip", "taco_step.hpp", "taco_math.hpp", "taco_rollout.hpp", "taco_policy.hpp", "taco_fused.hpp", os.path.join("..", "..", "include", "taco_env.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-falign-loops=64",
          "-Wall", "-Wno-unused-function"]
 
 

@@ -18,6 +18,9 @@
 #include "taco_math.hpp"
 #include "../../include/taco_env.h"
 
+#ifndef TACO_AB_SERVE_ALWAYS
+#define TACO_AB_SERVE_ALWAYS 0  // A/B builds only: the battery server in every four-role quad launch, whatever its size
+#endif
 #ifndef TACO_AB_RT
 #define TACO_AB_RT 0  // A/B builds only: 1 = the PLAIN loop forms do the world-rate round trip as well (cost measurement, profiles/r03_a_*)
 #endif
@@ -851,7 +854,7 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
                                  __hip_atomic_store(&mb_seq[idx], (value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
     // (only while every wavefront of the launch has a SIMD to itself -- 1 024 on the MI355X -- or the server would take issue slots
     // from another workgroup's wavefront 0: 19.0 vs 18.4 us at 8 192 envs)
-    const bool bat_served = SPLIT && LPE == 4 && (P.flags & TACO_F_BATTERY_CONSUMPTION) != 0 && (FUSED || gridDim.x * 4u <= 1024u);   // (FUSED: one workgroup per CU)
+    const bool bat_served = SPLIT && LPE == 4 && (P.flags & TACO_F_BATTERY_CONSUMPTION) != 0 && (FUSED || TACO_AB_SERVE_ALWAYS || gridDim.x * 4u <= 1024u);   // (FUSED: one workgroup per CU)
     const int euler_role = bat_served ? 3 : 1;   // which role wavefront serves the euler angles: the reward wavefront while it is idle (no battery to serve),
                                                  // otherwise the states wavefront (which may first have a stack history to move)
     Carry K;
