@@ -784,8 +784,16 @@ static int launch_critic(const taco_policy_cfg *c, const float *blob, size_t row
         const size_t nblocks = (rows + taco::CR_ROWS - 1) / taco::CR_ROWS;
         const size_t walk = (nblocks + cus - 1) / cus;
         const unsigned grid = (unsigned)((nblocks + walk - 1) / walk);
-        if (ring_n > 0) hipLaunchKernelGGL(taco::taco_critic_lstm_kernel<true>, dim3(grid), dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
-        else hipLaunchKernelGGL(taco::taco_critic_lstm_kernel<false>, dim3(grid), dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
+        if (ring_n > 0 && c->states_len >= 2 && rows % (size_t)ring_n == 0 && rows / (size_t)ring_n >= 2) {
+            // frame ring with at least two slots: blocks of 16 envs x two consecutive slots share the input projection (taco_critic_lstm_pair_kernel)
+            const size_t pb = (((size_t)ring_n + 15) / 16) * ((rows / (size_t)ring_n + 1) / 2);
+            const size_t pw = (pb + cus - 1) / cus;
+            hipLaunchKernelGGL(taco::taco_critic_lstm_pair_kernel, dim3((unsigned)((pb + pw - 1) / pw)), dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
+        } else if (ring_n > 0) {
+            hipLaunchKernelGGL(taco::taco_critic_lstm_kernel<true>, dim3(grid), dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
+        } else {
+            hipLaunchKernelGGL(taco::taco_critic_lstm_kernel<false>, dim3(grid), dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
+        }
         hipError_t he = hipGetLastError();
         if (he != hipSuccess) return hip_fail(he, "taco_critic_lstm_kernel launch");
         const size_t nchunks = (rows + taco::CR_MLP_ROWS - 1) / taco::CR_MLP_ROWS;
