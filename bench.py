@@ -695,17 +695,29 @@ def main():
                 torch.cuda.empty_cache()
             if not args.no_large_n:
                 out["large_n"] = []
-                for big_n, ls in ((262144, 1), (1048576, 1), (262144, 5)):   # BASELINE configs[4]'s env count; four residency rounds; 5 state frames
+                # BASELINE configs[4]'s env count; four residency rounds; 5 state frames as stacks (VecTask.step) and on the ROLLOUT path, where the
+                # replay store keeps the stacks as a frame ring and a step writes one frame (taco_rollout_io.states_newest_only)
+                for big_n, ls, ring in ((262144, 1, False), (1048576, 1, False), (262144, 5, False), (262144, 5, True)):
                     bcfg = config.baseline_config(1, num_envs=big_n)
                     bcfg["env"]["lenStates"] = ls
                     benv = FpvBase(bcfg, sim_device=str(dev), rl_device=str(dev), copy_outputs=False)
                     bacts = make_actions(big_n, 4, 7, dev)
-                    b_med, b_ws, b_first = steady_windows(benv.step_raw, bacts, torch, 0.25, 5, 200)
+                    step_fn = benv.step_raw
+                    if ring:
+                        frames = torch.zeros(2, big_n, 26, device=dev)
+                        brew = torch.zeros(big_n, device=dev)
+                        flip = [0]
+
+                        def step_fn(a, benv=benv, frames=frames, brew=brew, flip=flip):
+                            flip[0] ^= 1
+                            benv.step_into(a, benv.obs_buf, benv.obs_buf, None, None, brew, None, states_newest=frames[flip[0]])
+                    b_med, b_ws, b_first = steady_windows(step_fn, bacts, torch, 0.25, 5, 200)
                     bg, bb = benv.launch_geometry()
-                    nb = algo_bytes(ls)
+                    nb = ALGO_BYTES_PER_ENV_STEP if ring else algo_bytes(ls)
                     ach = nb * big_n / (b_med * 1e-6) / 1e9
-                    tr, _ = pmc_traffic(big_n) if ls == 1 else (None, None)
-                    out["large_n"].append({"envs": big_n, "len_states": ls, "kernel_avg_us": b_med, "env_steps_per_s": big_n / (b_med * 1e-6),
+                    tr, _ = pmc_traffic(big_n) if (ls == 1 and not ring) else (None, None)
+                    out["large_n"].append({"envs": big_n, "len_states": ls, "path": "rollout (frame ring: one states frame written per step)" if ring else "VecTask.step (stacks materialised)",
+                                           "kernel_avg_us": b_med, "env_steps_per_s": big_n / (b_med * 1e-6),
                                            "algorithmic_bytes_per_env_step": nb, "achieved_GBps": ach, "frac_of_hbm_peak": ach / HBM_PEAK_GBPS,
                                            "traffic": tr, "traffic_frac_of_hbm_peak": (tr / (b_med * 1e-6) / 1e9 / HBM_PEAK_GBPS) if tr else None,
                                            "kernel_form": benv.kernel_form, "grid": bg, "block": bb, "windows_us": b_ws,
