@@ -3,7 +3,7 @@
     python tools/fuzz.py [--cases 60] [--seed 0]
 
 Every case draws a task, an env count (ragged sizes on purpose, one in six above the 8 192 / 16 384 / 65 536 geometry thresholds), all 19
-boolean flags, delay_time, rotor_response_time, difficulty, clip limits, PhysX substeps, episode length and the two stack lengths, then
+boolean flags (+ world_rate_roundtrip and record_flag, one case in five each), delay_time, rotor_response_time, difficulty, clip limits, PhysX substeps, episode length and the two stack lengths, then
 steps both sides on the same action stream.  tests/test_parity_gpu.py::test_random_configurations runs a bounded slice of the same generator.
 """
 import argparse
@@ -20,7 +20,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 FLAGS = ("random_copter_pos", "random_copter_quat", "random_copter_vel", "random_target_pos", "random_target_yaw", "battery_consumption",
          "random_voltage", "rotor_noise", "rotor_delay", "rotor_response", "random_rotordynamic_coe", "random_rotor_delay",
          "random_rotor_response", "random_rotor_speed", "random_aerodynamic_coe", "ramdom_delay_time", "ramdom_deploy_time", "random_command",
-         "observation_noise")
+         "observation_noise", "world_rate_roundtrip", "record_flag")   # + the two cfg keys of round 3 (the reference's literal rate data flow; rpy tracked for every env)
 
 
 def draw_case(rng):
@@ -35,7 +35,7 @@ def draw_case(rng):
         n = int(rng.choice([8192 + 5, 16384 + 33, 65536 + 129])) + int(rng.integers(0, 50))
     cfg = config.default_cfg(task, n)
     for k in FLAGS:
-        cfg[k] = bool(rng.random() < 0.5)
+        cfg[k] = bool(rng.random() < (0.5 if k not in ("world_rate_roundtrip", "record_flag") else 0.2))
     cfg["delay_time"] = int(rng.choice([0, 1, 9, 10, 20, 35, 60]))
     cfg["rotor_response_time"] = float(rng.choice([0.016, 0.017, 0.018, 0.03]))
     cfg["difficulty"] = float(rng.choice([0.0, 0.3, 1.0]))
