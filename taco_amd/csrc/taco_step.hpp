@@ -1055,10 +1055,21 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
         a_in = make_float4(FX.act_lds[el * 4 + 0], FX.act_lds[el * 4 + 1], FX.act_lds[el * 4 + 2], FX.act_lds[el * 4 + 3]);
         have_act = true;
     };
+    // ... or, with 1..9 pending slots, only from slot `dlen` on: the substeps before it run first and the action is patched into the slot table
+    // right before its first use (`patch_at`; the random walk of the deploy time takes envs there in the documented config 5, and a
+    // workgroup that waited for the actor up front ran actor and step one after the other: the tail of the whole rollout kernel).
+    int patch_at = 10;   // the substep before which the action must be in the slot table; 10 = the substeps never read it
+    const int dlen0 = dlen;
     if constexpr (FUSED) {
         draw_T();
-        const bool early = dense || dlen + T > TACO_RING_SLOTS - 10 || dlen < 10;
-        if (__builtin_amdgcn_ballot_w64(early) != 0) fetch_action();
+        const bool now = dense || dlen + T > TACO_RING_SLOTS - 10 || dlen < 1;   // (no pending slot at all: substep 0 already runs on this action)
+        if (__builtin_amdgcn_ballot_w64(now) != 0) {
+            fetch_action();
+        } else {
+#pragma unroll
+            for (int k = 9; k >= 1; --k)
+                if (__builtin_amdgcn_ballot_w64(dlen <= k) != 0) patch_at = k;   // (ends at min(dlen) over the wavefront: the first substep that reads it)
+        }
     }
     act[0] = clampf(a_in.x, -P.clip_act, P.clip_act);  // VT:304; actions_old <- actions <- a (FA:321-322) is implicit in hist
     act[1] = clampf(a_in.y, -P.clip_act, P.clip_act);
@@ -1532,12 +1543,33 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
         };
         if (euler_served) { eu_io[lane] = roq; eu_io[64 + lane] = rcq; }   // (published by the first MB_POST(3, ...))
         int ks = 0;
+        // FUSED, 1..9 pending slots somewhere in the wavefront: the actor's action arrives here, at the top of the substep that reads slot
+        // min(dlen) (whose delayed action, fetched during the previous substep, is fetched again).  The new action joins what the PID consumes: if it is not
+        // finite the FIN / PLAIN forms hand over to the exact one, as they do for every other input.
+        bool force_exact = false;
+        auto late_patch = [&]() {
+            fetch_action();
+            act[0] = clampf(a_in.x, -P.clip_act, P.clip_act); act[1] = clampf(a_in.y, -P.clip_act, P.clip_act);
+            act[2] = clampf(a_in.z, -P.clip_act, P.clip_act); act[3] = clampf(a_in.w, -P.clip_act, P.clip_act);
+            act4 = make_float4(act[0], act[1], act[2], act[3]);
+            if (active) buf_st4(rH, act4, voff, (uint32_t)(clk.hh & (HIST_ROWS - 1)) * row_bytes);  // this step's action, row hh
+            const float ac = pick4(sub, act[0], act[1], act[2], act[3]);
+            float *slotsw = reinterpret_cast<float *>(slots);
+#pragma unroll
+            for (int sl = 1; sl < 10; ++sl)
+                if (sl >= dlen0) slotsw[(sl * EPW + el) * 4 + sub] = ac;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // (same wavefront writes and reads the table: in order)
+            dq_next = slotsf[(slot_of(ks) * EPW + el) * 4 + sub];
+            const float mag = (absf(act[0]) + absf(act[1])) + (absf(act[2]) + absf(act[3]));
+            force_exact = __builtin_amdgcn_ballot_w64(!(mag < 1e30f)) != 0;
+        };
         auto run_form = [&](auto form) {
 #pragma unroll 1
             while (ks < 10) {
+                if constexpr (FUSED) { if (ks == patch_at) late_patch(); }
                 const bool rare = substep(form, ks);
                 ++ks;
-                if (rare) break;
+                if (rare || (FUSED && force_exact)) break;
             }
         };
         if (noise_served) {   // the noise table is complete before the first substep reads it (posted ~a pre-phase ago: normally no wait)
@@ -1560,15 +1592,13 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
             if (!wave_tracks_rpy) run_form(std::integral_constant<int, 2>{});
             else run_form(std::integral_constant<int, 10>{});
         } else if (fin) {
-#pragma unroll 1
-            while (ks < 10) {
-                const bool rare = substep(std::integral_constant<int, 1>{}, ks);
-                ++ks;
-                if (rare) break;
-            }
+            run_form(std::integral_constant<int, 1>{});
         }
 #pragma unroll 1
-        for (; ks < 10; ++ks) substep(std::integral_constant<int, 0>{}, ks);
+        for (; ks < 10; ++ks) {
+            if constexpr (FUSED) { if (ks == patch_at) late_patch(); }
+            substep(std::integral_constant<int, 0>{}, ks);
+        }
         if (bat_served) {
             MB_WAIT(1, 11);
             bat_E = mb_bs[el * 4]; bat_u1 = mb_bs[el * 4 + 1]; bat_t = mb_bs[el * 4 + 2];

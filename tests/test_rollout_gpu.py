@@ -217,7 +217,8 @@ def test_rollout_run_is_graph_capturable_and_replays_are_the_next_rollouts():
 @pytest.mark.parametrize("n,task,len_states,kw", [
     (4096, "mix", 5, dict(observation_noise=True, rotor_noise=True, ramdom_delay_time=True, ramdom_deploy_time=True, random_rotordynamic_coe=True)),  # config 5's flags
     (333, "pos", 1, dict()),                                  # ragged last workgroup, one frame
-    (1000, "flip", 3, dict(delay_time=5)),                    # fewer than ten pending slots: the step waits for the actor (early path)
+    (1000, "flip", 3, dict(delay_time=5)),                    # 2..9 pending slots: the action is patched into the slot table mid-loop
+    (700, "rotate", 1, dict(delay_time=1, ramdom_delay_time=True)),   # 0..1 pending slots (and up to 4 by the random delay): waits for the actor up front / patches at substep 1
     (500, "rotate", 2, dict(delay_time=85, ramdom_deploy_time=True)),   # the delay line's overflow regime: DENSE envs take the early path
     (600, "mix", 5, dict(battery_consumption=False)),         # no battery server
 ])
