@@ -1055,20 +1055,21 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
         a_in = make_float4(FX.act_lds[el * 4 + 0], FX.act_lds[el * 4 + 1], FX.act_lds[el * 4 + 2], FX.act_lds[el * 4 + 3]);
         have_act = true;
     };
-    // ... or, with 1..9 pending slots, only from slot `dlen` on: the substeps before it run first and the action is patched into the slot table
+    // ... or, with 0..9 pending slots, only from slot `dlen` on: the substeps before it run first and the action is patched into the slot table
     // right before its first use (`patch_at`; the random walk of the deploy time takes envs there in the documented config 5, and a
     // workgroup that waited for the actor up front ran actor and step one after the other: the tail of the whole rollout kernel).
     int patch_at = 10;   // the substep before which the action must be in the slot table; 10 = the substeps never read it
     const int dlen0 = dlen;
     if constexpr (FUSED) {
         draw_T();
-        const bool now = dense || dlen + T > TACO_RING_SLOTS - 10 || dlen < 1;   // (no pending slot at all: substep 0 already runs on this action)
+        const bool now = dense || dlen + T > TACO_RING_SLOTS - 10;   // (the literal slot ring is written ahead of the substeps)
         if (__builtin_amdgcn_ballot_w64(now) != 0) {
             fetch_action();
         } else {
 #pragma unroll
-            for (int k = 9; k >= 1; --k)
-                if (__builtin_amdgcn_ballot_w64(dlen <= k) != 0) patch_at = k;   // (ends at min(dlen) over the wavefront: the first substep that reads it)
+            for (int k = 9; k >= 0; --k)
+                if (__builtin_amdgcn_ballot_w64(dlen <= k) != 0) patch_at = k;   // (ends at min(dlen) over the wavefront: the first substep that reads it;
+                                                                                   // 0 = no pending slot at all: only the pre-phase runs ahead of the actor)
         }
     }
     act[0] = clampf(a_in.x, -P.clip_act, P.clip_act);  // VT:304; actions_old <- actions <- a (FA:321-322) is implicit in hist
@@ -1543,7 +1544,7 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
         };
         if (euler_served) { eu_io[lane] = roq; eu_io[64 + lane] = rcq; }   // (published by the first MB_POST(3, ...))
         int ks = 0;
-        // FUSED, 1..9 pending slots somewhere in the wavefront: the actor's action arrives here, at the top of the substep that reads slot
+        // FUSED, 0..9 pending slots somewhere in the wavefront: the actor's action arrives here, at the top of the substep that reads slot
         // min(dlen) (whose delayed action, fetched during the previous substep, is fetched again).  The new action joins what the PID consumes: if it is not
         // finite the FIN / PLAIN forms hand over to the exact one, as they do for every other input.
         bool force_exact = false;
@@ -1556,7 +1557,7 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
             const float ac = pick4(sub, act[0], act[1], act[2], act[3]);
             float *slotsw = reinterpret_cast<float *>(slots);
 #pragma unroll
-            for (int sl = 1; sl < 10; ++sl)
+            for (int sl = 0; sl < 10; ++sl)
                 if (sl >= dlen0) slotsw[(sl * EPW + el) * 4 + sub] = ac;
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // (same wavefront writes and reads the table: in order)
             dq_next = slotsf[(slot_of(ks) * EPW + el) * 4 + sub];
