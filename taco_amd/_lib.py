@@ -13,7 +13,7 @@ RING_SLOTS = 100
 BLOB_ROWS = NUM_FIELDS + 4 * RING_SLOTS
 
 TASKS = {"pos": 0, "rotate": 1, "flip": 2, "mix": 3}
-FORMS = {"auto": 0, "quad_roles": 1, "lane_roles": 2, "quad": 3, "lane": 4, "lane_throughput": 5}  # TACO_FORM_* (include/taco_env.h)
+FORMS = {"auto": 0, "quad_roles": 1, "lane_roles": 2, "quad": 3, "lane": 4, "lane_throughput": 5, "quad_served": 6}  # TACO_FORM_* (include/taco_env.h)
 FLAG_BITS = {
     "random_copter_pos": 0, "random_copter_quat": 1, "random_copter_vel": 2, "random_target_pos": 3,
     "random_target_yaw": 4, "battery_consumption": 5, "random_voltage": 6, "rotor_noise": 7, "rotor_delay": 8,

@@ -32,6 +32,7 @@ int hip_fail(hipError_t e, const char *what) {
 }
 
 constexpr int kBlockSmall = 64;   // one wavefront per workgroup
+constexpr int kBlockPair = 128;   // the served quad form: one step wavefront + one serving wavefront
 constexpr int kBlockLarge = 256;  // the four-role forms: one step wavefront + three role wavefronts
 
 }  // namespace
@@ -294,6 +295,7 @@ template <bool OUT> const void *kernel_of(int form) {
         case TACO_FORM_QUAD_ROLES: return (const void *)taco::taco_step_kernel<kBlockLarge, 4, true, false, OUT>;
         case TACO_FORM_LANE_ROLES: return (const void *)taco::taco_step_kernel<kBlockLarge, 1, true, false, OUT>;
         case TACO_FORM_QUAD: return (const void *)taco::taco_step_kernel<kBlockSmall, 4, false, false, OUT>;
+        case TACO_FORM_QUAD_SERVED: return (const void *)taco::taco_step_kernel<kBlockPair, 4, true, false, OUT>;
         case TACO_FORM_LANE_THROUGHPUT: return (const void *)taco::taco_step_kernel<kBlockSmall, 1, false, true, OUT>;
         default: return (const void *)taco::taco_step_kernel<kBlockSmall, 1, false, false, OUT>;
     }
@@ -312,6 +314,7 @@ FormInfo form_info(int form, bool out = false, bool wide = false) {
         case TACO_FORM_QUAD_ROLES: return {4, kBlockLarge, 1, fn};
         case TACO_FORM_LANE_ROLES: return {1, kBlockLarge, 1, fn};
         case TACO_FORM_QUAD: return {4, kBlockSmall, 0, fn};
+        case TACO_FORM_QUAD_SERVED: return {4, kBlockPair, 1, fn};
         default: return {1, kBlockSmall, 0, fn};
     }
 }
@@ -329,7 +332,9 @@ int choose_form(const taco_cfg &c) {
     if (c.num_envs <= kQuadMaxEnvs) {
         // flip envs (the euler server) keep the role form up to the quad limit: 18.1 vs 19.1 us at 16 384 flip envs (profiles/r03_f_ab_step_servers.txt)
         const bool euler_served = c.task_mode == TACO_TASK_FLIP || c.task_mode == TACO_TASK_MIX || (c.flags & TACO_F_TRACK_RPY) != 0;
-        if (euler_served) return TACO_FORM_QUAD_ROLES;
+        // ... above 12 288 envs without frame stacks as the SERVED pair (a step wavefront that runs the whole step + one serving wavefront: fewer
+        // wavefronts to dispatch, one barrier; flip 16 384: 17.8 vs 18.3 us; a tie at 12 288), with stacks the roles also move the history
+        if (euler_served) return (!stacks && c.num_envs > 12288) ? TACO_FORM_QUAD_SERVED : TACO_FORM_QUAD_ROLES;
         // three helper wavefronts per 16 envs take over the post-phase: pays while every wavefront still has a SIMD to itself.  With
         // frame stacks the role wavefronts also move the stack history under the substeps, which pays up to the quad limit
         // (16 384 envs, 5 state frames: 19.2 us vs 22.1 us; 5 + 5 frames: 19.9 us vs 26.0 us; without stacks 18.0 us vs 17.5 us).
@@ -938,7 +943,7 @@ int taco_rollout_run(taco_env *e, const taco_policy_cfg *c, const float *blob, c
 
 int taco_set_kernel_form(taco_env *e, int form) {
     if (!e) return fail(TACO_ERR_INVALID_ARG, "env is null");
-    if (form < TACO_FORM_AUTO || form > TACO_FORM_LANE_THROUGHPUT) return fail(TACO_ERR_INVALID_ARG, "taco_set_kernel_form: unknown form");
+    if (form < TACO_FORM_AUTO || form > TACO_FORM_QUAD_SERVED) return fail(TACO_ERR_INVALID_ARG, "taco_set_kernel_form: unknown form");
     e->form = form == TACO_FORM_AUTO ? choose_form(e->cfg) : form;
     e->form_pinned = form != TACO_FORM_AUTO;
     return TACO_OK;

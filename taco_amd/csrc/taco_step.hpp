@@ -735,7 +735,13 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     static_assert(!FUSED || (BLOCK == 256 && LPE == 4 && SPLIT && !OUT && !RESET_ONLY && !CAP), "FUSED is the four-role quad form inside the rollout kernel");
     static_assert(!WIDE || (BLOCK == 256 && SPLIT && !RESET_ONLY), "WIDE is a variant of the four-role forms");
     static_assert(!RESET_ONLY || (BLOCK == 64 && LPE == 1 && !SPLIT && !CAP && !OUT), "RESET_ONLY exists in the plain one-lane form only");
-    static_assert(!SPLIT || BLOCK == 256, "SPLIT is the four-role form: one step wavefront + three role wavefronts per workgroup");
+    static_assert(!SPLIT || BLOCK == 256 || (BLOCK == 128 && LPE == 4 && !WIDE && !FUSED),
+                  "SPLIT is the four-role form (one step wavefront + three role wavefronts per workgroup) or the two-wavefront SERVED quad form");
+    // ROLES: the four-role forms.  PAIR (<128, 4, true>): the SERVED quad form -- wavefront 0 runs the WHOLE step as the one-wavefront quad form does
+    // (post-phase included), wavefront 1 only serves it (rotor-noise table, euler angles) and leaves.  For launches of 8 193 ... 16 384 envs
+    // (one step wavefront per SIMD either way) whose flags give the servers work: the role forms' barriers and hand-over cost more there
+    // than their parallel post-phase saves.
+    constexpr bool ROLES = SPLIT && BLOCK == 256, PAIR = SPLIT && BLOCK == 128;
     static_assert(!CAP || (BLOCK == 64 && LPE == 1 && !SPLIT), "CAP is the one-wavefront-per-workgroup throughput form");
     // Per-wavefront LDS scratch, used for two things one after the other:
     //   substeps : the 10 pending-action slots this step consumes, slots[s][lane] as float4 (10 KiB) -- keeps 40 values
@@ -773,7 +779,7 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     const bool in_range = i_raw < P.n;
     const bool active = in_range && sub == 0;  // the lane that stores for its env
     // post-phase roles (SPLIT: wave 0 = the step itself; wave 1 = battery server, then reward + done; wave 2 = obs stack; wave 3 = states stack)
-    const bool roleS = !SPLIT || wv == 3, roleO = !SPLIT || wv == 2, roleR = !SPLIT || wv == 1;
+    const bool roleS = ROLES ? wv == 3 : (!SPLIT || wv == 0), roleO = ROLES ? wv == 2 : (!SPLIT || wv == 0), roleR = ROLES ? wv == 1 : (!SPLIT || wv == 0);
     const uint32_t wave_env0 = SPLIT ? (uint32_t)(blockIdx.x * 64 / LPE) : (uint32_t)((blockIdx.x * BLOCK + wv * 64) / LPE);  // first env of this wavefront
     if (wave_env0 >= (uint32_t)P.n) return;  // a wavefront past the last env has nothing to do (SPLIT: the whole workgroup shares wave_env0, so
                                              // the two barriers below stay uniform)
@@ -854,7 +860,7 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
                                  __hip_atomic_store(&mb_seq[idx], (value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
     // (only while every wavefront of the launch has a SIMD to itself -- 1 024 on the MI355X -- or the server would take issue slots
     // from another workgroup's wavefront 0: 19.0 vs 18.4 us at 8 192 envs)
-    const bool bat_served = SPLIT && LPE == 4 && (P.flags & TACO_F_BATTERY_CONSUMPTION) != 0 && (FUSED || TACO_AB_SERVE_ALWAYS || gridDim.x * 4u <= 1024u);   // (FUSED: one workgroup per CU)
+    const bool bat_served = ROLES && LPE == 4 && (P.flags & TACO_F_BATTERY_CONSUMPTION) != 0 && (FUSED || TACO_AB_SERVE_ALWAYS || gridDim.x * 4u <= 1024u);   // (FUSED: one workgroup per CU)
     const int euler_role = bat_served ? 3 : 1;   // which role wavefront serves the euler angles: the reward wavefront while it is idle (no battery to serve),
                                                  // otherwise the states wavefront (which may first have a stack history to move)
     Carry K;
@@ -1658,13 +1664,13 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     if (grp == TACO_TASK_FLIP) cmd1 = clampf(flip_radian - roll_cont, -kTwoPi, kTwoPi);  // FA:831-832 / :930-931
     K.p = p; K.v = v; K.w = w; K.q = q; K.bat_V = bat_V; K.cmd0 = cmd0; K.cmd1 = cmd1; K.flip_radian = flip_radian; K.progress = progress;
     K.act[0] = act[0]; K.act[1] = act[1]; K.act[2] = act[2]; K.act[3] = act[3]; K.c_tp = c_tp; K.c_tq = c_tq;
-    if (SPLIT && sub == 0) {  // hand the Carry to the three role wavefronts
+    if (ROLES && sub == 0) {  // hand the Carry to the three role wavefronts
         float4 *h4 = reinterpret_cast<float4 *>(hand + el * CARRY_WORDS);
         h4[0] = make_float4(p.x, p.y, p.z, bat_V); h4[1] = make_float4(v.x, v.y, v.z, cmd0); h4[2] = make_float4(w.x, w.y, w.z, cmd1);
         h4[3] = make_float4(q.x, q.y, q.z, q.w); h4[4] = make_float4(act[0], act[1], act[2], act[3]);
         h4[5] = make_float4(flip_radian, as_f(progress), 0.0f, 0.0f); h4[6] = c_tp; h4[7] = c_tq;
     }
-    if (SPLIT) __syncthreads();  // barrier 2 of 2 (every wavefront executes exactly the same two)
+    if (ROLES) __syncthreads();  // barrier 2 of 2 (every wavefront executes exactly the same two; the served pair form has nothing to hand over: one barrier)
     if constexpr (FUSED) {
         if (!have_act) {  // (wave-uniform) the common case: the actor finished under the substeps -- barrier 2 is its completion too
             fetch_action();
@@ -1707,12 +1713,12 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
         CST(C_LINVEL, make_float4(v.x, v.y, v.z, as_f((int)make_dw(dlen, zlead, q_m, q_rem0, q_lens, dense))));
         CST(C_MISC, make_float4(bat_t, cmd0, cmd1, flip_radian));
     }
-    if (SPLIT) { TACO_STAMP(4); TACO_STAMP(5); return; }  // wave 0 is done; the roles below belong to the other three wavefronts
+    if (ROLES) { TACO_STAMP(4); TACO_STAMP(5); return; }  // wave 0 is done; the roles below belong to the other three wavefronts
     } else {
         if (wv == 1 && lane < 8) mb_seq[lane] = 0;
         __syncthreads();  // barrier 1 of 2
         if constexpr (NOISE_TAB) {
-            if (wv == 2 && noise_served) {   // the step's 10 x EPW rotor-noise blocks -> rn_tab (first: wavefront 0 needs them at its first substep)
+            if (wv == (ROLES ? 2 : 1) && noise_served) {   // the step's 10 x EPW rotor-noise blocks -> rn_tab (first: wavefront 0 needs them at its first substep)
                 const float n_sc = (float)((1 + 10.0 / 700) - (1 - 10.0 / 700)), n_lo = (float)(1 - 10.0 / 700);
 #pragma unroll 1
                 for (int b = lane; b < 10 * EPW; b += 64) {
@@ -1793,6 +1799,7 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
                 MB_POST(1, ks == 9 ? 11 : ks + 1);
             }
         }
+        if constexpr (PAIR) return;   // (the serving wavefront of the two-wavefront form has no post-phase role and nothing to wait for)
         __syncthreads();  // barrier 2 of 2
         const float4 *h4 = reinterpret_cast<const float4 *>(hand + el * CARRY_WORDS);
         const float4 a0 = h4[0], a1 = h4[1], a2 = h4[2], a3 = h4[3], a4 = h4[4], a5 = h4[5];
@@ -1880,7 +1887,7 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
                     if (w4 < TILE_W4 && off < buf_bytes) *reinterpret_cast<f32x4_t *>(ob + off) = clamp4(t4[w4], clip);
                 }
             }
-        } else if (SPLIT) {
+        } else if (ROLES) {
             // the history words were moved by shift_history while the substeps ran: only the newest frame of every row is left
             const f32x2_t *tp = reinterpret_cast<const f32x2_t *>(tile);
             const uint32_t L13 = (uint32_t)len * 13u, hist = L13 - 13u;
@@ -1942,7 +1949,7 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
         fr[18] = fr[18] + P.df * (nrm[9] * (float)(0.06 / 3) + 0.0f);
         fr[23] = fr[23] + P.df * (nrm[10] * (float)(0.06 / 3 / 3) + 0.0f);
     }
-    if (roleO) put_frame(P.obs, P.obs_prev, P.obs_bytes, P.len_obs, fr, SPLIT || (fl & TACO_F_OBSERVATION_NOISE) != 0, OUT ? P.obs_out : nullptr, P.clip_obs);
+    if (roleO) put_frame(P.obs, P.obs_prev, P.obs_bytes, P.len_obs, fr, ROLES || (fl & TACO_F_OBSERVATION_NOISE) != 0, OUT ? P.obs_out : nullptr, P.clip_obs);
     if constexpr (FUSED) {
         if (roleO && sub == 0) {  // ... and into the actor's input rows: the observation the next step's action is computed from never leaves the CU
 #pragma unroll
@@ -2063,7 +2070,7 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
 
 // the launch-per-step forms: one step_core per launch
 template <int BLOCK, int LPE, bool SPLIT = false, bool CAP = false, bool OUT = false, bool RESET_ONLY = false, bool WIDE = false>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT || CAP) ? (WIDE ? 2 : 4) : 1, CAP ? 4 : 8))) void taco_step_kernel(const StepParams P) {
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT || CAP) ? ((WIDE || BLOCK == 128) ? 2 : 4) : 1, CAP ? 4 : 8))) void taco_step_kernel(const StepParams P) {
     step_core<BLOCK, LPE, SPLIT, CAP, OUT, RESET_ONLY, WIDE, false>(P, FusedCtx{});
 }
 

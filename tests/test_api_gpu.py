@@ -126,7 +126,7 @@ def test_full_size_parity_on_random_slices(idx, steps):
     assert (prog >= 1).all() and (prog <= flat["max_episode_length"]).all()
 
 
-@pytest.mark.parametrize("idx,n,steps,form", [(2, 16384, 60, "quad"), (3, 16384, 60, "quad_roles"), (4, 32768, 40, "lane_roles"), (1, 65536, 25, "lane_throughput")])
+@pytest.mark.parametrize("idx,n,steps,form", [(2, 16384, 60, "quad"), (3, 16384, 60, "quad_served"), (4, 32768, 40, "lane_roles"), (1, 65536, 25, "lane_throughput")])
 def test_whole_batch_parity_at_the_per_rank_shapes(idx, n, steps, form):
     """SURVEY 8(d)'s configs 3 / 4 / 5 at their per-GPU shapes (rotate 16 384, flip 16 384, mix 32 768 with every flag and 5 state frames)
     and the first throughput-form size, in the kernel form the product picks there: EVERY env against the oracle (all host threads),

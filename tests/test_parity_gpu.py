@@ -132,7 +132,7 @@ def test_delay_line_overflow_regime():
     run_pair(cfg, steps=500, check_every=5, hover_bias=True)
 
 
-@pytest.mark.parametrize("form", ["auto", "quad", "lane", "lane_throughput", "lane_roles"])
+@pytest.mark.parametrize("form", ["auto", "quad", "lane", "lane_throughput", "lane_roles", "quad_served"])
 @pytest.mark.parametrize("len_obs", [1, 3])
 def test_gather_block_matches_outputs(len_obs, form):
     """the packed per-rank block the kernel fills for the all-gather == pack_block(obs, rew, done, time_outs), in every instantiation
@@ -186,14 +186,14 @@ def test_state_blob_roundtrip_and_restore():
 
 @pytest.mark.parametrize("task,n", [("pos", 1000), ("mix", 333), ("flip", 257), ("rotate", 4096)])
 def test_quad_layout_equals_one_lane_per_env(task, n):
-    """The five instantiations of the step kernel (4 lanes per env with and without the role wavefronts / 1 lane per env with 64- and
-    256-thread workgroups and with role wavefronts) are the same function: every output and every state word bit-identical, all randomisation on, stacked frames."""
+    """The six instantiations of the step kernel (4 lanes per env with and without the role wavefronts or with one serving wavefront / 1 lane per
+    env with 64- and 256-thread workgroups and with role wavefronts) are the same function: every output and every state word bit-identical, all randomisation on, stacked frames."""
     from taco_amd.vec_env import FpvBase
     kw = dict(env_lenObservations=2, env_lenStates=3, env_maxEpisodeLength=40, seed=11)
     if task == "mix":
         kw.update(rotor_noise=True, observation_noise=True, ramdom_deploy_time=True, ramdom_delay_time=True)
     envs = []
-    for form, lpe, block in (("quad", 4, 64), ("lane", 1, 64), ("lane_throughput", 1, 64), ("quad_roles", 4, 256), ("lane_roles", 1, 256)):
+    for form, lpe, block in (("quad", 4, 64), ("lane", 1, 64), ("lane_throughput", 1, 64), ("quad_roles", 4, 256), ("lane_roles", 1, 256), ("quad_served", 4, 128)):
         e = FpvBase(config.default_cfg(task, n, **kw), copy_outputs=False, kernel_form=form)
         assert e.kernel_form == form
         assert e.launch_geometry() == ((n * lpe + 63) // 64, block)  # one step wavefront per 64 / lpe envs in every form
@@ -203,7 +203,7 @@ def test_quad_layout_equals_one_lane_per_env(task, n):
         for e in envs:
             e.step_raw(acts[t])
         ref = envs[1]
-        for e in (envs[0], envs[2], envs[3], envs[4]):
+        for e in (envs[0], envs[2], envs[3], envs[4], envs[5]):
             for name in ("obs_buf", "states_buf", "rew_buf", "reset_buf", "timeout_buf"):
                 assert_bits_equal(getattr(e, name).cpu().numpy(), getattr(ref, name).cpu().numpy(), f"step {t} {name}")
         if t % 10 == 9:
@@ -257,7 +257,7 @@ def test_full_fuzz_run():
             print(f"fuzz: {i + 1} / {cases} cases clean", flush=True)
 
 
-@pytest.mark.parametrize("form", ["auto", "quad", "lane", "lane_throughput", "lane_roles"])
+@pytest.mark.parametrize("form", ["auto", "quad", "lane", "lane_throughput", "lane_roles", "quad_served"])
 def test_loop_forms_hand_over_on_rare_forms_and_nonfinite_inputs(form):
     """The substep loop runs a FIN form (no NaN-carrying selects) and a PLAIN form (compile-time flags, unrolled integrator) while a
     wave-uniform predicate says they are the same function as the exact form.  Two stress cases against the oracle, in every
@@ -384,7 +384,7 @@ def test_hip_kernel_equals_the_references_own_step(case, mode, golden):
     print(f"HIP glue_{case} [{mode}] maxima: " + ", ".join(f"{k} {v:.2e}" for k, v in maxima.items()))
 
 
-@pytest.mark.parametrize("form", ["quad_roles", "quad", "lane", "lane_roles", "lane_throughput"])
+@pytest.mark.parametrize("form", ["quad_roles", "quad", "lane", "lane_roles", "lane_throughput", "quad_served"])
 def test_world_rate_roundtrip_mode_equals_the_oracle_bitwise(form):
     """the reference's literal data flow of the angular rate (TACO_F_WORLD_RATE_ROUNDTRIP): every instantiation against the oracle in the same mode"""
     cfg = config.baseline_config(4, num_envs=600)   # mix, every randomisation on, 5 state frames
