@@ -112,7 +112,7 @@ class FpvBase:
             self.set_kernel_form(kernel_form)
 
     def set_kernel_form(self, name):
-        """pin one of the five instantiations of the step kernel (`_lib.FORMS`; "auto" = the library's choice for this env count)"""
+        """pin one of the six instantiations of the step kernel (`_lib.FORMS`; "auto" = the library's choice for this env count)"""
         _lib.check(self.lib.taco_set_kernel_form(self._h, _lib.FORMS[name]), self.lib)
 
     def set_rollout_fusion(self, on=True):
