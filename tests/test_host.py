@@ -170,3 +170,25 @@ def test_checkpoint_merge_and_slice_by_global_env_id():
         checkpoint.load_state_dict(Env(3, 6, 12), checkpoint.state_dict(parts[0]))
     with pytest.raises(ValueError, match="num_envs_global"):
         checkpoint.load_state_dict(Env(0, 5, 13), merged)
+
+
+def test_replay_store_frame_ring_views_are_the_state_stacks():
+    """RolloutBuffer keeps the state stacks as a frame ring [H + T][N][D]; states_buf [H,N,T,D] / next_states [N,T,D] are overlapping strided
+    views of it: stack (slot, env) = ring rows slot .. slot + T - 1 of that env.  The view arithmetic, on CPU tensors (no GPU needed)."""
+    import torch
+    from taco_amd.rollout import RolloutBuffer
+    H, N, T, D = 6, 5, 3, 4
+    buf = object.__new__(RolloutBuffer)
+    buf.num_envs, buf.states_len, buf.states_dim, buf.horizon_len = N, T, D, H
+    buf._frames = torch.arange((H + T) * N * D, dtype=torch.float32).view(H + T, N, D)
+    sb = buf._stack_view(0, H)
+    assert sb.shape == (H, N, T, D)
+    for t in range(H):
+        for n in range(N):
+            for k in range(T):
+                assert torch.equal(sb[t, n, k], buf._frames[t + k, n])
+    buf.step = 4
+    ns = buf.next_states
+    assert ns.shape == (N, T, D) and torch.equal(ns[2, 1], buf._frames[5, 2]) and torch.equal(ns.contiguous()[:, -1], buf._frames[4 + T - 1])
+    flat = sb.reshape(-1, T, D)                       # what a PPO update does before indexing minibatches: materialises a copy
+    assert flat.shape == (H * N, T, D) and torch.equal(flat[3 * N + 2], sb[3, 2])
