@@ -32,7 +32,7 @@ def draw_case(rng):
     elif r < 0.85:
         n = int(rng.integers(700, 6000))
     else:
-        n = int(rng.choice([8192 + 5, 16384 + 33, 65536 + 129])) + int(rng.integers(0, 50))
+        n = int(rng.choice([8192 + 5, 12288 + 7, 16384 + 33, 65536 + 129])) + int(rng.integers(0, 50))   # (12 295+: the served pair form for flip-like launches)
     cfg = config.default_cfg(task, n)
     for k in FLAGS:
         cfg[k] = bool(rng.random() < (0.5 if k not in ("world_rate_roundtrip", "record_flag") else 0.2))
