@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TACO_ENV_LIB", os.path.join(HERE, "libtaco_env.so"))  # override = A/B builds of the same ABI (taken as it is, never rebuilt)
 SKIP_ABI_CHECK = os.environ.get("TACO_ENV_LIB_SKIP_ABI", "") == "1"   # explicit opt-out for A/B runs ACROSS ABI revisions (missing symbols are stubbed)
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 NUM_FIELDS = 67
 RING_SLOTS = 100
 BLOB_ROWS = NUM_FIELDS + 4 * RING_SLOTS

@@ -692,6 +692,7 @@ static int policy_cfg_ok(const taco_policy_cfg *c) {
     if (c->lstm_hidden < 0 || c->lstm_hidden > taco::POL_MAXW) return fail(TACO_ERR_INVALID_ARG, "policy: lstm_hidden must be 0..256");
     if (c->lstm_hidden > 0 && (c->states_len > taco::POL_MAXT || c->states_dim > 32)) return fail(TACO_ERR_INVALID_ARG, "policy: the LSTM critic takes at most 8 frames of at most 32 features");
     if (c->lstm_hidden == 0 && p16(c->states_len * c->states_dim) > taco::POL_MAXW) return fail(TACO_ERR_INVALID_ARG, "policy: states_len * states_dim must be <= 256 without an encoder");
+    if (c->flags & ~(int32_t)TACO_P_EXACT_CELL) return fail(TACO_ERR_INVALID_ARG, "policy: unknown bits in cfg.flags");
     return TACO_OK;
 }
 
@@ -785,6 +786,7 @@ static int launch_critic(const taco_policy_cfg *c, const float *blob, size_t row
         if (!workspace || ((uintptr_t)workspace & 15u) != 0) return fail(TACO_ERR_INVALID_ARG, "critic: the batched form needs a 16-byte aligned workspace (taco_critic_workspace_bytes)");
         if (((uintptr_t)states & 15u) != 0) return fail(TACO_ERR_INVALID_ARG, "critic: the batched form needs 16-byte aligned state stacks");
         const int cus = cu_limit > 0 ? cu_limit : device_cus();
+        const bool exact = (c->flags & TACO_P_EXACT_CELL) != 0;
         // a persistent workgroup per CU walking blocks b, b + grid, ...: shrink the grid to the smallest that keeps the longest walk as short
         const size_t nblocks = (rows + taco::CR_ROWS - 1) / taco::CR_ROWS;
         const size_t walk = (nblocks + cus - 1) / cus;
@@ -793,11 +795,15 @@ static int launch_critic(const taco_policy_cfg *c, const float *blob, size_t row
             // frame ring with at least two slots: blocks of 16 envs x two consecutive slots share the input projection (taco_critic_lstm_pair_kernel)
             const size_t pb = (((size_t)ring_n + 15) / 16) * ((rows / (size_t)ring_n + 1) / 2);
             const size_t pw = (pb + cus - 1) / cus;
-            hipLaunchKernelGGL(taco::taco_critic_lstm_pair_kernel, dim3((unsigned)((pb + pw - 1) / pw)), dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
+            const dim3 pg((unsigned)((pb + pw - 1) / pw));
+            if (exact) hipLaunchKernelGGL(taco::taco_critic_lstm_pair_kernel<true>, pg, dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
+            else hipLaunchKernelGGL(taco::taco_critic_lstm_pair_kernel<false>, pg, dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
         } else if (ring_n > 0) {
-            hipLaunchKernelGGL(taco::taco_critic_lstm_kernel<true>, dim3(grid), dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
+            if (exact) hipLaunchKernelGGL((taco::taco_critic_lstm_kernel<true, true>), dim3(grid), dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
+            else hipLaunchKernelGGL((taco::taco_critic_lstm_kernel<true, false>), dim3(grid), dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
         } else {
-            hipLaunchKernelGGL(taco::taco_critic_lstm_kernel<false>, dim3(grid), dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
+            if (exact) hipLaunchKernelGGL((taco::taco_critic_lstm_kernel<false, true>), dim3(grid), dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
+            else hipLaunchKernelGGL((taco::taco_critic_lstm_kernel<false, false>), dim3(grid), dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
         }
         hipError_t he = hipGetLastError();
         if (he != hipSuccess) return hip_fail(he, "taco_critic_lstm_kernel launch");

@@ -192,6 +192,27 @@ TD void lstm_cell(float ai, float af, float ag, float ao, float c_old, float &c_
     h = with_sign_of(1.0f - tc, c) / ((1.0f + eo) * (1.0f + tc));
 }
 
+// The same cell on the hardware's transcendental pipe (v_exp_f32 = 2^x and v_rcp_f32, 1 ulp each) for the batched critic kernels, whose
+// SIMD time is MFMA time + VALU time with no slack (profiles/r03_q_rollout_pmc.json): 8 quarter-rate + ~19 full-rate instructions per
+// cell instead of 142.  Same three-division form; |error| <= 3e-7 on c' and h against lstm_cell (tests/test_policy_gpu.py), so the
+// values stay inside the 1e-5 bar to the reference's vectors but are no longer bit-identical to the CPU restatement of the policy.
+// e^-a for a < -88 is +inf: 1/(1+inf) = 0 and the numerators are finite, so saturated gates give exact zeros, never NaN.
+TD void lstm_cell_fast(float ai, float af, float ag, float ao, float c_old, float &c_new, float &h) {
+    constexpr float L2E = 1.44269504088896341f;
+    const float ei = __builtin_amdgcn_exp2f(-L2E * ai), ef = __builtin_amdgcn_exp2f(-L2E * af), eo = __builtin_amdgcn_exp2f(-L2E * ao);
+    const float tg = __builtin_amdgcn_exp2f((-2.0f * L2E) * absf(ag));
+    const float ig = with_sign_of(1.0f - tg, ag) * __builtin_amdgcn_rcpf((1.0f + ei) * (1.0f + tg));
+    const float c = fma(c_old, __builtin_amdgcn_rcpf(1.0f + ef), ig);
+    const float tc = __builtin_amdgcn_exp2f((-2.0f * L2E) * absf(c));
+    c_new = c;
+    h = with_sign_of(1.0f - tc, c) * __builtin_amdgcn_rcpf((1.0f + eo) * (1.0f + tc));
+}
+template <bool EXACT>
+TD void lstm_cell_batched(float ai, float af, float ag, float ao, float c_old, float &c_new, float &h) {
+    if constexpr (EXACT) lstm_cell(ai, af, ag, ao, c_old, c_new, h);
+    else lstm_cell_fast(ai, af, ag, ao, c_old, c_new, h);
+}
+
 // ---- Philox4x32-10 (Salmon et al., SC'11).  counter = (global env id, step index, stream, block), key = seed
 struct U4 { uint32_t x, y, z, w; };
 TD U4 philox(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {

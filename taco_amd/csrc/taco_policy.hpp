@@ -459,7 +459,9 @@ constexpr int CR_MLP_ROWS = 64;
 // pad16(lstm_hidden) == 128, states_len <= POL_MAXT, critic MLP = two hidden layers padded to 128
 // RING: the input is a frame ring (PolicyParams.ring_n) instead of materialised stacks -- a template parameter so that the fragment
 // addressing of either layout is compile-time arithmetic (as a run-time switch it cost 23 SGPR spills and 4 more VGPR spills)
-template <bool RING>
+// EXACT: the cell with the oracle's operations (taco_math.hpp lstm_cell) instead of the hardware's 2^x / reciprocal (lstm_cell_fast):
+// include/taco_env.h TACO_P_EXACT_CELL
+template <bool RING, bool EXACT>
 __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_kernel(const PolicyParams P) {
     __shared__ __attribute__((aligned(16))) float xs[2][POL_MAXT * CR_ROWS * 32];   // the block's state stacks as they lie in memory: [row][t][sd]
     __shared__ __attribute__((aligned(16))) float hb[3][CR_ROWS * CR_LD];   // h_t double buffer + [2] = h_T on its way to the workspace
@@ -628,7 +630,7 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_kernel(const Pol
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float cn;
-                lstm_cell(acc[rt][0][i], acc[rt][1][i], acc[rt][2][i], acc[rt][3][i], first ? 0.0f : cst[rt][i], cn, hv[rt][i]);
+                lstm_cell_batched<EXACT>(acc[rt][0][i], acc[rt][1][i], acc[rt][2][i], acc[rt][3][i], first ? 0.0f : cst[rt][i], cn, hv[rt][i]);
                 cst[rt][i] = cn;
             }
         float *hout = hb[t + 1 < T ? (t & 1) : 2] + (4 * g) * CR_LD + col;   // (the last timestep's h goes out through hb[2], see flush_hT)
@@ -705,6 +707,7 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_kernel(const Pol
 // next block, one barrier per timestep, h_T through the workspace -- is taco_critic_lstm_kernel's.
 // Rows: row = slot * N + env as everywhere; S = rows / N slots; an odd S leaves the last block's tile B without a slot (computed on zero
 // frames, written nowhere); env groups of 16 with a ragged last one.
+template <bool EXACT>
 __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_kernel(const PolicyParams P) {
     constexpr int FR = POL_MAXT + 1;   // frames a block reads: T + 1
     __shared__ __attribute__((aligned(16))) float xs[2][FR * 16 * 32];   // [frame][env][sd] as they lie in the ring
@@ -842,7 +845,7 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_kernel(cons
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float cn, hv;
-            lstm_cell(acc[0][i], acc[1][i], acc[2][i], acc[3][i], first ? 0.0f : cst[i], cn, hv);
+            lstm_cell_batched<EXACT>(acc[0][i], acc[1][i], acc[2][i], acc[3][i], first ? 0.0f : cst[i], cn, hv);
             cst[i] = cn;
             hout[i * CR_LD] = hv;
         }

@@ -106,11 +106,14 @@ def test_collect_refuses_what_it_cannot_do_exactly():
     assert len(buf.batch_idx_generator()) == 4 and sorted(sum(buf.batch_idx_generator(), [])) == list(range(64 * 4))
 
 
-@pytest.mark.parametrize("n,task,len_states,arch", [(300, "pos", 5, ([48, 32], 32, [40])), (96, "mix", 3, ([48, 32], 32, [40])),
-                                                     (333, "mix", 5, ([128, 128, 128], 128, [128, 128]))])   # the last: the batched critic's form
-def test_rollout_run_equals_the_python_loop(n, task, len_states, arch):
+@pytest.mark.parametrize("n,task,len_states,arch,exact", [(300, "pos", 5, ([48, 32], 32, [40]), False), (96, "mix", 3, ([48, 32], 32, [40]), False),
+                                                           (333, "mix", 5, ([128, 128, 128], 128, [128, 128]), True),   # the batched critic's form
+                                                           (333, "mix", 5, ([128, 128, 128], 128, [128, 128]), False)])
+def test_rollout_run_equals_the_python_loop(n, task, len_states, arch, exact):
     """taco_rollout_run (one C call: the actor + the env step per step, the critic batched over all H + 1 slots afterwards) == the act() /
-    collect() / bootstrap loop of ppo_asymmetry.py:308-342, bit for bit."""
+    collect() / bootstrap loop of ppo_asymmetry.py:308-342, bit for bit -- for the documented architecture with the exact LSTM cell
+    (TACO_P_EXACT_CELL); with the default cell the critic's values, and what GAE derives from them, agree to 2e-6 / 1e-4 and everything
+    else (trajectories, actions, log-probs, dones, time-outs, the env's state) stays bit-identical."""
     from taco_amd import policy as P
     from taco_amd.vec_env import FpvBase
     import test_policy_gpu as TP
@@ -121,7 +124,7 @@ def test_rollout_run_equals_the_python_loop(n, task, len_states, arch):
     outs = []
     for mode in ("run", "loop"):
         env = FpvBase(cfg, copy_outputs=False)
-        pol = P.ActorCritic(sd, 1, len_states, seed=21)
+        pol = P.ActorCritic(sd, 1, len_states, seed=21, exact_critic=exact)
         buf = _buffer(n, H, 1, len_states)
         for epoch in range(2):
             buf.reset()
@@ -143,9 +146,13 @@ def test_rollout_run_equals_the_python_loop(n, task, len_states, arch):
         outs.append({k: getattr(buf, k).clone() for k in ("obs_buf", "states_buf", "act_buf", "rew_buf", "done_buf", "value_buf", "logp_buf",
                                                             "mu_buf", "sigma_buf", "ret_buf", "adv_buf")} | {"last": last.clone(), "tmo": tmo,
                                                                                                              "state": env.get_state().view(torch.int32)})
+    batched_fast = arch[1] == 128 and not exact          # only the documented architecture runs the batched critic kernels
+    loose = {"value_buf": 2e-6, "last": 2e-6, "rew_buf": 2e-6, "ret_buf": 1e-4, "adv_buf": 1e-4} if batched_fast else {}
     for k in outs[0]:
         a, b = outs[0][k], outs[1][k]
-        if a.dtype == torch.float32:
+        if k in loose:
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=loose[k], err_msg=k)
+        elif a.dtype == torch.float32:
             assert_bits_equal(a.cpu().numpy(), b.cpu().numpy(), k)
         else:
             assert torch.equal(a, b), k
