@@ -348,13 +348,22 @@ def rollout_entry(n, horizon, dev, torch):
         cs.append(e0.elapsed_time(e1) * 1e-3 / 4)
     cs.sort()
     flops = 2 * rows * (T * 4 * hd2 * (26 + hd2) + 2 * hd2 * hd2 + hd2)
+    # what the kernels actually issue (v_mfma_f32_16x16x4_f32 = 2 048 flop): the paired-slot LSTM kernel runs blocks of 16 envs x 2 slots, per
+    # wavefront 64 MFMAs at the first timestep (x chains only: h_-1 = 0) and 288 at each later one (shared input projection); the MLP 544 per
+    # 16 rows.  K is padded 26 -> 32 in the x chains, so this is not a subset of the model count either; SQ_INSTS_MFMA in profiles/ agrees.
+    issued = 2048 * (((n + 15) // 16) * ((horizon + 2) // 2) * 8 * (64 + (T - 1) * 288) + ((rows + 15) // 16) * 544) if T >= 2 else None
     return {"config": 5, "what": "taco_rollout_run (actor forward + env step per step, replay store fused; critic batched over all slots afterwards) + GAE",
             "envs": n, "horizon": horizon, "len_states": T, "ms_per_rollout": fused_ms, "env_steps_per_s": n * horizon / ts[2],
             "per_step_chain": ("ONE persistent kernel (a workgroup owns 16 envs for the whole horizon; the actor's MFMAs run under the substeps): 4 launches per rollout"
                                if n <= 8192 else "actor launch + step launch per step (above 8 192 envs)"),
             "ms_per_rollout_launch_per_step": us[1] * 1e3,
             "critic": {"rows": rows, "ms": cs[2] * 1e3, "tflops": flops / cs[2] / 1e12, "frac_of_f32_mfma_peak": flops / cs[2] / 157.3e12,
-                       "note": "model flops 2 rows (T 4 H (26 + H) + 2 H H + H) over the LSTM + MLP kernels' time; peak 157.3 TFLOP/s (MI355X_MICROARCH.md)"}}
+                       "mfma_tflops_issued": issued / cs[2] / 1e12 if issued else None,
+                       "frac_of_f32_mfma_peak_issued": issued / cs[2] / 157.3e12 if issued else None,
+                       "lstm_cell": "hardware 2^x / reciprocal (default; TACO_P_EXACT_CELL keeps the oracle's operations, +23 % critic time)",
+                       "note": "tflops / frac_of_f32_mfma_peak: MODEL flops 2 rows (T 4 H (26 + H) + 2 H H + H) over the LSTM + MLP kernels' time -- the "
+                               "kernels skip the h chain of the first timestep and share input projections between neighbouring slots, so the matrix "
+                               "pipe's own utilisation is the *_issued pair (MFMA instructions issued x 2 048 flop); peak 157.3 TFLOP/s (MI355X_MICROARCH.md)"}}
 
 
 def shader_clock_mhz():

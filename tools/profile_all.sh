@@ -1,11 +1,12 @@
 #!/bin/bash
 # Reproduces everything under profiles/ for one build:  bash tools/profile_all.sh <tag>     (run ON the MI355X box, repo root)
-#   1. un-profiled bench line                          -> gpurun_out/<tag>_bench_4096.json
+#   1. (runs LAST, so that its roofline.traffic comes from this build's own PMC summary) un-profiled bench line -> gpurun_out/<tag>_bench_4096.json
 #   2. rocprofv3 --kernel-trace --stats of the bench   -> gpurun_out/<tag>_stats/
 #   3. three separate --pmc passes (SQ set, FETCH_SIZE, WRITE_SIZE) at 262144 envs and FETCH/WRITE at 4096 envs
 #   4. tools/pmc_summary.py                            -> gpurun_out/<tag>_pmc_summary.json, <tag>_kernel_stats_bench_4096.csv
 #   5. kernel trace of VecTask.step() calls            -> gpurun_out/<tag>_step_api_kernel_stats.csv
 #   5b. kernel trace of taco_rollout_run                -> gpurun_out/<tag>_rollout_kernel_stats.csv
+#   5c. SQ counters of the rollout's kernels (2 passes) -> gpurun_out/<tag>_rollout_pmc.json (tools/pmc_kernels.py)
 #   6. bench.py --gpus 2 over gloo on this one GPU     -> gpurun_out/<tag>_bench_2ranks_gloo_one_gpu.json
 # --pmc is never combined with any trace domain other than --kernel-trace; python3 is the program right after `--`.
 set -eo pipefail
@@ -13,7 +14,6 @@ TAG=${1:-r01_x}
 R=$(pwd)
 O=$R/gpurun_out
 mkdir -p "$O"
-python3 bench.py --steps 2000 --warmup 200 > "$O/${TAG}_bench_4096.json" 2> "$O/${TAG}_bench.err"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${TAG}_stats" -- python3 "$R/bench.py" --steps 2000 --warmup 200 --no-cpu-baseline > "$O/${TAG}_bench_prof.json" 2> "$O/${TAG}_bench_prof.err"
 SQ="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_WAIT_ANY"
@@ -29,9 +29,16 @@ rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d "$O/${TAG}_pmc_sq_4096
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${TAG}_step_api" -- python3 "$R/tools/prof_step.py" --api --envs 4096 --steps 200 >> "$O/${TAG}_pmc.log" 2>&1
 # 5b. one PPO rollout (config 5's flags, 4 096 envs x 32 steps): the persistent actor + step kernel, the batched critic, GAE
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${TAG}_rollout" -- python3 "$R/tools/prof_rollout.py" >> "$O/${TAG}_pmc.log" 2>&1
+# 5c. where the rollout's kernels spend their SIMD time: MFMA vs VALU instructions, busy cycles, LDS
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_INSTS_LDS --output-format csv -d "$O/${TAG}_rollout_pmc/a" -- python3 "$R/tools/prof_rollout.py" >> "$O/${TAG}_pmc.log" 2>&1
+rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d "$O/${TAG}_rollout_pmc/b" -- python3 "$R/tools/prof_rollout.py" >> "$O/${TAG}_pmc.log" 2>&1
 cd "$R"
+python3 tools/pmc_kernels.py "$O/${TAG}_rollout_pmc" "$O/${TAG}_rollout_pmc.json" taco_rollout_kernel taco_critic_lstm_pair_kernel taco_critic_mlp > /dev/null
 python3 tools/pmc_summary.py "$TAG"
 cp "$O/${TAG}_rollout"/*/*kernel_stats.csv "$O/${TAG}_rollout_kernel_stats.csv"
 cp "$O/${TAG}_step_api"/*/*kernel_stats.csv "$O/${TAG}_step_api_kernel_stats.csv"
+# 1. the un-profiled bench line, with this build's PMC summary where bench.py looks for it (profiles/, newest matching source hash)
+cp "$O/${TAG}_pmc_summary.json" profiles/
+python3 bench.py --steps 2000 --warmup 200 > "$O/${TAG}_bench_4096.json" 2> "$O/${TAG}_bench.err"
 # 6. the N > 1 code path end to end on this one GPU: 2 ranks over gloo (the driver runs the real thing over RCCL on 8 GPUs)
 TACO_BENCH_BACKEND=gloo TACO_BENCH_ONE_DEVICE=1 python3 bench.py --gpus 2 --steps 500 --warmup 100 --no-cpu-baseline --no-large-n --no-configs > "$O/${TAG}_bench_2ranks_gloo_one_gpu.json" 2> "$O/${TAG}_bench_2ranks.err" || true
