@@ -535,6 +535,26 @@ def main():
         sync_ranks()
         return max_over_ranks(time.perf_counter() - t0)
 
+    # ---- before it: the host path and the GPU brought to their running state on a TWIN env (the measured env's trajectory stays W + K steps
+    # from its reset).  A short region (the driver runs K = 20, W = 5) otherwise measures the process's first step() calls -- on a fresh box
+    # the interpreter and libraries still page in: 17.0 us per step instead of 14.0 in the same process a moment later (tools/short_run.py).
+    pre_warm = None
+    try:
+        twin = FpvBase(config.baseline_config(cfg_idx, num_envs=n_local), sim_device=str(dev), rl_device=str(dev))
+        t0 = time.perf_counter()
+        k = 0
+        while time.perf_counter() - t0 < 0.2:
+            for t in range(n_act):
+                twin.step(acts[t])
+            k += n_act
+        torch.cuda.synchronize()
+        pre_warm = {"steps": k, "seconds": time.perf_counter() - t0, "on": "a twin env of the same configuration (not the measured one)"}
+        del twin
+    except Exception as e:  # noqa: BLE001
+        pre_warm = {"error": repr(e)[:200]}
+    import gc
+    gc.collect()
+
     # ---- the main timed leg.  It holds no data-path collective (envs are independent); a failure inside it still yields a line.
     main_error = None
     try:
@@ -656,7 +676,8 @@ def main():
                        "api": "VecTask.step() (taco_amd.vec_env: returns the reference's (obs dict, rew, done, extras))" if world == 1 else "ShardedEnv.step_gathered() (taco_step on this rank's slice)",
                        "collective": ("1 RCCL all-gather of [obs|rew|done|timeout] per step" if (world > 1 and args.gather) else
                                       "none in the timed region: envs are independent, each rank steps its own slice"),
-                       "kernel": base.lib.taco_step_kernel_name().decode(), "kernel_form": base.kernel_form, "grid": grid, "block": block},
+                       "kernel": base.lib.taco_step_kernel_name().decode(), "kernel_form": base.kernel_form, "grid": grid, "block": block,
+                       "pre_warm": pre_warm},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_frac": (traffic / (k_avg_us * 1e-6) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                          "traffic_source": traffic_src, "kernel_avg_us": k_avg_us, "kernel_bracketed_median_us": k_med_us,
