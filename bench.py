@@ -9,7 +9,9 @@ the children's status.  Under torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE /
 
 A "step" is one VecTask.step() of the whole batch = ONE taco_step launch through the C ABI.  Workload at N = 1: BASELINE configs[1]
 (task_mode=pos, 4 096 envs, rotor_response_time=0.017).  For N > 1 every rank holds 4 096 envs (weak scaling; global env ids are disjoint
-contiguous slices) and the timed region holds no collective (envs are independent); value = N * 4096 * K / max-over-ranks time.  The
+contiguous slices) and the timed region holds no collective (envs are independent); value = N * 4096 * K / max-over-ranks time (every
+rank: W warm-up steps, synchronize + barrier + synchronize, t0, K steps, synchronize, t1, barrier; before the warm-up a twin env is stepped
+for 0.2 s so that a short region does not time the process's first calls).  The
 north-star's single RCCL all-gather of the packed obs|reward|done|time-out block per step is timed right after ("with_allgather": the
 serial form a single learner needs, and the overlapped form with the gather of step t running under step t + 1), then a strong-scaling
 leg (4 096 envs in TOTAL).  Inputs (the action stream a_t = clamp(0.3 N(0,1) + (-0.45,0,0,0), -1, 1)) are resident in HBM before any
@@ -519,8 +521,18 @@ def main():
         dist.all_gather(outs, t)
         return [float(o.item()) for o in outs]
 
+    def close_interval(t0):
+        """every rank's interval ends at ITS synchronize; the closing barrier follows (it is part of the bracket, not of any rank's K steps:
+        an RCCL or gloo barrier is 50-200 us, a fifth of a K = 20 region); the result is the MAX over ranks"""
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+        return max_over_ranks(el)
+
     def timed(step_fn, a, steps, warmup, finish=None):
-        """W untimed steps, then exactly K steps bracketed by barrier + synchronize; max over ranks"""
+        """W untimed steps, then exactly K steps bracketed by barrier + synchronize on both sides; max over ranks"""
         na = a.shape[0]
         for t in range(warmup):
             step_fn(a[t % na])
@@ -532,8 +544,7 @@ def main():
             step_fn(a[t % na])
         if finish:
             finish()
-        sync_ranks()
-        return max_over_ranks(time.perf_counter() - t0)
+        return close_interval(t0)
 
     # ---- before it: the host path and the GPU brought to their running state on a TWIN env (the measured env's trajectory stays W + K steps
     # from its reset).  A short region (the driver runs K = 20, W = 5) otherwise measures the process's first step() calls -- on a fresh box
@@ -641,7 +652,7 @@ def main():
     if not args.no_configs and not solo:
         short = max(50, min(args.steps, 300))
         baseline_legs = [sharded_config_leg(number, rank, world, dev, torch, timed, gather_floats, short) for number in (3, 4, 5) if number != args.config]
-        baseline_legs.append(sharded_rollout_leg(262144, 16, rank, world, dev, torch, sync_ranks, max_over_ranks))
+        baseline_legs.append(sharded_rollout_leg(262144, 16, rank, world, dev, torch, sync_ranks, close_interval))
         if dist:
             # ... and rank 0 alone on configs[1] while the others wait: the N = 1 number of THIS run, for agreement with the 1-GPU record
             try:
@@ -677,7 +688,8 @@ def main():
                        "collective": ("1 RCCL all-gather of [obs|rew|done|timeout] per step" if (world > 1 and args.gather) else
                                       "none in the timed region: envs are independent, each rank steps its own slice"),
                        "kernel": base.lib.taco_step_kernel_name().decode(), "kernel_form": base.kernel_form, "grid": grid, "block": block,
-                       "pre_warm": pre_warm},
+                       "pre_warm": pre_warm,
+                       "timing": "per rank: W warm-up steps, synchronize + barrier + synchronize, t0, K steps, synchronize, t1, barrier; elapsed = MAX over ranks of t1 - t0"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_frac": (traffic / (k_avg_us * 1e-6) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                          "traffic_source": traffic_src, "kernel_avg_us": k_avg_us, "kernel_bracketed_median_us": k_med_us,
@@ -795,7 +807,7 @@ def sharded_config_leg(number, rank, world, dev, torch, timed, gather_floats, st
         return {"config": number, "envs_total": total, "error": repr(e)[:300]}
 
 
-def sharded_rollout_leg(total, horizon, rank, world, dev, torch, sync_ranks, max_over_ranks):
+def sharded_rollout_leg(total, horizon, rank, world, dev, torch, sync_ranks, close_interval):
     """BASELINE configs[4]'s "LSTM-critic rollout" at its real shape: every rank rolls out its slice of the 262 144 envs (actor + env step per
     step, critic batched afterwards, GAE) -- data-parallel, no collective inside; value = total env-steps / max-over-ranks time."""
     import numpy as np
@@ -821,8 +833,7 @@ def sharded_rollout_leg(total, horizon, rank, world, dev, torch, sync_ranks, max
         reps = 4
         for _ in range(reps):
             run()
-        sync_ranks()
-        el = max_over_ranks(time.perf_counter() - t0) / reps
+        el = close_interval(t0) / reps
         del buf, env, pol
         torch.cuda.empty_cache()
         return {"config": 5, "what": "taco_rollout_run + GAE on every rank's slice (policy forward included), data-parallel", "envs_total": total, "envs_per_rank": n,
