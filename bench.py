@@ -491,7 +491,9 @@ def main():
     if world > 1:
         from taco_amd.dist import ShardedEnv
         env = ShardedEnv(cfg, rank=rank, world_size=world, device=dev, gather=args.gather and not solo)
-        step = env.step_gathered
+        # without --gather the timed leg needs no global view: every rank makes the launch a single-GPU VecTask.step() makes (no gather
+        # block bound: filling it costs 0.4 us per step at 4 096 envs, tools/host_cost.py); the gathered variants are timed right after
+        step = env.step_gathered if (args.gather and not solo) else env.step_local
         n_local = env.hi - env.lo
     else:
         env = FpvBase(cfg, sim_device=str(dev), rl_device=str(dev))   # copy_outputs=True: VecTask.step() as the PPO loop calls it
@@ -684,7 +686,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[{args.config - 1}]: " + what,
                        "envs_per_gpu": n_local, "envs_total": n_global, "parallelism": f"env-sharded x{world}",
-                       "api": "VecTask.step() (taco_amd.vec_env: returns the reference's (obs dict, rew, done, extras))" if world == 1 else "ShardedEnv.step_gathered() (taco_step on this rank's slice)",
+                       "api": "VecTask.step() (taco_amd.vec_env: returns the reference's (obs dict, rew, done, extras))" if world == 1 else
+                              ("ShardedEnv.step_gathered() (taco_step on this rank's slice + the all-gather)" if (args.gather and not solo) else
+                               "ShardedEnv.step_local() = VecTask.step() on this rank's slice"),
                        "collective": ("1 RCCL all-gather of [obs|rew|done|timeout] per step" if (world > 1 and args.gather) else
                                       "none in the timed region: envs are independent, each rank steps its own slice"),
                        "kernel": base.lib.taco_step_kernel_name().decode(), "kernel_form": base.kernel_form, "grid": grid, "block": block,

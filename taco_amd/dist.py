@@ -123,7 +123,22 @@ class ShardedEnv:
         self.pending = [None, None]
         self.k = 0
         self.block = self.blocks[0]
-        _lib.check(self.env.lib.taco_bind_gather_block(self.env._h, self.block.data_ptr()))
+        self._bound = None
+        self._bind(self.block)
+
+    def _bind(self, block):
+        """the block the step kernel fills besides its outputs (None: none -- the launch a single-GPU VecTask.step() makes)"""
+        ptr = block.data_ptr() if block is not None else None
+        if ptr != self._bound:
+            _lib.check(self.env.lib.taco_bind_gather_block(self.env._h, ptr))
+            self._bound = ptr
+
+    def step_local(self, local_actions):
+        """This rank's slice through VecTask.step() with NO gather block bound -- exactly the launch a single-GPU env makes; for callers
+        that need no global view of the step (a data-parallel learner: every rank acts on its own envs).  -> (obs dict, rew, done, extras)
+        of the local envs."""
+        self._bind(None)
+        return self.env.step(local_actions)
 
     def step_async(self, local_actions):
         """One step of this rank's envs + the all-gather of its block, issued without waiting for it: returns a GatheredBlocks whose
@@ -133,7 +148,7 @@ class ShardedEnv:
             self.pending[k].wait()
             self.pending[k] = None
         self.block = self.blocks[k]
-        _lib.check(self.env.lib.taco_bind_gather_block(self.env._h, self.block.data_ptr()))
+        self._bind(self.block)
         self.env.step_raw(local_actions)
         self.k = 1 - k
         if not self.gather or self.world_size == 1:

@@ -564,3 +564,28 @@ def test_yaml_launcher_equals_the_python_built_config(tmp_path):
     assert_bits_equal(rew.cpu().numpy(), got["rew"], "rew")
     assert np.array_equal(done.cpu().numpy(), got["done"])
     assert np.array_equal(env.get_state().view(torch.int32).cpu().numpy(), got["state"].view(np.int32))
+
+
+def test_sharded_env_step_local_is_the_single_gpu_launch_and_rebinding_works():
+    """ShardedEnv.step_local(): this rank's slice through VecTask.step() with no gather block bound (what bench.py's ungathered main leg
+    times for N > 1).  Same results as the block-filling step of a twin shard, and a gathered step after it fills its block again."""
+    from taco_amd.dist import ShardedEnv, unpack_block
+    cfg = config.default_cfg("mix", 333, seed=5, env_maxEpisodeLength=6)
+    dev = torch.device("cuda:0")
+    a = ShardedEnv(cfg, rank=1, world_size=2, device=dev, gather=False)     # envs 167 .. 332 of the job
+    b = ShardedEnv(cfg, rank=1, world_size=2, device=dev, gather=False)
+    n = a.hi - a.lo
+    g = torch.Generator(device="cpu").manual_seed(1)
+    for t in range(14):
+        act = (torch.rand(n, 4, generator=g) * 2 - 1).cuda()
+        blk = a.step_gathered(act)
+        obs_a, rew_a, done_a, tmo_a = unpack_block(blk, a.len_obs)
+        if t % 3 == 2:      # now and then the gathered path on b too: the block must be bound again and filled
+            blk_b = b.step_gathered(act)
+            assert torch.equal(blk_b, blk)
+            continue
+        o, rew_b, done_b, ex = b.step_local(act)
+        assert b._bound is None
+        assert torch.equal(o["obs"].reshape(n, -1), obs_a.reshape(n, -1)) and torch.equal(rew_b, rew_a)
+        assert torch.equal(done_b.to(done_a.dtype), done_a) and torch.equal(ex["time_outs"].to(tmo_a.dtype), tmo_a)
+    assert torch.equal(a.env.get_state(), b.env.get_state())
