@@ -818,9 +818,12 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_kernel(cons
     };
     auto h_chain = [&](const float *hprev, int tile) __attribute__((always_inline)) {
         const float *hrow = hprev + (16 * tile + r) * CR_LD + 4 * g;
+        float4 nx = *reinterpret_cast<const float4 *>(hrow);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
         for (int s = 0; s < KSH; ++s) {
-            const float4 a4 = *reinterpret_cast<const float4 *>(hrow + 16 * s);
+            const float4 a4 = nx;
+            if (s + 1 < KSH) nx = *reinterpret_cast<const float4 *>(hrow + 16 * (s + 1));   // on its way while this block's 16 MFMAs issue
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, wh[q][s].x, acc[q], 0, 0, 0);
 #pragma unroll
@@ -829,6 +832,8 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_kernel(cons
             for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, wh[q][s].z, acc[q], 0, 0, 0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wh[q][s].w, acc[q], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);   // this fragment's 16 MFMAs, then ONE more LDS read: two fragments ahead of the
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // MFMAs at any time (the two reads in front of the loop + one per block)
         }
     };
     auto zero_rule = [&]() __attribute__((always_inline)) {   // timestep 0: the skipped W_hh h_{-1} chain would have turned a -0 into +0 unless every weight is negative
