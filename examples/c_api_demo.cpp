@@ -19,7 +19,8 @@ int main() {
     cfg.num_envs = 4096; cfg.num_envs_global = 4096; cfg.task_mode = TACO_TASK_POS; cfg.len_obs = 1; cfg.len_states = 1;
     cfg.control_freq_inv = 10; cfg.substeps = 2; cfg.max_episode_length = 1000; cfg.delay_time = 20;
     cfg.flags = TACO_F_RANDOM_COPTER_POS | TACO_F_RANDOM_COPTER_QUAT | TACO_F_RANDOM_COPTER_VEL | TACO_F_RANDOM_TARGET_POS | TACO_F_RANDOM_TARGET_YAW |
-                TACO_F_BATTERY_CONSUMPTION | TACO_F_RANDOM_VOLTAGE | TACO_F_ROTOR_DELAY | TACO_F_ROTOR_RESPONSE | TACO_F_RANDOM_ROTOR_SPEED | TACO_F_RANDOM_COMMAND;
+                TACO_F_BATTERY_CONSUMPTION | TACO_F_RANDOM_VOLTAGE | TACO_F_ROTOR_DELAY | TACO_F_ROTOR_RESPONSE | TACO_F_RANDOM_ROTOR_SPEED | TACO_F_RANDOM_COMMAND |
+                TACO_F_WORLD_RATE_ROUNDTRIP;   // (the reference's own data flow of the angular rate: the default arithmetic)
     cfg.seed = 1; cfg.dt = 0.001; cfg.rotor_response_time = 0.017; cfg.difficulty = 1.0;
     cfg.clip_actions = cfg.clip_obs = cfg.clip_states = INFINITY;
     cfg.mass = 0.4600008; cfg.inertia[0] = 5.008029448e-4; cfg.inertia[1] = 7.008019272e-4; cfg.inertia[2] = 8.00804552e-4;

@@ -62,12 +62,13 @@ enum {
     TACO_F_RANDOM_DEPLOY_TIME = 1u << 16, /* cfg key "ramdom_deploy_time" (sic, fpv_asymmetry.py:90) */
     TACO_F_RANDOM_COMMAND = 1u << 17,
     TACO_F_OBSERVATION_NOISE = 1u << 18,
-    /* cfg key "world_rate_roundtrip" (no counterpart key in the reference: this is the reference's own DATA FLOW).  The reference keeps the
-     * angular velocity in the root state, world frame, and re-derives the body rates from it at every refresh_state (quat_rotate(conj(q), w),
-     * fpv_asymmetry.py:350) -- ten times per step.  The default step carries the body rates across the ten substeps and writes the world-frame
-     * value once (the same numbers up to one rounding per substep; DESIGN.md section 5 states the measured distance).  With this flag the
-     * kernel follows the reference literally: after every simulate() w = R(q) b, b = R(q)^T w.  Bit-identical to the oracle in its
-     * round-trip mode, which the fixtures generated by the reference's own VecTask.step() pin. */
+    /* cfg key "world_rate_roundtrip" (no counterpart key in the reference: this is the reference's own DATA FLOW, and the DEFAULT of the host
+     * layer -- a C caller should set it too).  The reference keeps the angular velocity in the root state, world frame, and re-derives the body
+     * rates from it at every refresh_state (quat_rotate(conj(q), w), fpv_asymmetry.py:350) -- ten times per step.  With this flag the kernel
+     * does the same: after every simulate() w = R(q) b, b = R(q)^T w; the fast (PLAIN) loop forms exist for this mode.  Without it the body
+     * rates are carried across the ten substeps and the world-frame value is written once: the same numbers up to one rounding per substep,
+     * which is OUTSIDE 1e-5 of the reference per step (2.1e-5 on the body rates against 7.9e-6; tests/util.py teacher_forced_one_step,
+     * DESIGN.md section 5) and runs the general loop forms.  Either way bit-identical to the oracle in the same mode. */
     TACO_F_WORLD_RATE_ROUNDTRIP = 1u << 19,
     /* cfg key "record_flag" (fpv_asymmetry.py:113, :386-388): copter_rpy_old / copter_rpy_continuous are kept up to date for EVERY env, as
      * the reference does (:339-347) -- they are consumed by the flip command only, so without this flag the kernel maintains them for

@@ -776,6 +776,25 @@ static inline void pack_frame(const rel_state *r, float V, const float act[4], f
     out[25] = (grp == ORC_TASK_POS) ? cmd[1] : (grp == ORC_TASK_ROTATE ? DIVC(cmd[1], 6.0f) : DIVC(cmd[1] / 2.0f, PI_F));
 }
 
+/* the twelve standard normals of one env's observation noise (FA:402-410 draws eleven): Box-Muller on uniforms 4+2pr, 5+2pr of STREAM_OBS */
+static inline void obs_normals(draw_ctx *D, float nrm[12]) {
+    D->stream = STREAM_OBS; D->have = 0;
+    for (int pr = 0; pr < 6; ++pr) {
+        float ua = 1.0f - draw_u(D, 4 + 2 * pr); /* (0,1] */
+        float ub = draw_u(D, 5 + 2 * pr);
+        float rad = sqrtf(-2.0f * orc_logf(ua));
+        float sn, cs;
+        sincos_own(TWO_PI_F * ub, &sn, &cs);
+        nrm[2 * pr] = rad * cs;
+        nrm[2 * pr + 1] = rad * sn;
+    }
+}
+/* test-fixture generator hook (tests/golden/make_glue_golden.py): the normals env `gid` consumes at step `step` */
+void orc_obs_normals(uint64_t seed, uint32_t gid, uint32_t step, float nrm[12]) {
+    draw_ctx D = {seed, gid, step, 0, 0, {0, 0, 0, 0}, 0};
+    obs_normals(&D, nrm);
+}
+
 static void step_env(const orc_env *e, int i, const float *actions, float *obs_buf, float *states_buf, float *rew_buf,
                      int64_t *reset_buf, uint8_t *timeout_buf) {
     const orc_cfg *c = &e->cfg;
@@ -889,15 +908,7 @@ static void step_env(const orc_env *e, int i, const float *actions, float *obs_b
         const float df = (float)d;
         D.stream = STREAM_OBS; D.have = 0;
         float nrm[12];
-        for (int pr = 0; pr < 6; ++pr) { /* Box-Muller on uniforms 4+2pr, 5+2pr */
-            float ua = 1.0f - draw_u(&D, 4 + 2 * pr); /* (0,1] */
-            float ub = draw_u(&D, 5 + 2 * pr);
-            float rad = sqrtf(-2.0f * orc_logf(ua));
-            float sn, cs;
-            sincos_own(TWO_PI_F * ub, &sn, &cs);
-            nrm[2 * pr] = rad * cs;
-            nrm[2 * pr + 1] = rad * sn;
-        }
+        obs_normals(&D, nrm);
         for (int k = 0; k < 3; ++k) on[k] = on[k] + df * (nrm[k] * (float)(0.06 / 3 / 3) + 0.0f);
         float nq[4], mq[4], m[9];
         float l = (float)(d * 0.05), ml = (float)(-(d * 0.05)), sc = (float)((d * 0.05) - (-(d * 0.05)));

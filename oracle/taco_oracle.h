@@ -164,6 +164,7 @@ float orc_atan2f(float y, float x);
 float orc_asinf(float x);
 float orc_logf(float x);
 void orc_philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]);
+void orc_obs_normals(uint64_t seed, uint32_t gid, uint32_t step, float nrm[12]); /* STREAM_OBS Box-Muller normals of one env-step */
 float orc_uniform(uint32_t bits);
 
 #ifdef __cplusplus

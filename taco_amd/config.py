@@ -118,7 +118,10 @@ def flat_cfg(cfg, env_offset=0, num_envs_local=None):
               "random_rotor_delay", "random_rotor_response", "random_rotor_speed", "random_aerodynamic_coe", "ramdom_delay_time",
               "ramdom_deploy_time", "random_command", "observation_noise"):
         d[k] = bool(cfg[k])
-    d["world_rate_roundtrip"] = bool(cfg.get("world_rate_roundtrip", False))  # the reference's literal data flow of the angular rate (taco_env.h)
+    # the angular rate's data flow: True (default) = the reference's own -- the body rates are re-derived from the world-frame root state after
+    # every simulate() (fpv_asymmetry.py:350); False = carried across the ten substeps (one rounding per substep apart: outside 1e-5 per step,
+    # tests/util.py teacher_forced_one_step)
+    d["world_rate_roundtrip"] = bool(cfg.get("world_rate_roundtrip", True))
     d["record_flag"] = bool(cfg.get("record_flag", False))                    # all envs track copter_rpy_continuous (fpv_asymmetry.py:113, :339-347)
     if int(cfg.get("delay_time_max", 100)) != 100:
         raise ValueError("delay_time_max must be 100 (hard-coded in the reference, fpv_asymmetry.py:329)")

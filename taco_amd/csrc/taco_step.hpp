@@ -21,9 +21,6 @@
 #ifndef TACO_AB_SERVE_ALWAYS
 #define TACO_AB_SERVE_ALWAYS 0  // A/B builds only: the battery server in every four-role quad launch, whatever its size
 #endif
-#ifndef TACO_AB_RT
-#define TACO_AB_RT 0  // A/B builds only: 1 = the PLAIN loop forms do the world-rate round trip as well (cost measurement, profiles/r03_a_*)
-#endif
 
 namespace taco {
 
@@ -1224,7 +1221,9 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     // unrolled; a lone wavefront pays ~10 issue slots for every taken branch)
     const Consts Crt{P.dt, P.rdt, P.h, P.half_h, P.inv_m, P.g, P.J0, P.J1, P.J2, P.hJi0, P.hJi1, P.hJi2, P.arm_x, P.arm_y};
     // (rotor noise: PLAIN forms exist for it where the noise table is served -- bit 4 of the form; + bit 3: euler/unwrap on or off)
-    const bool plain1 = (!(fl & TACO_F_ROTOR_NOISE) || noise_served) && !(fl & TACO_F_WORLD_RATE_ROUNDTRIP) && P.substeps == 2 && (fl & TACO_F_BATTERY_CONSUMPTION) != 0;
+    // The PLAIN forms are the DEFAULT arithmetic: the body rates make the reference's round trip through the root state after every simulate()
+    // (TACO_F_WORLD_RATE_ROUNDTRIP, FA:350); the "carried" mode (flag cleared) runs the general forms.
+    const bool plain1 = (!(fl & TACO_F_ROTOR_NOISE) || noise_served) && (fl & TACO_F_WORLD_RATE_ROUNDTRIP) != 0 && P.substeps == 2 && (fl & TACO_F_BATTERY_CONSUMPTION) != 0;
     // one lane per env: the PLAIN forms also carry the default airframe's constants as literals (kPlainConsts: the handle has exactly those)
     const bool plain = plain1 && (LPE != 1 || (fl & kPlainConsts) != 0);
     if constexpr (LPE == 1) {
@@ -1353,7 +1352,7 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
                 if (is_reset) { F = V3{0.0f, 0.0f, 0.0f}; tq = V3{0.0f, 0.0f, 0.0f}; }  // FA:629-630: no force during the reset step
             }
             const bool rare = integrate<PLAIN ? 2 : 0>(C, P.substeps, p, q, v, wb, F, tq);
-            if ((!PLAIN && (fl & TACO_F_WORLD_RATE_ROUNDTRIP)) || (PLAIN && TACO_AB_RT)) {  // the reference's data flow (FA:350): the rates pass through the root state
+            if (PLAIN || (fl & TACO_F_WORLD_RATE_ROUNDTRIP)) {  // the reference's data flow (FA:350): the rates pass through the root state
                 const V3 ww = quat_sandwich(q, wb);
                 wb = quat_rotate(conj(q), ww);
             }
@@ -1539,7 +1538,7 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
                 tqq = from_bits(bits(selm(k2, tz, txy)) & keep);
             }
             const bool rare = integrate_quad<PLAIN ? 2 : 0>(P, k3, pq, qq, vq, bq, Fq, tqq, Jq, hJiq, gzq, sm3);
-            if ((!PLAIN && (fl & TACO_F_WORLD_RATE_ROUNDTRIP)) || (PLAIN && TACO_AB_RT)) {  // FA:350 literally: w = R(q) b (quat_sandwich), b = quat_rotate(conj(q), w), lane j = component j
+            if (PLAIN || (fl & TACO_F_WORLD_RATE_ROUNDTRIP)) {  // FA:350 literally: w = R(q) b (quat_sandwich), b = quat_rotate(conj(q), w), lane j = component j
                 const float ww = bc3(qq), q1 = rot1(qq), q2 = rot2(qq);
                 float t = fma(q1, rot2(bq), -(q2 * rot1(bq)));
                 t = t + t;

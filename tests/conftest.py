@@ -20,6 +20,8 @@ def golden():
     import numpy as np
 
     def load(name):
-        return np.load(os.path.join(GOLDEN, name + ".npz"))
+        # a plain dict: an NpzFile inflates an array again on EVERY g["..."] access (the glue traces are indexed once per step)
+        with np.load(os.path.join(GOLDEN, name + ".npz")) as z:
+            return {k: z[k] for k in z.files}
 
     return load

@@ -19,6 +19,10 @@ from the reference tree with in-memory STUB modules for those dependencies (no r
     a step) by functions that return the uniforms of the build's counter-based generator for (seed, env id, step, stream, index), fed
     through the REFERENCE's own affine expressions -- so both sides consume the same numbers and every reset value, deploy length and
     command re-draw can be compared exactly.  A draw with an unexpected shape or order aborts the script.
+    The same holds for the draws made OUTSIDE the task module: `torch_rand_float` inside `control/battery_dynamics.py` (E_c at reset,
+    :38-45) and `control/thrust_dynamics.py` (rotor coefficients, response times, initial speeds :109-148; aero coefficients :201-210;
+    the per-substep rotor noise :68-78), and the observation noise of `compute_observation_state` (five `torch.normal` calls and one
+    `rand_quat`, fpv_asymmetry.py:402-410): the cases `cfg2` ... `cfg5` run the flag sets of BASELINE.json's configs 2 ... 5.
 
 What is stored per case: the action stream, and after every step the outputs (obs / states stacks, reward, reset, time-out) and the
 full task state in the layout of the state blob (include/taco_env.h TACO_S_*), delay line included.
@@ -120,15 +124,20 @@ load_file("isaacgymenvs.tasks.control.fpv_dynamics", TASKS / "control/fpv_dynami
 VT = importlib.import_module("isaacgymenvs.tasks.base.vec_task_asymmetry")
 FA = importlib.import_module("isaacgymenvs.tasks.fpv_asymmetry")
 np.Inf = np.inf  # (numpy 2 dropped the alias vec_task_asymmetry.py uses)
+BD = sys.modules["isaacgymenvs.tasks.control.battery_dynamics"]   # their own `torch_rand_float` names are patched per case as well
+TD = sys.modules["isaacgymenvs.tasks.control.thrust_dynamics"]
 
 
 # ------------------------------------------------------------------------------------------------ the build's random numbers
-STREAM_RESET, STREAM_CMD, STREAM_DEPLOY = 1, 2, 3
-RU = dict(POS=0, EULER=3, LINVEL=6, ANGVEL=9, FLIP_SIGN=12, TGT_XY=13, TGT_Z=15, TGT_YAW=16, DELAY=36)
+STREAM_RESET, STREAM_CMD, STREAM_DEPLOY, STREAM_ROTOR, STREAM_OBS = 1, 2, 3, 4, 5
+STREAM_UNUSED = None   # a draw whose result never reaches the arithmetic (throttle_para, thrust_dynamics.py:120): the build draws nothing
+RU = dict(POS=0, EULER=3, LINVEL=6, ANGVEL=9, FLIP_SIGN=12, TGT_XY=13, TGT_Z=15, TGT_YAW=16, BAT_E=17, OPARA=18, TAU=23, OMEGA0=27,
+          CFCT=31, DRAG=33, KT=35, DELAY=36)
 _lib = O.lib()
 _lib.orc_philox.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
 _lib.orc_uniform.argtypes = [C.c_uint32]
 _lib.orc_uniform.restype = C.c_float
+_lib.orc_obs_normals.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
 
 
 def uniform(seed, gid, step, stream, idx):
@@ -156,11 +165,23 @@ class Draws:
     def u(self, gid, stream, idx):
         return uniform(self.seed, gid, self.step, stream, idx)
 
+    def obs_normals(self):
+        """[n, 12] standard normals of this step's observation noise: the build's Box-Muller pairs (oracle/taco_oracle.c obs_normals)"""
+        out = np.zeros((self.n, 12), np.float32)
+        buf = (C.c_float * 12)()
+        for g in range(self.n):
+            _lib.orc_obs_normals(self.seed, g, self.step, buf)
+            out[g] = np.frombuffer(buf, np.float32)
+        return out
+
     def rand_float(self, lower, upper, shape, device):
         assert self.expect, f"unexpected torch_rand_float{shape} (step {self.step})"
         ids, stream, cols = self.expect.pop(0)
         assert tuple(shape) == (len(ids), len(cols)), f"torch_rand_float{tuple(shape)} where ({len(ids)}, {len(cols)}) was expected (step {self.step})"
-        U = torch.tensor([[self.u(g, stream, c) for c in cols] for g in ids], dtype=f32).reshape(len(ids), len(cols))
+        if stream is STREAM_UNUSED:
+            U = torch.full((len(ids), len(cols)), 0.5, dtype=f32)
+        else:
+            U = torch.tensor([[self.u(g, stream, c) for c in cols] for g in ids], dtype=f32).reshape(len(ids), len(cols))
         return (upper - lower) * U + lower   # the reference's own expression (torch_utils.py torch_rand_float) on the build's uniforms
 
 
@@ -297,8 +318,58 @@ def run_case(name, task, n, steps, seed, act_fn, **kw):
         assert not D.expect
         return r
 
+    def reset_controller_idx(self, env_ids):
+        """fpv_asymmetry.py:550-558 -> battery_dynamics.reset, rotor_dynamics.reset, aero_dynamics.reset: their draws in call order"""
+        ids = env_ids.tolist()
+        r = lambda name, cnt: (ids, STREAM_RESET, [RU[name] + k for k in range(cnt)])
+        q = []
+        if cfg["random_voltage"]:
+            q += [r("BAT_E", 1)]
+        if cfg["random_rotordynamic_coe"]:
+            q += [r("OPARA", 5), (ids, STREAM_UNUSED, list(range(6)))]
+        if cfg["rotor_response"] and cfg["random_rotor_response"]:
+            q += [r("TAU", 4)]
+        if cfg["random_rotor_speed"]:
+            q += [r("OMEGA0", 4)]
+        if cfg["random_aerodynamic_coe"]:
+            q += [r("CFCT", 2), r("DRAG", 2), r("KT", 1)]
+        D.expect = q
+        ret = orig_controller(self, env_ids)
+        assert not D.expect, "reset_controller_idx made fewer draws than expected"
+        # what the reset drew, before the first substep moves it: E_c and the four initial rotor speeds (NaN = env not reset this step)
+        D.reset_vals[ids, 0] = self.battery_dynamics.E_c[env_ids, 0].numpy()
+        D.reset_vals[ids, 1:5] = self.rotor_speed[env_ids].numpy()
+        return ret
+
+    def control_with_thrusts(self, reset_env_ids):
+        """fpv_asymmetry.py:608-635, once per substep: the rotor noise of substep k is uniforms 4k .. 4k+3 of STREAM_ROTOR"""
+        if cfg["rotor_noise"]:
+            D.expect = [(list(range(n)), STREAM_ROTOR, [4 * D.substep + k for k in range(4)])]
+        ret = orig_thrusts(self, reset_env_ids)
+        assert not D.expect, "control_with_thrusts made fewer draws than expected"
+        D.substep += 1
+        return ret
+
+    def compute_observation_state(self):
+        """fpv_asymmetry.py:390-421: with observation_noise five torch.normal calls (-> fake_normal) and one rand_quat (three
+        torch_rand_float(n, 1): uniforms 0, 1, 2 of STREAM_OBS)"""
+        D.obs_calls = 0
+        if cfg["observation_noise"]:
+            D.obs_z = D.obs_normals()
+            D.expect = [(list(range(n)), STREAM_OBS, [k]) for k in range(3)]
+        ret = orig_obs(self)
+        assert not D.expect and D.obs_calls == (5 if cfg["observation_noise"] else 0)
+        return ret
+
+    OBS_NORMAL_CALLS = [((n, 3), [0, 1, 2]), ((n, 3), [3, 4, 5]), ((n, 3), [6, 7, 8]), ((n,), [9]), ((n,), [10])]   # FA:403, :407-410
+
     def fake_normal(mean, std, size=None, **k):
         who = sys._getframe(1).f_code.co_name
+        if who == "compute_observation_state":   # z * std + mean, what torch.normal computes from its standard normal, on the build's z
+            shape, cols = OBS_NORMAL_CALLS[D.obs_calls]
+            assert tuple(size) == shape, f"torch.normal(size={tuple(size)}) where {shape} was expected (call {D.obs_calls})"
+            D.obs_calls += 1
+            return torch.from_numpy(D.obs_z[:, cols].copy()).reshape(shape) * std + mean
         if who == "pre_physics_step":      # FA:324 deploy length: 10 - clamp(round(N), +-1)
             return torch.tensor([[float(rounded_normal(D.u(i, STREAM_DEPLOY, 0), 1))] for i in range(n)], dtype=f32)
         if who == "reset_env_idx":         # FA:576 delay length: clamp(delay_time - clamp(round(N), +-3), min 0)
@@ -319,26 +390,32 @@ def run_case(name, task, n, steps, seed, act_fn, **kw):
 
     # ---- install, build the env with the reference's own constructor, run
     saved = (VT.VecTask.__init__, FA.torch_rand_float, torch.normal, torch.rand, FA.FpvBase.reset_target_idx, FA.FpvBase.reset_env_idx)
+    saved2 = (BD.torch_rand_float, TD.torch_rand_float, FA.FpvBase.reset_controller_idx, FA.FpvBase.control_with_thrusts,
+              FA.FpvBase.compute_observation_state)
     orig_env_idx = FA.FpvBase.reset_env_idx
+    orig_controller, orig_thrusts, orig_obs = saved2[2:]
 
     def reset_env_idx(self, env_ids):
         D.reset_ids = env_ids.tolist()
         return orig_env_idx(self, env_ids)
 
     VT.VecTask.__init__ = vt_init
-    FA.torch_rand_float = D.rand_float
+    FA.torch_rand_float = BD.torch_rand_float = TD.torch_rand_float = D.rand_float
     FA.FpvBase.reset_target_idx, FA.FpvBase.reset_env_idx = reset_target_idx, reset_env_idx
+    FA.FpvBase.reset_controller_idx, FA.FpvBase.control_with_thrusts = reset_controller_idx, control_with_thrusts
+    FA.FpvBase.compute_observation_state = compute_observation_state
     cls.reset_copter_idx, cls.reset_command_idx = reset_copter_idx, reset_command_idx
     torch.normal, torch.rand = fake_normal, fake_rand
     try:
         env = cls(cfg, "cpu", "cpu", -1, True, False, False)
-        rec = {k: [] for k in ("step", "obs", "states", "rew", "reset", "timeout", "blob")}
+        rec = {k: [] for k in ("step", "obs", "states", "rew", "reset", "timeout", "blob", "reset_vals")}
         record = kw.get("_record", lambda t: True)   # long cases keep the steps around the events of interest only (all actions are kept)
         n_resets = n_tmo = 0
         acts = act_fn(n, steps)
         hold = kw.get("_hold", False)
         for t in range(steps):
-            D.step = t
+            D.step, D.substep = t, 0
+            D.reset_vals = np.full((n, 5), np.nan, np.float32)
             if hold:  # a crude attitude / altitude stabiliser on top of the noise, so that envs live long enough to reach progress 500
                 acts[t] = np.clip(acts[t] + stabiliser(env), -1, 1)
             # reset_command_idx draws the "flips to add" vector only if some env sits at progress 500 (FA:888-890); otherwise the first
@@ -352,8 +429,11 @@ def run_case(name, task, n, steps, seed, act_fn, **kw):
                 rec["rew"].append(rew.numpy().copy()); rec["reset"].append(done.numpy().copy())
                 rec["timeout"].append(info["time_outs"].numpy().astype(np.uint8))
                 rec["blob"].append(blob_of(env, n))
+                rec["reset_vals"].append(D.reset_vals)
     finally:
         VT.VecTask.__init__, FA.torch_rand_float, torch.normal, torch.rand, FA.FpvBase.reset_target_idx, FA.FpvBase.reset_env_idx = saved
+        (BD.torch_rand_float, TD.torch_rand_float, FA.FpvBase.reset_controller_idx, FA.FpvBase.control_with_thrusts,
+         FA.FpvBase.compute_observation_state) = saved2
         for k, v in orig.items():
             setattr(cls, k, v)
     out = {k: np.stack(v) for k, v in rec.items()}
@@ -425,3 +505,14 @@ if __name__ == "__main__":
     around = lambda t: t < 40 or t % 50 == 0 or 495 <= t   # the first resets, a sparse middle, and the steps around progress 500
     run_case("flip", "flip", 24, 520, 15, actions(5, -0.5, noise=0.05), env_maxEpisodeLength=1000, _hold=True, _record=around, **common)
     run_case("mix", "mix", 36, 520, 16, actions(6, -0.5, crash_every=11, noise=0.05), env_maxEpisodeLength=1000, _hold=True, _record=around, **common)
+    # (7)-(10) the flag sets of BASELINE.json's configs 2 ... 5 (taco_amd/config.py baseline_config): configs 2-4 draw the battery's E_c and
+    #     the rotors' initial speeds at every reset (random_voltage / random_rotor_speed are ON by default); config 5 adds rotor / aero
+    #     coefficient and response-time randomisation, rotor noise per substep, observation noise, random delay / deploy lengths, 5 state frames
+    run_case("cfg2", "pos", 48, 170, 21, actions(7, 0.05, crash_every=5), env_maxEpisodeLength=70)
+    run_case("cfg3", "rotate", 32, 160, 22, actions(8, 0.05, crash_every=5), env_maxEpisodeLength=75)
+    run_case("cfg4", "flip", 24, 520, 23, actions(9, -0.5, noise=0.05), env_maxEpisodeLength=1000, _hold=True, _record=around)
+    cfg5 = dict(random_rotordynamic_coe=True, random_rotor_response=True, random_aerodynamic_coe=True, observation_noise=True, rotor_noise=True,
+                ramdom_delay_time=True, ramdom_deploy_time=True, env_lenStates=5)
+    run_case("cfg5", "mix", 36, 520, 24, actions(10, -0.5, crash_every=11, noise=0.05), env_maxEpisodeLength=1000, _hold=True, _record=around, **cfg5)
+    # (11) config 5's flags again with short episodes (many resets and time-outs with every draw live) and difficulty != 1
+    run_case("cfg5_short", "mix", 36, 200, 25, actions(11, 0.05, crash_every=4), env_maxEpisodeLength=60, difficulty=0.7, **cfg5)

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O
-from util import assert_bits_equal, assert_ulp
+from util import GLUE_CASES, assert_bits_equal, assert_ulp
 
 TWO_PI = np.float32(2 * np.pi)
 
@@ -265,7 +265,7 @@ GLUE_MAXIMA = {}
 
 
 @pytest.mark.parametrize("mode", ["roundtrip", "carried"])
-@pytest.mark.parametrize("case", ["pos", "overflow", "deploy", "rotate", "flip", "mix"])
+@pytest.mark.parametrize("case", GLUE_CASES)
 def test_task_glue_equals_the_references_own_step(case, mode, golden):
     from oracle import oracle as O
     from taco_amd import config
@@ -281,3 +281,41 @@ def test_task_glue_equals_the_references_own_step(case, mode, golden):
             check_against_glue_fixture(g, rec_steps[t], f"glue_{case} [{mode}] step {t}", orc.get_state(), obs, states, rew, done, tmo, maxima, seen)
     check_glue_trace_content(case, seen)
     print(f"glue_{case} [{mode}] running maxima: " + ", ".join(f"{k} {v:.2e}" for k, v in maxima.items()))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# Teacher-forced ONE-STEP parity with the reference's own step() (tests/util.py::teacher_forced_one_step): north_star's 1e-5, asserted for the
+# default arithmetic mode (world-rate round trip) on every consecutive pair of recorded steps of all eleven traces; the "carried" mode is held
+# to its own, looser, bound.  Also pins what a reset draws (E_c, initial rotor speeds) bit for bit.
+# ---------------------------------------------------------------------------------------------------------------------------------------
+class _OracleOneStep:
+    def __init__(self, cfg, mode):
+        from taco_amd import config
+        cfg["world_rate_roundtrip"] = mode == "roundtrip"
+        self.e = O.OracleEnv(config.flat_cfg(cfg), threads=1)
+
+    def load(self, blob, obs, states, reset, t):
+        e = self.e
+        e.set_state(blob)
+        e.obs_buf[:], e.states_buf[:], e.reset_buf[:] = obs, states, reset
+        e.step_count = t
+
+    def step(self, a):
+        o, s, r, d, tm = self.e.step(a)
+        return self.e.get_state(), o, s, r, d, tm
+
+    def reset_now(self):
+        self.e.reset_done()
+        return self.e.get_state()
+
+
+@pytest.mark.parametrize("mode", ["roundtrip", "carried"])
+@pytest.mark.parametrize("case", GLUE_CASES)
+def test_one_step_from_the_references_own_state(case, mode, golden):
+    from util import ONE_STEP_TOL, ONE_STEP_TOL_CARRIED, glue_case, teacher_forced_one_step
+    g = golden("glue_" + case)
+    cfg, _, _ = glue_case(g)
+    maxima, cnt = teacher_forced_one_step(g, _OracleOneStep(cfg, mode), f"glue_{case} [{mode}]",
+                                          ONE_STEP_TOL if mode == "roundtrip" else ONE_STEP_TOL_CARRIED)
+    assert cnt["pairs"] >= 60
+    print(f"one step, glue_{case} [{mode}] {cnt}: " + ", ".join(f"{k} {v:.1e}" for k, v in maxima.items()))

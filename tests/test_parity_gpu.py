@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from taco_amd import config
-from util import assert_bits_equal
+from util import GLUE_CASES, assert_bits_equal
 
 pytestmark = pytest.mark.gpu
 
@@ -362,7 +362,7 @@ def test_reset_done_resets_now_like_the_reference():
 #   carried  : root state 1.6e-3, obs / states 5.2e-4, reward 1.4e-6        roundtrip: 3.8e-4, 1.3e-4, 6.5e-7
 # ---------------------------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("mode", ["carried", "roundtrip"])
-@pytest.mark.parametrize("case", ["pos", "overflow", "deploy", "rotate", "flip", "mix"])
+@pytest.mark.parametrize("case", GLUE_CASES)
 def test_hip_kernel_equals_the_references_own_step(case, mode, golden):
     from taco_amd.vec_env import FpvBase
     from util import check_against_glue_fixture, check_glue_trace_content, glue_case
@@ -382,6 +382,52 @@ def test_hip_kernel_equals_the_references_own_step(case, mode, golden):
     check_glue_trace_content(case, seen)
     env.check()
     print(f"HIP glue_{case} [{mode}] maxima: " + ", ".join(f"{k} {v:.2e}" for k, v in maxima.items()))
+
+
+# Teacher-forced ONE-STEP parity of the HIP kernel with the reference's own step() (tests/util.py::teacher_forced_one_step): north_star's
+# "within 1e-5 of the reference", asserted for the default arithmetic mode on every consecutive pair of recorded steps of all eleven traces
+# (incl. the flag sets of BASELINE configs 2-5), from the REFERENCE's state: blob + frame stacks + reset flags + step counter loaded through
+# the C ABI (taco_set_state / taco_set_step_count), one taco_step, compared with what the reference held next.  What a reset draws (E_c, the
+# initial rotor speeds) is compared bit for bit through taco_reset_done.
+class _HipOneStep:
+    def __init__(self, cfg, mode):
+        from taco_amd.vec_env import FpvBase
+        cfg["world_rate_roundtrip"] = mode == "roundtrip"
+        cfg["record_flag"] = True
+        self.env = FpvBase(cfg, copy_outputs=False)
+
+    def load(self, blob, obs, states, reset, t):
+        e = self.env
+        e.set_state(torch.from_numpy(np.ascontiguousarray(blob).view(np.float32)))
+        e.obs_buf.copy_(torch.from_numpy(obs))
+        e.states_buf.copy_(torch.from_numpy(states))
+        e.reset_buf.copy_(torch.from_numpy(reset))
+        e.step_count = t
+
+    def _blob(self):
+        return self.env.get_state().cpu().numpy()
+
+    def step(self, a):
+        e = self.env
+        e.step_raw(torch.from_numpy(a).cuda())
+        return self._blob(), e.obs_buf.cpu().numpy(), e.states_buf.cpu().numpy(), e.rew_buf.cpu().numpy(), e.reset_buf.cpu().numpy(), e.timeout_buf.cpu().numpy()
+
+    def reset_now(self):
+        self.env.reset_done()
+        return self._blob()
+
+
+@pytest.mark.parametrize("mode", ["roundtrip", "carried"])
+@pytest.mark.parametrize("case", GLUE_CASES)
+def test_hip_one_step_from_the_references_own_state(case, mode, golden):
+    from util import ONE_STEP_TOL, ONE_STEP_TOL_CARRIED, glue_case, teacher_forced_one_step
+    g = golden("glue_" + case)
+    cfg, _, _ = glue_case(g)
+    impl = _HipOneStep(cfg, mode)
+    maxima, cnt = teacher_forced_one_step(g, impl, f"HIP glue_{case} [{mode}]", ONE_STEP_TOL if mode == "roundtrip" else ONE_STEP_TOL_CARRIED)
+    impl.env.check()
+    assert cnt["pairs"] >= 60
+    print(f"HIP one step, glue_{case} [{mode}] {cnt}: " + ", ".join(f"{k} {v:.1e}" for k, v in maxima.items()))
 
 
 @pytest.mark.parametrize("form", ["quad_roles", "quad", "lane", "lane_roles", "lane_throughput", "quad_served"])
