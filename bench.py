@@ -74,17 +74,20 @@ def make_actions(n, steps, seed, device):
 def time_kernel_launches(env, acts, steps, torch):
     """Duration of the step kernel from HIP events on the launch stream (torch.cuda.Event records on torch's current
     stream, which is the stream taco_step launches on).  Two estimates, microseconds:
-      back_to_back : one event pair around `steps` consecutive launches / steps  (kernel + inter-kernel gap: an upper bound
+      back_to_back : one event pair around max(1 000, steps) consecutive launches, after 200 untimed ones  (kernel + inter-kernel gap: an upper bound
                      that does not pay the event-record overhead per launch; this is what rocprofv3's average tracks)
       bracketed    : median of per-launch event pairs (adds ~2 us of event overhead at this kernel size)"""
     na = acts.shape[0]
+    for t in range(200):   # (untimed: the region below must not start on an idle GPU whatever --steps was)
+        env.step_raw(acts[t % na])
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    long_run = max(1000, steps)   # never fewer than 1 000 launches: the event pair's own cost (~1 us) must vanish in the average
     e0.record()
-    for t in range(steps):
+    for t in range(long_run):
         env.step_raw(acts[t % na])
     e1.record()
     torch.cuda.synchronize()
-    back_to_back = e0.elapsed_time(e1) * 1e3 / steps
+    back_to_back = e0.elapsed_time(e1) * 1e3 / long_run
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
     ends = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
     for t in range(steps):
@@ -231,16 +234,27 @@ def config_entry(idx, n, dev, torch, warm=0.1):
     med, ws, _ = steady_windows(env.step_raw, acts, torch, warm, 5, 400)
     b = algo_bytes(env.len_states)
     grid, block = env.launch_geometry()
+    extra = {}
+    if env.len_states > 1:
+        # ... that was the MATERIALISED stack (step_raw in place: 2 len - 1 frames moved per env-step).  VecTask.step() keeps the stack in a frame
+        # ring (taco_bind_states_ring): one frame written, the algorithmic 820 B -- the figure of this entry; the materialised one beside it
+        extra = {"materialised_stack": {"kernel_us": med, "algorithmic_bytes_per_env_step": b, "frac_of_hbm_peak": b * n / (med * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                                        "kernel_form": env.kernel_form}}
+        del env
+        env = FpvBase(cfg, sim_device=str(dev), rl_device=str(dev))
+        med, ws, _ = steady_windows(env.step, acts, torch, warm, 5, 400)
+        b = ALGO_BYTES_PER_ENV_STEP
+        extra["path"] = "VecTask.step(): state stack = strided view of the frame ring, one frame written per env-step"
     flags = [k for k in ("random_rotordynamic_coe", "random_rotor_response", "random_aerodynamic_coe", "observation_noise", "rotor_noise",
                          "ramdom_delay_time", "ramdom_deploy_time", "random_command") if cfg.get(k)]
     return {"config": idx + 1, "task_mode": cfg["task_mode"], "envs": n, "len_states": env.len_states, "flags_on": flags, "kernel_us": med,
             "env_steps_per_s": n / (med * 1e-6), "algorithmic_bytes_per_env_step": b, "achieved_GBps": b * n / (med * 1e-6) / 1e9,
-            "frac_of_hbm_peak": b * n / (med * 1e-6) / 1e9 / HBM_PEAK_GBPS, "kernel_form": env.kernel_form, "grid": grid, "block": block}
+            "frac_of_hbm_peak": b * n / (med * 1e-6) / 1e9 / HBM_PEAK_GBPS, "kernel_form": env.kernel_form, "grid": grid, "block": block, **extra}
 
 
 def graph_entry(n, acts, dev, torch, steps_in_graph=64):
-    """the same workload as ONE HIP graph of `steps_in_graph` steps (each step = the step kernel reading the device-resident clock + the
-    one-thread clock advance), replayed back to back: what the per-step kernel boundary costs when the host is out of the loop"""
+    """the same workload as ONE HIP graph of `steps_in_graph` steps (each step = ONE kernel node: the step kernel reads the device-resident
+    clock and its last-ticket workgroup advances it), replayed back to back: what the per-step kernel boundary costs when the host is out of the loop"""
     from taco_amd import config
     from taco_amd.vec_env import FpvBase
     env = FpvBase(config.baseline_config(1, num_envs=n), sim_device=str(dev), rl_device=str(dev), copy_outputs=False)
@@ -267,7 +281,7 @@ def graph_entry(n, acts, dev, torch, steps_in_graph=64):
     ws.sort()
     env.check()
     return {"steps_per_graph": steps_in_graph, "us_per_step": ws[2], "env_steps_per_s": n / (ws[2] * 1e-6), "windows_us": ws,
-            "what": "taco_step captured into a HIP graph (2 kernel nodes per step: step + clock advance), 20 replays per window"}
+            "what": "taco_step captured into a HIP graph (ONE kernel node per step: the step kernel advances the device-resident clock itself), 20 replays per window"}
 
 
 def documented_policy(rng, hd=128):
@@ -743,13 +757,13 @@ def main():
                 out["large_n"] = []
                 # BASELINE configs[4]'s env count; four residency rounds; 5 state frames as stacks (VecTask.step) and on the ROLLOUT path, where the
                 # replay store keeps the stacks as a frame ring and a step writes one frame (taco_rollout_io.states_newest_only)
-                for big_n, ls, ring in ((262144, 1, False), (1048576, 1, False), (262144, 5, False), (262144, 5, True)):
+                for big_n, ls, ring in ((262144, 1, False), (1048576, 1, False), (262144, 5, "api"), (262144, 5, False), (262144, 5, True)):
                     bcfg = config.baseline_config(1, num_envs=big_n)
                     bcfg["env"]["lenStates"] = ls
-                    benv = FpvBase(bcfg, sim_device=str(dev), rl_device=str(dev), copy_outputs=False)
+                    benv = FpvBase(bcfg, sim_device=str(dev), rl_device=str(dev), copy_outputs=(ring == "api"))
                     bacts = make_actions(big_n, 4, 7, dev)
-                    step_fn = benv.step_raw
-                    if ring:
+                    step_fn = benv.step if ring == "api" else benv.step_raw
+                    if ring is True:
                         frames = torch.zeros(2, big_n, 26, device=dev)
                         brew = torch.zeros(big_n, device=dev)
                         flip = [0]
@@ -762,7 +776,10 @@ def main():
                     nb = ALGO_BYTES_PER_ENV_STEP if ring else algo_bytes(ls)
                     ach = nb * big_n / (b_med * 1e-6) / 1e9
                     tr, _ = pmc_traffic(big_n) if (ls == 1 and not ring) else (None, None)
-                    out["large_n"].append({"envs": big_n, "len_states": ls, "path": "rollout (frame ring: one states frame written per step)" if ring else "VecTask.step (stacks materialised)",
+                    out["large_n"].append({"envs": big_n, "len_states": ls,
+                                           "path": {True: "rollout (replay store's frame ring: one states frame written per step)",
+                                                    "api": "VecTask.step() (frame ring behind states_buf: one states frame written per step, the stack a strided view)",
+                                                    False: "step_raw in place" + (" (stack materialised: 2 len - 1 frames moved per env-step)" if ls > 1 else "")}[ring],
                                            "kernel_avg_us": b_med, "env_steps_per_s": big_n / (b_med * 1e-6),
                                            "algorithmic_bytes_per_env_step": nb, "achieved_GBps": ach, "frac_of_hbm_peak": ach / HBM_PEAK_GBPS,
                                            "traffic": tr, "traffic_frac_of_hbm_peak": (tr / (b_med * 1e-6) / 1e9 / HBM_PEAK_GBPS) if tr else None,
@@ -797,7 +814,9 @@ def sharded_config_leg(number, rank, world, dev, torch, timed, gather_floats, st
         k_us, _ = time_kernel_launches(senv.env, sacts, min(steps, 200), torch)
         entry = {"config": number, "task_mode": task, "envs_total": total, "envs_per_rank": n_local, "len_states": senv.env.len_states, "steps": steps,
                  "value": total * steps / el, "unit": "env-steps/s", "ms_per_step": el / steps * 1e3, "kernel_us_per_rank": gather_floats(k_us),
-                 "kernel_form": senv.env.kernel_form, "frac_of_hbm_peak_per_gpu": algo_bytes(senv.env.len_states) * n_local / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBPS}
+                 "kernel_form": senv.env.kernel_form, "states_path": "frame ring (one frame per env-step)" if senv.env._ring_on else "in place",
+                 # (a state stack lives in the frame ring: the algorithmic 820 B; SURVEY 8d's + 104 B per frame is for a MATERIALISED stack)
+                 "frac_of_hbm_peak_per_gpu": (ALGO_BYTES_PER_ENV_STEP if senv.env._ring_on else algo_bytes(senv.env.len_states)) * n_local / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBPS}
         try:
             senv.gather = True
             el_g = timed(senv.step_gathered, sacts, steps, 10)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TACO_ABI_VERSION 5
+#define TACO_ABI_VERSION 6
 
 typedef enum taco_status {
     TACO_OK = 0,
@@ -164,9 +164,11 @@ void taco_destroy(taco_env *env);
  * One kernel launch, asynchronous on `stream`; no host synchronisation. */
 /* HIP graphs: the step index, ring head and history row advance with every call.  On the eager path they are kernel arguments (and every
  * launch leaves the next values in the workspace's control block); a call on a CAPTURING stream enqueues the step kernel reading that
- * device-resident clock plus a one-thread kernel that advances it, so the captured graph can be replayed any number of times and continues
- * exactly where the eager steps (or earlier replays) stopped.  After a capture the host's copy of the clock is stale: every later call
- * takes the device path (two launches) until taco_get_step_count / taco_set_step_count / taco_get_state have re-read it (they block). */
+ * device-resident clock and advancing it itself (the workgroup that is last to have read it writes the next values): ONE graph node per
+ * step, and the captured graph can be replayed any number of times, continuing exactly where the eager steps (or earlier replays) stopped.
+ * From the first capture on the clock lives on the device for good (the graph may be replayed at any time): every later launch of the handle
+ * takes the device path, and taco_get_step_count / taco_set_step_count / taco_get_state / taco_set_state / taco_get_field /
+ * taco_states_ring_row / taco_step_ring / an eager taco_rollout_run re-read it first (they block, device-wide). */
 int taco_step(taco_env *env, const float *actions, float *obs_buf, float *states_buf, float *rew_buf, int64_t *reset_buf,
               uint8_t *timeout_buf, void *stream);
 
@@ -181,7 +183,7 @@ typedef struct taco_rollout_io {
     const float *obs_prev;     /* [num_envs][len_obs][26]     slot t   (read only when len_obs > 1), or NULL       */
     float *obs_next;           /* [num_envs][len_obs][26]     slot t+1                                            */
     const float *states_prev;  /* [num_envs][len_states][26]  slot t, or NULL                                     */
-    float *states_next;        /* [num_envs][len_states][26]  slot t+1                                            */
+    float *states_next;        /* [num_envs][len_states][26]  slot t+1; NULL = the bound frame ring (taco_bind_states_ring) */
     float *rew;                /* [num_envs]  rew_buf[t]                                                          */
     int64_t *reset_buf;        /* [num_envs]  in/out, as taco_step                                                */
     uint8_t *timeout_buf;      /* [num_envs]                                                                      */
@@ -313,6 +315,24 @@ int taco_bind_rollout_stamps(taco_env *env, uint64_t *stamps);
  * env).  NULL unbinds. */
 int taco_gather_row_floats(int len_obs);
 int taco_bind_gather_block(taco_env *env, float *block);
+
+/* A FRAME RING behind VecTask.step()'s state stacks (no counterpart in the reference, whose states_buf is shifted by one frame per step,
+ * fpv_asymmetry.py:413: len_states - 1 frames read and len_states written per env-step).  Bind a DEVICE ring [rows][num_envs][26] f32 (zeroed,
+ * 16-byte aligned, rows >= 2 * (len_states - 1) + 1; period = rows - (len_states - 1)); a taco_step_rollout call with states_next == NULL then
+ * writes ONE states frame per env: the step with ring phase ph (0, 1, ... period - 1, 0, ...; part of the step clock, so captured steps advance it
+ * on the device) writes row ph + len_states - 1 and, while ph >= period - (len_states - 1), a twin at row ph - period + len_states - 1, so that
+ * rows [ph, ph + len_states) ALWAYS hold the stack that step produced, oldest frame first: the reference's [num_envs][len_states][26] tensor is the
+ * strided view ring[ph : ph + len_states] with the first two axes swapped (taco_amd/vec_env.py hands exactly that to the PPO loop).  104 B written
+ * per env-step (+ (len_states - 1) / period of that for the twins) instead of (2 len_states - 1) x 104 B moved.  taco_states_ring_row = the
+ * phase of the LAST step (the first row of its window; blocks after graph replays, -1 on error).  Binding resets the phase to 0 (blocks);
+ * NULL unbinds.  Calls with states_next != NULL are unaffected. */
+int taco_bind_states_ring(taco_env *env, float *ring, int rows);
+int taco_states_ring_row(taco_env *env);
+/* taco_step_rollout on the bound ring (io->states_next == NULL) that also reports the ring phase the launch uses: *phase = the first row of
+ * the window this step fills -- what a host layer needs to hand out the right strided view without a second call.  Refuses a capturing
+ * stream (TACO_ERR_STATE, nothing is enqueued: a replay's window cannot be told in advance; capture taco_step_rollout instead); after graph
+ * replays it first re-reads the device clock (blocks once). */
+int taco_step_ring(taco_env *env, const taco_rollout_io *io, void *stream, int32_t *phase);
 
 /* env.difficulty = x (ppo_asymmetry.py:173-175, :376); takes effect at the next taco_step. */
 int taco_set_difficulty(taco_env *env, double difficulty);

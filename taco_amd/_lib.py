@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TACO_ENV_LIB", os.path.join(HERE, "libtaco_env.so"))  # override = A/B builds of the same ABI (taken as it is, never rebuilt)
 SKIP_ABI_CHECK = os.environ.get("TACO_ENV_LIB_SKIP_ABI", "") == "1"   # explicit opt-out for A/B runs ACROSS ABI revisions (missing symbols are stubbed)
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 NUM_FIELDS = 67
 RING_SLOTS = 100
 BLOB_ROWS = NUM_FIELDS + 4 * RING_SLOTS
@@ -24,7 +24,8 @@ FLAG_BITS = {
 # every symbol include/taco_env.h declares
 EXPORTS = ["taco_abi_version", "taco_source_hash", "taco_last_error", "taco_workspace_bytes", "taco_create", "taco_destroy", "taco_step",
            "taco_gather_row_floats", "taco_bind_gather_block", "taco_set_difficulty", "taco_get_step_count", "taco_set_step_count", "taco_get_state", "taco_set_state",
-           "taco_step_kernel_name", "taco_launch_geometry", "taco_set_kernel_form", "taco_get_kernel_form", "taco_check", "taco_get_field", "taco_step_rollout", "taco_reset_done", "taco_gae_workspace_bytes", "taco_gae", "taco_occupancy", "taco_bind_phase_stamps", "taco_policy_blob_floats", "taco_policy_act", "taco_rollout_run", "taco_policy_act_stamped", "taco_critic_values", "taco_critic_workspace_bytes", "taco_peek_step_count", "taco_critic_values_ring", "taco_set_rollout_fusion", "taco_bind_rollout_stamps"]
+           "taco_step_kernel_name", "taco_launch_geometry", "taco_set_kernel_form", "taco_get_kernel_form", "taco_check", "taco_get_field", "taco_step_rollout", "taco_reset_done", "taco_gae_workspace_bytes", "taco_gae", "taco_occupancy", "taco_bind_phase_stamps", "taco_policy_blob_floats", "taco_policy_act", "taco_rollout_run", "taco_policy_act_stamped", "taco_critic_values", "taco_critic_workspace_bytes", "taco_peek_step_count", "taco_critic_values_ring", "taco_set_rollout_fusion", "taco_bind_rollout_stamps", "taco_bind_states_ring",
+           "taco_states_ring_row", "taco_step_ring"]
 
 
 class TacoCfg(C.Structure):
@@ -130,6 +131,12 @@ def _declare(lib, ab_build=False):
     lib.taco_set_rollout_fusion.restype = C.c_int
     lib.taco_bind_rollout_stamps.argtypes = [C.c_void_p, C.c_void_p]
     lib.taco_bind_rollout_stamps.restype = C.c_int
+    lib.taco_bind_states_ring.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.taco_bind_states_ring.restype = C.c_int
+    lib.taco_states_ring_row.argtypes = [C.c_void_p]
+    lib.taco_states_ring_row.restype = C.c_int
+    lib.taco_step_ring.argtypes = [C.c_void_p, C.POINTER(RolloutIO), C.c_void_p, C.POINTER(C.c_int32)]
+    lib.taco_step_ring.restype = C.c_int
     lib.taco_bind_phase_stamps.argtypes = [C.c_void_p, C.c_void_p]
     lib.taco_bind_phase_stamps.restype = C.c_int
     lib.taco_occupancy.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -152,17 +159,20 @@ def _open(path, test_hooks=False):
     TACO_ENV_LIB override (A/B builds of the same ABI) is taken as it is."""
     overridden = not test_hooks and "TACO_ENV_LIB" in os.environ
     if not overridden:
-        try:
-            from . import build as _build
-            if _build.needs_build(path):
-                _build.build(test_hooks=test_hooks)
-        except FileNotFoundError as e:
-            if not os.path.exists(path):   # a deployment without csrc/ next to the package: the binary is taken as it is, if there is one
-                raise TacoError(f"{path} is missing and its sources are not next to the package ({e}); build it from a source checkout with "
+        from . import build as _build
+        have_sources = os.path.isdir(_build.CSRC) and all(os.path.exists(os.path.join(_build.CSRC, d)) for d in _build.DEPS)
+        if not have_sources:
+            # a deployment without csrc/ next to the package: the binary is taken as it is, if there is one (nothing to compare it with)
+            if not os.path.exists(path):
+                raise TacoError(f"{path} is missing and its sources are not next to the package; build it from a source checkout with "
+                                "`python -m taco_amd.build` (hipcc, gfx950).  There is no CPU fallback for the step path.")
+        else:
+            try:   # sources present: an edited csrc/ never runs through a stale binary -- a failing build (hipcc absent included) is an error
+                if _build.needs_build(path):
+                    _build.build(test_hooks=test_hooks)
+            except Exception as e:  # noqa: BLE001 -- report the build failure, never fall back to anything else
+                raise TacoError(f"{path} is missing or stale (built from other sources than csrc/) and building it failed ({e}); run "
                                 "`python -m taco_amd.build` (hipcc, gfx950).  There is no CPU fallback for the step path.") from e
-        except Exception as e:  # noqa: BLE001 -- report the build failure, never fall back to anything else
-            raise TacoError(f"{path} is missing or stale (built from other sources than csrc/) and building it failed ({e}); run "
-                            "`python -m taco_amd.build` (hipcc, gfx950).  There is no CPU fallback for the step path.") from e
     if not os.path.exists(path):
         raise TacoError(f"{path} is missing: build it with `python -m taco_amd.build` (hipcc, gfx950). "
                         "There is no CPU fallback for the step path.")

@@ -65,7 +65,8 @@ def load_state_dict(env, sd, strict=True):
     env.difficulty = sd["difficulty"]
     env.step_count = sd["step_count"]
     env.set_state(sd["blob"][:, lo:lo + n].contiguous())
-    for name in _PER_ENV:
+    env.load_stacks(sd["obs_buf"][lo:lo + n], sd["states_buf"][lo:lo + n])   # (the state stack may live in a frame ring: vec_env.load_stacks)
+    for name in ("rew_buf", "reset_buf", "timeout_buf"):
         getattr(env, name).copy_(sd[name][lo:lo + n].to(env.device))
 
 

@@ -56,11 +56,13 @@ struct taco_env {
     int fusion_off;   // taco_set_rollout_fusion(env, 0): taco_rollout_run launches the actor and the step per step even where the persistent kernel applies
     unsigned long long *rollout_stamps;  // optional profiling buffer of the persistent rollout kernel (taco_bind_rollout_stamps)
     uint32_t *ctl;        // control block (last 256 bytes of the workspace): device-resident step clock + sticky status word
-    int clock_on_device;  // a launch was captured into a HIP graph: replays advance the device clock only, the fields above may be stale
-                          // (taco_get_step_count re-reads them); until then every launch reads the device clock
+    int clock_on_device;  // a launch of this handle has been captured into a HIP graph (sticky): replays advance the device clock only, so from
+                          // then on every launch reads the device clock and every host-side use of the fields above re-reads them first
     void *capture_stream; // the stream a launch of this handle was last seen CAPTURING on (refresh_clock refuses to synchronise while it still is)
     int params_imported;  // taco_set_state has been called: rotor / aero parameters may differ per env from now on (see kUniformParams)
     float *gather;  // optional per-rank all-gather block, see taco_bind_gather_block
+    float *st_ring;   // optional frame ring behind the state stacks, see taco_bind_states_ring: [st_rows][num_envs][26]
+    int st_rows, st_period, st_phase;   // st_period = st_rows - (len_states - 1); st_phase: ring phase of the NEXT step (part of the step clock)
     unsigned long long *stamps;  // optional phase stamps, see taco_bind_phase_stamps
     taco::StepParams P;
 };
@@ -181,7 +183,7 @@ __device__ __forceinline__ float &word(float *S, int npad, int i, int field) {
     const int sl = taco::field_slot(field);
     return S[taco::tile_word(taco::NUM_CHUNKS, sl >> 2, i) + (sl & 3)];
 }
-__global__ void advance_clock_kernel(uint32_t *ctl, uint32_t steps) {  // behind every launch that took its clock from the control block (graph replays)
+__global__ void advance_clock_kernel(uint32_t *ctl, uint32_t steps) {  // behind a captured PERSISTENT ROLLOUT kernel (a captured step kernel advances the clock itself)
     ctl[taco::kCtlStep] += steps;
     ctl[taco::kCtlHead] = (ctl[taco::kCtlHead] + 10u * steps) % TACO_RING_SLOTS;
     ctl[taco::kCtlHh] = (ctl[taco::kCtlHh] + steps) % taco::HIST_ROWS;
@@ -398,6 +400,7 @@ int taco_create(const taco_cfg *cfg, int device, void *workspace, size_t workspa
     e->head = 0;
     e->hh = 0;
     e->gather = nullptr;
+    e->st_ring = nullptr; e->st_rows = 0; e->st_period = 0; e->st_phase = 0;
     e->stamps = nullptr;
     e->params_imported = 0;
     e->form = choose_form(e->cfg);
@@ -419,8 +422,12 @@ void taco_destroy(taco_env *env) { delete env; }
 
 namespace {
 int launch_step(taco_env *e, const taco_rollout_io *io, void *stream) {
-    if (!io->actions || !io->obs_next || !io->states_next || !io->rew || !io->reset_buf || !io->timeout_buf)
+    // states_next == NULL with a frame ring bound (taco_bind_states_ring): the launch writes ONE states frame into the ring row of its phase
+    const bool ring_mode = io->states_next == nullptr && e->st_ring != nullptr && e->cfg.len_states > 1;
+    if (!io->actions || !io->obs_next || (!io->states_next && !ring_mode) || !io->rew || !io->reset_buf || !io->timeout_buf)
         return fail(TACO_ERR_INVALID_ARG, "taco_step: null buffer pointer");
+    if (ring_mode && (io->states_prev || io->states_out || io->states_newest_only))
+        return fail(TACO_ERR_INVALID_ARG, "taco_step_rollout on the bound states ring: states_prev / states_out must be NULL and states_newest_only 0");
     if (((uintptr_t)io->actions & 15u) != 0) return fail(TACO_ERR_INVALID_ARG, "actions must be 16-byte aligned");
     // The step counter, the ring head and the history row travel in the kernel arguments and advance on the host with every call; a launch
     // that is being CAPTURED into a HIP graph would replay one step index for ever, so it reads the device-resident copy of the clock
@@ -449,10 +456,15 @@ int launch_step(taco_env *e, const taco_rollout_io *io, void *stream) {
     P.states_bytes = (uint32_t)((size_t)n_envs * e->cfg.len_states * 26 * sizeof(float));
     // states_newest_only: `states_next` is ONE frame per env ([num_envs][26], a row of the replay store's frame ring): the launch runs as a
     // len_states = 1 step -- nothing is shifted, nothing of an older stack is read
-    const bool newest_only = io->states_newest_only != 0 && e->cfg.len_states > 1;
+    const bool newest_only = (io->states_newest_only != 0 && e->cfg.len_states > 1) || ring_mode;
     if (newest_only) {
         if (io->states_out) return fail(TACO_ERR_INVALID_ARG, "states_newest_only writes no stack: states_out must be NULL");
         P.len_states = 1; P.states_bytes = (uint32_t)(n_envs * 26 * sizeof(float)); P.states_prev = P.states;
+    }
+    P.st_period = 0; P.st_phase = 0; P.st_front = 0;
+    if (ring_mode) {
+        P.states = e->st_ring; P.states_prev = e->st_ring;
+        P.st_period = e->st_period; P.st_phase = e->st_phase; P.st_front = e->cfg.len_states - 1;
     }
     P.gather_row = (uint32_t)taco_gather_row_floats(e->cfg.len_obs);
     P.gather_bytes = (uint32_t)((size_t)n_envs * P.gather_row * sizeof(float));
@@ -470,14 +482,11 @@ int launch_step(taco_env *e, const taco_rollout_io *io, void *stream) {
                                     (hipStream_t)stream);
     if (he == hipSuccess) he = hipGetLastError();
     if (he != hipSuccess) return hip_fail(he, "taco_step_kernel launch");
-    if (e->clock_on_device) {
-        hipLaunchKernelGGL(advance_clock_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, e->ctl, 1u);
-        he = hipGetLastError();
-        if (he != hipSuccess) return hip_fail(he, "advance_clock_kernel launch");
-    }
+    // (a launch that took its clock from the control block -- use_ctl -- advances it itself: last-ticket workgroup, taco_step.hpp)
     e->step_count += 1;
     e->head = (e->head + 10) % TACO_RING_SLOTS;
     e->hh = (e->hh + 1) % taco::HIST_ROWS;
+    if (ring_mode) e->st_phase = (e->st_phase + 1) % e->st_period;
     return TACO_OK;
 }
 }  // namespace
@@ -559,9 +568,8 @@ int taco_bind_gather_block(taco_env *e, float *block) {
 }
 
 namespace {
-// re-read the clock the graph replays advanced (blocking): afterwards the host's copy is current again and launches go back to the eager path.
-// `stream` non-NULL: the read is ordered on the caller's stream (the entry points that take one export / import state in that stream's
-// order anyway) and only that stream is waited for; NULL: the whole device is (taco_get_step_count / taco_set_step_count have no stream).
+// re-read the clock the graph replays advanced (blocking, device-wide): afterwards the host's copy is current again and launches go back to
+// the eager path.
 // Synchronising while a stream is capturing is illegal (it would invalidate the capture): TACO_ERR_STATE instead.
 int refresh_clock(taco_env *e, void *stream = nullptr) {
     if (e->capture_stream != nullptr) {
@@ -571,20 +579,21 @@ int refresh_clock(taco_env *e, void *stream = nullptr) {
         e->capture_stream = nullptr;
     }
     if (!e->clock_on_device) return TACO_OK;
-    uint32_t c[3];
+    uint32_t c[4];
     hipError_t he;
-    if (stream != nullptr) {
-        he = hipMemcpyAsync(c, e->ctl, sizeof(c), hipMemcpyDeviceToHost, (hipStream_t)stream);
-        if (he == hipSuccess) he = hipStreamSynchronize((hipStream_t)stream);
-    } else {
-        he = hipDeviceSynchronize();
-        if (he == hipSuccess) he = hipMemcpy(c, e->ctl, sizeof(c), hipMemcpyDeviceToHost);
-    }
+    // (the whole device, whatever stream the caller named: the replays that advanced the clock may have run on ANOTHER stream the caller's has
+    // not waited for -- adopting a stale clock would corrupt the Philox counters and the delay ring's head silently; this path is rare)
+    (void)stream;
+    he = hipDeviceSynchronize();
+    if (he == hipSuccess) he = hipMemcpy(c, e->ctl, sizeof(c), hipMemcpyDeviceToHost);
     if (he != hipSuccess) return hip_fail(he, "reading the device-resident step clock");
     e->step_count = (e->step_count & ~(int64_t)0xffffffff) | c[taco::kCtlStep];  // (the kernel's Philox counter is the low 32 bits)
     e->head = (int)c[taco::kCtlHead];
     e->hh = (int)c[taco::kCtlHh];
-    e->clock_on_device = 0;
+    if (e->st_period > 0) e->st_phase = (int)(c[taco::kCtlPhase] % (uint32_t)e->st_period);
+    // clock_on_device stays set: a graph captured from this handle may be replayed again at any time, behind the host's back -- from the first
+    // capture on every launch takes its clock from the device and every host-side read of it comes here (rounds 2-3 went back to the host's
+    // copy after one re-read: a replay after that left it stale, silently)
     return TACO_OK;
 }
 }  // namespace
@@ -945,6 +954,42 @@ int taco_rollout_run(taco_env *e, const taco_policy_cfg *c, const float *blob, c
     hipError_t he = hipGetLastError();
     if (he != hipSuccess) return hip_fail(he, "timeout_bootstrap_kernel launch");
     return TACO_OK;
+}
+
+int taco_bind_states_ring(taco_env *e, float *ring, int rows) {
+    if (!e) return fail(TACO_ERR_INVALID_ARG, "env is null");
+    const int front = e->cfg.len_states - 1;
+    if (ring) {
+        if (front < 1) return fail(TACO_ERR_INVALID_ARG, "taco_bind_states_ring: len_states is 1, there is no stack to keep");
+        if (rows < 2 * front + 1) return fail(TACO_ERR_INVALID_ARG, "taco_bind_states_ring: rows must be >= 2 * (len_states - 1) + 1");
+        if (((uintptr_t)ring & 15u) != 0) return fail(TACO_ERR_INVALID_ARG, "taco_bind_states_ring: ring must be 16-byte aligned");
+    }
+    const int rc = refresh_clock(e);
+    if (rc != TACO_OK) return rc;
+    const uint32_t zero = 0u;
+    hipError_t he = hipDeviceSynchronize();   // (a step in flight would write ITS successor phase behind this)
+    if (he == hipSuccess) he = hipMemcpy(e->ctl + taco::kCtlPhase, &zero, sizeof(zero), hipMemcpyHostToDevice);
+    if (he != hipSuccess) return hip_fail(he, "taco_bind_states_ring: resetting the ring phase");
+    e->st_ring = ring; e->st_rows = ring ? rows : 0; e->st_period = ring ? rows - front : 0; e->st_phase = 0;
+    return TACO_OK;
+}
+int taco_states_ring_row(taco_env *e) {
+    if (!e || !e->st_ring) return fail(TACO_ERR_INVALID_ARG, "taco_states_ring_row: no ring bound"), -1;
+    if (refresh_clock(e) != TACO_OK) return -1;
+    return (e->st_phase + e->st_period - 1) % e->st_period;   // the phase of the LAST step: it wrote row phase + len_states - 1, the newest frame of the window
+}
+
+int taco_step_ring(taco_env *e, const taco_rollout_io *io, void *stream, int32_t *phase) {
+    if (!e) return fail(TACO_ERR_INVALID_ARG, "env is null");
+    if (!io || !phase) return fail(TACO_ERR_INVALID_ARG, "taco_step_ring: null argument");
+    if (!e->st_ring || io->states_next) return fail(TACO_ERR_INVALID_ARG, "taco_step_ring: bind a ring (taco_bind_states_ring) and pass states_next = NULL");
+    if (is_capturing(stream))
+        return fail(TACO_ERR_STATE, "taco_step_ring cannot be captured into a HIP graph: every replay fills another window of the frame ring, which the "
+                                    "caller of this entry point wants to be told (capture taco_step_rollout with states_next = NULL instead)");
+    const int rc0 = refresh_clock(e, stream);   // (after graph replays: the host's phase is made current first -- blocking, once)
+    if (rc0 != TACO_OK) return rc0;
+    *phase = e->st_phase;
+    return launch_step(e, io, stream);
 }
 
 int taco_set_kernel_form(taco_env *e, int form) {

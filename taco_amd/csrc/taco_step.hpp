@@ -51,6 +51,13 @@ struct StepParams {
     int hw_rows;         // how many of the most recent history rows the up-front loads fetch (1..4): the deepest run queue this configuration
                          // can reach (taco_capi.hip derive()); lanes with a deeper queue gather per lane -- a performance hint, never semantics
     uint32_t obs_bytes, states_bytes, gather_bytes, gather_row;  // gather_row = floats per env in the gather block (multiple of 32)
+    // FRAME RING behind VecTask.step()'s state stacks (taco_bind_states_ring; st_period == 0: off).  `states` is then the ring
+    // [st_front + st_period][n][26] (st_front = len_states - 1), states_bytes one ROW of it, len_states == 1 for the launch: the step with ring
+    // phase ph (part of the step clock) writes its ONE new frame to row st_front + ph -- and, while ph >= st_period - st_front, also to row
+    // st_front + ph - st_period, so that rows [ph, ph + st_front] always hold the stack of that step, oldest frame first: the reference's
+    // [n][len][26] stack is the strided view ring[ph : ph + len].permute(1, 0, 2), nothing is ever shifted (FA:392, :413 shift by one per step
+    // and never clear: exactly a ring).
+    int st_period, st_phase, st_front;
     // fp32 images of the Python doubles the reference feeds into tensor ops
     float dt, rdt, clip_act, df;  // rdt = RN(1/dt); taco_create refuses a dt for which div_const(x, dt, rdt) != x / dt
     float clip_obs, clip_states;  // bounds of obs_out / states_out (+inf = none)
@@ -89,8 +96,9 @@ enum Chunk : uint32_t {
 };
 constexpr int HIST_ROWS = 16;  // action history: hist[tile][k][64] float4, the action of the step whose (count & 15) == k
 // control block: the last 256 bytes of the workspace.  Words: 0 step count, 1 ring head, 2 history row (the step CLOCK: every eager launch
-// leaves the next values here, a graph-captured launch reads them and is followed by advance_clock_kernel), 3 -, 4 sticky status bits
-enum : uint32_t { kCtlStep = 0, kCtlHead = 1, kCtlHh = 2, kCtlStatus = 4, kCtlBytes = 256 };
+// leaves the next values here, a graph-captured launch reads them and the last of its workgroups to have read them advances them), 4 sticky status bits,
+// 3 phase of the states frame ring (taco_bind_states_ring), 5 ticket counter of a captured step (see step_core)
+enum : uint32_t { kCtlStep = 0, kCtlHead = 1, kCtlHh = 2, kCtlPhase = 3, kCtlStatus = 4, kCtlTicket = 5, kCtlBytes = 256 };
 constexpr uint32_t kStatusMailboxTimeout = 1u;  // a battery-mailbox wait gave up (the affected envs' voltage was poisoned with NaN)
 constexpr uint32_t kRowBytes = 1024;  // one row (chunk, history row or ring slot) of one tile: 64 lanes x 16 B
 // float index of word 0 of (row r, env i) in an array with `rows` rows per tile (host-side kernels of taco_capi.hip)
@@ -751,13 +759,37 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     // (read unconditionally by scalar loads through the constant address space and selected without a branch: while a captured step kernel
     // runs nothing writes the clock -- the advance kernel comes after it -- and on the eager path the loaded values are simply not used)
     const __attribute__((address_space(4))) uint32_t *ctl_c = (const __attribute__((address_space(4))) uint32_t *)P.ctl;
-    const uint32_t c_step = ctl_c[kCtlStep], c_head = ctl_c[kCtlHead], c_hh = ctl_c[kCtlHh];
+    const uint32_t c_step = ctl_c[kCtlStep], c_head = ctl_c[kCtlHead], c_hh = ctl_c[kCtlHh], c_phase = ctl_c[kCtlPhase];
     const bool from_ctl = P.use_ctl != 0;
-    const struct { uint32_t step; int head, hh; } clk{FUSED ? FX.step : (from_ctl ? c_step : P.step), FUSED ? FX.head : (from_ctl ? (int)c_head : P.head),
-                                                      FUSED ? FX.hh : (from_ctl ? (int)c_hh : P.hh)};
-    if (!FUSED && !RESET_ONLY && !from_ctl && blockIdx.x == 0 && threadIdx.x == 0) {
-        P.ctl[kCtlStep] = P.step + 1u; P.ctl[kCtlHead] = (uint32_t)((P.head + 10) % TACO_RING_SLOTS); P.ctl[kCtlHh] = (uint32_t)((P.hh + 1) % HIST_ROWS);
+    const struct { uint32_t step; int head, hh, phase; } clk{FUSED ? FX.step : (from_ctl ? c_step : P.step), FUSED ? FX.head : (from_ctl ? (int)c_head : P.head),
+                                                             FUSED ? FX.hh : (from_ctl ? (int)c_hh : P.hh), from_ctl ? (int)c_phase : P.st_phase};
+    uint32_t ticket = 0u;
+    if constexpr (!FUSED && !RESET_ONLY) {
+        const uint32_t ph1 = P.st_period > 0 ? (uint32_t)((clk.phase + 1) % P.st_period) : 0u;
+        if (!from_ctl) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                P.ctl[kCtlStep] = P.step + 1u; P.ctl[kCtlHead] = (uint32_t)((P.head + 10) % TACO_RING_SLOTS); P.ctl[kCtlHh] = (uint32_t)((P.hh + 1) % HIST_ROWS);
+                if (P.st_period > 0) P.ctl[kCtlPhase] = ph1;   // (a launch that does not write the ring leaves its phase alone)
+            }
+        } else if (threadIdx.x == 0) {
+            // A CAPTURED step (its kernel arguments are frozen in the graph) advances the device-resident clock itself: every workgroup takes a
+            // ticket once its own scalar reads of the clock have landed, and the one that draws the last ticket -- every workgroup of the launch
+            // has read the clock by then -- writes the next values and re-arms the counter (`advance_clock` below, where the step's up-front
+            // loads have landed: the ticket comes back with them, no wait of its own).  The next launch of the stream sees them: ONE graph node
+            // per step (rounds 2-3 appended a one-thread kernel to every captured step).
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            ticket = __hip_atomic_fetch_add(&P.ctl[kCtlTicket], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
+    auto advance_clock = [&]() {   // (thread 0 of every workgroup of a captured launch)
+        if constexpr (!FUSED && !RESET_ONLY) {
+            if (from_ctl && threadIdx.x == 0 && ticket == gridDim.x - 1u) {
+                P.ctl[kCtlTicket] = 0u;
+                P.ctl[kCtlStep] = c_step + 1u; P.ctl[kCtlHead] = (c_head + 10u) % TACO_RING_SLOTS; P.ctl[kCtlHh] = (c_hh + 1u) % HIST_ROWS;
+                if (P.st_period > 0) P.ctl[kCtlPhase] = (uint32_t)((clk.phase + 1) % P.st_period);
+            }
+        }
+    };
     constexpr int EPW = 64 / LPE;  // envs per wavefront
     constexpr int WAVE_LDS_WORDS = 10 * EPW * 4;
     static_assert(WAVE_LDS_WORDS >= EPW * 26, "tile must fit in the per-wave scratch");
@@ -951,6 +983,7 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // (the target pose and the unwrapped angles it stored are loaded further down)
     }
     if (P.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TACO_STAMP(1); }  // all up-front loads have landed
+    advance_clock();
     V3 p{c_pos.x, c_pos.y, c_pos.z};
     Q4 q{c_quat.x, c_quat.y, c_quat.z, c_quat.w};
     V3 v{c_lin.x, c_lin.y, c_lin.z};
@@ -1933,7 +1966,18 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
         }
     };
     // states first (noise-free frame), then obs (possibly noised)
-    if (roleS) put_frame(P.states, P.states_prev, P.states_bytes, P.len_states, fr, true, OUT ? P.states_out : nullptr, P.clip_states);
+    if (roleS) {
+        if (!FUSED && P.st_period > 0) {   // the frame ring behind VecTask.step()'s state stacks (StepParams.st_period): one frame, two while the window wraps
+            float *const row = P.states + (size_t)(P.st_front + clk.phase) * (P.states_bytes / 4u);
+            put_frame(row, row, P.states_bytes, 1, fr, true, nullptr, P.clip_states);
+            if (clk.phase >= P.st_period - P.st_front) {
+                float *const twin = row - (size_t)P.st_period * (P.states_bytes / 4u);
+                put_frame(twin, twin, P.states_bytes, 1, fr, false, nullptr, P.clip_states);
+            }
+        } else {
+            put_frame(P.states, P.states_prev, P.states_bytes, P.len_states, fr, true, OUT ? P.states_out : nullptr, P.clip_states);
+        }
+    }
     if (roleO && (fl & TACO_F_OBSERVATION_NOISE)) {  // FA:402-410
         if (!noise_ready) gen_obs_noise();
 #pragma unroll

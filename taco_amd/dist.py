@@ -114,7 +114,7 @@ class ShardedEnv:
         self.sizes = shard_sizes(self.n_global, world_size)
         self.m = max(self.sizes)
         self.env = FpvBase(cfg, rl_device=str(device), sim_device=str(device), env_offset=self.lo, num_envs_local=self.hi - self.lo,
-                           copy_outputs=False)
+                           copy_outputs=False, states_ring=True)   # (in place on the obs buffer; a state stack lives in the frame ring)
         self.len_obs = self.env.len_obs
         row = block_row(self.len_obs)
         # two block / result pairs alternate so that step t + 1 can fill its block while the gather of step t is still reading the other

@@ -42,7 +42,7 @@ class FpvBase:
 
     def __init__(self, cfg, rl_device="cuda:0", sim_device="cuda:0", graphics_device_id=-1, headless=True,
                  virtual_screen_capture=False, force_render=False, env_offset=0, num_envs_local=None, copy_outputs=True, kernel_form="auto",
-                 lib=None):
+                 lib=None, states_ring=None):
         self.cfg = cfg
         if self.task_mode is not None:
             cfg["task_mode"] = self.task_mode
@@ -84,10 +84,20 @@ class FpvBase:
         # default clip of +inf that copy is the buffer's content.  `env.obs_buf` / `env.states_buf` are always the current pair.
         self._want_pp = bool(copy_outputs)
         self._finite_clip = bool(math.isfinite(self.clip_obs) or math.isfinite(self.clip_states))
+        # A state stack (len_states > 1, the documented 5) behind step() is a FRAME RING (taco_bind_states_ring): the kernel writes ONE frame per
+        # env-step and `states_buf` / the tensor step() returns is a strided [num_envs, len_states, 26] view of it -- the reference's shifted
+        # stack (fpv_asymmetry.py:413) moves 9 frames per env-step for the same content.  (copy_outputs=False keeps the contiguous in-place
+        # stack; a finite clip keeps the materialised path, whose OUT instantiation writes the clamped copy.)
+        # states_ring: None = with copy_outputs; True / False force it (ShardedEnv steps in place on the obs buffer but keeps the ring)
+        self._ring_on = (self._want_pp if states_ring is None else bool(states_ring)) and self.len_states > 1 and not self._finite_clip
         npp = 2 if self._want_pp else 1
         self._obs_pp = [torch.zeros((self.num_envs, self.len_obs, self.num_obs), device=dev, dtype=torch.float32) for _ in range(npp)]
-        self._states_pp = [torch.zeros((self.num_envs, self.len_states, self.num_states), device=dev, dtype=torch.float32) for _ in range(npp)]
+        self._states_pp = [] if self._ring_on else \
+            [torch.zeros((self.num_envs, self.len_states, self.num_states), device=dev, dtype=torch.float32) for _ in range(npp)]
         self._pp = 0
+        # a graph captured around step() would freeze ONE (current -> next) pair of the alternating obs buffers: with an obs stack every replay
+        # would shift the never-updated `current` one (refused in step())
+        self._capture_unsafe = self._want_pp and self.len_obs > 1 and not self._finite_clip
         self.rew_buf = torch.zeros(self.num_envs, device=dev, dtype=torch.float32)
         self.reset_buf = torch.ones(self.num_envs, device=dev, dtype=torch.long)
         self.timeout_buf = torch.zeros(self.num_envs, device=dev, dtype=torch.bool)
@@ -110,6 +120,16 @@ class FpvBase:
         self._difficulty = float(cfg["difficulty"])
         if kernel_form != "auto":
             self.set_kernel_form(kernel_form)
+        if self._ring_on:
+            front, row_bytes = self.len_states - 1, self.num_envs * self.num_states * 4
+            self._st_period = int(min(64, max(front + 1, (1 << 30) // row_bytes - front)))   # <= 1 GiB of ring, twins <= front / period of a frame per step
+            self._st_ring = torch.zeros((self._st_period + front, self.num_envs, self.num_states), device=dev, dtype=torch.float32)
+            with torch.cuda.device(dev):
+                torch.cuda.synchronize()   # (the bind resets the ring phase on the device, behind the workspace's initialisation)
+                _lib.check(self.lib.taco_bind_states_ring(self._h, self._st_ring.data_ptr(), self._st_period + front), self.lib)
+            self._st_views = [self._st_ring[k:k + self.len_states].permute(1, 0, 2) for k in range(self._st_period)]
+            self._st_last = self._st_period - 1   # the window of the last step (before the first: zeros, like every other)
+            self._st_phase = C.c_int32(0)
 
     def set_kernel_form(self, name):
         """pin one of the six instantiations of the step kernel (`_lib.FORMS`; "auto" = the library's choice for this env count)"""
@@ -155,7 +175,34 @@ class FpvBase:
 
     @property
     def states_buf(self):
+        """[num_envs, len_states, 26]; with the frame ring a STRIDED view (each frame contiguous, frames num_envs * 26 floats apart): reads,
+        copy_() into it, .cpu(), indexing all work; .view() needs .reshape() / .contiguous()"""
+        if self._ring_on:
+            ph = self.lib.taco_states_ring_row(self._h)   # (the library's word: graph replays advance the phase on the device)
+            if ph < 0:
+                raise _lib.TacoError(f"libtaco_env: {self.lib.taco_last_error().decode()}")
+            self._st_last = ph
+            return self._st_views[ph]
         return self._states_pp[self._pp]
+
+    def load_stacks(self, obs=None, states=None):
+        """make `obs` / `states` ([num_envs, len, 26]) the env's current frame stacks (checkpoint restore)"""
+        if obs is not None:
+            self.obs_buf.copy_(obs.to(self.device))
+        if states is not None:
+            states = states.to(self.device)
+            if not self._ring_on:
+                self.states_buf.copy_(states)
+                return
+            # ring: restart at phase 0 -- the window of the "last step" is rows [period - 1, period - 1 + len), and the frames the NEXT windows
+            # share with it must also sit in the twin rows [0, len - 1)
+            front = self.len_states - 1
+            with torch.cuda.device(self.device):
+                torch.cuda.synchronize()
+                _lib.check(self.lib.taco_bind_states_ring(self._h, self._st_ring.data_ptr(), self._st_period + front), self.lib)
+            self._st_last = self._st_period - 1
+            self._st_views[self._st_last].copy_(states)
+            self._st_ring[0:front].copy_(states[:, 1:].transpose(0, 1))
 
     @property
     def progress_buf(self):
@@ -205,9 +252,24 @@ class FpvBase:
             actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
         if actions.shape != (self.num_envs, self.num_acts):
             raise ValueError(f"actions must be [{self.num_envs}, {self.num_acts}], got {tuple(actions.shape)}")
+        if self._ring_on:   # (in place for obs, the bound frame ring for the state stack)
+            io = _lib.RolloutIO(actions.data_ptr(), None, self.obs_buf.data_ptr(), None, None, self.rew_buf.data_ptr(), self.reset_buf.data_ptr(),
+                                self.timeout_buf.data_ptr(), None)
+            self._ring_step(io)
+            return
         rc = self.lib.taco_step(self._h, actions.data_ptr(), self.obs_buf.data_ptr(), self.states_buf.data_ptr(), self.rew_buf.data_ptr(),
                                 self.reset_buf.data_ptr(), self.timeout_buf.data_ptr(), _stream_ptr(self.device).value)
         _lib.check(rc)
+
+    def _ring_step(self, io):
+        """one launch on the frame ring (taco_step_ring); remembers which window it fills"""
+        rc = self.lib.taco_step_ring(self._h, C.byref(io), _stream_ptr(self.device), C.byref(self._st_phase))
+        if rc != 0:
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.TacoError("VecTask.step() with a state stack cannot be captured into a HIP graph (each replay fills another window of the "
+                                     "frame ring): capture step_raw() of an env built with copy_outputs=False, RolloutBuffer.run(), or taco_step_rollout")
+            _lib.check(rc, self.lib)
+        self._st_last = self._st_phase.value
 
     def step_into(self, actions, obs_prev, obs_next, states_prev, states_next, rew, done_f32=None, states_newest=None):
         """taco_step_rollout: like step_raw, but the frame stacks are read from `*_prev` and written to `*_next` (replay-buffer
@@ -256,25 +318,35 @@ class FpvBase:
             actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
         if actions.shape != (self.num_envs, self.num_acts):
             raise ValueError(f"actions must be [{self.num_envs}, {self.num_acts}], got {tuple(actions.shape)}")
+        if self._capture_unsafe and torch.cuda.is_current_stream_capturing():
+            raise _lib.TacoError("VecTask.step() with an observation stack alternates between two buffer pairs and cannot be captured into a HIP graph: "
+                                 "capture step_raw() of an env built with copy_outputs=False")
         cur = self._pp
         nxt = cur ^ 1 if (self._want_pp and not self._finite_clip) else cur   # (finite clip: the clamped copies are what survives)
         k = self._out_k if self._finite_clip else 0
         io = self._step_io.get((cur, k))
         if io is None:   # the argument block of this (buffer pair, output pair) combination: built once, only the action pointer changes
             obs_out, states_out = self._out[k] if self._finite_clip else (None, None)
+            ring = self._ring_on
             io = _lib.RolloutIO(None, self._obs_pp[cur].data_ptr() if nxt != cur else None, self._obs_pp[nxt].data_ptr(),
-                                self._states_pp[cur].data_ptr() if nxt != cur else None, self._states_pp[nxt].data_ptr(), self.rew_buf.data_ptr(),
+                                self._states_pp[cur].data_ptr() if (nxt != cur and not ring) else None,
+                                None if ring else self._states_pp[nxt].data_ptr(), self.rew_buf.data_ptr(),
                                 self.reset_buf.data_ptr(), self.timeout_buf.data_ptr(), None,
                                 obs_out.data_ptr() if obs_out is not None else None, states_out.data_ptr() if states_out is not None else None)
             self._step_io[(cur, k)] = io
         io.actions = actions.data_ptr()
-        rc = self.lib.taco_step_rollout(self._h, C.byref(io), _stream_ptr(self.device))
-        if rc != 0:
-            _lib.check(rc, self.lib)
+        if self._ring_on:
+            self._ring_step(io)
+        else:
+            rc = self.lib.taco_step_rollout(self._h, C.byref(io), _stream_ptr(self.device))
+            if rc != 0:
+                _lib.check(rc, self.lib)
         self._pp = nxt
         if self._finite_clip:
             self._out_k ^= 1
             obs, st = self._out[k]
+        elif self._ring_on:
+            obs, st = self._obs_pp[nxt], self._st_views[self._st_last]
         else:
             obs, st = self._obs_pp[nxt], self._states_pp[nxt]
         if self._same_device:

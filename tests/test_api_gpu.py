@@ -417,34 +417,101 @@ def test_step_returns_kernel_written_clamped_copies(n, len_states, form):
     env.check()
 
 
-@pytest.mark.parametrize("n,len_obs,len_states,form", [(300, 1, 1, "auto"), (300, 2, 5, "auto"), (20000, 1, 5, "auto"), (70000, 1, 1, "auto"), (300, 3, 3, "lane"), (300, 1, 4, "quad")])
-def test_step_returns_the_other_buffer_pair_without_a_copy(n, len_obs, len_states, form):
-    """Default clip (+inf): step() is the launch step_raw() makes -- the frame stacks are read from the current buffer pair and written to the
-    other one (prev / next of taco_step_rollout), which is returned as it is.  Bit-identical to an env stepped in place, through every store
-    path; the tensors of step t survive step t + 1 and are reused by step t + 2; env.obs_buf / states_buf are always the current pair."""
+def _bits(t):
+    return t.contiguous().view(torch.int32)
+
+
+@pytest.mark.parametrize("n,len_obs,len_states,form", [(300, 1, 1, "auto"), (300, 2, 5, "auto"), (20000, 1, 5, "auto"), (70000, 1, 1, "auto"), (300, 3, 3, "lane"), (300, 1, 4, "quad"),
+                                                       (5000, 1, 8, "auto")])
+def test_step_returns_kernel_written_buffers_without_a_copy(n, len_obs, len_states, form):
+    """Default clip (+inf): step() is ONE launch and nothing else.  The obs stack is read from the current buffer and written to the other one
+    of an alternating pair; a state stack (len_states > 1) lives in a FRAME RING (taco_bind_states_ring): the launch writes one frame per env
+    and step() returns the strided [n, len, 26] view of the window it filled.  Bit-identical to an env stepped in place on contiguous stacks,
+    through every store path, across several wraps of the ring (its twin rows); the tensors of step t survive the following steps (at least
+    one for the obs pair, period - len_states for the ring); env.obs_buf / states_buf always name what the last step produced."""
     from taco_amd.vec_env import FpvBase
     kw = dict(env_lenStates=len_states, env_lenObservations=len_obs, env_maxEpisodeLength=30, observation_noise=True)
     env = FpvBase(config.default_cfg("mix", n, **kw), kernel_form=form)
     ref = FpvBase(config.default_cfg("mix", n, **kw), kernel_form=form, copy_outputs=False)
+    ring = len_states > 1
+    assert env._ring_on == ring
+    steps = 3 * env._st_period + 7 if ring else 45
     g = torch.Generator().manual_seed(1)
     acts = (0.3 * torch.randn((6, n, 4), generator=g)).clamp(-1, 1).cuda()
     held = []
-    for t in range(45):
+    for t in range(steps):
         d, rew, done, info = env.step(acts[t % 6])
         ref.step_raw(acts[t % 6])
         assert d["obs"].data_ptr() == env.obs_buf.data_ptr() and d["states"].data_ptr() == env.states_buf.data_ptr()
-        assert torch.equal(d["obs"].view(torch.int32), ref.obs_buf.view(torch.int32)) and torch.equal(d["states"].view(torch.int32), ref.states_buf.view(torch.int32)), t
+        assert tuple(d["states"].shape) == (n, len_states, 26)
+        assert torch.equal(_bits(d["obs"]), _bits(ref.obs_buf)) and torch.equal(_bits(d["states"]), _bits(ref.states_buf)), t
         assert torch.equal(rew.view(torch.int32), ref.rew_buf.view(torch.int32)) and torch.equal(done, ref.reset_buf)
+        for back, (old, copy) in enumerate(reversed(held[-(env._st_period - len_states if ring else 1):])):
+            assert torch.equal(_bits(old), _bits(copy)), f"the tensors of step {t - 1 - back} must survive step {t}"
         if held:
-            assert torch.equal(held[-1][0].view(torch.int32), held[-1][1].view(torch.int32)), "the previous step's tensors must survive this step"
             assert held[-1][0].data_ptr() != d["states"].data_ptr()
-        if len(held) > 1:
+        if len(held) > 1 and not ring:
             assert held[-2][0].data_ptr() == d["states"].data_ptr()          # two pairs alternate
         held.append((d["states"], d["states"].clone()))
     assert torch.equal(env.get_state().view(torch.int32), ref.get_state().view(torch.int32))
-    env.step_raw(acts[0]); ref.step_raw(acts[0])                              # in place on the current pair
-    assert torch.equal(env.states_buf.view(torch.int32), ref.states_buf.view(torch.int32))
+    env.step_raw(acts[0]); ref.step_raw(acts[0])                              # in place on the current obs buffer / the ring
+    assert torch.equal(_bits(env.states_buf), _bits(ref.states_buf)) and torch.equal(_bits(env.obs_buf), _bits(ref.obs_buf))
     env.check()
+
+
+def test_ring_backed_state_stack_through_capture_checkpoint_and_the_c_abi(tmp_path):
+    """The frame ring behind the state stack (include/taco_env.h taco_bind_states_ring): (1) VecTask.step() refuses to be captured with it
+    (every replay fills another window); (2) the C entry point itself IS capturable -- the ring phase is part of the device-resident clock, a
+    captured step is ONE kernel node that advances it -- and replays continue the run bit for bit, the window named by taco_states_ring_row;
+    (3) a checkpoint taken at an arbitrary ring phase restores into a fresh env (phase 0, twins rebuilt) and both continue identically."""
+    import ctypes as C
+    from taco_amd import _lib, checkpoint
+    from taco_amd.vec_env import FpvBase
+    n, T = 900, 5
+    kw = dict(env_maxEpisodeLength=35, env_lenStates=T, seed=4, ramdom_deploy_time=True, observation_noise=True, rotor_noise=True)
+    env = FpvBase(config.default_cfg("mix", n, **kw))
+    ref = FpvBase(config.default_cfg("mix", n, **kw), copy_outputs=False)
+    g = torch.Generator().manual_seed(8)
+    acts = (0.3 * torch.randn((8, n, 4), generator=g)).clamp(-1, 1).cuda()
+    for t in range(11):
+        env.step(acts[t % 8]); ref.step_raw(acts[t % 8])
+    # (3) checkpoint at phase 11 -> fresh env
+    checkpoint.save(env, str(tmp_path / "ring.pt"))
+    twin = FpvBase(config.default_cfg("mix", n, **kw))
+    checkpoint.load(twin, str(tmp_path / "ring.pt"))
+    assert torch.equal(_bits(twin.states_buf), _bits(ref.states_buf))
+    # (1) step() under capture is refused
+    act = torch.zeros((n, 4), device="cuda")
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    io = _lib.RolloutIO(act.data_ptr(), None, env.obs_buf.data_ptr(), None, None, env.rew_buf.data_ptr(), env.reset_buf.data_ptr(), env.timeout_buf.data_ptr(), None)
+    with torch.cuda.stream(s):
+        graph.capture_begin()
+        with pytest.raises(_lib.TacoError, match="cannot be captured"):
+            env.step(act)                         # refused, nothing enqueued
+        # (2) ... the C entry point without the window report is capturable: two steps on the action in `act`
+        for _ in range(2):
+            _lib.check(env.lib.taco_step_rollout(env._h, C.byref(io), C.c_void_p(s.cuda_stream)), env.lib)
+        graph.capture_end()
+    torch.cuda.current_stream().wait_stream(s)
+    t = 11
+    for rep in range(40):                         # 80 steps: more than a period of the ring
+        act.copy_(acts[t % 8])
+        for k in range(2):
+            ref.step_raw(acts[t % 8]); twin.step(acts[t % 8])
+        t += 2
+        graph.replay()
+        assert torch.equal(_bits(env.states_buf), _bits(ref.states_buf)) and torch.equal(_bits(twin.states_buf), _bits(ref.states_buf)), rep
+        assert torch.equal(_bits(env.obs_buf), _bits(ref.obs_buf))
+    assert env.step_count == ref.step_count == 91
+    for t2 in range(t, t + 9):                    # eagerly on, through step(): the host picks the ring phase up again
+        d, *_ = env.step(acts[t2 % 8]); ref.step_raw(acts[t2 % 8]); twin.step(acts[t2 % 8])
+        assert torch.equal(_bits(d["states"]), _bits(ref.states_buf))
+    assert torch.equal(env.get_state().view(torch.int32), ref.get_state().view(torch.int32))
+    assert torch.equal(twin.get_state().view(torch.int32), ref.get_state().view(torch.int32))
+    assert torch.equal(_bits(twin.states_buf), _bits(ref.states_buf))
+    env.check(); twin.check()
 
 
 def _run_bench(extra, env_extra=None, timeout=420):

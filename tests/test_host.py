@@ -146,6 +146,9 @@ def test_checkpoint_merge_and_slice_by_global_env_id():
         def set_state(self, b):
             self.blob = b.clone()
 
+        def load_stacks(self, obs, states):   # (FpvBase.load_stacks: the state stack may live in a frame ring there)
+            self.obs_buf.copy_(obs); self.states_buf.copy_(states)
+
     def filled(lo, n, total, step=17):
         e = Env(lo, n, total)
         ids = torch.arange(lo, lo + n, dtype=torch.float32)
