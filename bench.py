@@ -404,15 +404,22 @@ def latency_floor(env, acts, kernel_avg_us, torch):
     kernel's own shader-clock stamps (taco_bind_phase_stamps) of workgroup 0 give the critical path in clocks -- step wavefront entry -> its
     last store, and the latest role wavefront's end; at the GPU's peak shader clock that is the floor the launch cannot beat without
     shortening the stream.  instr_per_step_wavefront comes from the committed PMC summary of the same build when there is one."""
-    ph = env.phase_stamps(acts[0], steps=200, back_to_back=True)
-    st = env._last_stamps.cpu().tolist()
+    # (workgroup 0 holds 16 envs: at ~1 % resets per env-step one stamped launch in six sees reset_env in its `loads` phase, ~4 400 clocks; the
+    # floor is the reset-free path, so the shortest of seven stamped launches is reported and the longest beside it)
+    runs = []
+    for k in range(7):
+        ph_k = env.phase_stamps(acts[k % acts.shape[0]], steps=40 + k, back_to_back=True)
+        st_k = env._last_stamps.cpu().tolist()
+        runs.append((st_k[5] - st_k[0], ph_k, st_k))
+    runs.sort(key=lambda r: r[0])
+    _, ph, st = runs[0]
     wave0 = st[5] - st[0]
     roles_end = max(st[6:9]) - st[0] if max(st[6:9]) > 0 else wave0
     mhz, src = shader_clock_mhz()
     ticks = max(wave0, roles_end)
     out = {"critical_path_clocks": ticks, "step_wavefront_clocks": wave0, "phases_clocks": {"loads": ph[0], "pre_phase": ph[1], "ten_substeps": ph[2],
            "state_stores_and_frames": ph[3], "tail": ph[4]}, "shader_clock_mhz": mhz, "clock_source": src, "us": ticks / mhz,
-           "frac_of_kernel_avg": ticks / mhz / kernel_avg_us,
+           "frac_of_kernel_avg": ticks / mhz / kernel_avg_us, "step_wavefront_clocks_longest_of_7": runs[-1][0],
            "note": "kernel_avg_us - us = dispatch of 256 workgroups x 4 wavefronts + the drain of the last stores (GPU-side launch boundary)"}
     try:
         import glob

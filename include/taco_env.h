@@ -142,8 +142,8 @@ const char *taco_source_hash(void);
 const char *taco_last_error(void);
 
 /* Bytes of device workspace taco_create needs for `cfg` (16 float4 state chunks + 16 float4 action-history rows +
- * 100 float4 ring slots per env, laid out in tiles of 64 envs, env count padded to whole tiles; the pointer must be
- * 256-byte aligned). */
+ * 100 float4 ring slots per env, laid out in tiles of 64 envs, env count padded to whole tiles; + 8 bytes per 16 envs for the
+ * device-resident step clock + a 256-byte control block; the pointer must be 256-byte aligned). */
 size_t taco_workspace_bytes(const taco_cfg *cfg);
 
 /* Replaces FpvBase.__init__ -> VecTask.__init__ -> create_sim/prepare_sim (fpv_asymmetry.py:54-200,
@@ -163,9 +163,10 @@ void taco_destroy(taco_env *env);
  *   timeout_buf [num_envs]               u8  out     extras["time_outs"]
  * One kernel launch, asynchronous on `stream`; no host synchronisation. */
 /* HIP graphs: the step index, ring head and history row advance with every call.  On the eager path they are kernel arguments (and every
- * launch leaves the next values in the workspace's control block); a call on a CAPTURING stream enqueues the step kernel reading that
- * device-resident clock and advancing it itself (the workgroup that is last to have read it writes the next values): ONE graph node per
- * step, and the captured graph can be replayed any number of times, continuing exactly where the eager steps (or earlier replays) stopped.
+ * launch leaves the next values in the workspace); a call on a CAPTURING stream enqueues the step kernel reading that device-resident
+ * clock and advancing it itself -- the workspace holds one copy of the clock per 16 envs, read and rewritten by the one wavefront that
+ * steps those envs, so no synchronisation between workgroups exists: ONE graph node per step, no slower than an eager step, and the
+ * captured graph can be replayed any number of times, continuing exactly where the eager steps (or earlier replays) stopped.
  * From the first capture on the clock lives on the device for good (the graph may be replayed at any time): every later launch of the handle
  * takes the device path, and taco_get_step_count / taco_set_step_count / taco_get_state / taco_set_state / taco_get_field /
  * taco_states_ring_row / taco_step_ring / an eager taco_rollout_run re-read it first (they block, device-wide). */

@@ -56,6 +56,7 @@ struct taco_env {
     int fusion_off;   // taco_set_rollout_fusion(env, 0): taco_rollout_run launches the actor and the step per step even where the persistent kernel applies
     unsigned long long *rollout_stamps;  // optional profiling buffer of the persistent rollout kernel (taco_bind_rollout_stamps)
     uint32_t *ctl;        // control block (last 256 bytes of the workspace): device-resident step clock + sticky status word
+    uint32_t *wclk;       // the same clock per 16 envs, where captured kernels take it from (taco_step.hpp "wclk"): in front of the control block
     int clock_on_device;  // a launch of this handle has been captured into a HIP graph (sticky): replays advance the device clock only, so from
                           // then on every launch reads the device clock and every host-side use of the fields above re-reads them first
     void *capture_stream; // the stream a launch of this handle was last seen CAPTURING on (refresh_clock refuses to synchronise while it still is)
@@ -183,14 +184,22 @@ __device__ __forceinline__ float &word(float *S, int npad, int i, int field) {
     const int sl = taco::field_slot(field);
     return S[taco::tile_word(taco::NUM_CHUNKS, sl >> 2, i) + (sl & 3)];
 }
-__global__ void advance_clock_kernel(uint32_t *ctl, uint32_t steps) {  // behind a captured PERSISTENT ROLLOUT kernel (a captured step kernel advances the clock itself)
-    ctl[taco::kCtlStep] += steps;
-    ctl[taco::kCtlHead] = (ctl[taco::kCtlHead] + 10u * steps) % TACO_RING_SLOTS;
-    ctl[taco::kCtlHh] = (ctl[taco::kCtlHh] + steps) % taco::HIST_ROWS;
+// host-initiated changes of the device-resident clock (taco_set_step_count, taco_bind_states_ring): every per-16-env pair + the control block
+__global__ void set_clock_kernel(uint32_t *wclk, uint32_t *ctl, int groups, int set_step, uint32_t step, int clear_phase) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < groups) {
+        if (set_step) wclk[2 * i] = step;
+        if (clear_phase) wclk[2 * i + 1] &= 0xffffu;
+    }
+    if (i == 0) {
+        if (set_step) ctl[taco::kCtlStep] = step;
+        if (clear_phase) ctl[taco::kCtlPhase] = 0u;
+    }
 }
-__global__ void init_state_kernel(float *S, float *hist, float *ring, uint32_t *ctl, int npad, float tau0, int delay_time) {
+__global__ void init_state_kernel(float *S, float *hist, float *ring, uint32_t *ctl, uint32_t *wclk, int npad, float tau0, int delay_time) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < (int)(taco::kCtlBytes / 4)) ctl[i] = 0u;
+    if (i < (int)taco::wclk_words(npad)) wclk[i] = 0u;
     if (i >= npad) return;
     for (int c = 0; c < (int)taco::NUM_CHUNKS; ++c)
         for (int k = 0; k < 4; ++k) S[taco::tile_word(taco::NUM_CHUNKS, c, i) + k] = 0.0f;
@@ -343,8 +352,11 @@ int choose_form(const taco_cfg &c) {
         return c.num_envs <= (stacks ? kQuadMaxEnvs : kSplitMaxEnvs) ? TACO_FORM_QUAD_ROLES : TACO_FORM_QUAD;
     }
     // One lane per env, 16 385 ... 65 536 envs with frame stacks: the same four-role form (64 envs per workgroup) hides the stack
-    // history, which a lone wavefront moves at only ~5 GB/s (tools/ubench/shift), under the substeps.
-    if (stacks && c.num_envs <= kSplitLaneMaxEnvs) return TACO_FORM_LANE_ROLES;
+    // history, which a lone wavefront moves at only ~5 GB/s (tools/ubench/shift), under the substeps.  Likewise -- stacks or not -- when the
+    // role wavefronts have something to SERVE: the rotor-noise table (config 5's flags on the states frame ring, one frame written:
+    // 23.5 vs 31.4 us at 32 768 envs, 28.9 vs 33.3 at 65 536; profiles/r04_d_ring_form_ab.txt) or the euler angles of flip envs.
+    const bool served = (c.flags & TACO_F_ROTOR_NOISE) != 0 || c.task_mode == TACO_TASK_FLIP || c.task_mode == TACO_TASK_MIX || (c.flags & TACO_F_TRACK_RPY) != 0;
+    if ((stacks || served) && c.num_envs <= kSplitLaneMaxEnvs) return TACO_FORM_LANE_ROLES;
     return c.num_envs >= kThroughputMinEnvs ? TACO_FORM_LANE_THROUGHPUT : TACO_FORM_LANE;
 }
 void grid_of_form(const taco_env *e, int form, int *grid, int *block) {
@@ -372,7 +384,8 @@ const char *taco_step_kernel_name(void) { return "taco_step_kernel"; }
 size_t taco_workspace_bytes(const taco_cfg *cfg) {
     if (!cfg || cfg->num_envs <= 0) return 0;
     const size_t npad = (size_t)round_up(cfg->num_envs, 64);
-    return (size_t)(taco::NUM_CHUNKS + taco::HIST_ROWS + TACO_RING_SLOTS) * npad * 4 * sizeof(float) + taco::kCtlBytes;
+    return (size_t)(taco::NUM_CHUNKS + taco::HIST_ROWS + TACO_RING_SLOTS) * npad * 4 * sizeof(float) +
+           (taco::wclk_words((int)npad) * sizeof(uint32_t) + 255) / 256 * 256 + taco::kCtlBytes;
 }
 
 int taco_create(const taco_cfg *cfg, int device, void *workspace, size_t workspace_bytes, void *stream, taco_env **out) {
@@ -393,7 +406,8 @@ int taco_create(const taco_cfg *cfg, int device, void *workspace, size_t workspa
     e->S = (float *)workspace;
     e->hist = e->S + (size_t)taco::NUM_CHUNKS * e->npad * 4;
     e->ring = e->hist + (size_t)taco::HIST_ROWS * e->npad * 4;
-    e->ctl = (uint32_t *)(e->ring + (size_t)TACO_RING_SLOTS * e->npad * 4);
+    e->wclk = (uint32_t *)(e->ring + (size_t)TACO_RING_SLOTS * e->npad * 4);
+    e->ctl = (uint32_t *)((char *)e->wclk + (taco::wclk_words(e->npad) * sizeof(uint32_t) + 255) / 256 * 256);
     e->clock_on_device = 0;
     e->capture_stream = nullptr;
     e->step_count = 0;
@@ -410,7 +424,7 @@ int taco_create(const taco_cfg *cfg, int device, void *workspace, size_t workspa
     e->rollout_stamps = nullptr;
     std::memset(&e->P, 0, sizeof(e->P));
     derive(e);
-    hipLaunchKernelGGL(init_state_kernel, dim3((e->npad + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->S, e->hist, e->ring, e->ctl, e->npad,
+    hipLaunchKernelGGL(init_state_kernel, dim3((e->npad + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->S, e->hist, e->ring, e->ctl, e->wclk, e->npad,
                        (float)cfg->rotor_response_time, cfg->delay_time);
     he = hipGetLastError();
     if (he != hipSuccess) { delete e; return hip_fail(he, "init_state_kernel launch"); }
@@ -449,7 +463,7 @@ int launch_step(taco_env *e, const taco_rollout_io *io, void *stream) {
     P.stamps = e->stamps;
     P.obs_out = io->obs_out; P.states_out = io->states_out;
     if ((((uintptr_t)P.obs_out | (uintptr_t)P.states_out) & 15u) != 0) return fail(TACO_ERR_INVALID_ARG, "obs_out / states_out must be 16-byte aligned");
-    P.ctl = e->ctl;
+    P.ctl = e->ctl; P.wclk = e->wclk;
     P.use_ctl = e->clock_on_device;
     P.step = (uint32_t)e->step_count;
     P.obs_bytes = (uint32_t)((size_t)n_envs * e->cfg.len_obs * 26 * sizeof(float));
@@ -482,7 +496,7 @@ int launch_step(taco_env *e, const taco_rollout_io *io, void *stream) {
                                     (hipStream_t)stream);
     if (he == hipSuccess) he = hipGetLastError();
     if (he != hipSuccess) return hip_fail(he, "taco_step_kernel launch");
-    // (a launch that took its clock from the control block -- use_ctl -- advances it itself: last-ticket workgroup, taco_step.hpp)
+    // (every launch leaves the next clock on the device itself -- taco_step.hpp "wclk" --, captured or not)
     e->step_count += 1;
     e->head = (e->head + 10) % TACO_RING_SLOTS;
     e->hh = (e->hh + 1) % taco::HIST_ROWS;
@@ -507,7 +521,7 @@ int taco_reset_done(taco_env *e, int64_t *reset_buf, void *stream) {
     taco::StepParams P = e->P;
     P.S = e->S; P.ring = e->ring; P.hist = e->hist;
     P.reset = (long long *)reset_buf;
-    P.ctl = e->ctl; P.use_ctl = e->clock_on_device;
+    P.ctl = e->ctl; P.wclk = e->wclk; P.use_ctl = e->clock_on_device;
     P.step = (uint32_t)e->step_count; P.head = e->head; P.hh = e->hh;   // the clock of the NEXT step: it does not advance here
     P.stamps = nullptr;
     void *args[] = {&P};
@@ -611,9 +625,13 @@ int taco_set_step_count(taco_env *e, int64_t n) {
     if (!e || n < 0) return fail(TACO_ERR_INVALID_ARG, "taco_set_step_count: bad argument");
     const int rc = refresh_clock(e);
     if (rc != TACO_OK) return rc;
-    const uint32_t word = (uint32_t)n;
-    hipError_t he = hipDeviceSynchronize();   // an eager step still in flight would overwrite the word with ITS successor
-    if (he == hipSuccess) he = hipMemcpy(e->ctl + taco::kCtlStep, &word, sizeof(word), hipMemcpyHostToDevice);
+    hipError_t he = hipDeviceSynchronize();   // an eager step still in flight would overwrite the words with ITS successor
+    if (he == hipSuccess) {
+        const int groups = e->npad / 16;
+        hipLaunchKernelGGL(set_clock_kernel, dim3((groups + 255) / 256), dim3(256), 0, (hipStream_t) nullptr, e->wclk, e->ctl, groups, 1, (uint32_t)n, 0);
+        he = hipGetLastError();
+        if (he == hipSuccess) he = hipDeviceSynchronize();
+    }
     if (he != hipSuccess) return hip_fail(he, "writing the device-resident step clock");
     e->step_count = n;
     return TACO_OK;
@@ -910,9 +928,10 @@ int taco_rollout_run(taco_env *e, const taco_policy_cfg *c, const float *blob, c
         // the whole per-step chain as ONE persistent launch (taco_fused.hpp): a workgroup owns 16 envs for all `horizon` steps
         taco::RolloutParams R{};
         R.S = e->P;
-        R.S.S = e->S; R.S.ring = e->ring; R.S.hist = e->hist; R.S.reset = (long long *)reset_buf; R.S.ctl = e->ctl; R.S.use_ctl = e->clock_on_device;
+        R.S.S = e->S; R.S.ring = e->ring; R.S.hist = e->hist; R.S.reset = (long long *)reset_buf; R.S.ctl = e->ctl; R.S.wclk = e->wclk; R.S.use_ctl = e->clock_on_device;
+        R.S.st_period = 0; R.S.st_phase = e->st_phase; R.S.st_front = 0;
         R.S.step = (uint32_t)e->step_count; R.S.head = e->head; R.S.hh = e->hh; R.S.gather_row = (uint32_t)taco_gather_row_floats(1); R.S.gather_bytes = 0;
-        R.blob = blob; R.pseed_lo = (uint32_t)seed; R.pseed_hi = (uint32_t)(seed >> 32); R.call0 = call0; R.clock = clock; R.call_delta = call_delta;
+        R.blob = blob; R.pseed_lo = (uint32_t)seed; R.pseed_hi = (uint32_t)(seed >> 32); R.call0 = call0; R.call_delta = call_delta;
         R.act_lo = (float)act_lo; R.act_hi = (float)act_hi;
         R.obs_store = b->obs_store; R.frames = b->states_store; R.act_buf = b->act_buf; R.mu_buf = b->mu_buf; R.sigma_buf = b->sigma_buf;
         R.logp_buf = b->logp_buf; R.rew_buf = b->rew_buf; R.done_buf = b->done_buf; R.timeout_buf = b->timeout_buf;
@@ -920,12 +939,7 @@ int taco_rollout_run(taco_env *e, const taco_policy_cfg *c, const float *blob, c
         hipLaunchKernelGGL(taco::taco_rollout_kernel, dim3((unsigned)((n + taco::POL_ROWS - 1) / taco::POL_ROWS)), dim3(taco::FU_THREADS), 0, (hipStream_t)stream, R);
         hipError_t he = hipGetLastError();
         if (he != hipSuccess) return hip_fail(he, "taco_rollout_kernel launch");
-        if (e->clock_on_device) {
-            hipLaunchKernelGGL(advance_clock_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, e->ctl, (uint32_t)horizon);
-            he = hipGetLastError();
-            if (he != hipSuccess) return hip_fail(he, "advance_clock_kernel launch");
-        }
-        e->step_count += horizon;
+        e->step_count += horizon;   // (the kernel left the clock after `horizon` steps on the device itself)
         e->head = (e->head + 10 * horizon) % TACO_RING_SLOTS;
         e->hh = (e->hh + horizon) % taco::HIST_ROWS;
     }
@@ -966,9 +980,13 @@ int taco_bind_states_ring(taco_env *e, float *ring, int rows) {
     }
     const int rc = refresh_clock(e);
     if (rc != TACO_OK) return rc;
-    const uint32_t zero = 0u;
     hipError_t he = hipDeviceSynchronize();   // (a step in flight would write ITS successor phase behind this)
-    if (he == hipSuccess) he = hipMemcpy(e->ctl + taco::kCtlPhase, &zero, sizeof(zero), hipMemcpyHostToDevice);
+    if (he == hipSuccess) {
+        const int groups = e->npad / 16;
+        hipLaunchKernelGGL(set_clock_kernel, dim3((groups + 255) / 256), dim3(256), 0, (hipStream_t) nullptr, e->wclk, e->ctl, groups, 0, 0u, 1);
+        he = hipGetLastError();
+        if (he == hipSuccess) he = hipDeviceSynchronize();
+    }
     if (he != hipSuccess) return hip_fail(he, "taco_bind_states_ring: resetting the ring phase");
     e->st_ring = ring; e->st_rows = ring ? rows : 0; e->st_period = ring ? rows - front : 0; e->st_phase = 0;
     return TACO_OK;

@@ -33,8 +33,7 @@ struct RolloutParams {
                            // per-step output pointers below replace its obs / states / rew / ... members
     const float *blob;     // packed policy weights (taco_amd/policy.py::pack_state_dict): the documented actor at its head
     uint32_t pseed_lo, pseed_hi, call0;
-    const uint32_t *clock; // non-NULL (captured launch): the actor's noise counter of step t is *clock + call_delta + t
-    uint32_t call_delta;
+    uint32_t call_delta;   // captured launch (S.use_ctl): the actor's noise counter of step t is (the device-resident step word) + call_delta + t
     float act_lo, act_hi;
     float *obs_store;      // [horizon + 1][n][26]
     float *frames;         // [horizon + len_states][n][26]   the states frame ring
@@ -59,10 +58,14 @@ __global__ __launch_bounds__(FU_THREADS) void taco_rollout_kernel(const RolloutP
     const int actor = wave == 2 ? 0 : wave == 6 ? 1 : wave == 3 ? 2 : wave == 7 ? 3 : -1;        // which of the four actor wavefronts it is
     if (R.stamps && blockIdx.x == 0 && lane == 0) R.stamps[wave] = (__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 4) & 3u;   // HW_ID.SIMD_ID
     // the step clock, as the step kernel takes it: kernel arguments, or the device-resident copy when this launch was captured into a graph
-    const __attribute__((address_space(4))) uint32_t *ctl_c = (const __attribute__((address_space(4))) uint32_t *)R.S.ctl;
+    // (the workgroup's own pair of the per-16-env clock, taco_step.hpp "wclk": read here, rewritten by this workgroup when the rollout is done)
+    const __attribute__((address_space(4))) uint32_t *wc =
+        (const __attribute__((address_space(4))) uint32_t *)(R.S.wclk + (size_t)blockIdx.x * kWclkWordsPerGroup);
     const bool from_ctl = R.S.use_ctl != 0;
-    const uint32_t step0 = from_ctl ? ctl_c[kCtlStep] : R.S.step;
-    const int head0 = from_ctl ? (int)ctl_c[kCtlHead] : R.S.head, hh0 = from_ctl ? (int)ctl_c[kCtlHh] : R.S.hh;
+    const uint32_t c_step = wc[0], c_aux = wc[1];
+    const uint32_t step0 = from_ctl ? c_step : R.S.step;
+    const int head0 = from_ctl ? wclk_head(c_aux) : R.S.head, hh0 = from_ctl ? wclk_hh(c_aux) : R.S.hh;
+    const int phase0 = from_ctl ? wclk_phase(c_aux) : R.S.st_phase;
     const int H = R.horizon;
     const size_t frame = (size_t)n * 26;
     // the starting observation -> the actor's input rows (columns 26..31 stay zero: the weights' k range is padded to 32)
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(FU_THREADS) void taco_rollout_kernel(const RolloutP
         };
         PolicyParams PP{};   // what sample4 reads
         PP.n = n; PP.deterministic = 0; PP.seed_lo = R.pseed_lo; PP.seed_hi = R.pseed_hi; PP.act_lo = R.act_lo; PP.act_hi = R.act_hi; PP.action_env = nullptr;
-        const uint32_t call_base = R.clock ? R.clock[0] + R.call_delta : R.call0;
+        const uint32_t call_base = from_ctl ? step0 + R.call_delta : R.call0;   // (the workgroup's own clock pair: the control block is rewritten by workgroup 0 when IT is done)
 #pragma unroll 1
         for (int t = 0; t < H; ++t) {
             __syncthreads();   // barrier 1 of the step: obs_t is in xin
@@ -192,11 +195,14 @@ __global__ __launch_bounds__(FU_THREADS) void taco_rollout_kernel(const RolloutP
         }
         if (R.stamps && tid == 0) R.stamps[136 + blockIdx.x] = __builtin_readcyclecounter() - loop_t0;
     }
-    // eager launch: leave the clock after `horizon` steps in the control block, as every step launch does (a captured launch is followed by
-    // advance_clock_kernel instead: nothing may write the clock while other workgroups still read it)
-    if (!from_ctl && blockIdx.x == 0 && tid == 0) {
-        R.S.ctl[kCtlStep] = R.S.step + (uint32_t)H; R.S.ctl[kCtlHead] = (uint32_t)((R.S.head + 10 * H) % TACO_RING_SLOTS);
-        R.S.ctl[kCtlHh] = (uint32_t)((R.S.hh + H) % HIST_ROWS);
+    // leave the clock after `horizon` steps in this workgroup's pair and (workgroup 0) in the control block, as every step launch does: no
+    // wavefront of this workgroup reads the pair any more (they took it H steps of barriers ago), nobody reads the control block in a launch
+    if (wave == 0 && lane == 0) {
+        const uint32_t nstep = step0 + (uint32_t)H;
+        const int nhead = (head0 + 10 * H) % TACO_RING_SLOTS, nhh = (hh0 + H) % HIST_ROWS;
+        uint32_t *w = R.S.wclk + (size_t)blockIdx.x * kWclkWordsPerGroup;
+        w[0] = nstep; w[1] = wclk_aux(nhead, nhh, phase0);
+        if (blockIdx.x == 0) { R.S.ctl[kCtlStep] = nstep; R.S.ctl[kCtlHead] = (uint32_t)nhead; R.S.ctl[kCtlHh] = (uint32_t)nhh; }
     }
 }
 

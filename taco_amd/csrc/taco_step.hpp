@@ -42,8 +42,9 @@ struct StepParams {
     float *gather;       // optional [n][len_obs*26 + 3] f32: obs stack | reward | done | time-out (one all-gather block per rank)
     float *obs_out;      // optional [n][len_obs][26]: clamp(new obs stack, +-clip_obs), the copy VecTask.step returns (VT:331); NULL = none
     float *states_out;   // optional [n][len_states][26]: clamp(new states stack, +-clip_states) (VT:332)
-    uint32_t *ctl;       // control block in the workspace (kCtl*): the device-resident step clock + the sticky status word
-    int use_ctl;         // 1: take step / head / hh from ctl (launch captured into a HIP graph: kernel arguments are frozen); 0: from below
+    uint32_t *ctl;       // control block in the workspace (kCtl*): the device-resident step clock (the copy the HOST reads back) + the sticky status word
+    uint32_t *wclk;      // [ceil(npad / 16)][2] the device-resident step clock AS THE KERNELS READ IT: one {step, aux} pair per 16 envs (see "wclk" below)
+    int use_ctl;         // 1: take step / head / hh / ring phase from wclk (launch captured into a HIP graph: kernel arguments are frozen); 0: from below
     // geometry / cfg
     int n, npad, env_offset, task_mode, mix_n1, mix_n2, len_obs, len_states, substeps, max_len, delay_time, head;
     uint32_t flags, seed_lo, seed_hi, step;
@@ -95,10 +96,23 @@ enum Chunk : uint32_t {
     NUM_CHUNKS = 16
 };
 constexpr int HIST_ROWS = 16;  // action history: hist[tile][k][64] float4, the action of the step whose (count & 15) == k
-// control block: the last 256 bytes of the workspace.  Words: 0 step count, 1 ring head, 2 history row (the step CLOCK: every eager launch
-// leaves the next values here, a graph-captured launch reads them and the last of its workgroups to have read them advances them), 4 sticky status bits,
-// 3 phase of the states frame ring (taco_bind_states_ring), 5 ticket counter of a captured step (see step_core)
-enum : uint32_t { kCtlStep = 0, kCtlHead = 1, kCtlHh = 2, kCtlPhase = 3, kCtlStatus = 4, kCtlTicket = 5, kCtlBytes = 256 };
+// control block: the last 256 bytes of the workspace.  Words: 0 step count, 1 ring head, 2 history row, 3 phase of the states frame ring
+// (taco_bind_states_ring) -- the step CLOCK as the host reads it back (refresh_clock): workgroup 0 of every launch leaves the NEXT values
+// here --, 4 sticky status bits.
+enum : uint32_t { kCtlStep = 0, kCtlHead = 1, kCtlHh = 2, kCtlPhase = 3, kCtlStatus = 4, kCtlBytes = 256 };
+// wclk: the same clock where the KERNELS take it from when their arguments are frozen in a HIP graph: one {step, aux} pair per 16 envs
+// (aux = ring head | history row << 8 | frame-ring phase << 16), all pairs equal between launches.  A step wavefront reads the pair of its own
+// envs and leaves the next values there when it is done -- every word has ONE reader-writer per launch, so a captured step advances the clock
+// with no synchronisation between workgroups at all and is ONE graph node.  (Round 2-3 kept one global clock and appended a one-thread
+// kernel to every captured step: +1.2 us per step; a last-ticket scheme on the global words cost more -- 256 agent-scope atomics on one
+// address take ~10 us on an eight-XCD part, and vmcnt retires in order.)  Eager launches take the clock from their arguments and write the
+// pairs just the same, so that a capture can start at any time.
+constexpr uint32_t kWclkWordsPerGroup = 2;
+__host__ __device__ constexpr uint32_t wclk_aux(int head, int hh, int phase) { return (uint32_t)head | ((uint32_t)hh << 8) | ((uint32_t)phase << 16); }
+__host__ __device__ constexpr int wclk_head(uint32_t aux) { return (int)(aux & 0xffu); }
+__host__ __device__ constexpr int wclk_hh(uint32_t aux) { return (int)((aux >> 8) & 0xffu); }
+__host__ __device__ constexpr int wclk_phase(uint32_t aux) { return (int)(aux >> 16); }
+__host__ __device__ constexpr size_t wclk_words(int npad) { return (size_t)(npad / 16) * kWclkWordsPerGroup; }
 constexpr uint32_t kStatusMailboxTimeout = 1u;  // a battery-mailbox wait gave up (the affected envs' voltage was poisoned with NaN)
 constexpr uint32_t kRowBytes = 1024;  // one row (chunk, history row or ring slot) of one tile: 64 lanes x 16 B
 // float index of word 0 of (row r, env i) in an array with `rows` rows per tile (host-side kernels of taco_capi.hip)
@@ -758,35 +772,29 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     // at any time); the device-resident copy when this launch was captured into a HIP graph (its arguments are frozen)
     // (read unconditionally by scalar loads through the constant address space and selected without a branch: while a captured step kernel
     // runs nothing writes the clock -- the advance kernel comes after it -- and on the eager path the loaded values are simply not used)
-    const __attribute__((address_space(4))) uint32_t *ctl_c = (const __attribute__((address_space(4))) uint32_t *)P.ctl;
-    const uint32_t c_step = ctl_c[kCtlStep], c_head = ctl_c[kCtlHead], c_hh = ctl_c[kCtlHh], c_phase = ctl_c[kCtlPhase];
+    // (this wavefront's pair of wclk: envs [wave_env0, wave_env0 + 64 / LPE) -- the expression of wave_env0 below)
+    const uint32_t clk_env0 = SPLIT ? (uint32_t)(blockIdx.x * 64 / LPE) : (uint32_t)((blockIdx.x * BLOCK + (threadIdx.x >> 6) * 64) / LPE);
+    const __attribute__((address_space(4))) uint32_t *wc =
+        (const __attribute__((address_space(4))) uint32_t *)(P.wclk + (size_t)(clk_env0 >> 4) * kWclkWordsPerGroup);
     const bool from_ctl = P.use_ctl != 0;
-    const struct { uint32_t step; int head, hh, phase; } clk{FUSED ? FX.step : (from_ctl ? c_step : P.step), FUSED ? FX.head : (from_ctl ? (int)c_head : P.head),
-                                                             FUSED ? FX.hh : (from_ctl ? (int)c_hh : P.hh), from_ctl ? (int)c_phase : P.st_phase};
-    uint32_t ticket = 0u;
-    if constexpr (!FUSED && !RESET_ONLY) {
-        const uint32_t ph1 = P.st_period > 0 ? (uint32_t)((clk.phase + 1) % P.st_period) : 0u;
-        if (!from_ctl) {
-            if (blockIdx.x == 0 && threadIdx.x == 0) {
-                P.ctl[kCtlStep] = P.step + 1u; P.ctl[kCtlHead] = (uint32_t)((P.head + 10) % TACO_RING_SLOTS); P.ctl[kCtlHh] = (uint32_t)((P.hh + 1) % HIST_ROWS);
-                if (P.st_period > 0) P.ctl[kCtlPhase] = ph1;   // (a launch that does not write the ring leaves its phase alone)
-            }
-        } else if (threadIdx.x == 0) {
-            // A CAPTURED step (its kernel arguments are frozen in the graph) advances the device-resident clock itself: every workgroup takes a
-            // ticket once its own scalar reads of the clock have landed, and the one that draws the last ticket -- every workgroup of the launch
-            // has read the clock by then -- writes the next values and re-arms the counter (`advance_clock` below, where the step's up-front
-            // loads have landed: the ticket comes back with them, no wait of its own).  The next launch of the stream sees them: ONE graph node
-            // per step (rounds 2-3 appended a one-thread kernel to every captured step).
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            ticket = __hip_atomic_fetch_add(&P.ctl[kCtlTicket], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    auto advance_clock = [&]() {   // (thread 0 of every workgroup of a captured launch)
+    uint32_t c_step = 0u, c_aux = 0u;
+    if (!FUSED && clk_env0 < (uint32_t)P.n) { c_step = wc[0]; c_aux = wc[1]; }   // (wave-uniform; a wavefront past the last env returns below)
+    const struct { uint32_t step; int head, hh, phase; } clk{FUSED ? FX.step : (from_ctl ? c_step : P.step), FUSED ? FX.head : (from_ctl ? wclk_head(c_aux) : P.head),
+                                                             FUSED ? FX.hh : (from_ctl ? wclk_hh(c_aux) : P.hh), from_ctl ? wclk_phase(c_aux) : P.st_phase};
+    // the next values, left in this wavefront's pairs (and, by workgroup 0, in the control block) when the step wavefront is done: by then every
+    // wavefront of the workgroup has its copy (the role wavefronts wait for theirs ahead of barrier 2)
+    auto publish_clock = [&]() {
         if constexpr (!FUSED && !RESET_ONLY) {
-            if (from_ctl && threadIdx.x == 0 && ticket == gridDim.x - 1u) {
-                P.ctl[kCtlTicket] = 0u;
-                P.ctl[kCtlStep] = c_step + 1u; P.ctl[kCtlHead] = (c_head + 10u) % TACO_RING_SLOTS; P.ctl[kCtlHh] = (c_hh + 1u) % HIST_ROWS;
-                if (P.st_period > 0) P.ctl[kCtlPhase] = (uint32_t)((clk.phase + 1) % P.st_period);
+            if ((threadIdx.x & 63) == 0) {
+                const int nhead = clk.head + 10 >= TACO_RING_SLOTS ? clk.head + 10 - TACO_RING_SLOTS : clk.head + 10, nhh = (clk.hh + 1) & (HIST_ROWS - 1);
+                const int nphase = P.st_period > 0 ? (clk.phase + 1 == P.st_period ? 0 : clk.phase + 1) : clk.phase;   // (a launch that does not write the ring leaves its phase alone)
+                const uint32_t nstep = clk.step + 1u, naux = wclk_aux(nhead, nhh, nphase);
+                uint32_t *w = P.wclk + (size_t)(clk_env0 >> 4) * kWclkWordsPerGroup;
+#pragma unroll
+                for (int gq = 0; gq < (64 / LPE) / 16; ++gq) { w[2 * gq] = nstep; w[2 * gq + 1] = naux; }
+                if (blockIdx.x == 0 && threadIdx.x == 0) {
+                    P.ctl[kCtlStep] = nstep; P.ctl[kCtlHead] = (uint32_t)nhead; P.ctl[kCtlHh] = (uint32_t)nhh; P.ctl[kCtlPhase] = (uint32_t)nphase;
+                }
             }
         }
     };
@@ -983,7 +991,6 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // (the target pose and the unwrapped angles it stored are loaded further down)
     }
     if (P.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TACO_STAMP(1); }  // all up-front loads have landed
-    advance_clock();
     V3 p{c_pos.x, c_pos.y, c_pos.z};
     Q4 q{c_quat.x, c_quat.y, c_quat.z, c_quat.w};
     V3 v{c_lin.x, c_lin.y, c_lin.z};
@@ -1745,6 +1752,7 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
         CST(C_LINVEL, make_float4(v.x, v.y, v.z, as_f((int)make_dw(dlen, zlead, q_m, q_rem0, q_lens, dense))));
         CST(C_MISC, make_float4(bat_t, cmd0, cmd1, flip_radian));
     }
+    publish_clock();
     if (ROLES) { TACO_STAMP(4); TACO_STAMP(5); return; }  // wave 0 is done; the roles below belong to the other three wavefronts
     } else {
         if (wv == 1 && lane < 8) mb_seq[lane] = 0;
@@ -1831,6 +1839,8 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
                 MB_POST(1, ks == 9 ? 11 : ks + 1);
             }
         }
+        // (wavefront 0 rewrites this workgroup's clock pair when it is done: this wavefront's scalar reads of it have landed long ago -- made explicit)
+        if (from_ctl) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if constexpr (PAIR) return;   // (the serving wavefront of the two-wavefront form has no post-phase role and nothing to wait for)
         __syncthreads();  // barrier 2 of 2
         const float4 *h4 = reinterpret_cast<const float4 *>(hand + el * CARRY_WORDS);

@@ -72,9 +72,9 @@ int main(void) {
 
 def test_workspace_size_and_argument_errors(lib):
     c = _lib.make_cfg(config.flat_cfg(config.baseline_config(1)))
-    assert lib.taco_workspace_bytes(C.byref(c)) == (16 + 16 + 100) * 16 * 4096 + 256
+    assert lib.taco_workspace_bytes(C.byref(c)) == (16 + 16 + 100) * 16 * 4096 + 4096 // 16 * 8 + 256   # + the per-16-env step clock (2 words each)
     c65 = _lib.make_cfg(config.flat_cfg(config.baseline_config(1, num_envs=65)))
-    assert lib.taco_workspace_bytes(C.byref(c65)) == (16 + 16 + 100) * 16 * 128 + 256   # padded to whole tiles, + the control block
+    assert lib.taco_workspace_bytes(C.byref(c65)) == (16 + 16 + 100) * 16 * 128 + 256 + 256   # padded to whole tiles, + the step clock (8 x 8 B, padded to 256) + the control block
     assert lib.taco_workspace_bytes(None) == 0
     h = C.c_void_p()
     # invalid configuration / workspace are rejected before any HIP call

@@ -549,10 +549,12 @@ def test_bench_line_contract():
     assert c["kind"] == "port" and c["cores"] >= 1 and [x["config"] for x in c["configs"]] == [1, 3]
     assert d["parity"]["all_words_bit_equal"] and d["parity"]["done_flags_equal"]
     assert abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
-    # SURVEY 8(d) configs 3-5 at their per-GPU shapes; config 5's stacked states priced at SURVEY's 1 236 B
+    # SURVEY 8(d) configs 3-5 at their per-GPU shapes
     cfgs = d["configs"]
     assert [(x["config"], x.get("task_mode"), x["envs"]) for x in cfgs[:3]] == [(3, "rotate", 16384), (4, "flip", 16384), (5, "mix", 32768)]
-    assert cfgs[2]["len_states"] == 5 and cfgs[2]["algorithmic_bytes_per_env_step"] == 1236.0 and "observation_noise" in cfgs[2]["flags_on"]
+    # (config 5's state stack lives in the frame ring behind VecTask.step(): one frame written, the algorithmic 820 B; the materialised stack beside it at SURVEY's 1 236 B)
+    assert cfgs[2]["len_states"] == 5 and cfgs[2]["algorithmic_bytes_per_env_step"] == 820.0 and "observation_noise" in cfgs[2]["flags_on"]
+    assert cfgs[2]["materialised_stack"]["algorithmic_bytes_per_env_step"] == 1236.0 and cfgs[2]["materialised_stack"]["kernel_us"] > cfgs[2]["kernel_us"]
     assert cfgs[3]["config"] == 5 and cfgs[3]["env_steps_per_s"] > 0, cfgs[3]
     # the headline IS VecTask.step(): ping-pong buffer pairs, the launch step_raw() makes (the host-side dict is all it adds)
     assert "VecTask.step()" in d["metric"] and d["steady_state"]["api"] == "VecTask.step()"
