@@ -879,6 +879,7 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     float *const eq_tab = lds_all + WAVE_LDS_WORDS;
     __shared__ float eu_io[EULER_TAB ? (LPE == 4 ? 2 : 6) * 64 : 4];
     constexpr bool NOISE_TAB = SPLIT && !(WIDE && LPE == 4);
+    constexpr bool NOISE_INLINE = !SPLIT;   // the one-wavefront instantiations have nobody to serve a table: their PLAIN forms draw the rotor noise themselves
     // (rn_tab lives in `hand`: the table is read by the substeps, the Carry is written after the last one and read after barrier 2; the
     // server writes the next table only after barrier 1 of the next step)
     static_assert(!NOISE_TAB || (64 / LPE) * 40 >= 10 * (64 / LPE) * 4, "rn_tab must fit in the Carry block");
@@ -1263,7 +1264,8 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     // (rotor noise: PLAIN forms exist for it where the noise table is served -- bit 4 of the form; + bit 3: euler/unwrap on or off)
     // The PLAIN forms are the DEFAULT arithmetic: the body rates make the reference's round trip through the root state after every simulate()
     // (TACO_F_WORLD_RATE_ROUNDTRIP, FA:350); the "carried" mode (flag cleared) runs the general forms.
-    const bool plain1 = (!(fl & TACO_F_ROTOR_NOISE) || noise_served) && (fl & TACO_F_WORLD_RATE_ROUNDTRIP) != 0 && P.substeps == 2 && (fl & TACO_F_BATTERY_CONSUMPTION) != 0;
+    // (the instantiations without role wavefronts -- no one to serve a noise table -- draw the rotor noise inside their PLAIN forms, behind a launch-uniform branch)
+    const bool plain1 = (!(fl & TACO_F_ROTOR_NOISE) || noise_served || NOISE_INLINE) && (fl & TACO_F_WORLD_RATE_ROUNDTRIP) != 0 && P.substeps == 2 && (fl & TACO_F_BATTERY_CONSUMPTION) != 0;
     // one lane per env: the PLAIN forms also carry the default airframe's constants as literals (kPlainConsts: the handle has exactly those)
     const bool plain = plain1 && (LPE != 1 || (fl & kPlainConsts) != 0);
     if constexpr (LPE == 1) {
@@ -1280,10 +1282,13 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
             Consts C;  // PLAIN: the default airframe as literals; otherwise the handle's values (SGPR operands)
             if constexpr (PLAIN) C = kDefaultConsts; else C = Crt;
             // refresh_state, the part the inner loop consumes FA:339-350
-            if (EULER_TAB && (PLAIN ? (MODE & 8) != 0 : wave_tracks_rpy)) {
+            // (CAP: the throughput instantiation has ONE PLAIN form -- a second one for wavefronts that hold flip envs costs it 28 spilled VGPRs --
+            // with the euler / unwrap block behind a wave-uniform branch: four wavefronts share the SIMD there, a branch is cheap)
+            const bool eul = (PLAIN && !CAP) ? (MODE & 8) != 0 : wave_tracks_rpy;
+            if (EULER_TAB && eul) {
                 reinterpret_cast<float4 *>(eq_tab)[ks * 64 + lane] = make_float4(q.x, q.y, q.z, q.w);   // the euler server takes it from here
                 MB_POST(3, ks + 1);
-            } else if (PLAIN ? (MODE & 8) != 0 : wave_tracks_rpy) {
+            } else if (eul) {
                 V3 e = euler_xyz_v1(q);
                 unwrap(e.x, rpy_old[0], rpy_cont[0]);
                 unwrap(e.y, rpy_old[1], rpy_cont[1]);
@@ -1364,7 +1369,7 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
                 }
                 const float4 f4 = reinterpret_cast<const float4 *>(rn_tab)[ks * EPW + el];
                 omega[0] = omega[0] * f4.x; omega[1] = omega[1] * f4.y; omega[2] = omega[2] * f4.z; omega[3] = omega[3] * f4.w;
-            } else if (!PLAIN && (fl & TACO_F_ROTOR_NOISE)) {  // CTRL/thrust_dynamics.py:68-78
+            } else if ((!PLAIN || NOISE_INLINE) && (fl & TACO_F_ROTOR_NOISE)) {  // CTRL/thrust_dynamics.py:68-78
                 U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, clk.step, STREAM_ROTOR, (uint32_t)ks);
                 const float n_sc = (float)((1 + 10.0 / 700) - (1 - 10.0 / 700)), n_lo = (float)(1 - 10.0 / 700);
                 omega[0] = omega[0] * (n_sc * uniform(r.x) + n_lo);
@@ -1400,14 +1405,14 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
         };
         // the FIN form of the loop runs while `fin` holds (normally all ten substeps), the exact form takes over at the first rare form
         int ks = 0;
-        if (fin && plain && !wave_tracks_rpy) {
+        if (fin && plain && (CAP || !wave_tracks_rpy)) {
     #pragma unroll 1
             while (ks < 10) {
                 const bool rare = substep(std::integral_constant<int, 2>{}, ks);
                 ++ks;
                 if (rare) break;
             }
-        } else if (!CAP && fin && plain) {  // (the throughput instantiation keeps two forms: a third costs it 80 B of spills)
+        } else if (!CAP && fin && plain) {  // (the throughput instantiation keeps two forms: a third costs it 28 spilled VGPRs)
     #pragma unroll 1
             while (ks < 10) {
                 const bool rare = substep(std::integral_constant<int, 10>{}, ks);
@@ -1543,7 +1548,7 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
             }
             if constexpr (NOISY) {
                 omq = omq * rn_tab[(ks * EPW + el) * 4 + sub];   // CTRL/thrust_dynamics.py:68-78, the factor drawn by the obs role wavefront
-            } else if (!PLAIN && (fl & TACO_F_ROTOR_NOISE)) {  // CTRL/thrust_dynamics.py:68-78
+            } else if ((!PLAIN || NOISE_INLINE) && (fl & TACO_F_ROTOR_NOISE)) {  // CTRL/thrust_dynamics.py:68-78
                 if (noise_served) {
                     omq = omq * rn_tab[(ks * EPW + el) * 4 + sub];
                 } else {
