@@ -374,3 +374,27 @@ def policy_noise(seed, call, n, act_dim=4):
     fn = lib().orc_policy_noise; fn.restype = None
     fn(C.c_uint64(seed), C.c_uint32(call), C.c_int(n), C.c_int(act_dim), _p(eps))
     return eps
+
+
+def rollout(env, cfg, blob, horizon, seed, call0, gamma, obs0, states0, act_lo=-1.0, act_hi=1.0):
+    """orc_rollout: one PPO rollout (ppo_asymmetry.py:308-342) of OracleEnv `env` under the policy (cfg, blob), starting from the stacks
+    obs0 [n, obs_len, 26] / states0 [n, states_len, 26] and env.reset_buf.  -> dict of the replay-buffer arrays ([H(+1), n, ...], materialised
+    stacks) + last_value; env (state, reset_buf) is left where the rollout ended."""
+    n, H = env.n, int(horizon)
+    blob = _f32(blob)
+    assert blob.size == policy_blob_floats(cfg)
+    out = {"obs": np.zeros((H + 1, n, cfg.obs_len, 26), np.float32), "states": np.zeros((H + 1, n, cfg.states_len, 26), np.float32),
+           "act": np.zeros((H, n, 4), np.float32), "rew": np.zeros((H, n), np.float32), "done": np.zeros((H, n), np.float32),
+           "value": np.zeros((H, n), np.float32), "logp": np.zeros((H, n), np.float32), "mu": np.zeros((H, n, 4), np.float32),
+           "sigma": np.zeros((H, n, 4), np.float32), "timeout": np.zeros((H, n), np.uint8), "last_value": np.zeros(n, np.float32)}
+    out["obs"][0], out["states"][0] = obs0, states0
+    fn = lib().orc_rollout
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.POINTER(OrcPolicyCfg), C.c_void_p, C.c_int, C.c_uint64, C.c_uint32, C.c_double, C.c_double, C.c_double] + [C.c_void_p] * 12
+    rc = fn(env._h, C.byref(cfg), _p(blob), H, seed, call0, float(gamma), float(act_lo), float(act_hi), _p(env.reset_buf), _p(out["obs"]), _p(out["states"]),
+            _p(out["act"]), _p(out["rew"]), _p(out["done"]), _p(out["value"]), _p(out["logp"]), _p(out["mu"]), _p(out["sigma"]), _p(out["timeout"]),
+            _p(out["last_value"]))
+    if rc != 0:
+        raise ValueError("orc_rollout rejected its arguments")
+    env.obs_buf[:], env.states_buf[:] = out["obs"][H], out["states"][H]
+    return out

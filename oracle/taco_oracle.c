@@ -592,6 +592,7 @@ void orc_set_threads(orc_env *e, int n) { e->threads = n < 1 ? 1 : n; }
  * compared with that run bit for bit. */
 void orc_set_world_rate_roundtrip(orc_env *e, int on) { e->world_rate_roundtrip = on ? 1 : 0; }
 int64_t orc_step_count(const orc_env *e) { return e->step_count; }
+int orc_num_envs(const orc_env *e) { return e->cfg.num_envs; }
 void orc_set_step_count(orc_env *e, int64_t n) { e->step_count = n; }
 
 typedef struct { uint64_t seed; uint32_t gid, step, stream; uint32_t blk_id; uint32_t blk[4]; int have; } draw_ctx;

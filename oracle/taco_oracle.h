@@ -96,6 +96,7 @@ int orc_create(const orc_cfg *cfg, orc_env **out);
 void orc_destroy(orc_env *e);
 void orc_set_difficulty(orc_env *e, double difficulty);
 void orc_set_threads(orc_env *e, int nthreads);
+int orc_num_envs(const orc_env *e);
 void orc_set_world_rate_roundtrip(orc_env *e, int on); /* 1: body rates go through the root state every substep, as in the reference */
 /* One VecTask.step() (vec_task_asymmetry.py:290-334).  obs/states are the PERSISTENT frame stacks
  * [num_envs][len][26] (shifted in place, newest frame last, unclamped -- the caller clamps like the reference's
@@ -150,6 +151,10 @@ typedef struct orc_policy_cfg {
 size_t orc_policy_blob_floats(const orc_policy_cfg *c);
 int orc_policy_act(const orc_policy_cfg *c, const float *blob, int n, const float *obs, const float *states, const float *eps, int deterministic,
                    float *action, float *logp, float *value, float *mu, float *sigma);
+/* one PPO rollout (ppo_asymmetry.py:308-342 + buffer_asymmetry.py:49-68 store) on the oracle env: see taco_policy_oracle.c */
+int orc_rollout(orc_env *e, const orc_policy_cfg *c, const float *blob, int H, uint64_t pseed, uint32_t call0, double gamma, double act_lo,
+                double act_hi, int64_t *reset_buf, float *obs_store, float *states_store, float *act_buf, float *rew_buf, float *done_buf,
+                float *value_buf, float *logp_buf, float *mu_buf, float *sigma_buf, uint8_t *timeout_buf, float *last_value);
 void orc_policy_noise(uint64_t seed, uint32_t call, int n, int act_dim, float *eps);
 float orc_expf(float x);
 float orc_tanhf(float x);

@@ -12,6 +12,7 @@
  * tests/golden/policy.npz generated from the reference module on CPU. */
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include "taco_oracle.h"
 
@@ -203,4 +204,58 @@ int orc_policy_act(const orc_policy_cfg *c, const float *blob, int n, const floa
         act_one(c, blob, obs + i * od, states + i * sd, eps ? eps + (size_t)i * c->act_dim : NULL, deterministic || !eps,
                 action + (size_t)i * c->act_dim, logp + i, value + i, mu + (size_t)i * c->act_dim, sigma + (size_t)i * c->act_dim);
     return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ one PPO rollout, end to end
+ * PPO.run's horizon loop (IsaacGymEnvs/algorithms/ppo_asymmetry.py:308-342) with PPOReplayBuffer.store (buffer_asymmetry.py:49-68) on the
+ * oracle env: for t < H { (action, log_prob, value, mu, sigma) = agent.act(obs, states) (:309; the noise of step t = orc_policy_noise(pseed,
+ * call0 + t)); actions_clipped = clamp(action, act_lo, act_hi) (:310); env.step (:311) -> next stacks, reward, done, time-outs;
+ * rewards_augmented[truncated] += gamma * value(pre-step state) (:314-324: the value of the state the step started from is value[t] itself);
+ * store (:326-329) }, then last_values = agent.act(obs, states)[2] (:341).  What taco_rollout_run / RolloutBuffer.run() compute on the GPU, in
+ * the reference's order (the GPU batches the critic after the loop: nothing before GAE reads a value).
+ * Arrays: obs_store [H + 1][n][obs_len * 26], states_store [H + 1][n][states_len * 26] (slot 0 = the stacks to start from, filled by the
+ * caller; slot t + 1 = what step t leaves: MATERIALISED stacks, the reference's layout); act_buf / mu_buf / sigma_buf [H][n][4] (act_buf = the
+ * un-clipped sample, :326); rew_buf / done_buf / value_buf / logp_buf [H][n]; timeout_buf [H][n] u8; last_value [n].
+ * GAE is orc_gae (buffer_asymmetry.py:93-132) on these arrays. */
+int orc_rollout(orc_env *e, const orc_policy_cfg *c, const float *blob, int H, uint64_t pseed, uint32_t call0, double gamma, double act_lo,
+                double act_hi, int64_t *reset_buf, float *obs_store, float *states_store, float *act_buf, float *rew_buf, float *done_buf,
+                float *value_buf, float *logp_buf, float *mu_buf, float *sigma_buf, uint8_t *timeout_buf, float *last_value) {
+    if (!e || !c || c->act_dim != 4 || c->obs_dim != 26 || c->states_dim != 26 || H < 1) return -1;
+    const int n = orc_num_envs(e);
+    const size_t od = (size_t)c->obs_len * 26, sd = (size_t)c->states_len * 26;
+    const float lo = (float)act_lo, hi = (float)act_hi, g = (float)gamma;
+    float *eps = (float *)malloc(sizeof(float) * (size_t)n * 4), *aenv = (float *)malloc(sizeof(float) * (size_t)n * 4);
+    if (!eps || !aenv) { free(eps); free(aenv); return -1; }
+    int rc = 0;
+    for (int t = 0; t < H && rc == 0; ++t) {
+        float *obs_t = obs_store + (size_t)t * n * od, *st_t = states_store + (size_t)t * n * sd;
+        orc_policy_noise(pseed, call0 + (uint32_t)t, n, 4, eps);
+        rc = orc_policy_act(c, blob, n, obs_t, st_t, eps, 0, act_buf + (size_t)t * n * 4, logp_buf + (size_t)t * n, value_buf + (size_t)t * n,
+                            mu_buf + (size_t)t * n * 4, sigma_buf + (size_t)t * n * 4);
+        if (rc != 0) break;
+        for (size_t k = 0; k < (size_t)n * 4; ++k) {   /* torch.clip(actions, lo, hi): a NaN stays a NaN */
+            const float a = act_buf[(size_t)t * n * 4 + k];
+            aenv[k] = (a != a) ? a : (a < lo ? lo : (a > hi ? hi : a));
+        }
+        /* env.step works in place on its buffers (the stacks are shifted by one frame): slot t + 1 starts as a copy of slot t */
+        memcpy(obs_t + (size_t)n * od, obs_t, sizeof(float) * (size_t)n * od);
+        memcpy(st_t + (size_t)n * sd, st_t, sizeof(float) * (size_t)n * sd);
+        rc = orc_step(e, aenv, obs_t + (size_t)n * od, st_t + (size_t)n * sd, rew_buf + (size_t)t * n, reset_buf, timeout_buf + (size_t)t * n);
+        for (int i = 0; i < n; ++i) {
+            const size_t k = (size_t)t * n + i;
+            done_buf[k] = (float)reset_buf[i];
+            if (timeout_buf[k] != 0 && reset_buf[i] != 0) rew_buf[k] = rew_buf[k] + g * value_buf[k];   /* :320-324 */
+        }
+    }
+    if (rc == 0) {   /* :341 (only the value is kept) */
+        float *scr = (float *)malloc(sizeof(float) * (size_t)n * 13);
+        if (!scr) rc = -1;
+        else {
+            rc = orc_policy_act(c, blob, n, obs_store + (size_t)H * n * od, states_store + (size_t)H * n * sd, NULL, 1, scr, scr + (size_t)n * 4, last_value,
+                                scr + (size_t)n * 5, scr + (size_t)n * 9);
+            free(scr);
+        }
+    }
+    free(eps); free(aenv);
+    return rc;
 }

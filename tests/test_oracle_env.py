@@ -282,3 +282,47 @@ def test_reset_done_is_an_immediate_reset_idx():
     sa, sb = a.get_state().view(np.float32), b.get_state().view(np.float32)
     assert np.allclose(sb[7:10], v0 + np.array([[0.0], [0.0], [-9.81 * 0.01]]), atol=2e-5)   # b: the same reset state, ten substeps of free fall
     assert (np.linalg.norm(sa[7:10] - sb[7:10], axis=0) > 5e-3).all()                        # a: thrust and drag were applied
+
+
+def test_orc_rollout_is_the_act_step_store_loop():
+    """oracle/taco_policy_oracle.c orc_rollout (one PPO rollout, ppo_asymmetry.py:308-342) == the loop spelled out with the pieces the golden
+    vectors pin one by one: orc_policy_act (policy*.npz), OracleEnv.step (glue_*.npz), the time-out bootstrap (:314-324); two rollouts in a row."""
+    from taco_amd import policy as P
+    from util import assert_bits_equal
+    rng = np.random.default_rng(12)
+    n, H, T = 41, 9, 3
+    sd = {"log_std": rng.uniform(-1, 0.5, 4).astype(np.float32)}
+    for name, dims in (("actor_mlp", [26, 24, 4]), ("critic_mlp", [16, 20, 1])):
+        for i in range(len(dims) - 1):
+            sd[f"{name}.layers.{2 * i}.weight"] = (rng.standard_normal((dims[i + 1], dims[i])) * (1.5 / np.sqrt(dims[i]))).astype(np.float32)
+            sd[f"{name}.layers.{2 * i}.bias"] = (rng.standard_normal(dims[i + 1]) * 0.1).astype(np.float32)
+    sd["critic_encoder.layers.weight_ih_l0"] = (rng.standard_normal((64, 26)) * 0.3).astype(np.float32)
+    sd["critic_encoder.layers.weight_hh_l0"] = (rng.standard_normal((64, 16)) * 0.25).astype(np.float32)
+    sd["critic_encoder.layers.bias_ih_l0"] = (rng.standard_normal(64) * 0.1).astype(np.float32)
+    sd["critic_encoder.layers.bias_hh_l0"] = (rng.standard_normal(64) * 0.1).astype(np.float32)
+    pcfg = P.cfg_from_state_dict(sd, 1, T)
+    blob = P.pack_state_dict(pcfg, sd)
+    oc = O.policy_cfg(1, T, [24], 16, [20])
+    cfg = config.default_cfg("mix", n, env_lenStates=T, env_maxEpisodeLength=6, seed=2, observation_noise=True, rotor_noise=True, ramdom_deploy_time=True)
+    a_env, b_env = O.OracleEnv(config.flat_cfg(cfg)), O.OracleEnv(config.flat_cfg(cfg))
+    gamma, seen_tmo = 0.97, 0
+    for ro in range(2):
+        obs0, st0 = b_env.obs_buf.copy(), b_env.states_buf.copy()
+        got = O.rollout(a_env, oc, blob, H, 5, 100 + ro * H, gamma, obs0, st0)
+        for t in range(H):
+            assert_bits_equal(got["obs"][t], b_env.obs_buf, f"rollout {ro} slot {t} obs")
+            assert_bits_equal(got["states"][t], b_env.states_buf, f"rollout {ro} slot {t} states")
+            act, logp, val, mu, sig = O.policy_act(oc, blob, b_env.obs_buf, b_env.states_buf, eps=O.policy_noise(5, 100 + ro * H + t, n))
+            _, _, rew, done, tmo = b_env.step(np.clip(act, -1, 1))
+            rew = rew.copy()
+            both = (tmo != 0) & (done != 0)
+            rew[both] = rew[both] + np.float32(gamma) * val[both]
+            seen_tmo += int(both.sum())
+            for name, a, b in (("act", got["act"][t], act), ("logp", got["logp"][t], logp), ("value", got["value"][t], val), ("mu", got["mu"][t], mu),
+                               ("sigma", got["sigma"][t], sig), ("rew", got["rew"][t], rew), ("done", got["done"][t], done.astype(np.float32)),
+                               ("timeout", got["timeout"][t], tmo)):
+                assert_bits_equal(a, b, f"rollout {ro} step {t} {name}")
+        assert_bits_equal(got["last_value"], O.policy_act(oc, blob, b_env.obs_buf, b_env.states_buf, deterministic=True)[2], "last_value")
+        assert_bits_equal(a_env.get_state(), b_env.get_state(), "env state after the rollout")
+        assert np.array_equal(a_env.reset_buf, b_env.reset_buf)
+    assert seen_tmo > 10, "the time-out bootstrap never ran"

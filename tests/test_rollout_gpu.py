@@ -274,3 +274,60 @@ def test_persistent_rollout_kernel_equals_the_launch_per_step_path(n, task, len_
                 assert_bits_equal(a.cpu().numpy(), b.cpu().numpy(), f"rollout {epoch} {k}")
             else:
                 assert torch.equal(a, b), f"rollout {epoch} {k}"
+
+
+@pytest.mark.parametrize("n,task,len_states,fused,kw", [
+    # config 5's flags (taco_amd/config.py baseline_config(4)), ragged last workgroup: the PERSISTENT actor + step kernel
+    (1000, "mix", 5, True, dict(random_rotordynamic_coe=True, random_rotor_response=True, random_aerodynamic_coe=True, observation_noise=True,
+                                rotor_noise=True, ramdom_delay_time=True, ramdom_deploy_time=True)),
+    (333, "flip", 3, True, dict(delay_time=5)),        # the late-patch path of the persistent kernel (2..9 pending slots)
+    (700, "mix", 5, False, dict(observation_noise=True, rotor_noise=True)),   # the launch-per-step chain
+])
+def test_rollout_run_equals_the_oracle_rollout(n, task, len_states, fused, kw):
+    """taco_rollout_run DIRECTLY against the CPU oracle's orc_rollout (actor forward + clip + env step + store + time-out bootstrap per step,
+    the final value, then GAE; oracle/taco_policy_oracle.c, pinned piece by piece by the reference's own vectors): every replay-buffer array,
+    the returns / raw advantages, the env's whole state and reset_buf bit for bit, over two rollouts with episode ends and time-outs.  (The
+    exact LSTM cell -- TACO_P_EXACT_CELL -- is the one that equals the oracle op for op; the default cell is held to 2e-6 in test_policy_gpu.)"""
+    from oracle import oracle as O
+    from taco_amd import policy as P
+    from taco_amd.vec_env import FpvBase
+    import test_policy_gpu as TP
+    H, gamma, lam = 16, 0.99, 0.95
+    rng = np.random.default_rng(17)
+    arch = ([128, 128, 128], 128, [128, 128])
+    sd = TP._random_policy(rng, 1, len_states, *arch)
+    cfg = config.default_cfg(task, n, env_lenStates=len_states, env_maxEpisodeLength=19, seed=6, **kw)
+    env = FpvBase(cfg, copy_outputs=False)
+    env.set_rollout_fusion(fused)
+    stamps = torch.zeros(136 + (n + 15) // 16, dtype=torch.int64, device="cuda")
+    env.bind_rollout_stamps(stamps)
+    pol = P.ActorCritic(sd, 1, len_states, seed=31, exact_critic=True)
+    buf = _buffer(n, H, 1, len_states, gamma, lam)
+    orc = O.OracleEnv(config.flat_cfg(cfg), threads=8)
+    oc = O.policy_cfg(1, len_states, *arch)
+    blob = P.pack_state_dict(pol.cfg, sd)
+    n_tmo = n_done = 0
+    for ro in range(2):
+        buf.reset()
+        last = buf.run(env, pol)
+        buf.compute_returns_and_advantage(last, normalize=False)
+        exp = O.rollout(orc, oc, blob, H, 31, ro * H, gamma, orc.obs_buf.copy(), orc.states_buf.copy())
+        adv_o, ret_o = O.gae(exp["rew"], exp["done"], exp["value"], exp["last_value"], gamma, lam)
+        got = {"obs": buf._obs_store.cpu().numpy().reshape(H + 1, n, 1, 26),
+               "states": torch.stack([buf._stack_view(t, 1)[0] for t in range(H + 1)]).cpu().numpy(),
+               "act": buf.act_buf.cpu().numpy(), "rew": buf.rew_buf.cpu().numpy()[:, :, 0], "done": buf.done_buf.cpu().numpy()[:, :, 0],
+               "value": buf.value_buf.cpu().numpy()[:, :, 0], "logp": buf.logp_buf.cpu().numpy()[:, :, 0], "mu": buf.mu_buf.cpu().numpy(),
+               "sigma": buf.sigma_buf.cpu().numpy(), "timeout": buf.time_outs.cpu().numpy(), "last_value": last.cpu().numpy()[:, 0]}
+        for k in exp:
+            assert_bits_equal(got[k], exp[k], f"rollout {ro} {k}")
+        assert_bits_equal(buf.adv_buf.cpu().numpy()[:, :, 0], adv_o, f"rollout {ro} raw advantage")
+        assert_bits_equal(buf.ret_buf.cpu().numpy()[:, :, 0], ret_o, f"rollout {ro} returns")
+        gs, es = env.get_state().cpu().numpy().view(np.uint32).copy(), orc.get_state().copy()
+        untracked = np.array([not env.tracks_rpy(i) for i in range(n)])   # (copter_rpy_old / _continuous: kept for flip envs only, nothing else reads them)
+        gs[20:26, untracked] = es[20:26, untracked] = 0
+        assert_bits_equal(gs, es, f"rollout {ro} env state")
+        assert np.array_equal(env.reset_buf.cpu().numpy(), orc.reset_buf)
+        n_tmo += int(exp["timeout"].sum()); n_done += int(exp["done"].sum())
+    assert n_tmo > 0 and n_done >= n_tmo and (task != "mix" or n_done > n_tmo)
+    assert (stamps[8:8 + 2 * H].min() > 0) == fused, "the persistent kernel ran / did not run as asked"
+    env.check()
