@@ -454,6 +454,16 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_policy_kernel(const PolicyPa
 constexpr int CR_ROWS = 32;   // rows per LSTM block (two 16-row MFMA tiles)
 constexpr int CR_LD = 132;    // h / MLP activation row stride in floats (width 128): 528 B, 8 consecutive rows cover all 32 banks
 constexpr int CR_MLP_ROWS = 64;
+// Conflict-free activation tiles (the pair LSTM kernel's h_t, the critic MLP's layers).  A ds_read_b128 is served in four 16-lane groups
+// (MI355X_MICROARCH.md, LDS): {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 -- with lane = 16 g + r reading row r, 16-byte slot
+// 4 s + g of an MFMA operand fragment, a group is the 16 rows r, rows 0-3 / 12-15 at slot c and rows 4-11 at slot c ^ 1 (or the other way
+// round).  With the padded stride of 132 floats (33 slots) row r's slot c lies on bank slot (r + c) mod 16: rows 11 and 12 of every group met
+// (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 44 % in rounds 2-3).  Storing slot c of row r at position c ^ b(r), b(r) = 1 for rows 4..11 (mod
+// 16) and 0 otherwise, makes both halves of a group read position-consistent columns: 16 rows -> 16 different bank slots.  b() is a lane
+// constant on both sides (readers: b(r); the producers' lanes write rows 4 g + i, and b(4 g + i) = b of g alone), so every address is still
+// one lane register + immediates; the ds_write_b32 of the producers and the b128 row copies stay conflict-free as well.
+__device__ __forceinline__ int cr_b(int row) { return ((row + 4) >> 3) & 1; }
+__device__ __forceinline__ int cr_sw4(int row, int c4) { return row * CR_LD + ((c4 ^ cr_b(row)) << 2); }   // float index of (row, 4 c4) in a swizzled tile
 
 // requirements (checked by the host, which falls back to taco_policy_kernel's critic role otherwise): pad16(states_dim) == 32,
 // pad16(lstm_hidden) == 128, states_len <= POL_MAXT, critic MLP = two hidden layers padded to 128
@@ -817,7 +827,7 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_kernel(cons
         }
     };
     auto h_chain = [&](const float *hprev, int tile) __attribute__((always_inline)) {
-        const float *hrow = hprev + (16 * tile + r) * CR_LD + 4 * g;
+        const float *hrow = hprev + (16 * tile + r) * CR_LD + 4 * (g ^ cr_b(r));   // (swizzled tile: cr_sw4)
         float4 nx = *reinterpret_cast<const float4 *>(hrow);
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
@@ -846,7 +856,7 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_kernel(cons
             }
     };
     auto cells = [&](int t, int tile, float (&cst)[4], bool first) __attribute__((always_inline)) {
-        float *hout = hb[t + 1 < T ? (t & 1) : 2] + (16 * tile + 4 * g) * CR_LD + col;
+        float *hout = hb[t + 1 < T ? (t & 1) : 2] + (16 * tile + 4 * g) * CR_LD + (col ^ (cr_b(4 * g) << 2));   // rows 4 g + i: b(row) = b(4 g)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float cn, hv;
@@ -863,7 +873,7 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_kernel(cons
             const int e = tid + 64 * POL_NW * j, row = e >> 5, k4 = e & 31;
             const int slot = 2 * pair + (row >> 4), env = e0 + (row & 15);
             if (slot < S && env < N)
-                *reinterpret_cast<float4 *>(P.hT + ((size_t)slot * N + env) * hp + 4 * k4) = *reinterpret_cast<const float4 *>(hb[2] + row * CR_LD + 4 * k4);
+                *reinterpret_cast<float4 *>(P.hT + ((size_t)slot * N + env) * hp + 4 * k4) = *reinterpret_cast<const float4 *>(hb[2] + cr_sw4(row, k4));
         }
     };
     for (int k = 0; k < nb; ++k) {
@@ -929,7 +939,7 @@ __global__ __launch_bounds__(64 * POL_NW, 4) void taco_critic_mlp_kernel(const P
     auto layer = [&](const float *in, float *out, const float4 (&wf)[KS], float bias) {
 #pragma unroll
         for (int rt = 0; rt < CR_MLP_ROWS / 16; ++rt) {
-            const float *arow = in + (16 * rt + r) * CR_LD + 4 * g;
+            const float *arow = in + (16 * rt + r) * CR_LD + 4 * (g ^ cr_b(r));   // (swizzled tiles: cr_sw4)
             pf32x4 acc = {bias, bias, bias, bias};
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
@@ -940,7 +950,7 @@ __global__ __launch_bounds__(64 * POL_NW, 4) void taco_critic_mlp_kernel(const P
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wf[s].w, acc, 0, 0, 0);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) out[(16 * rt + 4 * g + i) * CR_LD + col] = acc[i] < 0.0f ? 0.0f : acc[i];
+            for (int i = 0; i < 4; ++i) out[(16 * rt + 4 * g + i) * CR_LD + (col ^ (cr_b(4 * g) << 2))] = acc[i] < 0.0f ? 0.0f : acc[i];
         }
     };
     const int nchunks = (P.n + CR_MLP_ROWS - 1) / CR_MLP_ROWS;
@@ -949,7 +959,7 @@ __global__ __launch_bounds__(64 * POL_NW, 4) void taco_critic_mlp_kernel(const P
         for (int e = tid; e < CR_MLP_ROWS * (hp / 4); e += 64 * POL_NW) {  // 64 rows x 32 float4
             const int row = e >> 5, k4 = e & 31;
             const float4 v = (row0 + row < (size_t)P.n) ? *reinterpret_cast<const float4 *>(P.hT + (row0 + row) * hp + 4 * k4) : float4{0.0f, 0.0f, 0.0f, 0.0f};
-            *reinterpret_cast<float4 *>(xb + row * CR_LD + 4 * k4) = v;
+            *reinterpret_cast<float4 *>(xb + cr_sw4(row, k4)) = v;
         }
         __syncthreads();
         layer(xb, yb, w1, c1);
@@ -957,7 +967,7 @@ __global__ __launch_bounds__(64 * POL_NW, 4) void taco_critic_mlp_kernel(const P
         layer(yb, xb, w2, c2);
         __syncthreads();
         if (wave < CR_MLP_ROWS / 16) {  // the 128 -> 1 head (padded to a 16-column tile): wavefront w takes row tile w
-            const float *arow = xb + (16 * wave + r) * CR_LD + 4 * g;
+            const float *arow = xb + (16 * wave + r) * CR_LD + 4 * (g ^ cr_b(r));
             pf32x4 acc = {c3, c3, c3, c3};
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
@@ -1011,7 +1021,7 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_actor_kernel(const PolicyPar
     auto layer = [&](const float *in, float *out, const float4 *wf, int ks, float bias) {
 #pragma unroll
         for (int rt = 0; rt < CR_MLP_ROWS / 16; ++rt) {
-            const float *arow = in + (16 * rt + r) * CR_LD + 4 * g;
+            const float *arow = in + (16 * rt + r) * CR_LD + 4 * (g ^ cr_b(r));   // (swizzled tiles: cr_sw4)
             pf32x4 acc = {bias, bias, bias, bias};
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
@@ -1024,7 +1034,7 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_actor_kernel(const PolicyPar
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) out[(16 * rt + 4 * g + i) * CR_LD + col] = acc[i] < 0.0f ? 0.0f : acc[i];
+            for (int i = 0; i < 4; ++i) out[(16 * rt + 4 * g + i) * CR_LD + (col ^ (cr_b(4 * g) << 2))] = acc[i] < 0.0f ? 0.0f : acc[i];
         }
     };
     const int kin = P.obs_len * P.obs_dim;
@@ -1033,7 +1043,7 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_actor_kernel(const PolicyPar
         const int row0 = c * CR_MLP_ROWS;
         for (int e = tid; e < CR_MLP_ROWS * ip; e += 64 * POL_NW) {  // obs [row][kin] -> xb[row][32], zero beyond kin and beyond the last row
             const int row = e >> 5, k = e & 31;
-            xb[row * CR_LD + k] = (row0 + row < P.n && k < kin) ? P.obs[(size_t)(row0 + row) * kin + k] : 0.0f;
+            xb[cr_sw4(row, k >> 2) + (k & 3)] = (row0 + row < P.n && k < kin) ? P.obs[(size_t)(row0 + row) * kin + k] : 0.0f;
         }
         __syncthreads();
         layer(xb, yb, w0, 2, c0);
@@ -1043,7 +1053,7 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_actor_kernel(const PolicyPar
         layer(xb, yb, w2, 8, c2);
         __syncthreads();
         if (wave < CR_MLP_ROWS / 16) {  // the 128 -> 4 head (one 16-column tile) with its tanh: wavefront w takes row tile w
-            const float *arow = yb + (16 * wave + r) * CR_LD + 4 * g;
+            const float *arow = yb + (16 * wave + r) * CR_LD + 4 * (g ^ cr_b(r));
             pf32x4 acc = {c3, c3, c3, c3};
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
@@ -1054,7 +1064,7 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_actor_kernel(const PolicyPar
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, w3[s].w, acc, 0, 0, 0);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) xb[(16 * wave + 4 * g + i) * CR_LD + r] = tanh_own(acc[i]);
+            for (int i = 0; i < 4; ++i) xb[(16 * wave + 4 * g + i) * CR_LD + r] = tanh_own(acc[i]);   // (the head's output, read by sample4: plain rows)
         }
         __syncthreads();
         if (tid < 4 * CR_MLP_ROWS) sample4(P, xb, CR_LD, row0, tid >> 2, tid & 3, log_std, call);
