@@ -360,8 +360,11 @@ class FpvBase:
         """fpv_asymmetry.py:475-517: re-initialise the envs `env_ids` NOW (fresh state, controller memory, delay line, target; command
         re-drawn for them and for envs at progress 500; progress_buf and reset_buf of `env_ids` cleared, :510-511) -- one launch of the
         RESET_ONLY instantiation on a scratch mask, the step clock does not advance.  Inside step() the same reset is fused into the step
-        kernel, driven by reset_buf; to only MARK envs for the next step() write env.reset_buf[ids] = 1, as the reference's callers do."""
-        ids = torch.as_tensor(env_ids, device=self.device, dtype=torch.long).flatten()
+        kernel, driven by reset_buf; to only MARK envs for the next step() write env.reset_buf[ids] = 1, as the reference's callers do.
+        (Called with ids other than the flagged ones -- which the reference's own callers never do -- the reference re-draws the commands of
+        the envs flagged in reset_buf, :500-503 / :587-604; this one those of `env_ids`.  env_ids: indices, or a bool mask.)"""
+        ids = torch.as_tensor(env_ids, device=self.device)
+        ids = ids.flatten().nonzero().flatten() if ids.dtype == torch.bool else ids.to(torch.long).flatten()   # (a bool mask means mask.nonzero())
         if ids.numel() == 0:
             return
         if not hasattr(self, "_reset_mask"):

@@ -40,5 +40,7 @@ cp "$O/${TAG}_step_api"/*/*kernel_stats.csv "$O/${TAG}_step_api_kernel_stats.csv
 # 1. the un-profiled bench line, with this build's PMC summary where bench.py looks for it (profiles/, newest matching source hash)
 cp "$O/${TAG}_pmc_summary.json" profiles/
 python3 bench.py --steps 2000 --warmup 200 > "$O/${TAG}_bench_4096.json" 2> "$O/${TAG}_bench.err"
+# 7. eager (clock in the kernel arguments / on the device) vs HIP-graph replays of 1, 16, 64 steps: what the device-resident clock costs
+python3 tools/clock_path_ab.py > "$O/${TAG}_clock_path_ab.txt" 2>/dev/null || true
 # 6. the N > 1 code path end to end on this one GPU: 2 ranks over gloo (the driver runs the real thing over RCCL on 8 GPUs)
 TACO_BENCH_BACKEND=gloo TACO_BENCH_ONE_DEVICE=1 python3 bench.py --gpus 2 --steps 500 --warmup 100 --no-cpu-baseline --no-large-n --no-configs > "$O/${TAG}_bench_2ranks_gloo_one_gpu.json" 2> "$O/${TAG}_bench_2ranks.err" || true
