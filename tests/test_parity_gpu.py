@@ -23,13 +23,16 @@ def action_stream(n, steps, seed):
     return np.clip(a, -1, 1).astype(np.float32)
 
 
-def run_pair(cfg, steps, seed=0, check_every=1, hover_bias=False, form="auto", lib=None, slow_server=False):
+def run_pair(cfg, steps, seed=0, check_every=1, hover_bias=False, form="auto", lib=None, slow_server=False, api=False):
+    """api: a second env is stepped through VecTask.step() (the alternating obs buffers, the state stack on the frame ring or the kernel-written
+    clamped copies) and what it RETURNS is held against the oracle's clamped buffers as well"""
     from oracle import oracle as O
     from taco_amd import _lib
     from taco_amd.vec_env import FpvBase
     flat = config.flat_cfg(cfg)
     n = flat["num_envs"]
     env = FpvBase(cfg, copy_outputs=False, kernel_form=form, lib=lib)
+    api_env = FpvBase(cfg, kernel_form=form, lib=lib) if api else None
     if slow_server:
         _lib.check(lib.taco_test_slow_battery_server(env._h, 1), lib)
     orc = O.OracleEnv(flat, threads=8)
@@ -49,8 +52,17 @@ def run_pair(cfg, steps, seed=0, check_every=1, hover_bias=False, form="auto", l
     for t in range(steps):
         env.step_raw(acts_d[t])
         orc.step(acts[t])
+        if api_env is not None:
+            d, a_rew, a_done, a_info = api_env.step(acts_d[t])
         if t % check_every == 0 or t == steps - 1:
             what = f"step {t}"
+            if api_env is not None:   # VecTask.step()'s return values = clamp(buffers) (vec_task_asymmetry.py:331-334)
+                co, cs = np.float32(flat["clip_obs"]), np.float32(flat["clip_states"])
+                assert_bits_equal(d["obs"].cpu().numpy(), np.clip(orc.obs_buf, -co, co), what + " step() obs")
+                assert_bits_equal(d["states"].cpu().numpy(), np.clip(orc.states_buf, -cs, cs), what + " step() states")
+                assert_bits_equal(a_rew.cpu().numpy(), orc.rew_buf, what + " step() reward")
+                assert_bits_equal(a_done.cpu().numpy(), orc.reset_buf, what + " step() done")
+                assert_bits_equal(a_info["time_outs"].cpu().numpy().astype(np.uint8), orc.timeout_buf, what + " step() time_outs")
             assert_bits_equal(env.reset_buf.cpu().numpy(), orc.reset_buf, what + " reset_buf")
             assert_bits_equal(env.timeout_buf.cpu().numpy().astype(np.uint8), orc.timeout_buf, what + " timeout_buf")
             assert_bits_equal(env.rew_buf.cpu().numpy(), orc.rew_buf, what + " rew_buf")
@@ -233,7 +245,7 @@ def test_random_configurations():
     for i in range(40):
         cfg, steps = fuzz.draw_case(rng)
         try:
-            run_pair(cfg, steps, seed=i, check_every=1 if steps > 8 else 2, hover_bias=bool(i & 1))
+            run_pair(cfg, steps, seed=i, check_every=1 if steps > 8 else 2, hover_bias=bool(i & 1), api=cfg["env"]["numEnvs"] <= 20000)   # (+ what VecTask.step() returns)
         except AssertionError as e:
             raise AssertionError(f"case {i}: {fuzz.describe(cfg)}: {e}") from e
 

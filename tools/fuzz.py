@@ -72,7 +72,7 @@ def main():
     for i in range(args.cases):
         cfg, steps = draw_case(rng)
         try:
-            done = run_pair(cfg, steps, seed=i, check_every=1 if steps > 8 else 2, hover_bias=bool(i & 1))
+            done = run_pair(cfg, steps, seed=i, check_every=1 if steps > 8 else 2, hover_bias=bool(i & 1), api=cfg["env"]["numEnvs"] <= 20000)
         except Exception:
             print(f"case {i} FAILED: {describe(cfg)}", flush=True)
             raise
