@@ -475,10 +475,11 @@ int launch_step(taco_env *e, const taco_rollout_io *io, void *stream) {
         if (io->states_out) return fail(TACO_ERR_INVALID_ARG, "states_newest_only writes no stack: states_out must be NULL");
         P.len_states = 1; P.states_bytes = (uint32_t)(n_envs * 26 * sizeof(float)); P.states_prev = P.states;
     }
-    P.st_period = 0; P.st_phase = 0; P.st_front = 0;
+    P.st_period = 0; P.st_front = 0;
+    P.st_phase = e->st_phase;   // (every launch republishes the clock, the ring phase included: a launch that does not write the ring hands it on unchanged)
     if (ring_mode) {
         P.states = e->st_ring; P.states_prev = e->st_ring;
-        P.st_period = e->st_period; P.st_phase = e->st_phase; P.st_front = e->cfg.len_states - 1;
+        P.st_period = e->st_period; P.st_front = e->cfg.len_states - 1;
     }
     P.gather_row = (uint32_t)taco_gather_row_floats(e->cfg.len_obs);
     P.gather_bytes = (uint32_t)((size_t)n_envs * P.gather_row * sizeof(float));

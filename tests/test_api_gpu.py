@@ -422,7 +422,7 @@ def _bits(t):
 
 
 @pytest.mark.parametrize("n,len_obs,len_states,form", [(300, 1, 1, "auto"), (300, 2, 5, "auto"), (20000, 1, 5, "auto"), (70000, 1, 1, "auto"), (300, 3, 3, "lane"), (300, 1, 4, "quad"),
-                                                       (5000, 1, 8, "auto")])
+                                                       (5000, 1, 8, "auto"), (333, 1, 2, "auto")])
 def test_step_returns_kernel_written_buffers_without_a_copy(n, len_obs, len_states, form):
     """Default clip (+inf): step() is ONE launch and nothing else.  The obs stack is read from the current buffer and written to the other one
     of an alternating pair; a state stack (len_states > 1) lives in a FRAME RING (taco_bind_states_ring): the launch writes one frame per env

@@ -38,10 +38,10 @@ if __name__ == "__main__":
     res = {}
     for r in range(rounds):
         for lib in libs:
-            name, _, mode = lib.partition("@")   # lib.so@rt = run that library with the round-trip flag set; @rec = record_flag
+            name, _, mode = lib.partition("@")   # lib.so@carried = run that library WITHOUT the world-rate round trip (the default since round 4); @rec = record_flag
             for case in cases:
                 env = dict(os.environ, TACO_ENV_LIB=os.path.abspath(name), TACO_ENV_LIB_SKIP_ABI="1")
-                out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", case, "1" if mode == "rt" else "0", "1" if mode == "rec" else "0"],
+                out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", case, "0" if mode == "carried" else "1", "1" if mode == "rec" else "0"],
                                      env=env, capture_output=True, text=True, cwd=ROOT)
                 if out.returncode != 0:
                     print(lib, case, "FAILED", out.stderr[-500:], flush=True)
