@@ -326,7 +326,9 @@ int taco_bind_gather_block(taco_env *env, float *block);
  * strided view ring[ph : ph + len_states] with the first two axes swapped (taco_amd/vec_env.py hands exactly that to the PPO loop).  104 B written
  * per env-step (+ (len_states - 1) / period of that for the twins) instead of (2 len_states - 1) x 104 B moved.  taco_states_ring_row = the
  * phase of the LAST step (the first row of its window; blocks after graph replays, -1 on error).  Binding resets the phase to 0 (blocks);
- * NULL unbinds.  Calls with states_next != NULL are unaffected. */
+ * NULL unbinds.  Calls with states_next != NULL are unaffected.  Finite clip_states: pass io->states_out = a SECOND ring of the same geometry;
+ * it receives clamp(frame, +-clip_states) at the same rows -- the clamped copy VecTask.step returns (vec_task_asymmetry.py:332) is the same
+ * view of that ring, since clamping a stack is clamping its frames. */
 int taco_bind_states_ring(taco_env *env, float *ring, int rows);
 int taco_states_ring_row(taco_env *env);
 /* taco_step_rollout on the bound ring (io->states_next == NULL) that also reports the ring phase the launch uses: *phase = the first row of

@@ -440,8 +440,8 @@ int launch_step(taco_env *e, const taco_rollout_io *io, void *stream) {
     const bool ring_mode = io->states_next == nullptr && e->st_ring != nullptr && e->cfg.len_states > 1;
     if (!io->actions || !io->obs_next || (!io->states_next && !ring_mode) || !io->rew || !io->reset_buf || !io->timeout_buf)
         return fail(TACO_ERR_INVALID_ARG, "taco_step: null buffer pointer");
-    if (ring_mode && (io->states_prev || io->states_out || io->states_newest_only))
-        return fail(TACO_ERR_INVALID_ARG, "taco_step_rollout on the bound states ring: states_prev / states_out must be NULL and states_newest_only 0");
+    if (ring_mode && (io->states_prev || io->states_newest_only))
+        return fail(TACO_ERR_INVALID_ARG, "taco_step_rollout on the bound states ring: states_prev must be NULL and states_newest_only 0");
     if (((uintptr_t)io->actions & 15u) != 0) return fail(TACO_ERR_INVALID_ARG, "actions must be 16-byte aligned");
     // The step counter, the ring head and the history row travel in the kernel arguments and advance on the host with every call; a launch
     // that is being CAPTURED into a HIP graph would replay one step index for ever, so it reads the device-resident copy of the clock
@@ -472,7 +472,8 @@ int launch_step(taco_env *e, const taco_rollout_io *io, void *stream) {
     // len_states = 1 step -- nothing is shifted, nothing of an older stack is read
     const bool newest_only = (io->states_newest_only != 0 && e->cfg.len_states > 1) || ring_mode;
     if (newest_only) {
-        if (io->states_out) return fail(TACO_ERR_INVALID_ARG, "states_newest_only writes no stack: states_out must be NULL");
+        // (ring mode: states_out = a second ring of the same geometry for the clamped frames)
+        if (io->states_out && !ring_mode) return fail(TACO_ERR_INVALID_ARG, "states_newest_only writes no stack: states_out must be NULL");
         P.len_states = 1; P.states_bytes = (uint32_t)(n_envs * 26 * sizeof(float)); P.states_prev = P.states;
     }
     P.st_period = 0; P.st_front = 0;

@@ -1983,12 +1983,14 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     // states first (noise-free frame), then obs (possibly noised)
     if (roleS) {
         if (!FUSED && P.st_period > 0) {   // the frame ring behind VecTask.step()'s state stacks (StepParams.st_period): one frame, two while the window wraps
-            float *const row = P.states + (size_t)(P.st_front + clk.phase) * (P.states_bytes / 4u);
-            put_frame(row, row, P.states_bytes, 1, fr, true, nullptr, P.clip_states);
-            if (clk.phase >= P.st_period - P.st_front) {
-                float *const twin = row - (size_t)P.st_period * (P.states_bytes / 4u);
-                put_frame(twin, twin, P.states_bytes, 1, fr, false, nullptr, P.clip_states);
-            }
+            // (OUT: a second ring of the same geometry receives clamp(frame, +-clip_states) -- the clamped copy of a stack is the stack of the
+            // clamped frames, so VecTask.step()'s return value (VT:332) is the same strided view of THAT ring)
+            const size_t roff = (size_t)(P.st_front + clk.phase) * (P.states_bytes / 4u), toff = (size_t)P.st_period * (P.states_bytes / 4u);
+            float *const row = P.states + roff;
+            float *const crow = (OUT && P.states_out) ? P.states_out + roff : nullptr;
+            put_frame(row, row, P.states_bytes, 1, fr, true, crow, P.clip_states);
+            if (clk.phase >= P.st_period - P.st_front)
+                put_frame(row - toff, row - toff, P.states_bytes, 1, fr, false, crow ? crow - toff : nullptr, P.clip_states);
         } else {
             put_frame(P.states, P.states_prev, P.states_bytes, P.len_states, fr, true, OUT ? P.states_out : nullptr, P.clip_states);
         }

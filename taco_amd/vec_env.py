@@ -87,9 +87,10 @@ class FpvBase:
         # A state stack (len_states > 1, the documented 5) behind step() is a FRAME RING (taco_bind_states_ring): the kernel writes ONE frame per
         # env-step and `states_buf` / the tensor step() returns is a strided [num_envs, len_states, 26] view of it -- the reference's shifted
         # stack (fpv_asymmetry.py:413) moves 9 frames per env-step for the same content.  (copy_outputs=False keeps the contiguous in-place
-        # stack; a finite clip keeps the materialised path, whose OUT instantiation writes the clamped copy.)
+        # stack.  Finite clipObservations / clipStates: a SECOND ring receives the clamped frames -- clamping a stack is clamping its frames --
+        # and step() returns the view of that one; `states_buf` stays the unclamped stack, as in the reference.)
         # states_ring: None = with copy_outputs; True / False force it (ShardedEnv steps in place on the obs buffer but keeps the ring)
-        self._ring_on = (self._want_pp if states_ring is None else bool(states_ring)) and self.len_states > 1 and not self._finite_clip
+        self._ring_on = (self._want_pp if states_ring is None else bool(states_ring)) and self.len_states > 1
         npp = 2 if self._want_pp else 1
         self._obs_pp = [torch.zeros((self.num_envs, self.len_obs, self.num_obs), device=dev, dtype=torch.float32) for _ in range(npp)]
         self._states_pp = [] if self._ring_on else \
@@ -98,6 +99,7 @@ class FpvBase:
         # a graph captured around step() would freeze ONE (current -> next) pair of the alternating obs buffers: with an obs stack every replay
         # would shift the never-updated `current` one (refused in step())
         self._capture_unsafe = self._want_pp and self.len_obs > 1 and not self._finite_clip
+        self._ring_clamped = self._ring_on and self._finite_clip   # (step() hands out clamped copies: a second ring holds the clamped frames)
         self.rew_buf = torch.zeros(self.num_envs, device=dev, dtype=torch.float32)
         self.reset_buf = torch.ones(self.num_envs, device=dev, dtype=torch.long)
         self.timeout_buf = torch.zeros(self.num_envs, device=dev, dtype=torch.bool)
@@ -105,7 +107,7 @@ class FpvBase:
         self.obs_dict = {}
         # finite clipObservations / clipStates: the clamped copies step() returns are written by the step kernel itself (its OUT
         # instantiation) into two alternating pairs -- no torch.clamp launch, no allocation per step
-        self._out = [(torch.zeros_like(self._obs_pp[0]), torch.zeros_like(self._states_pp[0])) for _ in range(2)] if self._finite_clip else None
+        self._out = [(torch.zeros_like(self._obs_pp[0]), None if self._ring_on else torch.zeros_like(self._states_pp[0])) for _ in range(2)] if self._finite_clip else None
         self._out_k = 0
         self._step_io = {}
         self._same_device = self.rl_device == self.device
@@ -128,6 +130,8 @@ class FpvBase:
                 torch.cuda.synchronize()   # (the bind resets the ring phase on the device, behind the workspace's initialisation)
                 _lib.check(self.lib.taco_bind_states_ring(self._h, self._st_ring.data_ptr(), self._st_period + front), self.lib)
             self._st_views = [self._st_ring[k:k + self.len_states].permute(1, 0, 2) for k in range(self._st_period)]
+            self._st_ring_c = torch.zeros_like(self._st_ring) if self._ring_clamped else None
+            self._st_views_c = [self._st_ring_c[k:k + self.len_states].permute(1, 0, 2) for k in range(self._st_period)] if self._ring_clamped else None
             self._st_last = self._st_period - 1   # the window of the last step (before the first: zeros, like every other)
             self._st_phase = C.c_int32(0)
 
@@ -203,6 +207,8 @@ class FpvBase:
             self._st_last = self._st_period - 1
             self._st_views[self._st_last].copy_(states)
             self._st_ring[0:front].copy_(states[:, 1:].transpose(0, 1))
+            if self._ring_clamped:
+                self._st_ring_c.copy_(torch.clamp(self._st_ring, -self.clip_states, self.clip_states))
 
     @property
     def progress_buf(self):
@@ -254,7 +260,7 @@ class FpvBase:
             raise ValueError(f"actions must be [{self.num_envs}, {self.num_acts}], got {tuple(actions.shape)}")
         if self._ring_on:   # (in place for obs, the bound frame ring for the state stack)
             io = _lib.RolloutIO(actions.data_ptr(), None, self.obs_buf.data_ptr(), None, None, self.rew_buf.data_ptr(), self.reset_buf.data_ptr(),
-                                self.timeout_buf.data_ptr(), None)
+                                self.timeout_buf.data_ptr(), None, None, self._st_ring_c.data_ptr() if self._ring_clamped else None)
             self._ring_step(io)
             return
         rc = self.lib.taco_step(self._h, actions.data_ptr(), self.obs_buf.data_ptr(), self.states_buf.data_ptr(), self.rew_buf.data_ptr(),
@@ -328,6 +334,8 @@ class FpvBase:
         if io is None:   # the argument block of this (buffer pair, output pair) combination: built once, only the action pointer changes
             obs_out, states_out = self._out[k] if self._finite_clip else (None, None)
             ring = self._ring_on
+            if ring and self._ring_clamped:
+                states_out = self._st_ring_c   # (the ring of clamped frames: the kernel writes the same rows of it)
             io = _lib.RolloutIO(None, self._obs_pp[cur].data_ptr() if nxt != cur else None, self._obs_pp[nxt].data_ptr(),
                                 self._states_pp[cur].data_ptr() if (nxt != cur and not ring) else None,
                                 None if ring else self._states_pp[nxt].data_ptr(), self.rew_buf.data_ptr(),
@@ -345,6 +353,8 @@ class FpvBase:
         if self._finite_clip:
             self._out_k ^= 1
             obs, st = self._out[k]
+            if self._ring_on:
+                st = self._st_views_c[self._st_last]
         elif self._ring_on:
             obs, st = self._obs_pp[nxt], self._st_views[self._st_last]
         else:
