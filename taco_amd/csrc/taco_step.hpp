@@ -829,6 +829,25 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     // `out` (optional): the clamped copy VecTask.step hands to the caller (VT:331-332) receives clamp(word, +-clip) next to every word moved
     auto clamp2 = [](f32x2_t v, float c) { return f32x2_t{clampf(v.x, -c, c), clampf(v.y, -c, c)}; };
     auto clamp4 = [](f32x4_t v, float c) { return f32x4_t{clampf(v.x, -c, c), clampf(v.y, -c, c), clampf(v.z, -c, c), clampf(v.w, -c, c)}; };
+    // The OUTPUT pointers (frame stacks, reward / time-out / done images, the gather block, the clamped copies) are consumed only by the post-phase:
+    // the launch-per-step forms read them from the kernel-argument segment WHERE THEY ARE USED, behind an opaque copy of the segment pointer.
+    // As ordinary kernel arguments the compiler loaded them at the kernel's entry and kept them -- an SGPR pair each -- alive across the step
+    // wavefront's whole path: the OUT instantiations' loop carried 16 spill reloads per substep for it (finite-clip step() at 4 096 envs
+    // 15.5 -> 14.2 us, round 4).  (FUSED: P is a per-step copy in registers inside the rollout kernel, not the kernel's argument.)
+    auto lazy_arg = [&](size_t off) -> float * {
+        const __attribute__((address_space(4))) char *ka = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        return *(float *const __attribute__((address_space(4))) *)(ka + off);
+    };
+#define TACO_ARG(field) (FUSED ? (float *)P.field : lazy_arg(offsetof(StepParams, field)))
+    // ... all of them at ONE point of the consuming wavefront's path: the role wavefronts at their entry (they idle at barrier 1 anyway; read at
+    // their use sites the scalar-load latency sat on the tail of the launch: + 0.2 us at 4 096 envs), the one-wavefront forms behind the substep loop
+    struct { float *obs, *states, *obs_prev, *states_prev, *rew, *done_f32, *gather, *obs_out, *states_out; uint8_t *timeout; } A{};
+    auto load_out_args = [&]() {
+        A.obs = TACO_ARG(obs); A.states = TACO_ARG(states); A.obs_prev = TACO_ARG(obs_prev); A.states_prev = TACO_ARG(states_prev);
+        A.rew = TACO_ARG(rew); A.done_f32 = TACO_ARG(done_f32); A.gather = TACO_ARG(gather); A.timeout = (uint8_t *)TACO_ARG(timeout);
+        A.obs_out = OUT ? TACO_ARG(obs_out) : nullptr; A.states_out = OUT ? TACO_ARG(states_out) : nullptr;
+    };
     auto shift_history = [&](float *buf, const float *prev, uint32_t buf_bytes, int len, float *out, float clip) {
         const rsrc_t rB = make_rsrc(buf, buf_bytes), rP = make_rsrc(prev, buf_bytes);
         // (the clamped copies go out through plain global stores with an explicit range check: a third buffer descriptor here cost the
@@ -1674,6 +1693,7 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     }
 
     TACO_STAMP(3);  // substeps done
+    if (!ROLES) load_out_args();   // (this wavefront runs the post-phase itself)
     if (FUSED && !bat_served && __builtin_expect(mb_timeout, 0)) {  // (the wait for the actor's action gave up; with the battery served this is reported above)
         if (lane == 0) atomicOr(&P.ctl[kCtlStatus], kStatusMailboxTimeout);
         bat_V = nanf32();
@@ -1760,6 +1780,7 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     publish_clock();
     if (ROLES) { TACO_STAMP(4); TACO_STAMP(5); return; }  // wave 0 is done; the roles below belong to the other three wavefronts
     } else {
+        load_out_args();
         if (wv == 1 && lane < 8) mb_seq[lane] = 0;
         __syncthreads();  // barrier 1 of 2
         if constexpr (NOISE_TAB) {
@@ -1777,8 +1798,8 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
                 if constexpr (LPE == 4) MB_POST(2, 1);
             }
         }
-        if (wv == 3 && P.len_states > 1) shift_history(P.states, P.states_prev, P.states_bytes, P.len_states, OUT ? P.states_out : nullptr, P.clip_states);
-        if (wv == 2 && P.len_obs > 1) shift_history(P.obs, P.obs_prev, P.obs_bytes, P.len_obs, OUT ? P.obs_out : nullptr, P.clip_obs);
+        if (wv == 3 && P.len_states > 1) shift_history(A.states, A.states_prev, P.states_bytes, P.len_states, A.states_out, P.clip_states);
+        if (wv == 2 && P.len_obs > 1) shift_history(A.obs, A.obs_prev, P.obs_bytes, P.len_obs, A.obs_out, P.clip_obs);
         if constexpr (EULER_TAB) {
             if (LPE == 1 && wv == euler_role && euler_served) {   // one lane per env: the scalar get_euler_xyz_v1 + three unwraps per attitude
                 MB_WAIT(3, 1);
@@ -1986,13 +2007,13 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
             // (OUT: a second ring of the same geometry receives clamp(frame, +-clip_states) -- the clamped copy of a stack is the stack of the
             // clamped frames, so VecTask.step()'s return value (VT:332) is the same strided view of THAT ring)
             const size_t roff = (size_t)(P.st_front + clk.phase) * (P.states_bytes / 4u), toff = (size_t)P.st_period * (P.states_bytes / 4u);
-            float *const row = P.states + roff;
-            float *const crow = (OUT && P.states_out) ? P.states_out + roff : nullptr;
+            float *const row = A.states + roff;
+            float *const crow = (OUT && A.states_out) ? A.states_out + roff : nullptr;
             put_frame(row, row, P.states_bytes, 1, fr, true, crow, P.clip_states);
             if (clk.phase >= P.st_period - P.st_front)
                 put_frame(row - toff, row - toff, P.states_bytes, 1, fr, false, crow ? crow - toff : nullptr, P.clip_states);
         } else {
-            put_frame(P.states, P.states_prev, P.states_bytes, P.len_states, fr, true, OUT ? P.states_out : nullptr, P.clip_states);
+            put_frame(A.states, A.states_prev, P.states_bytes, P.len_states, fr, true, A.states_out, P.clip_states);
         }
     }
     if (roleO && (fl & TACO_F_OBSERVATION_NOISE)) {  // FA:402-410
@@ -2009,7 +2030,7 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
         fr[18] = fr[18] + P.df * (nrm[9] * (float)(0.06 / 3) + 0.0f);
         fr[23] = fr[23] + P.df * (nrm[10] * (float)(0.06 / 3 / 3) + 0.0f);
     }
-    if (roleO) put_frame(P.obs, P.obs_prev, P.obs_bytes, P.len_obs, fr, ROLES || (fl & TACO_F_OBSERVATION_NOISE) != 0, OUT ? P.obs_out : nullptr, P.clip_obs);
+    if (roleO) put_frame(A.obs, A.obs_prev, P.obs_bytes, P.len_obs, fr, ROLES || (fl & TACO_F_OBSERVATION_NOISE) != 0, A.obs_out, P.clip_obs);
     if constexpr (FUSED) {
         if (roleO && sub == 0) {  // ... and into the actor's input rows: the observation the next step's action is computed from never leaves the CU
 #pragma unroll
@@ -2019,9 +2040,10 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     // Optional all-gather block, one 128-byte-aligned row per env: [obs stack | reward | done | time-out | pad].  The obs part is written by
     // the wavefront that holds the obs frame (the newest frame from registers, older frames re-read from this env's just-written obs row),
     // the three tail words by the reward wavefront below.
-    if (roleO && P.gather && active) {
-        const rsrc_t rG = make_rsrc(P.gather, P.gather_bytes);
-        const rsrc_t rO = make_rsrc(P.obs, P.obs_bytes);
+    float *const gather_p = A.gather;
+    if (roleO && gather_p && active) {
+        const rsrc_t rG = make_rsrc(gather_p, P.gather_bytes);
+        const rsrc_t rO = make_rsrc(A.obs, P.obs_bytes);
         if (P.len_obs > 1) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the obs rows were stored by other lanes of this wavefront
         const uint32_t g0 = (uint32_t)i * P.gather_row * 4u;
         const uint32_t hist_pairs = (uint32_t)(P.len_obs - 1) * 13u;
@@ -2107,12 +2129,12 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
 
     // ------------------------------------------------------------------ store
     if (active) {
-        P.rew[i] = rew;
+        A.rew[i] = rew;
         P.reset[i] = rs;
-        P.timeout[i] = tmo ? 1 : 0;
-        if (P.done_f32) P.done_f32[i] = (float)rs;
-        if (P.gather) {  // tail of this env's all-gather row (the obs part is written above)
-            const rsrc_t rG = make_rsrc(P.gather, P.gather_bytes);
+        A.timeout[i] = tmo ? 1 : 0;
+        if (A.done_f32) A.done_f32[i] = (float)rs;
+        if (gather_p) {  // tail of this env's all-gather row (the obs part is written above)
+            const rsrc_t rG = make_rsrc(gather_p, P.gather_bytes);
             const uint32_t tail = (uint32_t)i * P.gather_row * 4u + (uint32_t)P.len_obs * 104u;
             llvm_amdgcn_raw_buffer_store_f32(rew, rG, (int)tail, 0, 0);
             llvm_amdgcn_raw_buffer_store_f32((float)rs, rG, (int)(tail + 4u), 0, 0);
@@ -2123,6 +2145,7 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     TACO_STAMP(5);
     if (SPLIT && P.stamps && blockIdx.x == 0 && lane == 0) P.stamps[5 + wv] = __builtin_readcyclecounter();  // [6..8]: the role wavefronts' ends
 #undef TACO_STAMP
+#undef TACO_ARG
 #undef MB_WAIT
 #undef MB_POST
 #undef MB_SEQ
