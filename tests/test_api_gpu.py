@@ -505,6 +505,16 @@ def test_ring_backed_state_stack_through_capture_checkpoint_and_the_c_abi(tmp_pa
         graph.replay()
         assert torch.equal(_bits(env.states_buf), _bits(ref.states_buf)) and torch.equal(_bits(twin.states_buf), _bits(ref.states_buf)), rep
         assert torch.equal(_bits(env.obs_buf), _bits(ref.obs_buf))
+    # ... and an OBS stack on the alternating buffer pair refuses capture too (a replay would shift the never-updated buffer of the frozen pair)
+    env2 = FpvBase(config.default_cfg("pos", 64, env_lenObservations=2))
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        g2.capture_begin()
+        with pytest.raises(_lib.TacoError, match="cannot be captured"):
+            env2.step(act[:64])
+        env2.step_raw(act[:64])                    # (in place on the current buffers: capturable)
+        g2.capture_end()
+    torch.cuda.current_stream().wait_stream(s)
     assert env.step_count == ref.step_count == 91
     for t2 in range(t, t + 9):                    # eagerly on, through step(): the host picks the ring phase up again
         d, *_ = env.step(acts[t2 % 8]); ref.step_raw(acts[t2 % 8]); twin.step(acts[t2 % 8])
