@@ -106,9 +106,12 @@ def all_gather_blocks(block, n_global, world_size, group=None, out=None, async_o
 class ShardedEnv:
     """This rank's slice of a `numEnvs`-wide job on its own MI355X."""
 
-    def __init__(self, cfg, rank, world_size, device, gather=True, group=None):
+    def __init__(self, cfg, rank, world_size, device, gather=True, group=None, collective_when_alone=False):
         from .vec_env import FpvBase
         self.rank, self.world_size, self.group, self.gather = rank, world_size, group, gather
+        # a 1-rank job needs no collective; collective_when_alone issues it anyway -- what lets a ONE-GPU box execute the RCCL branch for real
+        # (RCCL refuses two ranks on one device): tests/test_api_gpu.py::test_rccl_backend_runs_the_gather_path_on_one_rank
+        self.collective_when_alone = bool(collective_when_alone)
         self.n_global = int(cfg["env"]["numEnvs"])
         self.lo, self.hi = shard_bounds(self.n_global, world_size, rank)
         self.sizes = shard_sizes(self.n_global, world_size)
@@ -151,7 +154,7 @@ class ShardedEnv:
         self._bind(self.block)
         self.env.step_raw(local_actions)
         self.k = 1 - k
-        if not self.gather or self.world_size == 1:
+        if not self.gather or (self.world_size == 1 and not self.collective_when_alone):
             return GatheredBlocks(self.block[: self.hi - self.lo], [self.hi - self.lo])
         g = all_gather_blocks(self.block, self.n_global, self.world_size, self.group, out=self.outs[k], async_op=True)
         self.pending[k] = g

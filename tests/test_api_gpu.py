@@ -669,3 +669,59 @@ def test_sharded_env_step_local_is_the_single_gpu_launch_and_rebinding_works():
         assert torch.equal(o["obs"].reshape(n, -1), obs_a.reshape(n, -1)) and torch.equal(rew_b, rew_a)
         assert torch.equal(done_b.to(done_a.dtype), done_a) and torch.equal(ex["time_outs"].to(tmo_a.dtype), tmo_a)
     assert torch.equal(a.env.get_state(), b.env.get_state())
+
+
+def test_rccl_backend_runs_the_gather_path_on_one_rank():
+    """torch.distributed's "nccl" backend IS RCCL on ROCm.  The test box has ONE GPU and RCCL refuses two ranks on one device, so the N > 1 tests
+    run over gloo -- here the RCCL branch itself executes, with a 1-rank group: communicator init, ShardedEnv.step_async / step_gathered issuing
+    all_gather_into_tensor on the kernel-filled device block (async handle, the two alternating blocks, the stream-side wait), results equal to
+    the env's own buffers.  In a child process (a process group is process-wide state)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys, torch
+sys.path.insert(0, os.getcwd())
+import torch.distributed as dist
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29583", rank=0, world_size=1)
+from taco_amd import config
+from taco_amd.dist import ShardedEnv, unpack_block
+from taco_amd.vec_env import FpvBase
+dev = torch.device("cuda:0")
+n = 3000
+cfg = config.default_cfg("mix", n, env_lenObservations=2, env_lenStates=3, env_maxEpisodeLength=20, observation_noise=True)
+env = ShardedEnv(cfg, rank=0, world_size=1, device=dev, gather=True, collective_when_alone=True)
+ref = FpvBase(config.default_cfg("mix", n, env_lenObservations=2, env_lenStates=3, env_maxEpisodeLength=20, observation_noise=True), copy_outputs=False)
+g = torch.Generator().manual_seed(2)
+acts = (0.3 * torch.randn((6, n, 4), generator=g)).clamp(-1, 1).to(dev)
+pend = []
+for t in range(40):
+    ref.step_raw(acts[t % 6])
+    if t % 2:                                     # serial form
+        rows = env.step_gathered(acts[t % 6])
+    else:                                         # overlapped form: waited for one step later
+        pend.append(env.step_async(acts[t % 6]))
+        if len(pend) > 1:
+            pend.pop(0).wait()
+        continue
+    while pend:
+        pend.pop(0).wait()
+    obs, rew, done, tmo = unpack_block(rows, env.len_obs)
+    torch.cuda.synchronize()
+    assert torch.equal(obs, ref.obs_buf) and torch.equal(rew, ref.rew_buf) and torch.equal(done, ref.reset_buf) and torch.equal(tmo, ref.timeout_buf), t
+env.drain()
+assert dist.get_backend() == "nccl"
+# ... and the collectives bench.py brackets its timed region with (barrier, MAX-reduction and all_gather of fp64 scalars on the device)
+t = torch.tensor([3.5], device=dev, dtype=torch.float64)
+dist.barrier(); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+outs = [torch.zeros_like(t)]
+dist.all_gather(outs, t)
+assert float(t.item()) == 3.5 and float(outs[0].item()) == 3.5
+print("RCCL-GATHER-OK")
+dist.destroy_process_group()
+'''
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "RCCL-GATHER-OK" in out.stdout, (out.stdout + out.stderr)[-3000:]
