@@ -428,10 +428,11 @@ TD float quad_rotate(float qv, float w, float v) {
 // row I (integrate above) in the quad layout.  qq = (x y z w) over the four lanes; pq vq bq Fq tqq components 0..2 in lanes 0..2.
 // Jq / hJiq: this lane's inertia terms; gzq = (-0, -0, g, -0) (fma(RF, 1/m, -0) == RF * (1/m) exactly); sm3 = sign bit in lane 3,
 // k3 = all ones in lane 3.
-template <int SUBS = 0>
+template <int SUBS = 0, bool DEFER = false>
 TD bool integrate_quad(const StepParams &P, uint32_t k3, float &pq, float &qq, float &vq, float &bq, float Fq, float tqq, float Jq, float hJiq,
                        float gzq, uint32_t sm3) {
     bool any_big = false;
+    uint64_t bad = 0;   // DEFER: the lanes that met a rare form (nothing was branched on; the caller redoes the call with DEFER = false)
     auto iteration = [&]() {
         const float L = Jq * bq;
         const float g = fma(rot1(bq), rot2(L), -(rot2(bq) * rot1(L)));
@@ -450,7 +451,8 @@ TD bool integrate_quad(const StepParams &P, uint32_t k3, float &pq, float &qq, f
         float c = fma(fma(fma(fma(2.4801587302e-5f, A2, -1.3888888889e-3f), A2, 4.1666666667e-2f), A2, -0.5f), A2, 1.0f);
         float k = P.half_h * sp;
         const bool big = !(A2 <= 0.25f);
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(big) != 0, 0)) {
+        if constexpr (DEFER) bad |= __builtin_amdgcn_ballot_w64(big);
+        else if (__builtin_expect(__builtin_amdgcn_ballot_w64(big) != 0, 0)) {
             any_big = true;
             const float wn = __builtin_sqrtf(w2);
             float sn, cs;
@@ -471,7 +473,8 @@ TD bool integrate_quad(const StepParams &P, uint32_t k3, float &pq, float &qq, f
         const float n2 = fma(n3, n3, fma(n2_, n2_, fma(n1, n1, bc0(nsq))));
         float inv = fma(-0.5f, n2, 1.5f);
         const bool off = !(absf(n2 - 1.0f) <= 1e-3f);
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(off) != 0, 0)) {
+        if constexpr (DEFER) bad |= __builtin_amdgcn_ballot_w64(off);
+        else if (__builtin_expect(__builtin_amdgcn_ballot_w64(off) != 0, 0)) {
             const float ie = 1.0f / __builtin_sqrtf(n2);
             inv = off ? ie : inv;
         }
@@ -479,7 +482,7 @@ TD bool integrate_quad(const StepParams &P, uint32_t k3, float &pq, float &qq, f
     };
     if constexpr (SUBS == 2) { iteration(); iteration(); }
     else for (int it = 0; it < P.substeps; ++it) iteration();
-    return any_big;
+    return DEFER ? bad != 0 : any_big;
 }
 
 // reset_idx for one env (FA:475-517), in the reference's call order: reset_copter_idx -> reset_controller_idx ->
@@ -495,25 +498,39 @@ TD bool integrate_quad(const StepParams &P, uint32_t k3, float &pq, float &qq, f
 // sub, 4 + sub, 8 + sub (three Philox evaluations per lane instead of up to ten) and the quad reads each block's four uniforms from the
 // lane that made them (DPP quad_perm broadcasts).  Same numbers, ~200 instructions fewer on the path of every wavefront that holds a
 // resetting env -- at 4 096 envs that is some wavefront of nearly every launch, i.e. the launch time.
+// which STREAM_RESET blocks a configuration draws from (launch-uniform), as a bit mask
+TD uint32_t reset_blocks_wanted(uint32_t fl) {
+    const bool rc = (fl & TACO_F_RANDOM_ROTORDYNAMIC_COE) != 0, ra = (fl & TACO_F_RANDOM_AERODYNAMIC_COE) != 0;
+    const bool rtau = (fl & TACO_F_ROTOR_RESPONSE) && (fl & TACO_F_RANDOM_ROTOR_RESPONSE), rspd = (fl & TACO_F_RANDOM_ROTOR_SPEED) != 0;
+    const bool rquat = (fl & TACO_F_RANDOM_COPTER_QUAT) != 0, rvel = (fl & TACO_F_RANDOM_COPTER_VEL) != 0;
+    return 1u | ((rquat || rvel) ? 2u : 0u) | (rvel ? 4u : 0u) | ((rvel || (fl & TACO_F_RANDOM_TARGET_POS)) ? 8u : 0u) |
+           (((fl & (TACO_F_RANDOM_TARGET_YAW | TACO_F_RANDOM_VOLTAGE)) || rc) ? 16u : 0u) | ((rc || rtau) ? 32u : 0u) |
+           ((rtau || rspd) ? 64u : 0u) | ((rspd || ra) ? 128u : 0u) | (ra ? 256u : 0u) | ((fl & TACO_F_RANDOM_DELAY_TIME) ? 512u : 0u);
+}
+// this lane's block of round `rnd` of the quad layout's share-out (block 4 rnd + sub), as the four uniforms
+TD float4 reset_block_quad(const StepParams &P, uint32_t step, int gid, int rnd, int sub) {
+    const U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, step, STREAM_RESET, (uint32_t)(4 * rnd + sub));
+    return make_float4(uniform(r.x), uniform(r.y), uniform(r.z), uniform(r.w));
+}
+// `drawn` (LPE == 4, optional): the three rounds' blocks, [rnd * 64 + lane], drawn ahead by the role wavefronts (step_core: "reset draws")
 template <int LPE>
 TD void reset_env(const StepParams &P, uint32_t step, rsrc_t rS, uint32_t voff, uint32_t row_bytes, int gid, int grp, bool mix, bool store, int sub,
                   float4 &c_pos, float4 &c_quat, float4 &c_lin, float4 &c_ang, float4 &c_pp, float4 &c_pi, float4 &c_om, float4 &c_misc, float4 &c_tau,
-                  float4 &c_op, float4 &c_a0, float4 &c_a1) {
+                  float4 &c_op, float4 &c_a0, float4 &c_a1, const __attribute__((address_space(3))) f32x4_t *drawn = nullptr) {
     const uint32_t fl = P.flags;
     const bool rc = (fl & TACO_F_RANDOM_ROTORDYNAMIC_COE) != 0, ra = (fl & TACO_F_RANDOM_AERODYNAMIC_COE) != 0;
     const bool rtau = (fl & TACO_F_ROTOR_RESPONSE) && (fl & TACO_F_RANDOM_ROTOR_RESPONSE), rspd = (fl & TACO_F_RANDOM_ROTOR_SPEED) != 0;
     const bool rpos = (fl & TACO_F_RANDOM_COPTER_POS) != 0, rquat = (fl & TACO_F_RANDOM_COPTER_QUAT) != 0, rvel = (fl & TACO_F_RANDOM_COPTER_VEL) != 0;
-    // which blocks this configuration draws from (launch-uniform), as a bit mask
-    const uint32_t want = 1u | ((rquat || rvel) ? 2u : 0u) | (rvel ? 4u : 0u) | ((rvel || (fl & TACO_F_RANDOM_TARGET_POS)) ? 8u : 0u) |
-                          (((fl & (TACO_F_RANDOM_TARGET_YAW | TACO_F_RANDOM_VOLTAGE)) || rc) ? 16u : 0u) | ((rc || rtau) ? 32u : 0u) |
-                          ((rtau || rspd) ? 64u : 0u) | ((rspd || ra) ? 128u : 0u) | (ra ? 256u : 0u) | ((fl & TACO_F_RANDOM_DELAY_TIME) ? 512u : 0u);
+    const uint32_t want = reset_blocks_wanted(fl);
     float qu[3][4] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};  // LPE == 4: this lane's uniforms of blocks sub, 4 + sub, 8 + sub
     if constexpr (LPE == 4) {
 #pragma unroll
         for (int rnd = 0; rnd < 3; ++rnd) {
             if ((want >> (4 * rnd)) & 15u) {  // (launch-uniform: some lane's block of this round is drawn from)
-                const U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, step, STREAM_RESET, (uint32_t)(4 * rnd + sub));
-                qu[rnd][0] = uniform(r.x); qu[rnd][1] = uniform(r.y); qu[rnd][2] = uniform(r.z); qu[rnd][3] = uniform(r.w);
+                float4 u;
+                if (drawn) { const f32x4_t d = drawn[rnd * 64 + (int)(threadIdx.x & 63)]; u = make_float4(d.x, d.y, d.z, d.w); }
+                else u = reset_block_quad(P, step, gid, rnd, sub);
+                qu[rnd][0] = u.x; qu[rnd][1] = u.y; qu[rnd][2] = u.z; qu[rnd][3] = u.w;
             }
         }
     }
@@ -897,6 +914,15 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     static_assert(!EULER_TAB || 2 * TILE_WORDS >= 11 * 64 * (LPE == 4 ? 1 : 4), "eq_tab must fit in the role wavefronts' frame tiles");
     float *const eq_tab = lds_all + WAVE_LDS_WORDS;
     __shared__ float eu_io[EULER_TAB ? (LPE == 4 ? 2 : 6) * 64 : 4];
+    // Reset draws SERVED in the four-role quad forms: a resetting env consumes up to ten Philox blocks of STREAM_RESET, shared out over its quad as
+    // three per lane (reset_env) -- ~200 instructions on the path of the wavefront that decides the launch time (some wavefront of nearly every
+    // 4 096-env launch holds a resetting env).  The blocks depend on counters only, and the three role wavefronts idle at barrier 1 while wavefront 0
+    // waits for its loads: each draws ONE round (block 4 (wv - 1) + sub of its lane's env) into rs_tab ahead of the barrier, every step, whether or
+    // not an env resets; wavefront 0 passes the barrier before its reset and reads its lane's three entries.  Same counters, same uniforms.
+    // (rs_tab lives in the role wavefronts' frame tiles like eq_tab: read by the reset, before wavefront 0's first substep writes an attitude there)
+    constexpr bool DRAWS_SERVED = ROLES && LPE == 4 && !FUSED && !RESET_ONLY;
+    static_assert(!DRAWS_SERVED || 2 * TILE_WORDS >= 3 * 64 * 4, "rs_tab must fit in the role wavefronts' frame tiles");
+    __attribute__((address_space(3))) f32x4_t *const rs_tab = (__attribute__((address_space(3))) f32x4_t *)(lds_all + WAVE_LDS_WORDS);
     constexpr bool NOISE_TAB = SPLIT && !(WIDE && LPE == 4);
     constexpr bool NOISE_INLINE = !SPLIT;   // the one-wavefront instantiations have nobody to serve a table: their PLAIN forms draw the rotor noise themselves
     // (rn_tab lives in `hand`: the table is read by the substeps, the Carry is written after the last one and read after barrier 2; the
@@ -1006,8 +1032,10 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     }
     // reset_idx (FA:475-517): the lanes that reset get their fresh state in the registers the up-front loads filled (see reset_env)
     const bool wave_has_reset = __builtin_amdgcn_ballot_w64(is_reset) != 0;
+    if constexpr (DRAWS_SERVED) __syncthreads();   // barrier 1 of 2 (here in these forms: the role wavefronts' reset draws are in rs_tab, see below)
     if (wave_has_reset) {
-        if (is_reset) reset_env<LPE>(P, clk.step, rS, voff, row_bytes, gid, grp, mix, active, sub, c_pos, c_quat, c_lin, c_ang, c_pp, c_pi, c_om, c_misc, c_tau, c_op, c_a0, c_a1);
+        if (is_reset) reset_env<LPE>(P, clk.step, rS, voff, row_bytes, gid, grp, mix, active, sub, c_pos, c_quat, c_lin, c_ang, c_pp, c_pi, c_om, c_misc, c_tau, c_op, c_a0, c_a1,
+                                     DRAWS_SERVED ? rs_tab : nullptr);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // (the target pose and the unwrapped angles it stored are loaded further down)
     }
     if (P.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TACO_STAMP(1); }  // all up-front loads have landed
@@ -1028,8 +1056,8 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     const float opara[5] = {c_op.x, c_op.y, c_op.z, c_op.w, c_a0.x};
     float bat_E = c_pp.w, bat_u1 = c_pi.w, bat_t = c_misc.x, bat_V = c_ang.w;
     if constexpr (SPLIT) {
-        __syncthreads();  // barrier 1 of 2: wavefront 1 has zeroed the mailbox counters (the helpers have been waiting here since their
-                          // launch and wavefront 0 arrives a load round trip later, so it does not wait)
+        if constexpr (!DRAWS_SERVED) __syncthreads();  // barrier 1 of 2: wavefront 1 has zeroed the mailbox counters (the helpers have been waiting here since
+                                                       // their launch and wavefront 0 arrives a load round trip later, so it does not wait)
         if (bat_served) {  // the battery server can start on the first substep's voltage while wavefront 0 finishes its pre-phase
             mb_om[lane] = pick4(sub, omega[0], omega[1], omega[2], omega[3]);
             mb_bs[lane] = pick4(sub, bat_E, bat_u1, bat_t, 0.0f);
@@ -1478,6 +1506,19 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
         // the delayed action of substep k + 1 is fetched during substep k: its LDS latency would otherwise sit at the head of every substep
         auto slot_of = [&](int k) { int r = (dlen - 1 < k) ? dlen - 1 : k; return r > 9 ? 9 : r; };
         float dq_next = slotsf[(slot_of(0) * EPW + el) * 4 + sub];
+        float fix_p = 0.0f, fix_q = 0.0f, fix_v = 0.0f, fix_b = 0.0f, fix_F = 0.0f, fix_t = 0.0f;   // the integrator's inputs of the running substep (PLAIN forms)
+        auto roundtrip = [&]() {  // FA:350 literally: w = R(q) b (quat_sandwich), b = quat_rotate(conj(q), w), lane j = component j
+            const float ww = bc3(qq), q1 = rot1(qq), q2 = rot2(qq);
+            float t = fma(q1, rot2(bq), -(q2 * rot1(bq)));
+            t = t + t;
+            const float wq = fma(q1, rot2(t), fma(-q2, rot1(t), fma(ww, t, bq)));
+            bq = from_bits(bits(quad_rotate(-qq, ww, wq)) & ~k3);  // (lane 3 holds no rate component: kept at +0)
+        };
+        auto redo_integrate = [&]() {   // the PLAIN forms' rare case: see the end of `substep`
+            pq = fix_p; qq = fix_q; vq = fix_v; bq = fix_b;
+            integrate_quad<2>(P, k3, pq, qq, vq, bq, fix_F, fix_t, Jq, hJiq, gzq, sm3);
+            roundtrip();
+        };
         auto substep = [&](auto fin_c, const int ks) -> bool {
             // loop forms: 0 exact, 1 FIN, 2 FIN + PLAIN (battery computed here), 6 FIN + PLAIN + battery served by wavefront 1; + 8: with
             // euler/unwrap (wavefronts that hold flip envs)
@@ -1601,13 +1642,19 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
                 Fq = from_bits(bits(selm(k2, Fz, dragq * vbq)) & keep);
                 tqq = from_bits(bits(selm(k2, tz, txy)) & keep);
             }
-            const bool rare = integrate_quad<PLAIN ? 2 : 0>(P, k3, pq, qq, vq, bq, Fq, tqq, Jq, hJiq, gzq, sm3);
-            if (PLAIN || (fl & TACO_F_WORLD_RATE_ROUNDTRIP)) {  // FA:350 literally: w = R(q) b (quat_sandwich), b = quat_rotate(conj(q), w), lane j = component j
-                const float ww = bc3(qq), q1 = rot1(qq), q2 = rot2(qq);
-                float t = fma(q1, rot2(bq), -(q2 * rot1(bq)));
-                t = t + t;
-                const float wq = fma(q1, rot2(t), fma(-q2, rot1(t), fma(ww, t, bq)));
-                bq = from_bits(bits(quad_rotate(-qq, ww, wq)) & ~k3);  // (lane 3 holds no rate component: kept at +0)
+            bool rare;
+            if constexpr (PLAIN) {
+                // The integrator's four rare-form tests (two per sub-iteration) cost a lone wavefront ~30 clocks each as branches (VALU compare ->
+                // SGPR -> s_cbranch, nothing else to issue meanwhile): the PLAIN forms run the common forms unconditionally, OR the four tests
+                // together and leave the ONE branch to the loop (run_form: "rare" ends it); a wavefront that did meet a rare form redoes the
+                // integrator from the substep's start values with the branching form (redo_integrate: same values as before, lane by lane).
+                fix_p = pq; fix_q = qq; fix_v = vq; fix_b = bq; fix_F = Fq; fix_t = tqq;
+                rare = integrate_quad<2, true>(P, k3, pq, qq, vq, bq, Fq, tqq, Jq, hJiq, gzq, sm3);
+                roundtrip();
+                asm volatile("" ::"v"(pq), "v"(qq), "v"(vq), "v"(bq));   // (or the compiler branches around the rest of the substep as soon as `rare` is known)
+            } else {
+                rare = integrate_quad<0>(P, k3, pq, qq, vq, bq, Fq, tqq, Jq, hJiq, gzq, sm3);
+                if (fl & TACO_F_WORLD_RATE_ROUNDTRIP) roundtrip();
             }
             return rare;
         };
@@ -1634,13 +1681,18 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
             force_exact = __builtin_amdgcn_ballot_w64(!(mag < 1e30f)) != 0;
         };
         auto run_form = [&](auto form) {
+            bool rare = false;
+            if (ks < 10) {
+                bool more;   // (one wave-uniform flag, bitwise: `rare || ks == 10` as control flow is a second branch per substep)
 #pragma unroll 1
-            while (ks < 10) {
-                if constexpr (FUSED) { if (ks == patch_at) late_patch(); }
-                const bool rare = substep(form, ks);
-                ++ks;
-                if (rare || (FUSED && force_exact)) break;
+                do {
+                    if constexpr (FUSED) { if (ks == patch_at) late_patch(); }
+                    rare = substep(form, ks);
+                    ++ks;
+                    more = !(bool)((int)rare | (int)(ks >= 10) | (int)(FUSED && force_exact));
+                } while (more);
             }
+            if constexpr ((decltype(form)::value & 2) != 0) { if (rare) redo_integrate(); }
         };
         if (noise_served) {   // the noise table is complete before the first substep reads it (posted ~a pre-phase ago: normally no wait)
             MB_WAIT(2, 1);
@@ -1782,6 +1834,12 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     } else {
         load_out_args();
         if (wv == 1 && lane < 8) mb_seq[lane] = 0;
+        if constexpr (DRAWS_SERVED) {   // the reset draws, round wv - 1 (see rs_tab)
+            if ((reset_blocks_wanted(fl) >> (4 * (wv - 1))) & 15u) {
+                const float4 u = reset_block_quad(P, clk.step, gid, wv - 1, sub);
+                rs_tab[(wv - 1) * 64 + lane] = f32x4_t{u.x, u.y, u.z, u.w};
+            }
+        }
         __syncthreads();  // barrier 1 of 2
         if constexpr (NOISE_TAB) {
             if (wv == (ROLES ? 2 : 1) && noise_served) {   // the step's 10 x EPW rotor-noise blocks -> rn_tab (first: wavefront 0 needs them at its first substep)
