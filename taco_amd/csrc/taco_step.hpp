@@ -507,11 +507,13 @@ TD uint32_t reset_blocks_wanted(uint32_t fl) {
            (((fl & (TACO_F_RANDOM_TARGET_YAW | TACO_F_RANDOM_VOLTAGE)) || rc) ? 16u : 0u) | ((rc || rtau) ? 32u : 0u) |
            ((rtau || rspd) ? 64u : 0u) | ((rspd || ra) ? 128u : 0u) | (ra ? 256u : 0u) | ((fl & TACO_F_RANDOM_DELAY_TIME) ? 512u : 0u);
 }
-// this lane's block of round `rnd` of the quad layout's share-out (block 4 rnd + sub), as the four uniforms
-TD float4 reset_block_quad(const StepParams &P, uint32_t step, int gid, int rnd, int sub) {
-    const U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, step, STREAM_RESET, (uint32_t)(4 * rnd + sub));
+// one Philox block as its four uniforms
+TD float4 uniform_block(const StepParams &P, uint32_t step, int gid, uint32_t stream, uint32_t ctr) {
+    const U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, step, stream, ctr);
     return make_float4(uniform(r.x), uniform(r.y), uniform(r.z), uniform(r.w));
 }
+// this lane's block of round `rnd` of the quad layout's share-out (block 4 rnd + sub)
+TD float4 reset_block_quad(const StepParams &P, uint32_t step, int gid, int rnd, int sub) { return uniform_block(P, step, gid, STREAM_RESET, (uint32_t)(4 * rnd + sub)); }
 // `drawn` (LPE == 4, optional): the three rounds' blocks, [rnd * 64 + lane], drawn ahead by the role wavefronts (step_core: "reset draws")
 template <int LPE>
 TD void reset_env(const StepParams &P, uint32_t step, rsrc_t rS, uint32_t voff, uint32_t row_bytes, int gid, int grp, bool mix, bool store, int sub,
@@ -1092,13 +1094,15 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
         if (grp == TACO_TASK_POS) {
             cmd0 = 0.0f; cmd1 = 0.0f;
         } else {
-            U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, clk.step, STREAM_CMD, 0u);
+            float cu_x, cu_y;   // uniforms 0, 1 of STREAM_CMD block 0 (DRAWS_SERVED: drawn by the states role wavefront, lane 2 of the env's quad)
+            if constexpr (DRAWS_SERVED) { const f32x4_t d = rs_tab[2 * 64 + el * 4 + 2]; cu_x = d.x; cu_y = d.y; }
+            else { const float4 d = uniform_block(P, clk.step, gid, STREAM_CMD, 0u); cu_x = d.x; cu_y = d.y; }
             if (grp == TACO_TASK_ROTATE) {
                 cmd0 = 1.0f;
-                cmd1 = (fl & TACO_F_RANDOM_COMMAND) ? 12.0f * uniform(r.x) + -6.0f : 1.0f;
+                cmd1 = (fl & TACO_F_RANDOM_COMMAND) ? 12.0f * cu_x + -6.0f : 1.0f;
             } else {
                 if (at_time) {
-                    float uu = uniform(r.y), t = 0.0f;
+                    float uu = cu_y, t = 0.0f;
                     if (uu < 1.0f / 8) t = -3.0f;
                     if (uu >= 1.0f / 8 && uu < 2.0f / 8) t = -2.0f;
                     if (uu >= 2.0f / 8 && uu < 3.0f / 8) t = -1.0f;
@@ -1835,8 +1839,11 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
         load_out_args();
         if (wv == 1 && lane < 8) mb_seq[lane] = 0;
         if constexpr (DRAWS_SERVED) {   // the reset draws, round wv - 1 (see rs_tab)
-            if ((reset_blocks_wanted(fl) >> (4 * (wv - 1))) & 15u) {
-                const float4 u = reset_block_quad(P, clk.step, gid, wv - 1, sub);
+            // (round 2 holds blocks 8 and 9 only: lane 2 of every quad draws the env's command block there, STREAM_CMD block 0 -- consumed by
+            // reset_command_idx of the rotate / flip envs, at a reset and at progress 500)
+            const bool cmd_lane = wv == 3 && sub == 2 && P.task_mode != TACO_TASK_POS;
+            if (((reset_blocks_wanted(fl) >> (4 * (wv - 1))) & 15u) || (wv == 3 && P.task_mode != TACO_TASK_POS)) {
+                const float4 u = uniform_block(P, clk.step, gid, cmd_lane ? STREAM_CMD : STREAM_RESET, cmd_lane ? 0u : (uint32_t)(4 * (wv - 1) + sub));
                 rs_tab[(wv - 1) * 64 + lane] = f32x4_t{u.x, u.y, u.z, u.w};
             }
         }
