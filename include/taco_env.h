@@ -381,7 +381,8 @@ enum {
 int taco_set_kernel_form(taco_env *env, int form);
 int taco_get_kernel_form(const taco_env *env);  /* the TACO_FORM_* in use (never AUTO), or TACO_ERR_INVALID_ARG */
 /* Introspection (profiling aid): bind a DEVICE array of 16 uint64; every following taco_step makes lane 0 of workgroup 0 record
- * the shader clock (s_memtime) at: 0 kernel entry, 1 up-front loads landed, 2 pre-phase done (reset / delay line / slot table),
+ * the shader clock (s_memtime) at: 0 kernel entry, 1 up-front loads landed, [9] reset_idx of the workgroup's resetting envs done (no env
+ * resets: right behind 1), 2 pre-phase done (delay line / slot table),
  * 3 ten substeps done, 4 state stores + frame stacks done, 5 kernel end (in the four-role instantiations these are
  * wavefront 0's: 4 and 5 coincide after its state stores; [6..8] = the ends of role wavefronts 1..3: reward, obs stack, states stack).  NULL unbinds.  Costs a scalar branch per phase. */
 int taco_bind_phase_stamps(taco_env *env, uint64_t *stamps);

@@ -1035,12 +1035,13 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     // reset_idx (FA:475-517): the lanes that reset get their fresh state in the registers the up-front loads filled (see reset_env)
     const bool wave_has_reset = __builtin_amdgcn_ballot_w64(is_reset) != 0;
     if constexpr (DRAWS_SERVED) __syncthreads();   // barrier 1 of 2 (here in these forms: the role wavefronts' reset draws are in rs_tab, see below)
+    if (P.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TACO_STAMP(1); }  // all up-front loads have landed
     if (wave_has_reset) {
         if (is_reset) reset_env<LPE>(P, clk.step, rS, voff, row_bytes, gid, grp, mix, active, sub, c_pos, c_quat, c_lin, c_ang, c_pp, c_pi, c_om, c_misc, c_tau, c_op, c_a0, c_a1,
                                      DRAWS_SERVED ? rs_tab : nullptr);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // (the target pose and the unwrapped angles it stored are loaded further down)
     }
-    if (P.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TACO_STAMP(1); }  // all up-front loads have landed
+    TACO_STAMP(9);  // reset_idx done (no wait for its stores)
     V3 p{c_pos.x, c_pos.y, c_pos.z};
     Q4 q{c_quat.x, c_quat.y, c_quat.z, c_quat.w};
     V3 v{c_lin.x, c_lin.y, c_lin.z};
