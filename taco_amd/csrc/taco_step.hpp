@@ -428,22 +428,32 @@ TD float quad_rotate(float qv, float w, float v) {
 // row I (integrate above) in the quad layout.  qq = (x y z w) over the four lanes; pq vq bq Fq tqq components 0..2 in lanes 0..2.
 // Jq / hJiq: this lane's inertia terms; gzq = (-0, -0, g, -0) (fma(RF, 1/m, -0) == RF * (1/m) exactly); sm3 = sign bit in lane 3,
 // k3 = all ones in lane 3.
-template <int SUBS = 0, bool DEFER = false>
+// the linear lines of one sub-iteration of row I in the quad layout: v <- v + h (R(q) F / m + g), p <- p + h v, with q the attitude BEFORE the
+// sub-iteration's update (lane j = component j; gzq = (-0, -0, g, -0)).  Used by integrate_quad and, in the four-role quad forms, by the
+// wavefront that runs the linear chain behind the step wavefront (step_core: "linear chain served"): one definition, the same bits.
+TD void linear_iteration_quad(const StepParams &P, float qq, float Fq, float gzq, float &vq, float &pq) {
+    const float ww = bc3(qq);
+    const float q1 = rot1(qq), q2 = rot2(qq);
+    float t = fma(q1, rot2(Fq), -(q2 * rot1(Fq)));
+    t = t + t;
+    const float RF = fma(q1, rot2(t), fma(-q2, rot1(t), fma(ww, t, Fq)));
+    vq = fma(P.h, fma(RF, P.inv_m, gzq), vq);
+    pq = fma(P.h, vq, pq);
+}
+// NOLIN: the angular lines only (pq, vq, Fq are not touched); q_mid <- the attitude after the FIRST sub-iteration (what the second one's
+// linear lines rotate the force with) -- the linear chain runs elsewhere, see linear_iteration_quad.
+template <int SUBS = 0, bool DEFER = false, bool NOLIN = false>
 TD bool integrate_quad(const StepParams &P, uint32_t k3, float &pq, float &qq, float &vq, float &bq, float Fq, float tqq, float Jq, float hJiq,
-                       float gzq, uint32_t sm3) {
+                       float gzq, uint32_t sm3, float &q_mid) {
     bool any_big = false;
     uint64_t bad = 0;   // DEFER: the lanes that met a rare form (nothing was branched on; the caller redoes the call with DEFER = false)
+    int it_no = 0;
     auto iteration = [&]() {
         const float L = Jq * bq;
         const float g = fma(rot1(bq), rot2(L), -(rot2(bq) * rot1(L)));
         bq = fma(hJiq, tqq - g, bq);
         const float ww = bc3(qq);
-        const float q1 = rot1(qq), q2 = rot2(qq);
-        float t = fma(q1, rot2(Fq), -(q2 * rot1(Fq)));
-        t = t + t;
-        const float RF = fma(q1, rot2(t), fma(-q2, rot1(t), fma(ww, t, Fq)));
-        vq = fma(P.h, fma(RF, P.inv_m, gzq), vq);
-        pq = fma(P.h, vq, pq);
+        if constexpr (!NOLIN) linear_iteration_quad(P, qq, Fq, gzq, vq, pq);
         const float sqb = bq * bq, b1 = bc1(bq), b2 = bc2(bq);
         const float w2 = fma(b2, b2, fma(b1, b1, bc0(sqb)));
         const float A2 = (P.half_h * P.half_h) * w2;
@@ -479,6 +489,7 @@ TD bool integrate_quad(const StepParams &P, uint32_t k3, float &pq, float &qq, f
             inv = off ? ie : inv;
         }
         qq = n * inv;
+        if (it_no++ == 0) q_mid = qq;
     };
     if constexpr (SUBS == 2) { iteration(); iteration(); }
     else for (int it = 0; it < P.substeps; ++it) iteration();
@@ -925,6 +936,19 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     constexpr bool DRAWS_SERVED = ROLES && LPE == 4 && !FUSED && !RESET_ONLY;
     static_assert(!DRAWS_SERVED || 2 * TILE_WORDS >= 3 * 64 * 4, "rs_tab must fit in the role wavefronts' frame tiles");
     __attribute__((address_space(3))) f32x4_t *const rs_tab = (__attribute__((address_space(3))) f32x4_t *)(lds_all + WAVE_LDS_WORDS);
+    // Linear chain SERVED in the four-role quad forms.  Inside a step nothing feeds back from the linear state into the angular chain: rate PID,
+    // allocator, rotors, torque, body rates and attitude never read position or linear velocity; v and p only consume the attitude (before each of
+    // the two sub-iterations) and the rotors' thrust.  So wavefront 0 keeps the angular chain -- the part that is serial from substep to substep --
+    // and leaves, per substep, the two attitudes and its lanes' pair thrust sums in lin_ring (three LDS writes; the counter, mb_seq[5], is
+    // published at the top of the NEXT substep, when the integrator's rare-form test of this one is settled); the obs role wavefront (idle until the
+    // post-phase) runs body-frame velocity, drag, force rotation and the v / p updates behind it (linear_iteration_quad: the same expressions),
+    // hands p and v to the Carry and stores their words of the state -- ~80 of the ~315 instructions of every substep leave the critical path
+    // (wavefront 0 issues one instruction per ~5 clocks whatever its type), at the price of the server's last substep (~500 clocks) before barrier 2.
+    constexpr bool LIN_SERVED = ROLES && LPE == 4 && !FUSED;
+    __shared__ float lin_ring[LIN_SERVED ? (10 * 3 + 1) * 64 : 4];   // [substep][0: q before the substep, 1: q after its first sub-iteration, 2: rf + swp(rf)][lane]
+                                                                     // ([.][0] is written at the end of the substep BEFORE: the server starts on it one counter earlier)
+    __shared__ float lin_init[LIN_SERVED ? 5 * 64 : 4];        // [p, v, drag coefficient, kt, keep mask][lane]: posted with counter value 1
+    const bool lin_served = LIN_SERVED && P.substeps == 2;     // (the server runs exactly two sub-iterations)
     constexpr bool NOISE_TAB = SPLIT && !(WIDE && LPE == 4);
     constexpr bool NOISE_INLINE = !SPLIT;   // the one-wavefront instantiations have nobody to serve a table: their PLAIN forms draw the rotor noise themselves
     // (rn_tab lives in `hand`: the table is read by the substeps, the Carry is written after the last one and read after barrier 2; the
@@ -1519,11 +1543,17 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
             const float wq = fma(q1, rot2(t), fma(-q2, rot1(t), fma(ww, t, bq)));
             bq = from_bits(bits(quad_rotate(-qq, ww, wq)) & ~k3);  // (lane 3 holds no rate component: kept at +0)
         };
-        auto redo_integrate = [&]() {   // the PLAIN forms' rare case: see the end of `substep`
+        auto redo_integrate = [&](int ks_of) {   // the PLAIN forms' rare case: see the end of `substep`; ks_of: that substep
             pq = fix_p; qq = fix_q; vq = fix_v; bq = fix_b;
-            integrate_quad<2>(P, k3, pq, qq, vq, bq, fix_F, fix_t, Jq, hJiq, gzq, sm3);
+            float q_mid = 0.0f;
+            integrate_quad<2, false, LIN_SERVED>(P, k3, pq, qq, vq, bq, fix_F, fix_t, Jq, hJiq, gzq, sm3, q_mid);
+            if constexpr (LIN_SERVED) { lin_ring[(ks_of * 3 + 1) * 64 + lane] = q_mid; lin_ring[(ks_of * 3 + 3) * 64 + lane] = qq; }   // (not published yet: the counter follows at the top of the next substep)
             roundtrip();
         };
+        if (lin_served) {   // the linear chain's start values (published by the first substep's MB_POST(5, 1))
+            lin_init[lane] = pq; lin_init[64 + lane] = vq; lin_init[128 + lane] = dragq; lin_init[192 + lane] = kt; lin_init[256 + lane] = from_bits(keep);
+            lin_ring[lane] = qq;
+        }
         auto substep = [&](auto fin_c, const int ks) -> bool {
             // loop forms: 0 exact, 1 FIN, 2 FIN + PLAIN (battery computed here), 6 FIN + PLAIN + battery served by wavefront 1; + 8: with
             // euler/unwrap (wavefronts that hold flip envs)
@@ -1547,23 +1577,23 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
                 else pit = asin(num);
                 unwrap(sub == 1 ? pit : at, roq, rcq);
             }
-            const float vbq = quad_rotate(-qq, bc3(qq), vq);  // FA:350 body-frame linear velocity
+            const bool lin_off = PLAIN ? LIN_SERVED : lin_served;   // the linear chain runs in the obs role wavefront (PLAIN: two sub-iterations by definition)
+            // the voltage of this substep has been in the making in wavefront 1 since the previous substep's rotor update (~850 clocks ago; it needs
+            // ~650): counter and value are read HERE, at the top, ~45 instructions ahead of their use (LDS executes a wavefront's reads in order, so
+            // a value read after a sufficient counter is the right one)
+            int seq_early = 0;
+            float v_early = 0.0f;
+            if (served) {
+                asm volatile("" ::: "memory");
+                seq_early = MB_SEQ(1);
+                v_early = __hip_atomic_load(&mb_v[el], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             const float dq = dq_next;  // slot min(L - 1, ks), FA:366
             dq_next = slotsf[(slot_of(ks + 1) * EPW + el) * 4 + sub];
             const float d0 = bc0(dq);
             // angular_vel_control FA:637-650: lane j runs PID axis j on action component j + 1
             const float u0 = (d0 + 1.0f) / 2.0f * 1000.0f;
             const float upid = pid_axis<FIN>(P.dt, P.rdt, kpq, dppf<QP(1, 2, 3, 3)>(dq) * 20.0f, bq, ppq, piq);
-            // the voltage of this substep is being computed by wavefront 1 since the previous substep's rotor update: read counter and
-            // value here, ~40 instructions ahead of their use (LDS executes a wavefront's reads in order, so a value read after a
-            // sufficient counter is the right one)
-            int seq_early = 0;
-            float v_early = 0.0f;
-            if (served) {
-                asm volatile("" ::"v"(upid) : "memory");  // not before the PID is done: gives wavefront 1 the time it needs
-                seq_early = MB_SEQ(1);
-                v_early = __hip_atomic_load(&mb_v[el], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
             // control_allocator CTRL/fpv_dynamics.py:35-46: lane k computes motor k
             const float u1 = bc0(upid), u2 = bc1(upid);
             float u3 = bc2(upid);
@@ -1629,23 +1659,28 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
             }
             // AeroDynamics.sim_process CTRL/thrust_dynamics.py:173-199 + real->sim re-index CTRL/fpv_dynamics.py:48-56
             // fs = (rf2 rf3 rf0 rf1), ts = (-rt2 rt3 -rt0 rt1): the pair sums live in lanes (2,3) and (0,1)
-            float Fq, tqq;
+            float Fq = 0.0f, tqq;
             {
                 const float rf = cf * omq * omq;
                 const float rt = ct * rf;
-                const float vxy = norm2(bc0(vbq), bc1(vbq));
                 const float psum = rf + swp(rf);          // lanes 0,1: rf0 + rf1   lanes 2,3: rf2 + rf3
                 const float pdif = rf - swp(rf);          // lane 0: rf0 - rf1      lane 2: rf2 - rf3
                 const float srt = xorf(rt, m3);           // -rt0 rt1 -rt2 rt3
                 const float pz = srt + swp(srt);          // lanes 0,1: -rt0 + rt1  lanes 2,3: -rt2 + rt3
-                const float Fz = kt * vxy * vxy + (bc2(psum) + bc0(psum));
                 // tq.x = arm_y ((fs0+fs1) - (fs2+fs3)), tq.y = -arm_x ((fs0-fs1) - (fs2-fs3)): lane 0 / 1 read the pair terms of
                 // M = (pdif psum pdif psum) from lanes (3,1) / (2,0); tq.z = (ts0+ts1) + (ts2+ts3)
                 const float M = selm(keven, pdif, psum);
                 const float txy = Sq * (dppf<QP(3, 2, 2, 2)>(M) - dppf<QP(1, 0, 0, 0)>(M));
                 const float tz = bc2(pz) + bc0(pz);
-                Fq = from_bits(bits(selm(k2, Fz, dragq * vbq)) & keep);
                 tqq = from_bits(bits(selm(k2, tz, txy)) & keep);
+                if (lin_off) {
+                    lin_ring[(ks * 3 + 2) * 64 + lane] = psum;
+                } else {
+                    const float vbq = quad_rotate(-qq, bc3(qq), vq);  // FA:350 body-frame linear velocity
+                    const float vxy = norm2(bc0(vbq), bc1(vbq));
+                    const float Fz = kt * vxy * vxy + (bc2(psum) + bc0(psum));
+                    Fq = from_bits(bits(selm(k2, Fz, dragq * vbq)) & keep);
+                }
             }
             bool rare;
             if constexpr (PLAIN) {
@@ -1654,11 +1689,19 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
                 // together and leave the ONE branch to the loop (run_form: "rare" ends it); a wavefront that did meet a rare form redoes the
                 // integrator from the substep's start values with the branching form (redo_integrate: same values as before, lane by lane).
                 fix_p = pq; fix_q = qq; fix_v = vq; fix_b = bq; fix_F = Fq; fix_t = tqq;
-                rare = integrate_quad<2, true>(P, k3, pq, qq, vq, bq, Fq, tqq, Jq, hJiq, gzq, sm3);
+                float q_mid = 0.0f;
+                rare = integrate_quad<2, true, LIN_SERVED>(P, k3, pq, qq, vq, bq, Fq, tqq, Jq, hJiq, gzq, sm3, q_mid);
+                if constexpr (LIN_SERVED) { lin_ring[(ks * 3 + 1) * 64 + lane] = q_mid; lin_ring[(ks * 3 + 3) * 64 + lane] = qq; }   // (+ 3: the next substep's start attitude)
                 roundtrip();
                 asm volatile("" ::"v"(pq), "v"(qq), "v"(vq), "v"(bq));   // (or the compiler branches around the rest of the substep as soon as `rare` is known)
             } else {
-                rare = integrate_quad<0>(P, k3, pq, qq, vq, bq, Fq, tqq, Jq, hJiq, gzq, sm3);
+                float q_mid = 0.0f;
+                if (lin_off) {
+                    rare = integrate_quad<0, false, true>(P, k3, pq, qq, vq, bq, Fq, tqq, Jq, hJiq, gzq, sm3, q_mid);
+                    lin_ring[(ks * 3 + 1) * 64 + lane] = q_mid; lin_ring[(ks * 3 + 3) * 64 + lane] = qq;
+                } else {
+                    rare = integrate_quad<0>(P, k3, pq, qq, vq, bq, Fq, tqq, Jq, hJiq, gzq, sm3, q_mid);
+                }
                 if (fl & TACO_F_WORLD_RATE_ROUNDTRIP) roundtrip();
             }
             return rare;
@@ -1692,12 +1735,13 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
 #pragma unroll 1
                 do {
                     if constexpr (FUSED) { if (ks == patch_at) late_patch(); }
+                    if (((decltype(form)::value & 2) != 0 && LIN_SERVED) || lin_served) MB_POST(5, ks + 1);   // the linear chain may take substep ks - 1 (ks == 0: its start values)
                     rare = substep(form, ks);
                     ++ks;
                     more = !(bool)((int)rare | (int)(ks >= 10) | (int)(FUSED && force_exact));
                 } while (more);
             }
-            if constexpr ((decltype(form)::value & 2) != 0) { if (rare) redo_integrate(); }
+            if constexpr ((decltype(form)::value & 2) != 0) { if (rare) redo_integrate(ks - 1); }
         };
         if (noise_served) {   // the noise table is complete before the first substep reads it (posted ~a pre-phase ago: normally no wait)
             MB_WAIT(2, 1);
@@ -1724,8 +1768,10 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
 #pragma unroll 1
         for (; ks < 10; ++ks) {
             if constexpr (FUSED) { if (ks == patch_at) late_patch(); }
+            if (lin_served) MB_POST(5, ks + 1);
             substep(std::integral_constant<int, 0>{}, ks);
         }
+        if (lin_served) MB_POST(5, 11);   // ... and the tenth
         if (bat_served) {
             MB_WAIT(1, 11);
             bat_E = mb_bs[el * 4]; bat_u1 = mb_bs[el * 4 + 1]; bat_t = mb_bs[el * 4 + 2];
@@ -1787,7 +1833,9 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     K.act[0] = act[0]; K.act[1] = act[1]; K.act[2] = act[2]; K.act[3] = act[3]; K.c_tp = c_tp; K.c_tq = c_tq;
     if (ROLES && sub == 0) {  // hand the Carry to the three role wavefronts
         float4 *h4 = reinterpret_cast<float4 *>(hand + el * CARRY_WORDS);
-        h4[0] = make_float4(p.x, p.y, p.z, bat_V); h4[1] = make_float4(v.x, v.y, v.z, cmd0); h4[2] = make_float4(w.x, w.y, w.z, cmd1);
+        if (lin_served) { hand[el * CARRY_WORDS + 3] = bat_V; hand[el * CARRY_WORDS + 7] = cmd0; }   // (p and v come from the wavefront that ran the linear chain)
+        else { h4[0] = make_float4(p.x, p.y, p.z, bat_V); h4[1] = make_float4(v.x, v.y, v.z, cmd0); }
+        h4[2] = make_float4(w.x, w.y, w.z, cmd1);
         h4[3] = make_float4(q.x, q.y, q.z, q.w); h4[4] = make_float4(act[0], act[1], act[2], act[3]);
         h4[5] = make_float4(flip_radian, as_f(progress), 0.0f, 0.0f); h4[6] = c_tp; h4[7] = c_tq;
     }
@@ -1830,8 +1878,13 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
             }
         }
         dlen = dlen - 10 < 0 ? 0 : dlen - 10;
-        CST(C_POS, make_float4(p.x, p.y, p.z, as_f((int)make_pw(progress, q_lens))));
-        CST(C_LINVEL, make_float4(v.x, v.y, v.z, as_f((int)make_dw(dlen, zlead, q_m, q_rem0, q_lens, dense))));
+        if (lin_served) {   // (the x y z words are stored by the wavefront that ran the linear chain)
+            llvm_amdgcn_raw_buffer_store_f32(as_f((int)make_pw(progress, q_lens)), rS, (int)(voff + 12u + (uint32_t)C_POS * row_bytes), 0, 0);
+            llvm_amdgcn_raw_buffer_store_f32(as_f((int)make_dw(dlen, zlead, q_m, q_rem0, q_lens, dense)), rS, (int)(voff + 12u + (uint32_t)C_LINVEL * row_bytes), 0, 0);
+        } else {
+            CST(C_POS, make_float4(p.x, p.y, p.z, as_f((int)make_pw(progress, q_lens))));
+            CST(C_LINVEL, make_float4(v.x, v.y, v.z, as_f((int)make_dw(dlen, zlead, q_m, q_rem0, q_lens, dense))));
+        }
         CST(C_MISC, make_float4(bat_t, cmd0, cmd1, flip_radian));
     }
     publish_clock();
@@ -1910,6 +1963,41 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
             }
         }
         if (wv == 2 && (fl & TACO_F_OBSERVATION_NOISE)) { gen_obs_noise(); noise_ready = true; }
+        if constexpr (LIN_SERVED) {
+            if (wv == 2 && lin_served) {   // the linear chain, behind wavefront 0 (see lin_ring)
+                MB_WAIT(5, 1);
+                float pq = lin_init[lane], vq = lin_init[64 + lane];
+                const float dragq = lin_init[128 + lane], kt_ = lin_init[192 + lane];
+                const uint32_t keep = bits(lin_init[256 + lane]);
+                const uint32_t k2 = (sub == 2) ? ~0u : 0u;
+                const float gzq = pick4(sub, -0.0f, -0.0f, P.g, -0.0f);
+#pragma unroll 1
+                for (int ks = 0; ks < 10; ++ks) {
+                    // (the substep's start attitude came with the previous counter: body-frame velocity and drag are done when thrust and q1 arrive)
+                    const float q0 = lin_ring[(ks * 3) * 64 + lane];
+                    const float vbq = quad_rotate(-q0, bc3(q0), vq);  // FA:350 body-frame linear velocity
+                    const float vxy = norm2(bc0(vbq), bc1(vbq));
+                    const float kvv = kt_ * vxy * vxy, dv = dragq * vbq;
+                    MB_WAIT(5, ks + 2);
+                    const float q1 = lin_ring[(ks * 3 + 1) * 64 + lane], psum = lin_ring[(ks * 3 + 2) * 64 + lane];
+                    const float Fz = kvv + (bc2(psum) + bc0(psum));
+                    const float Fq = from_bits(bits(selm(k2, Fz, dv)) & keep);
+                    linear_iteration_quad(P, q0, Fq, gzq, vq, pq);
+                    linear_iteration_quad(P, q1, Fq, gzq, vq, pq);
+                }
+                if (sub < 3) {   // lane j holds component j: the Carry's p and v, and their words of the state
+                    hand[el * CARRY_WORDS + sub] = pq; hand[el * CARRY_WORDS + 4 + sub] = vq;
+                    if (in_range) {
+                        llvm_amdgcn_raw_buffer_store_f32(pq, rS, (int)(voff + 4u * (uint32_t)sub + (uint32_t)C_POS * row_bytes), 0, 0);
+                        llvm_amdgcn_raw_buffer_store_f32(vq, rS, (int)(voff + 4u * (uint32_t)sub + (uint32_t)C_LINVEL * row_bytes), 0, 0);
+                    }
+                }
+                if (__builtin_expect(mb_timeout, 0)) {
+                    if (lane == 0) atomicOr(&P.ctl[kCtlStatus], kStatusMailboxTimeout);
+                    if (sub < 3) hand[el * CARRY_WORDS + sub] = nanf32();
+                }
+            }
+        }
         if (bat_served && wv == 1) {  // battery server (the reward wavefront, idle until the post-phase): ten voltages, each one substep ahead of wavefront 0
             MB_WAIT(0, 1);
             float bE = mb_bs[el * 4], bu1 = mb_bs[el * 4 + 1], bt = mb_bs[el * 4 + 2];
