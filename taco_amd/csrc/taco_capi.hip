@@ -313,11 +313,15 @@ template <bool OUT> const void *kernel_of(int form) {
 }
 // `out`: the instantiation that also writes the clamped obs / states copies (taco_rollout_io.obs_out / states_out)
 // `wide`: the two-wavefronts-per-SIMD build of the four-role quad form (taco_step.hpp, WIDE), see wide_form()
-FormInfo form_info(int form, bool out = false, bool wide = false) {
+// `lin`: the build of the four-role quad form whose obs role wavefront runs the linear chain (taco_step.hpp, LIN), see lin_form(); WIDE implies it
+FormInfo form_info(int form, bool out = false, bool wide = false, bool lin = false) {
     const void *fn = out ? kernel_of<true>(form) : kernel_of<false>(form);
+    if (lin && !wide && form == TACO_FORM_QUAD_ROLES)
+        fn = out ? (const void *)taco::taco_step_kernel<kBlockLarge, 4, true, false, true, false, false, true>
+                 : (const void *)taco::taco_step_kernel<kBlockLarge, 4, true, false, false, false, false, true>;
     if (wide && form == TACO_FORM_QUAD_ROLES)
-        fn = out ? (const void *)taco::taco_step_kernel<kBlockLarge, 4, true, false, true, false, true>
-                 : (const void *)taco::taco_step_kernel<kBlockLarge, 4, true, false, false, false, true>;
+        fn = out ? (const void *)taco::taco_step_kernel<kBlockLarge, 4, true, false, true, false, true, true>
+                 : (const void *)taco::taco_step_kernel<kBlockLarge, 4, true, false, false, false, true, true>;
     if (wide && form == TACO_FORM_LANE_ROLES)
         fn = out ? (const void *)taco::taco_step_kernel<kBlockLarge, 1, true, false, true, false, true>
                  : (const void *)taco::taco_step_kernel<kBlockLarge, 1, true, false, false, false, true>;
@@ -338,6 +342,8 @@ bool wide_form(const taco_cfg &c, int form) {
     return c.num_envs <= 4096 && c.len_obs == 1 && c.len_states == 1 && (c.task_mode == TACO_TASK_POS || c.task_mode == TACO_TASK_ROTATE) &&
            !(c.flags & (TACO_F_ROTOR_NOISE | TACO_F_TRACK_RPY));
 }
+// the four-role quad form with the linear chain served by the obs role wavefront: while at most two wavefronts share a SIMD (taco_step.hpp "LIN")
+bool lin_form(const taco_cfg &c, int form) { return form == TACO_FORM_QUAD_ROLES && c.num_envs <= 8192; }
 int choose_form(const taco_cfg &c) {
     const bool stacks = c.len_obs > 1 || c.len_states > 1;
     if (c.num_envs <= kQuadMaxEnvs) {
@@ -494,7 +500,7 @@ int launch_step(taco_env *e, const taco_rollout_io *io, void *stream) {
     grid_of_form(e, form, &grid, &block);
     taco_cfg eff = e->cfg;
     if (newest_only) eff.len_states = 1;
-    hipError_t he = hipLaunchKernel(form_info(form, P.obs_out != nullptr || P.states_out != nullptr, wide_form(eff, form)).fn, dim3(grid), dim3(block), args, 0,
+    hipError_t he = hipLaunchKernel(form_info(form, P.obs_out != nullptr || P.states_out != nullptr, wide_form(eff, form), lin_form(eff, form)).fn, dim3(grid), dim3(block), args, 0,
                                     (hipStream_t)stream);
     if (he == hipSuccess) he = hipGetLastError();
     if (he != hipSuccess) return hip_fail(he, "taco_step_kernel launch");
@@ -1053,7 +1059,7 @@ int taco_bind_phase_stamps(taco_env *e, uint64_t *stamps) {
 
 int taco_occupancy(const taco_env *e, int *resident_blocks_per_cu, int *lds_bytes_per_block) {
     if (!e || !resident_blocks_per_cu || !lds_bytes_per_block) return fail(TACO_ERR_INVALID_ARG, "taco_occupancy: null argument");
-    const FormInfo f = form_info(e->form, false, wide_form(e->cfg, e->form));
+    const FormInfo f = form_info(e->form, false, wide_form(e->cfg, e->form), lin_form(e->cfg, e->form));
     hipFuncAttributes at;
     hipError_t he = hipFuncGetAttributes(&at, f.fn);
     if (he != hipSuccess) return hip_fail(he, "hipFuncGetAttributes");

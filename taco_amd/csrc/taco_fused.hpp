@@ -190,7 +190,7 @@ __global__ __launch_bounds__(FU_THREADS) void taco_rollout_kernel(const RolloutP
             FX.role = role; FX.step = step0 + (uint32_t)t; FX.head = (head0 + 10 * t) % TACO_RING_SLOTS; FX.hh = (hh0 + t) % HIST_ROWS;
             FX.act_lds = (lds_f32 *)act_lds; FX.act_seq = (lds_i32 *)&act_seq; FX.act_want = t + 1; FX.xin = (lds_f32 *)xin; FX.xin_ld = FU_XLD;
             FX.reset_lds = (lds_i32 *)reset_lds; FX.reset_seq = (lds_i32 *)&reset_seq; FX.reset_want = t;
-            step_core<256, 4, true, false, false, false, false, true>(Q, FX);   // (its two barriers are the step's two)
+            step_core<256, 4, true, false, false, false, false, true, true>(Q, FX);   // (its two barriers are the step's two)
             if (R.stamps && blockIdx.x == 0 && tid == 0 && t < 64) R.stamps[9 + 2 * t] = __builtin_readcyclecounter();
         }
         if (R.stamps && tid == 0) R.stamps[136 + blockIdx.x] = __builtin_readcyclecounter() - loop_t0;

@@ -779,8 +779,9 @@ struct FusedCtx {
     lds_i32 *reset_seq;  //   step while the roles are still in their post-phase: reset_buf in memory may not have been written yet);
     int reset_want;      //   valid once *reset_seq >= reset_want.  reset_want == 0 (first step of the kernel): the flags are read from reset_buf.
 };
-template <int BLOCK, int LPE, bool SPLIT, bool CAP, bool OUT, bool RESET_ONLY, bool WIDE, bool FUSED>
+template <int BLOCK, int LPE, bool SPLIT, bool CAP, bool OUT, bool RESET_ONLY, bool WIDE, bool FUSED, bool LIN = false>
 TD void step_core(const StepParams &P, const FusedCtx &FX) {
+    static_assert(!LIN || (BLOCK == 256 && LPE == 4 && SPLIT), "LIN is a variant of the four-role quad form");
     static_assert(!FUSED || (BLOCK == 256 && LPE == 4 && SPLIT && !OUT && !RESET_ONLY && !CAP), "FUSED is the four-role quad form inside the rollout kernel");
     static_assert(!WIDE || (BLOCK == 256 && SPLIT && !RESET_ONLY), "WIDE is a variant of the four-role forms");
     static_assert(!RESET_ONLY || (BLOCK == 64 && LPE == 1 && !SPLIT && !CAP && !OUT), "RESET_ONLY exists in the plain one-lane form only");
@@ -944,7 +945,11 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     // post-phase) runs body-frame velocity, drag, force rotation and the v / p updates behind it (linear_iteration_quad: the same expressions),
     // hands p and v to the Carry and stores their words of the state -- ~80 of the ~315 instructions of every substep leave the critical path
     // (wavefront 0 issues one instruction per ~5 clocks whatever its type), at the price of the server's last substep (~500 clocks) before barrier 2.
-    constexpr bool LIN_SERVED = ROLES && LPE == 4 && !FUSED;
+    // LIN (template parameter): the host picks the build per launch -- served up to 8 192 envs (at most two wavefronts per SIMD: 14.9 -> 14.5 us at
+    // 8 192), not beyond (at 12 288 the server's instructions cost the step wavefronts next to it more than they save: 15.6 -> 16.2 us), always in
+    // the rollout kernel's own CU.  (A run-time switch inside one kernel -- both builds of every PLAIN form compiled in -- cost the 4 096-env launch
+    // 0.3 us: profiles/r04_n_ab_linear_chain.txt.)
+    constexpr bool LIN_SERVED = ROLES && LPE == 4 && LIN;
     __shared__ float lin_ring[LIN_SERVED ? (10 * 3 + 1) * 64 : 4];   // [substep][0: q before the substep, 1: q after its first sub-iteration, 2: rf + swp(rf)][lane]
                                                                      // ([.][0] is written at the end of the substep BEFORE: the server starts on it one counter earlier)
     __shared__ float lin_init[LIN_SERVED ? 5 * 64 : 4];        // [p, v, drag coefficient, kt, keep mask][lane]: posted with counter value 1
@@ -1588,6 +1593,8 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
                 seq_early = MB_SEQ(1);
                 v_early = __hip_atomic_load(&mb_v[el], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
+            float vbq = 0.0f;
+            if (!lin_off) vbq = quad_rotate(-qq, bc3(qq), vq);  // FA:350 body-frame linear velocity (here: its instructions fill the LDS latency of the reads around it)
             const float dq = dq_next;  // slot min(L - 1, ks), FA:366
             dq_next = slotsf[(slot_of(ks + 1) * EPW + el) * 4 + sub];
             const float d0 = bc0(dq);
@@ -1676,7 +1683,6 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
                 if (lin_off) {
                     lin_ring[(ks * 3 + 2) * 64 + lane] = psum;
                 } else {
-                    const float vbq = quad_rotate(-qq, bc3(qq), vq);  // FA:350 body-frame linear velocity
                     const float vxy = norm2(bc0(vbq), bc1(vbq));
                     const float Fz = kt * vxy * vxy + (bc2(psum) + bc0(psum));
                     Fq = from_bits(bits(selm(k2, Fz, dragq * vbq)) & keep);
@@ -2306,9 +2312,21 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
 }
 
 // the launch-per-step forms: one step_core per launch
-template <int BLOCK, int LPE, bool SPLIT = false, bool CAP = false, bool OUT = false, bool RESET_ONLY = false, bool WIDE = false>
+template <int BLOCK, int LPE, bool SPLIT = false, bool CAP = false, bool OUT = false, bool RESET_ONLY = false, bool WIDE = false, bool LIN = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT || CAP) ? ((WIDE || BLOCK == 128) ? 2 : 4) : 1, CAP ? 4 : 8))) void taco_step_kernel(const StepParams P) {
-    step_core<BLOCK, LPE, SPLIT, CAP, OUT, RESET_ONLY, WIDE, false>(P, FusedCtx{});
+    // The kernel reads its ~370 bytes of arguments with scalar loads where the compiler's register allocation puts them: five to seven DEPENDENT
+    // groups (s_load ... s_waitcnt) ahead of the first state load, each a round trip to a cold scalar cache (a launch's argument block is fresh
+    // memory) -- 1 000 clocks of the latency-bound launch, and which build pays how many is an accident of SGPR pressure.  One dword of every
+    // 64-byte line up front, ONE wait: the groups behind it hit the cache.
+    if constexpr (LPE == 4) {
+        static_assert(sizeof(StepParams) > 320 && sizeof(StepParams) <= 384, "one touch per 64-byte line of the argument block");
+        const __attribute__((address_space(4))) char *ka = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+        uint32_t t0, t1, t2, t3, t4, t5;
+        asm volatile("s_load_dword %0, %6, 0x0\n\ts_load_dword %1, %6, 0x40\n\ts_load_dword %2, %6, 0x80\n\ts_load_dword %3, %6, 0xc0\n\t"
+                     "s_load_dword %4, %6, 0x100\n\ts_load_dword %5, %6, 0x140\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5) : "s"(ka) : "memory");
+    }
+    step_core<BLOCK, LPE, SPLIT, CAP, OUT, RESET_ONLY, WIDE, false, LIN>(P, FusedCtx{});
 }
 
 }  // namespace taco
