@@ -413,7 +413,14 @@ TD float rot1(float x) { return dppf<QP(1, 2, 0, 3)>(x); }  // lane j <- compone
 TD float rot2(float x) { return dppf<QP(2, 0, 1, 3)>(x); }  // lane j <- component (j + 2) mod 3
 TD float swp(float x) { return dppf<QP(1, 0, 3, 2)>(x); }   // neighbour inside the pairs (0,1) (2,3)
 TD float xorf(float x, uint32_t m) { return from_bits(bits(x) ^ m); }
-TD float pick4(int sub, float a, float b, float c, float d) { return sub == 0 ? a : (sub == 1 ? b : (sub == 2 ? c : d)); }
+// lane `sub` of the quad takes operand `sub`.  Bitwise on purpose (two lane masks, three v_bfi_b32): written as a chain of ternaries the compiler
+// turned every call into CONTROL FLOW -- exec-mask if / else blocks, ~18 instructions and three branches each; the ~25 calls on the step wavefront's
+// path ahead of its loop (slot table, scatter into the quad layout) were ~450 of its instructions.
+TD float pick4(int sub, float a, float b, float c, float d) {
+    const uint32_t m1 = 0u - (uint32_t)(sub & 1), m2 = 0u - (uint32_t)((sub >> 1) & 1);
+    const uint32_t lo = (bits(b) & m1) | (bits(a) & ~m1), hi = (bits(d) & m1) | (bits(c) & ~m1);
+    return from_bits((hi & m2) | (lo & ~m2));
+}
 // select by a precomputed lane mask (all ones: take a): one v_bfi_b32, no VCC round trip, never a branch
 TD float selm(uint32_t m, float a, float b) { return from_bits((bits(a) & m) | (bits(b) & ~m)); }
 // component j of TU:58-68 quat_rotate((qv, w), v); qv / v hold components 0..2 in lanes 0..2
