@@ -141,8 +141,15 @@ __global__ __launch_bounds__(FU_THREADS) void taco_rollout_kernel(const RolloutP
         PolicyParams PP{};   // what sample4 reads
         PP.n = n; PP.deterministic = 0; PP.seed_lo = R.pseed_lo; PP.seed_hi = R.pseed_hi; PP.act_lo = R.act_lo; PP.act_hi = R.act_hi; PP.action_env = nullptr;
         const uint32_t call_base = from_ctl ? step0 + R.call_delta : R.call0;   // (the workgroup's own clock pair: the control block is rewritten by workgroup 0 when IT is done)
+        // what the sampling does not need the MLP for: the distribution's scale (step-invariant) and, per step, the standard normal of (env, call) --
+        // drawn by the sampling wavefront AHEAD of barrier 1, where it idles (Philox, log, sqrt, sincos: ~1 000 clocks off the path between the
+        // head's last MFMA and the action a step wavefront with fewer than ten pending slots is waiting for: the tail of the kernel)
+        float scale_pre = 0.0f, ls_pre = 0.0f;
+        if (actor == 0) { const float e = expf_own(log_std[lane & 3]); scale_pre = e * e; ls_pre = log(scale_pre); }
 #pragma unroll 1
         for (int t = 0; t < H; ++t) {
+            float eps_pre = 0.0f;
+            if (actor == 0) eps_pre = sample_eps(PP, row0 + (lane >> 2), lane & 3, call_base + (uint32_t)t);
             __syncthreads();   // barrier 1 of the step: obs_t is in xin
             layer(xin, FU_XLD, xa, w0[0], w0[1], 2, c0[0], c0[1]);
             meet();
@@ -166,9 +173,8 @@ __global__ __launch_bounds__(FU_THREADS) void taco_rollout_kernel(const RolloutP
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // same wavefront writes and reads: in order
                 PP.action = R.act_buf + (size_t)t * n * 4; PP.mu = R.mu_buf + (size_t)t * n * 4; PP.sigma = R.sigma_buf + (size_t)t * n * 4;
                 PP.logp = R.logp_buf + (size_t)t * n;
-                sample4(PP, xb, FU_LD, row0, lane >> 2, lane & 3, log_std, call_base + (uint32_t)t, (lds_f32 *)act_lds);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                if (lane == 0) __hip_atomic_store(&act_seq, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // the action of step t is in act_lds
+                sample4(PP, xb, FU_LD, row0, lane >> 2, lane & 3, log_std, call_base + (uint32_t)t, (lds_f32 *)act_lds, &eps_pre, scale_pre, ls_pre,
+                        (lds_i32 *)&act_seq, t + 1);   // (posts act_seq = t + 1 as soon as the action of step t is in act_lds, ahead of the log-prob and the stores)
             }
             __syncthreads();   // barrier 2 of the step
         }

@@ -181,25 +181,41 @@ TD void lstm_resident(const float *Wih, const float *Whh, const float *bs, int h
 // distribution (:333-345) for act_dim == 4: thread (er, a) owns action component a of row er of the workgroup's tile (whole quads: the
 // log-prob's two sums run over the quad by DPP, in component order)
 // env_lds (optional, the fused rollout kernel): [rows][4] in LDS, receives the action clipped to [act_lo, act_hi] for EVERY row of the tile
-TD void sample4(const PolicyParams &P, const float *x, int ld, int row0, int er, int a, const float *log_std, uint32_t call, lds_f32 *env_lds = nullptr) {
+// the standard normal of (env, call, component a): counters only, so the fused rollout kernel draws it AHEAD of the MLP (its sampling wavefront idles
+// between two steps) -- the same expression either way
+TD float sample_eps(const PolicyParams &P, int env, int a, uint32_t call) {
+    const U4 rnd = philox(P.seed_lo, P.seed_hi, (uint32_t)env, call, STREAM_POLICY, 0u);
+    const uint32_t ba = (a & 2) ? rnd.z : rnd.x, bb = (a & 2) ? rnd.w : rnd.y;
+    const float ua = 1.0f - uniform(ba), ub = uniform(bb);
+    const float rad = __builtin_sqrtf(-2.0f * log(ua));
+    float sn, cs;
+    sincos(kTwoPi * ub, sn, cs);
+    return (a & 1) ? rad * sn : rad * cs;
+}
+// eps_pre (optional): sample_eps(P, row0 + er, a, call) evaluated by the caller; scale_pre / ls_pre (with eps_pre): exp(log_std)^2 and its log
+// env_seq / env_seq_val (with env_lds): the counter that tells the step wavefront the action is in env_lds -- posted as soon as it is, ahead of the log-prob
+TD void sample4(const PolicyParams &P, const float *x, int ld, int row0, int er, int a, const float *log_std, uint32_t call, lds_f32 *env_lds = nullptr,
+                const float *eps_pre = nullptr, float scale_pre = 0.0f, float ls_pre = 0.0f, lds_i32 *env_seq = nullptr, int env_seq_val = 0) {
     const int env = row0 + er;
     const bool live = env < P.n;
     const float mean = x[er * ld + a];
-    const float e = expf_own(log_std[a]);
-    const float scale = e * e;
+    float scale;
+    if (eps_pre) scale = scale_pre;
+    else { const float e = expf_own(log_std[a]); scale = e * e; }
     float act = mean;
     if (!P.deterministic) {
-        const U4 rnd = philox(P.seed_lo, P.seed_hi, (uint32_t)env, call, STREAM_POLICY, 0u);
-        const uint32_t ba = (a & 2) ? rnd.z : rnd.x, bb = (a & 2) ? rnd.w : rnd.y;
-        const float ua = 1.0f - uniform(ba), ub = uniform(bb);
-        const float rad = __builtin_sqrtf(-2.0f * log(ua));
-        float sn, cs;
-        sincos(kTwoPi * ub, sn, cs);
-        const float eps = (a & 1) ? rad * sn : rad * cs;
+        const float eps = eps_pre ? *eps_pre : sample_eps(P, env, a, call);
         act = mean + scale * eps;
     }
+    if (env_lds) {
+        env_lds[er * 4 + a] = clampf(act, P.act_lo, P.act_hi);
+        if (env_seq) {   // (one wavefront's LDS operations execute in order: the action words before the counter)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            if ((threadIdx.x & 63) == 0) __hip_atomic_store(env_seq, env_seq_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
     const float zz = (act - mean) / scale;
-    const float z2 = zz * zz, ls = log(scale);
+    const float z2 = zz * zz, ls = eps_pre ? ls_pre : log(scale);
     auto bcq = [](float v, int k) {
         const int iv = __builtin_bit_cast(int, v);
         const int o = k == 0 ? __builtin_amdgcn_update_dpp(0, iv, 0x00, 0xf, 0xf, true) : k == 1 ? __builtin_amdgcn_update_dpp(0, iv, 0x55, 0xf, 0xf, true)
@@ -208,7 +224,6 @@ TD void sample4(const PolicyParams &P, const float *x, int ld, int row0, int er,
     };
     float lp = 0.0f + bcq(z2, 0); lp = lp + bcq(z2, 1); lp = lp + bcq(z2, 2); lp = lp + bcq(z2, 3);
     float hld = 0.0f + bcq(ls, 0); hld = hld + bcq(ls, 1); hld = hld + bcq(ls, 2); hld = hld + bcq(ls, 3);
-    if (env_lds) env_lds[er * 4 + a] = clampf(act, P.act_lo, P.act_hi);
     if (live) {
         P.action[(size_t)env * 4 + a] = act;
         if (P.action_env) P.action_env[(size_t)env * 4 + a] = clampf(act, P.act_lo, P.act_hi);
