@@ -196,10 +196,12 @@ def test_state_blob_roundtrip_and_restore():
     assert torch.equal(a.get_state().view(torch.int32), b.get_state().view(torch.int32))
 
 
-@pytest.mark.parametrize("task,n", [("pos", 1000), ("mix", 333), ("flip", 257), ("rotate", 4096)])
+@pytest.mark.parametrize("task,n", [("pos", 1000), ("mix", 333), ("flip", 257), ("rotate", 4096), ("mix", 8232)])
 def test_quad_layout_equals_one_lane_per_env(task, n):
     """The six instantiations of the step kernel (4 lanes per env with and without the role wavefronts or with one serving wavefront / 1 lane per
-    env with 64- and 256-thread workgroups and with role wavefronts) are the same function: every output and every state word bit-identical, all randomisation on, stacked frames."""
+    env with 64- and 256-thread workgroups and with role wavefronts) are the same function: every output and every state word bit-identical, all randomisation on, stacked frames.
+    (Up to 8 192 envs the four-role quad form is the build whose obs role wavefront runs the linear chain, above it the build that keeps it in the
+    step wavefront -- taco_step.hpp LIN, taco_capi.hip lin_form: the 8 232-env case is the second.)"""
     from taco_amd.vec_env import FpvBase
     kw = dict(env_lenObservations=2, env_lenStates=3, env_maxEpisodeLength=40, seed=11)
     if task == "mix":
