@@ -533,15 +533,25 @@ TD float4 uniform_block(const StepParams &P, uint32_t step, int gid, uint32_t st
 // this lane's block of round `rnd` of the quad layout's share-out (block 4 rnd + sub)
 TD float4 reset_block_quad(const StepParams &P, uint32_t step, int gid, int rnd, int sub) { return uniform_block(P, step, gid, STREAM_RESET, (uint32_t)(4 * rnd + sub)); }
 // `drawn` (LPE == 4, optional): the three rounds' blocks, [rnd * 64 + lane], drawn ahead by the role wavefronts (step_core: "reset draws")
-template <int LPE>
+// FL: the randomisation flags this build of the function is for, or ~0u = read them from the handle.  A resetting env puts ~700 issue slots on
+// the path of the wavefront that decides most launches' time, a good third of them the tests and selects of the dozen flags reset_idx consults
+// (launch-uniform, but run-time: a scalar branch around every few instructions) -- the four-role quad forms call a build with the flags of the
+// documented configurations compiled in when the handle's flags are those (kResetFlagsBaseline: BASELINE configs 2-4; kResetFlagsAll: config 5).
+constexpr uint32_t kResetFlagMask = TACO_F_RANDOM_COPTER_POS | TACO_F_RANDOM_COPTER_QUAT | TACO_F_RANDOM_COPTER_VEL | TACO_F_RANDOM_TARGET_POS | TACO_F_RANDOM_TARGET_YAW |
+                                    TACO_F_RANDOM_VOLTAGE | TACO_F_ROTOR_RESPONSE | TACO_F_RANDOM_ROTORDYNAMIC_COE | TACO_F_RANDOM_ROTOR_RESPONSE | TACO_F_RANDOM_ROTOR_SPEED |
+                                    TACO_F_RANDOM_AERODYNAMIC_COE | TACO_F_RANDOM_DELAY_TIME;
+constexpr uint32_t kResetFlagsBaseline = TACO_F_RANDOM_COPTER_POS | TACO_F_RANDOM_COPTER_QUAT | TACO_F_RANDOM_COPTER_VEL | TACO_F_RANDOM_TARGET_POS | TACO_F_RANDOM_TARGET_YAW |
+                                         TACO_F_RANDOM_VOLTAGE | TACO_F_ROTOR_RESPONSE | TACO_F_RANDOM_ROTOR_SPEED;
+constexpr uint32_t kResetFlagsAll = kResetFlagMask;
+template <int LPE, uint32_t FL = ~0u>
 TD void reset_env(const StepParams &P, uint32_t step, rsrc_t rS, uint32_t voff, uint32_t row_bytes, int gid, int grp, bool mix, bool store, int sub,
                   float4 &c_pos, float4 &c_quat, float4 &c_lin, float4 &c_ang, float4 &c_pp, float4 &c_pi, float4 &c_om, float4 &c_misc, float4 &c_tau,
                   float4 &c_op, float4 &c_a0, float4 &c_a1, const __attribute__((address_space(3))) f32x4_t *drawn = nullptr) {
-    const uint32_t fl = P.flags;
+    const uint32_t fl = FL == ~0u ? P.flags : ((P.flags & ~kResetFlagMask) | (FL & kResetFlagMask));
     const bool rc = (fl & TACO_F_RANDOM_ROTORDYNAMIC_COE) != 0, ra = (fl & TACO_F_RANDOM_AERODYNAMIC_COE) != 0;
     const bool rtau = (fl & TACO_F_ROTOR_RESPONSE) && (fl & TACO_F_RANDOM_ROTOR_RESPONSE), rspd = (fl & TACO_F_RANDOM_ROTOR_SPEED) != 0;
     const bool rpos = (fl & TACO_F_RANDOM_COPTER_POS) != 0, rquat = (fl & TACO_F_RANDOM_COPTER_QUAT) != 0, rvel = (fl & TACO_F_RANDOM_COPTER_VEL) != 0;
-    const uint32_t want = reset_blocks_wanted(fl);
+    const uint32_t want = reset_blocks_wanted(fl);   // (FL: a constant)
     float qu[3][4] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};  // LPE == 4: this lane's uniforms of blocks sub, 4 + sub, 8 + sub
     if constexpr (LPE == 4) {
 #pragma unroll
@@ -1073,8 +1083,19 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     if constexpr (DRAWS_SERVED) __syncthreads();   // barrier 1 of 2 (here in these forms: the role wavefronts' reset draws are in rs_tab, see below)
     if (P.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TACO_STAMP(1); }  // all up-front loads have landed
     if (wave_has_reset) {
-        if (is_reset) reset_env<LPE>(P, clk.step, rS, voff, row_bytes, gid, grp, mix, active, sub, c_pos, c_quat, c_lin, c_ang, c_pp, c_pi, c_om, c_misc, c_tau, c_op, c_a0, c_a1,
-                                     DRAWS_SERVED ? rs_tab : nullptr);
+        if (is_reset) {
+            auto do_reset = [&](auto fl_c) {
+                reset_env<LPE, decltype(fl_c)::value>(P, clk.step, rS, voff, row_bytes, gid, grp, mix, active, sub, c_pos, c_quat, c_lin, c_ang, c_pp, c_pi, c_om, c_misc, c_tau, c_op,
+                                                      c_a0, c_a1, DRAWS_SERVED ? rs_tab : nullptr);
+            };
+            if constexpr (DRAWS_SERVED) {   // (the latency forms: see reset_env's FL)
+                if ((fl & kResetFlagMask) == kResetFlagsBaseline) do_reset(std::integral_constant<uint32_t, kResetFlagsBaseline>{});
+                else if ((fl & kResetFlagMask) == kResetFlagsAll) do_reset(std::integral_constant<uint32_t, kResetFlagsAll>{});
+                else do_reset(std::integral_constant<uint32_t, ~0u>{});
+            } else {
+                do_reset(std::integral_constant<uint32_t, ~0u>{});
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // (the target pose and the unwrapped angles it stored are loaded further down)
     }
     TACO_STAMP(9);  // reset_idx done (no wait for its stores)
