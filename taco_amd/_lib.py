@@ -240,3 +240,19 @@ def make_cfg(d):
     c.arm_y = float(d["arm_y"])
     c.gravity_z = float(d.get("gravity_z", -9.81))
     return c
+
+
+_raw_stream = None
+
+
+def stream_ptr(device):
+    """the HIP stream torch is on for `device`, as the pointer the C ABI takes (torch's own raw accessor where it exists: 0.1 us per call
+    instead of 1.8 us for building a torch.cuda.Stream object -- a quarter of step()'s host-side cost)"""
+    global _raw_stream
+    import torch
+    if _raw_stream is None:
+        _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", False)
+    if _raw_stream:
+        return C.c_void_p(_raw_stream(device.index if device.index is not None else torch.cuda.current_device()))
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+

@@ -170,7 +170,7 @@ class ActorCritic:
             action, mu, sigma = (torch.empty(n, a, device=dev) for _ in range(3))
             logp, value = torch.empty(n, device=dev), torch.empty(n, 1, device=dev)
             self._out = (action, logp, value, mu, sigma)
-        s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        s = _lib.stream_ptr(dev)
         _lib.check(self.lib.taco_policy_act_stamped(C.byref(self.cfg), self._blob.data_ptr(), n, obs.data_ptr(), st.data_ptr() if st is not None else None,
                                                     C.c_uint64(self.seed), C.c_uint32(self.calls), 1 if deterministic else 0, 1 if action_only else 0,
                                                     action.data_ptr(), logp.data_ptr(), value.data_ptr(), mu.data_ptr(), sigma.data_ptr(),
@@ -198,7 +198,7 @@ class ActorCritic:
         rows = st.numel() // (self.cfg.states_len * self.cfg.states_dim)
         out = torch.empty(rows, device=self.device)
         ws = self.critic_workspace(rows)
-        s = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        s = _lib.stream_ptr(self.device)
         _lib.check(self.lib.taco_critic_values(C.byref(self.cfg), self._blob.data_ptr(), rows, st.data_ptr(), out.data_ptr(), ws.data_ptr(),
                                                stamps.data_ptr() if stamps is not None else None, s))
         return out.view(*lead, 1)
@@ -215,7 +215,7 @@ class ActorCritic:
         slots, n = fr.shape[0] - T + 1, fr.shape[1]
         out = torch.empty(slots * n, device=self.device)
         ws = self.critic_workspace(slots * n)
-        s = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        s = _lib.stream_ptr(self.device)
         _lib.check(self.lib.taco_critic_values_ring(C.byref(self.cfg), self._blob.data_ptr(), slots, n, fr.data_ptr(), out.data_ptr(), ws.data_ptr(), s), self.lib)
         return out.view(slots, n, 1)
 

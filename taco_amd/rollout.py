@@ -97,7 +97,7 @@ class RolloutBuffer:
         lv = last_values.to(device=self.device, dtype=torch.float32).contiguous()
         if lv.numel() != self.num_envs:
             raise ValueError("last_values must hold one value per env")
-        s = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        s = _lib.stream_ptr(self.device)
         _lib.check(self.lib.taco_gae(self.rew_buf.data_ptr(), self.done_buf.data_ptr(), self.value_buf.data_ptr(), lv.data_ptr(),
                                      self.horizon_len, self.num_envs, float(self.gamma), float(self.lam),
                                      self.adv_buf.data_ptr(), self.ret_buf.data_ptr(), 1 if normalize else 0,
@@ -165,7 +165,7 @@ class RolloutBuffer:
         elif getattr(self, "_captured", False):
             self.sync_policy_counter(env, policy)
         self._call_delta = (policy.calls - self.lib.taco_peek_step_count(env._h)) & 0xffffffff   # == the C side's call_delta for this call
-        s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        s = _lib.stream_ptr(dev)
         _lib.check(self.lib.taco_rollout_run(env._h, C.byref(policy.cfg), policy._blob.data_ptr(), C.byref(b), H, C.c_uint64(policy.seed),
                                              C.c_uint32(policy.calls), float(self.gamma), float(act_low), float(act_high),
                                              env.reset_buf.data_ptr(), s))

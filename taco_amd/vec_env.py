@@ -30,8 +30,7 @@ class Box:
         return f"Box{self.shape}"
 
 
-def _stream_ptr(device):
-    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+_stream_ptr = _lib.stream_ptr
 
 
 class FpvBase:
