@@ -1088,7 +1088,7 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
                 reset_env<LPE, decltype(fl_c)::value>(P, clk.step, rS, voff, row_bytes, gid, grp, mix, active, sub, c_pos, c_quat, c_lin, c_ang, c_pp, c_pi, c_om, c_misc, c_tau, c_op,
                                                       c_a0, c_a1, DRAWS_SERVED ? rs_tab : nullptr);
             };
-            if constexpr (LPE == 4 && !RESET_ONLY) {   // (the latency forms -- every quad instantiation: see reset_env's FL)
+            if constexpr (!RESET_ONLY) {   // (see reset_env's FL)
                 if ((fl & kResetFlagMask) == kResetFlagsBaseline) do_reset(std::integral_constant<uint32_t, kResetFlagsBaseline>{});
                 else if ((fl & kResetFlagMask) == kResetFlagsAll) do_reset(std::integral_constant<uint32_t, kResetFlagsAll>{});
                 else do_reset(std::integral_constant<uint32_t, ~0u>{});
