@@ -864,7 +864,8 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     const bool in_range = i_raw < P.n;
     const bool active = in_range && sub == 0;  // the lane that stores for its env
     // post-phase roles (SPLIT: wave 0 = the step itself; wave 1 = battery server, then reward + done; wave 2 = obs stack; wave 3 = states stack)
-    const bool roleS = ROLES ? wv == 3 : (!SPLIT || wv == 0), roleO = ROLES ? wv == 2 : (!SPLIT || wv == 0), roleR = ROLES ? wv == 1 : (!SPLIT || wv == 0);
+    const bool roleS = ROLES ? wv == 3 : (!SPLIT || wv == 0), roleR = ROLES ? wv == 1 : (!SPLIT || wv == 0);
+    const bool roleO = ROLES ? wv == 2 : (!SPLIT || wv == 0);
     const uint32_t wave_env0 = SPLIT ? (uint32_t)(blockIdx.x * 64 / LPE) : (uint32_t)((blockIdx.x * BLOCK + wv * 64) / LPE);  // first env of this wavefront
     if (wave_env0 >= (uint32_t)P.n) return;  // a wavefront past the last env has nothing to do (SPLIT: the whole workgroup shares wave_env0, so
                                              // the two barriers below stay uniform)
@@ -995,6 +996,13 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     const int euler_role = bat_served ? 3 : 1;   // which role wavefront serves the euler angles: the reward wavefront while it is idle (no battery to serve),
                                                  // otherwise the states wavefront (which may first have a stack history to move)
     Carry K;
+    // the frame's operands in the quad layout (lane j of an env's quad: component j; lane 3: battery voltage / cmd0 / cmd1 / -), see the post-phase.
+    // QUAD_POST: the quad forms in which ONE wavefront runs the whole post-phase (one-wavefront quad form, served pair).  In the four-role forms the
+    // post-phase is three wavefronts wide and its end does not follow their instruction counts (same-box A/B: neutral to + 0.1 us there,
+    // profiles/r04_s_ab_post_phase.txt): they keep the scalar post-phase.
+    constexpr bool QUAD_POST = LPE == 4 && !FUSED && !ROLES;
+    struct { float p, v, w, a, tp; } QF{};
+    bool qf = false;
     const int i = in_range ? i_raw : P.n - 1;  // tail lanes shadow the last env and store nothing
     const int gid = P.env_offset + i;
     const uint32_t voff = (uint32_t)(i & 63) * 16u;  // this lane's byte offset inside every row of its tile
@@ -1882,6 +1890,14 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
             if (active) buf_st4(rH, act4, voff, (uint32_t)(clk.hh & (HIST_ROWS - 1)) * row_bytes);  // this step's action, row hh
         }
     }
+    // The target pose was loaded up front and is first READ by the post-phase, behind the state stores below.  gfx9 has one vmcnt counter for
+    // loads and stores, retired in order, and the stores sit in an exec-masked block the wavefront may skip -- so the wait the compiler put ahead
+    // of that first read was vmcnt(0), and a wavefront that runs the post-phase itself sat out the round trip of its own state stores before it
+    // started on the frame.  Pinned here, the wait comes ahead of the stores, where those loads have long landed (quad forms: 13.59 -> 13.47 us at
+    // 4 096 envs, flip 16 384 16.94 -> 16.74; the one-lane forms, whose SIMDs hold other wavefronts to run meanwhile, lose 1 % to the earlier wait
+    // and keep the compiler's placement: profiles/r04_s_ab_post_phase.txt).
+    if constexpr (!ROLES && LPE == 4)
+        asm volatile("" : "+v"(K.c_tp.x), "+v"(K.c_tp.y), "+v"(K.c_tp.z), "+v"(K.c_tp.w), "+v"(K.c_tq.x), "+v"(K.c_tq.y), "+v"(K.c_tq.z), "+v"(K.c_tq.w));
     if (active) {
         // Everything the substep loop evolved goes back to its SoA row NOW, so the registers are free for the
         // observation / reward code below.
@@ -2078,15 +2094,72 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     const V3 pt{c_tp.x, c_tp.y, c_tp.z};
     const Q4 qt{c_tq.x, c_tq.y, c_tq.z, c_tq.w};
     const Q4 cq = conj(q);
-    const V3 rel_pos{pt.x - p.x, pt.y - p.y, pt.z - p.z};
-    const V3 rel_v{0.0f - v.x, 0.0f - v.y, 0.0f - v.z};
-    const V3 rel_w{0.0f - w.x, 0.0f - w.y, 0.0f - w.z};
-    const V3 rel_pos_b = quat_rotate(cq, rel_pos);
     const bool frames = roleS || roleO;  // (SPLIT: the reward wavefront needs only R00, and only for flip envs)
-    Q4 rel_q_b{0.0f, 0.0f, 0.0f, 1.0f};
     float fr[26];
     float m[9];
     float tilt00 = 1.0f;  // R00 of the noise-free relative attitude: the flip reward's x_tiltage
+    V3 rel_pos{0.0f, 0.0f, 0.0f}, rel_v{0.0f, 0.0f, 0.0f}, rel_pos_b{0.0f, 0.0f, 0.0f};
+    Q4 rel_q_b{0.0f, 0.0f, 0.0f, 1.0f};
+    // ---- the frame built in the QUAD LAYOUT (QUAD_POST).  The four lanes of an env used to build the same 26 words each
+    // (~300 instructions of a wavefront that runs alone on its SIMD) and lane 0 wrote them to the tile.  Lane j now holds component j of every
+    // vector (as the substep loop does): ONE quat_rotate stream rotates the three relative vectors' component j (quad_rotate: the scalar code's
+    // operation sequence per component, DPP operands), lane j evaluates ROW j of quaternion_to_matrix (TJ:389-416 is cyclic in (i j k): the
+    // diagonal, the element right of it and the one left of it are one expression each under j -> j + 1; products and sums commute exactly),
+    // the constant divisions run once with the scalar words (battery, commands) riding in lane 3, and every lane writes its own words to the
+    // tile (seven ds_write_b32).  Same operations on the same operands word for word: the tile holds the same bits.
+    bool tile_filled = false;
+    if constexpr (QUAD_POST) {
+        qf = frames && !(roleO && ((fl & TACO_F_OBSERVATION_NOISE) || A.gather));   // (noise and the gather block work on the scalar frame)
+        if (qf) {
+            QF.p = pick4(sub, p.x, p.y, p.z, bat_V); QF.v = pick4(sub, v.x, v.y, v.z, cmd0); QF.w = pick4(sub, w.x, w.y, w.z, cmd1);
+            QF.a = pick4(sub, act[0], act[1], act[2], act[3]); QF.tp = pick4(sub, pt.x, pt.y, pt.z, 0.0f);
+        }
+        if (qf) {
+            const uint32_t k3 = (sub == 3) ? ~0u : 0u;
+            const float cqv = -pick4(sub, q.x, q.y, q.z, q.w), qw = q.w;
+            const float relp = QF.tp - QF.p, relv = 0.0f - QF.v, relw = 0.0f - QF.w;   // component j in lanes 0..2
+            const float rpb = quad_rotate(cqv, qw, relp), rvb = quad_rotate(cqv, qw, relv), rwb = quad_rotate(cqv, qw, relw);
+            rel_q_b = quat_mul(cq, qt);
+            const float rq = pick4(sub, rel_q_b.x, rel_q_b.y, rel_q_b.z, rel_q_b.w), rr = rel_q_b.w;
+            const float two_s = 2.0f / (((rel_q_b.x * rel_q_b.x + rel_q_b.y * rel_q_b.y) + rel_q_b.z * rel_q_b.z) + rr * rr);
+            const float q1 = rot1(rq), q2 = rot2(rq);
+            const float mD = 1.0f - two_s * (q1 * q1 + q2 * q2);   // m[4 j]
+            const float mU = two_s * (rq * q1 - q2 * rr);           // m[3 j + (j + 1) % 3]
+            const float mL = two_s * (rq * q2 + q1 * rr);           // m[3 j + (j + 2) % 3]
+            const float f23 = 4.0f * clampf(bc2(QF.p), 0.0f, 0.5f) - 1.0f;
+            const float y1 = TACO_DIVC(selm(k3, QF.p - 23.0f, rpb), 3.0f);   // fr[0..2] | fr[18]
+            const float y2 = selm(k3, QF.v, rvb / 2.0f);                     // fr[12..14] | fr[24]
+            const bool l3_rot = sub == 3 && grp == TACO_TASK_ROTATE;
+            const float x3 = selm(k3, grp == TACO_TASK_FLIP ? QF.w / 2.0f : QF.w, rwb);
+            float y3 = div_const(x3, l3_rot ? 6.0f : kPi, l3_rot ? 1.0f / 6.0f : 1.0f / kPi);   // fr[15..17] | fr[25]
+            y3 = (sub == 3 && grp == TACO_TASK_POS) ? QF.w : y3;
+            // word of the frame each lane writes, one byte per lane of the quad
+            const uint32_t sh = 8u * (uint32_t)sub;
+            auto wd = [&](uint32_t packed) { return (int)((packed >> sh) & 0xffu); };
+            float *const trow = tile + el * 26;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // (the tile is private to the wavefront: only the compiler needs the fences)
+            trow[wd(0x12020100u)] = y1;                              // 0 1 2 | 18
+            trow[wd(0x170b0703u)] = selm(k3, f23, mD);               // 3 7 11 | 23
+            trow[wd(0x17090804u)] = selm(k3, f23, mU);               // 4 8 9 | 23 (again: the same value)
+            trow[wd(0x170a0605u)] = selm(k3, f23, mL);               // 5 6 10 | 23
+            trow[wd(0x180e0d0cu)] = y2;                              // 12 13 14 | 24
+            trow[wd(0x1911100fu)] = y3;                              // 15 16 17 | 25
+            trow[19 + sub] = QF.a;                                   // 19 .. 22
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            tile_filled = true;
+            if (roleR) {   // (one-wavefront forms: the reward below takes what it shares with the frame from here)
+                rel_pos_b = V3{bc0(rpb), bc1(rpb), bc2(rpb)};
+                tilt00 = bc0(mD);
+            }
+        }
+    }
+    if (roleR || !tile_filled) {
+        rel_pos = V3{pt.x - p.x, pt.y - p.y, pt.z - p.z};
+        rel_v = V3{0.0f - v.x, 0.0f - v.y, 0.0f - v.z};
+    }
+    if (!tile_filled) {
+    const V3 rel_w{0.0f - w.x, 0.0f - w.y, 0.0f - w.z};
+    rel_pos_b = quat_rotate(cq, rel_pos);
     if (frames || wave_tracks_rpy) {
         rel_q_b = quat_mul(cq, qt);
         quat_to_matrix(rel_q_b, m);
@@ -2107,6 +2180,7 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
         fr[23] = 4.0f * clampf(p.z, 0.0f, 0.5f) - 1.0f;
         fr[24] = cmd0;
         fr[25] = (grp == TACO_TASK_POS) ? cmd1 : (grp == TACO_TASK_ROTATE ? TACO_DIVC(cmd1, 6.0f) : TACO_DIVC(cmd1 / 2.0f, kPi));
+    }
     }
 
     // ---- frame stacks [env][len][26] (newest frame last).  Two store paths:
@@ -2197,11 +2271,11 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
             const size_t roff = (size_t)(P.st_front + clk.phase) * (P.states_bytes / 4u), toff = (size_t)P.st_period * (P.states_bytes / 4u);
             float *const row = A.states + roff;
             float *const crow = (OUT && A.states_out) ? A.states_out + roff : nullptr;
-            put_frame(row, row, P.states_bytes, 1, fr, true, crow, P.clip_states);
+            put_frame(row, row, P.states_bytes, 1, fr, !tile_filled, crow, P.clip_states);
             if (clk.phase >= P.st_period - P.st_front)
                 put_frame(row - toff, row - toff, P.states_bytes, 1, fr, false, crow ? crow - toff : nullptr, P.clip_states);
         } else {
-            put_frame(A.states, A.states_prev, P.states_bytes, P.len_states, fr, true, A.states_out, P.clip_states);
+            put_frame(A.states, A.states_prev, P.states_bytes, P.len_states, fr, !tile_filled, A.states_out, P.clip_states);
         }
     }
     if (roleO && (fl & TACO_F_OBSERVATION_NOISE)) {  // FA:402-410
@@ -2218,7 +2292,7 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
         fr[18] = fr[18] + P.df * (nrm[9] * (float)(0.06 / 3) + 0.0f);
         fr[23] = fr[23] + P.df * (nrm[10] * (float)(0.06 / 3 / 3) + 0.0f);
     }
-    if (roleO) put_frame(A.obs, A.obs_prev, P.obs_bytes, P.len_obs, fr, ROLES || (fl & TACO_F_OBSERVATION_NOISE) != 0, A.obs_out, P.clip_obs);
+    if (roleO) put_frame(A.obs, A.obs_prev, P.obs_bytes, P.len_obs, fr, !tile_filled && (ROLES || (fl & TACO_F_OBSERVATION_NOISE) != 0), A.obs_out, P.clip_obs);
     if constexpr (FUSED) {
         if (roleO && sub == 0) {  // ... and into the actor's input rows: the observation the next step's action is computed from never leaves the CU
 #pragma unroll
@@ -2261,6 +2335,26 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     };
     long long rs = 0;
     bool tmo = false;
+    // QUAD_POST: the four lanes of an env ran the same scalar reward, a dozen IEEE divisions (~12 instructions each) four times over.  The
+    // reciprocals 1 / (1 + x) of the reward terms come in pairs of pairs: lane j of the quad divides for argument j -- ONE division instead of
+    // four -- and the quotients come back through DPP; the two normalisations of the rotate reward divide component j in lane j.  The same
+    // IEEE operations on the same operands, whichever lane performs them.
+    auto recip4 = [&](float a, float b, float c, float d, float &ea, float &eb, float &ec, float &ed) {
+        if constexpr (QUAD_POST) {
+            const float e = 1.0f / (1.0f + pick4(sub, a, b, c, d));
+            ea = bc0(e); eb = bc1(e); ec = bc2(e); ed = bc3(e);
+        } else {
+            ea = 1.0f / (1.0f + a); eb = 1.0f / (1.0f + b); ec = 1.0f / (1.0f + c); ed = 1.0f / (1.0f + d);
+        }
+    };
+    auto div3 = [&](float &x, float &y, float &z, float den) {
+        if constexpr (QUAD_POST) {
+            const float e = pick4(sub, x, y, z, 0.0f) / den;
+            x = bc0(e); y = bc1(e); z = bc2(e);
+        } else {
+            x = x / den; y = y / den; z = z / den;
+        }
+    };
     if constexpr (FUSED) {
         if (grp == TACO_TASK_ROTATE) {
             const float hori = norm2(rel_pos.x, rel_pos.y) - 1.2f, vert = absf(rel_pos.z);
@@ -2276,41 +2370,48 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     }
     if (grp == TACO_TASK_POS) {  // :20-47
         if constexpr (!FUSED) pos_dist = norm3(rel_pos_b.x, rel_pos_b.y, rel_pos_b.z);
-        float pr = 1.0f / (1.0f + pos_dist * pos_dist) + 1.0f / (1.0f + 10.0f * pos_dist * pos_dist);
         Q4 mq = quat_mul(q, conj(qt));  // quat_diff_rad TJ:145-164
         float nn = norm3(mq.x, mq.y, mq.z);
         nn = (nn > 1.0f) ? 1.0f : nn;
         float qd = 2.0f * asin(nn);
-        float rr = 1.0f / (1.0f + qd * qd) + 1.0f / (1.0f + 10.0f * qd * qd);
+        float e0, e1, e2, e3;
+        recip4(pos_dist * pos_dist, 10.0f * pos_dist * pos_dist, qd * qd, 10.0f * qd * qd, e0, e1, e2, e3);
+        float pr = e0 + e1;
+        float rr = e2 + e3;
         rew = TACO_DIVC(pr * rr, 100.0f);
     } else if (grp == TACO_TASK_ROTATE) {  // :50-104
         float nx0 = -rel_pos.x, nx1 = -rel_pos.y, nx2 = 0.0f;
         float nn = norm3(nx0, nx1, nx2) + 1e-8f;
-        nx0 = nx0 / nn; nx1 = nx1 / nn; nx2 = nx2 / nn;
+        div3(nx0, nx1, nx2, nn);
         float ny0 = cross_term(0.0f, nx2, 1.0f, nx1), ny1 = cross_term(1.0f, nx0, 0.0f, nx2), ny2 = cross_term(0.0f, nx1, 0.0f, nx0);
         float yn = norm3(ny0, ny1, ny2) + 1e-8f;
-        ny0 = ny0 / yn; ny1 = ny1 / yn; ny2 = ny2 / yn;
+        div3(ny0, ny1, ny2, yn);
         if constexpr (!FUSED) {
             float hori = norm2(rel_pos.x, rel_pos.y) - 1.2f;
             float vert = absf(rel_pos.z);
             pos_dist = __builtin_sqrtf(hori * hori + vert * vert);
         }
-        float pr = 1.0f / (1.0f + pos_dist * pos_dist) + 1.0f / (1.0f + 10.0f * pos_dist * pos_dist);
         float normal = (rel_v.x * nx0 + rel_v.y * nx1) + rel_v.z * nx2;
         float tang = (rel_v.x * ny0 + rel_v.y * ny1) + rel_v.z * ny2;
         float ld = norm3(normal - 0.0f, tang - cmd1, rel_v.z - 0.0f);
-        float lr = 1.0f / (1.0f + ld * ld) + 1.0f / (1.0f + 10.0f * ld * ld);
+        float e0, e1, e2, e3;
+        recip4(pos_dist * pos_dist, 10.0f * pos_dist * pos_dist, ld * ld, 10.0f * ld * ld, e0, e1, e2, e3);
+        float pr = e0 + e1;
+        float lr = e2 + e3;
         float hm[9];
         quat_to_matrix(q, hm);
         float ddir = 1.0f + (nx0 * hm[0] + nx1 * hm[3]) / norm2(hm[0], hm[3]);
-        float dr = 1.0f / (1.0f + ddir * ddir) + 1.0f / (1.0f + 10.0f * ddir * ddir);
+        recip4(ddir * ddir, 10.0f * ddir * ddir, ddir * ddir, 10.0f * ddir * ddir, e0, e1, e2, e3);
+        float dr = e0 + e1;
         rew = TACO_DIVC(pr * lr * dr, 100.0f);
     } else {  // :107-143
         if constexpr (!FUSED) pos_dist = norm3(rel_pos_b.x, rel_pos_b.y, rel_pos_b.z);
-        float pr = 1.0f / (1.0f + 1.0f * pos_dist) + 1.0f / (1.0f + 10.0f * pos_dist);
         float xr = 1.0f / (1.0f + 10.0f * (1.0f - tilt00));
         float cd = TACO_DIVC(cmd1 / 2.0f, kPi);
-        float cr = 1.0f / (1.0f + cd * cd) + 1.0f / (1.0f + 10.0f * cd * cd);
+        float e0, e1, e2, e3;
+        recip4(1.0f * pos_dist, 10.0f * pos_dist, cd * cd, 10.0f * cd * cd, e0, e1, e2, e3);
+        float pr = e0 + e1;
+        float cr = e2 + e3;
         rew = TACO_DIVC(pr * xr * cr, 100.0f);
     }
     if constexpr (!FUSED) done_flags(rs, tmo);
