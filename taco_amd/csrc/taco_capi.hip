@@ -14,6 +14,10 @@
 #include <new>
 
 #include "taco_step.hpp"
+// the argument list of taco_step_kernel (taco_step.hpp StepKernelArgs: the leading scalars arrive preloaded in registers)
+#define STEP_ARGS(P) uint32_t early_ = taco::pack_early((P).hh, (P).hw_rows, (P).stamps != nullptr, (P).use_ctl); \
+    void *args[] = {&(P).S, &(P).reset, &(P).act_in, &(P).hist, &(P).wclk, &(P).n, &(P).flags, &early_, &(P).env_offset, &(P)}
+
 #include "taco_rollout.hpp"
 #include "taco_policy.hpp"
 #include "taco_fused.hpp"
@@ -493,7 +497,8 @@ int launch_step(taco_env *e, const taco_rollout_io *io, void *stream) {
     P.head = e->head;
     P.hh = e->hh;
     int grid, block;
-    void *args[] = {&P};
+    P.stamps_on = P.stamps != nullptr;
+    STEP_ARGS(P);
     // (a handle created with a state stack launches the form chosen for stacks; the newest-frame-only launch of the same handle takes the
     // form its env count would get WITHOUT one -- the role wavefronts have no history to move -- unless the caller pinned a form)
     const int form = newest_only && !e->form_pinned ? e->form_ring : e->form;
@@ -531,8 +536,8 @@ int taco_reset_done(taco_env *e, int64_t *reset_buf, void *stream) {
     P.reset = (long long *)reset_buf;
     P.ctl = e->ctl; P.wclk = e->wclk; P.use_ctl = e->clock_on_device;
     P.step = (uint32_t)e->step_count; P.head = e->head; P.hh = e->hh;   // the clock of the NEXT step: it does not advance here
-    P.stamps = nullptr;
-    void *args[] = {&P};
+    P.stamps = nullptr; P.stamps_on = 0;
+    STEP_ARGS(P);
     const void *fn = (const void *)taco::taco_step_kernel<64, 1, false, false, false, true>;
     hipError_t he = hipLaunchKernel(fn, dim3((unsigned)((e->cfg.num_envs + 63) / 64)), dim3(64), args, 0, (hipStream_t)stream);
     if (he == hipSuccess) he = hipGetLastError();
@@ -936,7 +941,7 @@ int taco_rollout_run(taco_env *e, const taco_policy_cfg *c, const float *blob, c
         // the whole per-step chain as ONE persistent launch (taco_fused.hpp): a workgroup owns 16 envs for all `horizon` steps
         taco::RolloutParams R{};
         R.S = e->P;
-        R.S.S = e->S; R.S.ring = e->ring; R.S.hist = e->hist; R.S.reset = (long long *)reset_buf; R.S.ctl = e->ctl; R.S.wclk = e->wclk; R.S.use_ctl = e->clock_on_device;
+        R.S.S = e->S; R.S.ring = e->ring; R.S.hist = e->hist; R.S.reset = (long long *)reset_buf; R.S.ctl = e->ctl; R.S.wclk = e->wclk; R.S.use_ctl = e->clock_on_device; R.S.stamps_on = 0;
         R.S.st_period = 0; R.S.st_phase = e->st_phase; R.S.st_front = 0;
         R.S.step = (uint32_t)e->step_count; R.S.head = e->head; R.S.hh = e->hh; R.S.gather_row = (uint32_t)taco_gather_row_floats(1); R.S.gather_bytes = 0;
         R.blob = blob; R.pseed_lo = (uint32_t)seed; R.pseed_hi = (uint32_t)(seed >> 32); R.call0 = call0; R.call_delta = call_delta;

@@ -45,6 +45,7 @@ struct StepParams {
     uint32_t *ctl;       // control block in the workspace (kCtl*): the device-resident step clock (the copy the HOST reads back) + the sticky status word
     uint32_t *wclk;      // [ceil(npad / 16)][2] the device-resident step clock AS THE KERNELS READ IT: one {step, aux} pair per 16 envs (see "wclk" below)
     int use_ctl;         // 1: take step / head / hh / ring phase from wclk (launch captured into a HIP graph: kernel arguments are frozen); 0: from below
+    int stamps_on;       // stamps != NULL, as a flag the kernels can test without touching the pointer (StepKernelArgs: it arrives in a register)
     // geometry / cfg
     int n, npad, env_offset, task_mode, mix_n1, mix_n2, len_obs, len_states, substeps, max_len, delay_time, head;
     uint32_t flags, seed_lo, seed_hi, step;
@@ -65,6 +66,19 @@ struct StepParams {
     float h, half_h, inv_m, g, J0, J1, J2, hJi0, hJi1, hJi2, arm_x, arm_y;
     float flip_xy_sc, flip_xy_lo, flip_v_sc, flip_v_lo, dr_sc, dr_lo, tau_sc, tau_lo, tau_fixed, nq_sc, nq_lo;
 };
+
+// KERNEL-ARGUMENT PRELOAD.  gfx950 delivers the first user SGPRs' worth of kernel arguments IN REGISTERS when a wavefront starts (the build passes
+// -amdgpu-kernarg-preload-count; byref aggregates are not eligible, hence the leading scalars).  Everything the up-front loads of a step need -- the
+// state, flag, action and history pointers, the env count, the flags, the history row -- leads the argument list, so those loads are issued
+// without the round trip to the argument segment (a launch's argument block is fresh memory) that every wavefront used to sit out first; the
+// parameter block behind them (a complete StepParams: the leading scalars repeat its fields) is read while the state loads are in flight.
+struct StepKernelArgs {   // (the layout of the kernel-argument segment: what lazy_arg and the line touches address)
+    float *S; long long *reset; const float *act_in; float *hist; uint32_t *wclk; int n; uint32_t flags; uint32_t early; int env_offset;
+    StepParams P;
+};
+constexpr size_t kParamsOffset = offsetof(StepKernelArgs, P);
+// `early`: hh | hw_rows << 8 | stamps bound << 30 | use_ctl << 31
+inline __host__ __device__ uint32_t pack_early(int hh, int hw_rows, bool stamps, int use_ctl) { return (uint32_t)(hh & 15) | ((uint32_t)(hw_rows & 7) << 8) | (stamps ? 1u << 30 : 0u) | (use_ctl ? 1u << 31 : 0u); }
 
 // ---- workspace layout (TILE-major float4 rows): the 67 state words of an env are packed into 17 float4 CHUNKS; the envs are
 // grouped in TILES of 64 consecutive envs and chunk c of env i lives at byte ((i / 64) * NUM_CHUNKS + c) * 1024 + (i % 64) * 16.
@@ -797,7 +811,7 @@ struct FusedCtx {
     int reset_want;      //   valid once *reset_seq >= reset_want.  reset_want == 0 (first step of the kernel): the flags are read from reset_buf.
 };
 template <int BLOCK, int LPE, bool SPLIT, bool CAP, bool OUT, bool RESET_ONLY, bool WIDE, bool FUSED, bool LIN = false>
-TD void step_core(const StepParams &P, const FusedCtx &FX) {
+TD void step_core(const StepParams &Pin, const FusedCtx &FX) {
     static_assert(!LIN || (BLOCK == 256 && LPE == 4 && SPLIT), "LIN is a variant of the four-role quad form");
     static_assert(!FUSED || (BLOCK == 256 && LPE == 4 && SPLIT && !OUT && !RESET_ONLY && !CAP), "FUSED is the four-role quad form inside the rollout kernel");
     static_assert(!WIDE || (BLOCK == 256 && SPLIT && !RESET_ONLY), "WIDE is a variant of the four-role forms");
@@ -814,8 +828,9 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     //   substeps : the 10 pending-action slots this step consumes, slots[s][lane] as float4 (10 KiB) -- keeps 40 values
     //              out of the register file and lets substep k fetch its action with one ds_read_b128;
     //   post-step: the 64 x 26 frame tile that transposes lane-major registers into env-major bytes (6.5 KiB).
-#define TACO_STAMP(k) do { if (P.stamps && blockIdx.x == 0 && threadIdx.x == 0) P.stamps[k] = __builtin_readcyclecounter(); } while (0)
-    TACO_STAMP(0);
+#define TACO_STAMP(k) do { if (P.stamps_on && P.stamps && blockIdx.x == 0 && threadIdx.x == 0) P.stamps[k] = __builtin_readcyclecounter(); } while (0)
+    unsigned long long t_entry = 0;   // (stamp 0, written once the parameter block is there)
+    if (Pin.stamps_on) t_entry = __builtin_readcyclecounter();
     // the step clock: kernel arguments on the eager path (which also leaves the NEXT values in the control block, so that a capture can start
     // at any time); the device-resident copy when this launch was captured into a HIP graph (its arguments are frozen)
     // (read unconditionally by scalar loads through the constant address space and selected without a branch: while a captured step kernel
@@ -823,12 +838,96 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     // (this wavefront's pair of wclk: envs [wave_env0, wave_env0 + 64 / LPE) -- the expression of wave_env0 below)
     const uint32_t clk_env0 = SPLIT ? (uint32_t)(blockIdx.x * 64 / LPE) : (uint32_t)((blockIdx.x * BLOCK + (threadIdx.x >> 6) * 64) / LPE);
     const __attribute__((address_space(4))) uint32_t *wc =
-        (const __attribute__((address_space(4))) uint32_t *)(P.wclk + (size_t)(clk_env0 >> 4) * kWclkWordsPerGroup);
-    const bool from_ctl = P.use_ctl != 0;
+        (const __attribute__((address_space(4))) uint32_t *)(Pin.wclk + (size_t)(clk_env0 >> 4) * kWclkWordsPerGroup);
+    const bool from_ctl = Pin.use_ctl != 0;
     uint32_t c_step = 0u, c_aux = 0u;
-    if (!FUSED && clk_env0 < (uint32_t)P.n) { c_step = wc[0]; c_aux = wc[1]; }   // (wave-uniform; a wavefront past the last env returns below)
-    const struct { uint32_t step; int head, hh, phase; } clk{FUSED ? FX.step : (from_ctl ? c_step : P.step), FUSED ? FX.head : (from_ctl ? wclk_head(c_aux) : P.head),
-                                                             FUSED ? FX.hh : (from_ctl ? wclk_hh(c_aux) : P.hh), from_ctl ? wclk_phase(c_aux) : P.st_phase};
+    if (!FUSED && clk_env0 < (uint32_t)Pin.n) { c_step = wc[0]; c_aux = wc[1]; }   // (wave-uniform; a wavefront past the last env returns below)
+    struct { uint32_t step; int head, hh, phase; } clk{0u, 0, 0, 0};   // (filled behind the up-front loads: it reads the parameter block)
+    constexpr int EPW = 64 / LPE;  // envs per wavefront
+    constexpr int WAVE_LDS_WORDS = 10 * EPW * 4;
+    static_assert(WAVE_LDS_WORDS >= EPW * 26, "tile must fit in the per-wave scratch");
+    // SPLIT: only wavefront 0 needs the slot table; the obs / states role wavefronts need a frame tile each, the reward wavefront nothing
+    constexpr int TILE_WORDS = EPW * 26;
+    static_assert(TILE_WORDS % 4 == 0, "tiles stay 16-byte aligned");
+    constexpr int LDS_WORDS = SPLIT ? WAVE_LDS_WORDS + 2 * TILE_WORDS : (BLOCK / 64) * WAVE_LDS_WORDS;
+    __shared__ __attribute__((aligned(16))) float lds_all[LDS_WORDS];
+    const int lane = threadIdx.x & 63;
+    const int wv = FUSED ? FX.role : (int)(threadIdx.x >> 6);
+    float *tile = SPLIT ? lds_all + (wv == 0 ? 0 : WAVE_LDS_WORDS + (wv == 3 ? TILE_WORDS : 0)) : lds_all + wv * WAVE_LDS_WORDS;
+    float4 *slots = reinterpret_cast<float4 *>(tile);  // (wavefront 0 / non-SPLIT only)
+    const int sub = lane & (LPE - 1);  // lane inside the env's quad (0 when LPE == 1)
+    const int el = lane / LPE;         // env slot inside the wavefront
+    const int i_raw = SPLIT ? (blockIdx.x * 64 + lane) / LPE : (blockIdx.x * BLOCK + threadIdx.x) / LPE;
+    const bool in_range = i_raw < Pin.n;
+    const bool active = in_range && sub == 0;  // the lane that stores for its env
+    // post-phase roles (SPLIT: wave 0 = the step itself; wave 1 = battery server, then reward + done; wave 2 = obs stack; wave 3 = states stack)
+    const bool roleS = ROLES ? wv == 3 : (!SPLIT || wv == 0), roleR = ROLES ? wv == 1 : (!SPLIT || wv == 0);
+    const bool roleO = ROLES ? wv == 2 : (!SPLIT || wv == 0);
+    const uint32_t wave_env0 = SPLIT ? (uint32_t)(blockIdx.x * 64 / LPE) : (uint32_t)((blockIdx.x * BLOCK + wv * 64) / LPE);  // first env of this wavefront
+    if (wave_env0 >= (uint32_t)Pin.n) return;  // a wavefront past the last env has nothing to do (SPLIT: the whole workgroup shares wave_env0, so
+                                               // the two barriers below stay uniform)
+    // ------------------------------------------------------------------ the up-front loads (pre_physics_step FA:317-332 starts further down)
+    // Every load the step needs is issued HERE, before the reset flag is known and before anything reads the parameter block: the flag, the
+    // action, the 13 state chunks and the history rows are independent, so they share ONE memory round trip -- and everything their addresses
+    // need (state / flag / action / history pointers, env count, flags, the history row) arrives in registers with the wavefront
+    // (StepKernelArgs: kernel-argument preload), so that round trip no longer queues behind the one to the argument segment.
+    const int i = in_range ? i_raw : Pin.n - 1;  // tail lanes shadow the last env and store nothing
+    const uint32_t voff = (uint32_t)(i & 63) * 16u;  // this lane's byte offset inside every row of its tile
+    constexpr uint32_t row_bytes = kRowBytes;         // one float4 row (chunk, history row or ring slot) of a tile
+    // all of a wavefront's envs lie in one tile (EPW divides 64; tail lanes shadow env n - 1 of the same wavefront)
+    const uint32_t tile_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wave_env0 >> 6));
+    const rsrc_t rS = make_rsrc(reinterpret_cast<const char *>(Pin.S) + (size_t)tile_id * (NUM_CHUNKS * kRowBytes), NUM_CHUNKS * kRowBytes);
+    const rsrc_t rH = make_rsrc(reinterpret_cast<const char *>(Pin.hist) + (size_t)tile_id * (HIST_ROWS * kRowBytes), HIST_ROWS * kRowBytes);
+    const uint32_t fl = Pin.flags;
+    // rotor / aero parameters: per env only if something randomises them (launch-uniform switch, see kUniformParams)
+    const bool uniform_params = (fl & kUniformParams) != 0;
+    bool is_reset = false;
+    float4 a_in = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 c_pos{}, c_quat{}, c_lin{}, c_ang{}, c_pp{}, c_pi{}, c_om{}, c_misc{}, c_tau{}, c_op{}, c_a0{}, c_a1{};
+    // the four most recent history rows (wave-uniform addresses): they hold the two oldest queued runs whenever the
+    // queue is at most 4 runs deep, i.e. for delays up to ~40 ms; deeper queues fetch per lane further down
+    float4 hwin[4];
+    auto upfront_loads = [&]() {
+        if constexpr (FUSED) {
+            if (FX.reset_want > 0) is_reset = false;   // (comes from the reward role's mailbox, below: the loads are issued first)
+            else is_reset = Pin.reset[i] != 0;
+        } else {
+            is_reset = Pin.reset[i] != 0;
+        }
+        if constexpr (!RESET_ONLY && !FUSED) a_in = reinterpret_cast<const float4 *>(Pin.act_in)[i];
+        c_pos = CLD(C_POS); c_quat = CLD(C_QUAT); c_lin = CLD(C_LINVEL); c_ang = CLD(C_ANGVEL);
+        c_pp = CLD(C_PID_PREV); c_pi = CLD(C_PID_INT); c_om = CLD(C_OMEGA); c_misc = CLD(C_MISC);
+        if (!uniform_params) { c_tau = CLD(C_TAU); c_op = CLD(C_OPARA); c_a0 = CLD(C_AERO0); c_a1 = CLD(C_AERO1); }
+        // the history row of this step: a register on the eager path; a captured launch (frozen arguments) waits for its pair of the device clock
+        int hh_e = FUSED ? FX.hh : Pin.hh;
+        if (!FUSED && from_ctl) { uint32_t a = c_aux; asm volatile("" : "+v"(a)); hh_e = __builtin_amdgcn_readfirstlane(wclk_hh(a)); }   // (wave-uniform)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {  // (rows this configuration's queue never reaches are not fetched: hw_rows)
+            hwin[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (k < Pin.hw_rows) hwin[k] = buf_ld4(rH, voff, (uint32_t)((hh_e - 1 - k) & (HIST_ROWS - 1)) * row_bytes);
+        }
+    };
+    if constexpr (!FUSED) { if (!SPLIT || wv == 0) upfront_loads(); }   // (the rollout kernel, whose arguments are in registers anyway, keeps them where they were)
+    // ------------------------------------------------------------------ the parameter block
+    // Read from HERE on, behind the loads above, through a copy of the argument-segment pointer the compiler cannot see through: as ordinary
+    // kernel arguments its fields are loaded in the kernel's entry block, and the first use of any of them (or the first reuse of a register one
+    // of those scalar loads is still due to write) waits for ALL of them -- scalar loads return out of order, the wait is lgkmcnt(0) -- i.e. for
+    // the round trip to the argument segment, ahead of the state loads.  One dword of every 64-byte line of the block first and ONE wait: the
+    // compiler reads the fields in several dependent groups, each a round trip to a cold scalar cache unless its lines are already there.
+    const StepParams *Pp = &Pin;
+    if constexpr (!FUSED) {
+        static_assert(sizeof(StepKernelArgs) > 384 && sizeof(StepKernelArgs) <= 448, "one touch per 64-byte line of the argument block");
+        const __attribute__((address_space(4))) char *ka = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+        uint32_t t0, t1, t2, t3, t4, t5, t6;
+        asm volatile("s_load_dword %0, %7, 0x0\n\ts_load_dword %1, %7, 0x40\n\ts_load_dword %2, %7, 0x80\n\ts_load_dword %3, %7, 0xc0\n\t"
+                     "s_load_dword %4, %7, 0x100\n\ts_load_dword %5, %7, 0x140\n\ts_load_dword %6, %7, 0x180\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "+s"(ka) : : "memory");
+        Pp = (const StepParams *)(ka + kParamsOffset);
+    }
+    const StepParams &P = *Pp;
+    if (Pin.stamps_on && P.stamps && blockIdx.x == 0 && threadIdx.x == 0) P.stamps[0] = t_entry;
+    clk.step = FUSED ? FX.step : (from_ctl ? c_step : P.step); clk.head = FUSED ? FX.head : (from_ctl ? wclk_head(c_aux) : P.head);
+    clk.hh = FUSED ? FX.hh : (from_ctl ? wclk_hh(c_aux) : P.hh); clk.phase = from_ctl ? wclk_phase(c_aux) : P.st_phase;
     // the next values, left in this wavefront's pairs (and, by workgroup 0, in the control block) when the step wavefront is done: by then every
     // wavefront of the workgroup has its copy (the role wavefronts wait for theirs ahead of barrier 2)
     auto publish_clock = [&]() {
@@ -846,29 +945,6 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
             }
         }
     };
-    constexpr int EPW = 64 / LPE;  // envs per wavefront
-    constexpr int WAVE_LDS_WORDS = 10 * EPW * 4;
-    static_assert(WAVE_LDS_WORDS >= EPW * 26, "tile must fit in the per-wave scratch");
-    // SPLIT: only wavefront 0 needs the slot table; the obs / states role wavefronts need a frame tile each, the reward wavefront nothing
-    constexpr int TILE_WORDS = EPW * 26;
-    static_assert(TILE_WORDS % 4 == 0, "tiles stay 16-byte aligned");
-    constexpr int LDS_WORDS = SPLIT ? WAVE_LDS_WORDS + 2 * TILE_WORDS : (BLOCK / 64) * WAVE_LDS_WORDS;
-    __shared__ __attribute__((aligned(16))) float lds_all[LDS_WORDS];
-    const int lane = threadIdx.x & 63;
-    const int wv = FUSED ? FX.role : (int)(threadIdx.x >> 6);
-    float *tile = SPLIT ? lds_all + (wv == 0 ? 0 : WAVE_LDS_WORDS + (wv == 3 ? TILE_WORDS : 0)) : lds_all + wv * WAVE_LDS_WORDS;
-    float4 *slots = reinterpret_cast<float4 *>(tile);  // (wavefront 0 / non-SPLIT only)
-    const int sub = lane & (LPE - 1);  // lane inside the env's quad (0 when LPE == 1)
-    const int el = lane / LPE;         // env slot inside the wavefront
-    const int i_raw = SPLIT ? (blockIdx.x * 64 + lane) / LPE : (blockIdx.x * BLOCK + threadIdx.x) / LPE;
-    const bool in_range = i_raw < P.n;
-    const bool active = in_range && sub == 0;  // the lane that stores for its env
-    // post-phase roles (SPLIT: wave 0 = the step itself; wave 1 = battery server, then reward + done; wave 2 = obs stack; wave 3 = states stack)
-    const bool roleS = ROLES ? wv == 3 : (!SPLIT || wv == 0), roleR = ROLES ? wv == 1 : (!SPLIT || wv == 0);
-    const bool roleO = ROLES ? wv == 2 : (!SPLIT || wv == 0);
-    const uint32_t wave_env0 = SPLIT ? (uint32_t)(blockIdx.x * 64 / LPE) : (uint32_t)((blockIdx.x * BLOCK + wv * 64) / LPE);  // first env of this wavefront
-    if (wave_env0 >= (uint32_t)P.n) return;  // a wavefront past the last env has nothing to do (SPLIT: the whole workgroup shares wave_env0, so
-                                             // the two barriers below stay uniform)
     // Frame stacks with len > 1: the wavefront's EPW rows are one contiguous range of EPW * len * 13 eight-byte words.  Word w of the new
     // stack is word w + 13 of the previous one (one frame further) inside the first len - 1 frames of its row (the HISTORY words), and
     // comes from this step's frame in the last frame of the row: the whole wavefront copies 512 contiguous bytes per instruction instead of
@@ -886,7 +962,7 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     auto lazy_arg = [&](size_t off) -> float * {
         const __attribute__((address_space(4))) char *ka = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(ka));
-        return *(float *const __attribute__((address_space(4))) *)(ka + off);
+        return *(float *const __attribute__((address_space(4))) *)(ka + kParamsOffset + off);
     };
 #define TACO_ARG(field) (FUSED ? (float *)P.field : lazy_arg(offsetof(StepParams, field)))
     // ... all of them at ONE point of the consuming wavefront's path: the role wavefronts at their entry (they idle at barrier 1 anyway; read at
@@ -1003,15 +1079,8 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     constexpr bool QUAD_POST = LPE == 4 && !FUSED && !ROLES;
     struct { float p, v, w, a, tp; } QF{};
     bool qf = false;
-    const int i = in_range ? i_raw : P.n - 1;  // tail lanes shadow the last env and store nothing
     const int gid = P.env_offset + i;
-    const uint32_t voff = (uint32_t)(i & 63) * 16u;  // this lane's byte offset inside every row of its tile
-    constexpr uint32_t row_bytes = kRowBytes;         // one float4 row (chunk, history row or ring slot) of a tile
-    // all of a wavefront's envs lie in one tile (EPW divides 64; tail lanes shadow env n - 1 of the same wavefront)
-    const uint32_t tile_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wave_env0 >> 6));
-    const rsrc_t rS = make_rsrc(reinterpret_cast<const char *>(P.S) + (size_t)tile_id * (NUM_CHUNKS * kRowBytes), NUM_CHUNKS * kRowBytes);
     const rsrc_t rR = make_rsrc(reinterpret_cast<const char *>(P.ring) + (size_t)tile_id * (TACO_RING_SLOTS * kRowBytes), TACO_RING_SLOTS * kRowBytes);
-    const uint32_t fl = P.flags;
     const int grp = (P.task_mode != TACO_TASK_MIX) ? P.task_mode
                     : (gid < P.mix_n1 ? TACO_TASK_POS : (gid < P.mix_n2 ? TACO_TASK_ROTATE : TACO_TASK_FLIP));
     const bool mix = P.task_mode == TACO_TASK_MIX;
@@ -1046,36 +1115,13 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     };
     if (!SPLIT || wv == 0) {
     // ------------------------------------------------------------------ pre_physics_step FA:317-332
-    // Every load the step needs is issued up front, before the reset flag is known: the flag, the action, the 13 state
-    // chunks and the 10 ring slots of this step are independent, so they share ONE memory round trip.
-    bool is_reset;
-    if constexpr (FUSED) {
-        if (FX.reset_want > 0) is_reset = false;   // (comes from the reward role's mailbox, below: the loads are issued first)
-        else is_reset = P.reset[i] != 0;
-    } else {
-        is_reset = P.reset[i] != 0;
-    }
-    float4 a_in = (RESET_ONLY || FUSED) ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : reinterpret_cast<const float4 *>(P.act_in)[i];
-    float4 c_pos = CLD(C_POS), c_quat = CLD(C_QUAT), c_lin = CLD(C_LINVEL), c_ang = CLD(C_ANGVEL);
-    float4 c_pp = CLD(C_PID_PREV), c_pi = CLD(C_PID_INT), c_om = CLD(C_OMEGA), c_misc = CLD(C_MISC);
-    // rotor / aero parameters: per env only if something randomises them (launch-uniform switch, see kUniformParams)
-    const bool uniform_params = (P.flags & kUniformParams) != 0;
-    float4 c_tau, c_op, c_a0, c_a1;
+    // (the up-front loads were issued at the top of the kernel, see "up-front loads"; what is left here are the parameter VALUES of a launch
+    // without per-env randomisation)
+    if constexpr (FUSED) upfront_loads();
     if (uniform_params) {
         const float t0 = P.tau_fixed * 1.0f;  // what reset_env and init_state_kernel hold for every env
         c_tau = make_float4(t0, t0, t0, t0); c_op = make_float4(0.0f, 12.9466f, 0.1872f, -5.1220f);
         c_a0 = make_float4(0.5906f, 1.13e-05f, 0.05f, -0.386f); c_a1 = make_float4(-0.53f, 0.009f, 0.0f, 0.0f);
-    } else {
-        c_tau = CLD(C_TAU); c_op = CLD(C_OPARA); c_a0 = CLD(C_AERO0); c_a1 = CLD(C_AERO1);
-    }
-    const rsrc_t rH = make_rsrc(reinterpret_cast<const char *>(P.hist) + (size_t)tile_id * (HIST_ROWS * kRowBytes), HIST_ROWS * kRowBytes);
-    // the four most recent history rows (wave-uniform addresses): they hold the two oldest queued runs whenever the
-    // queue is at most 4 runs deep, i.e. for delays up to ~40 ms; deeper queues fetch per lane further down
-    float4 hwin[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {  // (rows this configuration's queue never reaches are not fetched: P.hw_rows)
-        hwin[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (k < P.hw_rows) hwin[k] = buf_ld4(rH, voff, (uint32_t)((clk.hh - 1 - k) & (HIST_ROWS - 1)) * row_bytes);
     }
     if constexpr (FUSED) {
         if (FX.reset_want > 0) {   // the previous step's done flags: posted by the reward role, ~a load round trip after this wavefront got here
@@ -1089,7 +1135,7 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     // reset_idx (FA:475-517): the lanes that reset get their fresh state in the registers the up-front loads filled (see reset_env)
     const bool wave_has_reset = __builtin_amdgcn_ballot_w64(is_reset) != 0;
     if constexpr (DRAWS_SERVED) __syncthreads();   // barrier 1 of 2 (here in these forms: the role wavefronts' reset draws are in rs_tab, see below)
-    if (P.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TACO_STAMP(1); }  // all up-front loads have landed
+    if (P.stamps_on) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TACO_STAMP(1); }  // all up-front loads have landed
     if (wave_has_reset) {
         if (is_reset) {
             auto do_reset = [&](auto fl_c) {
@@ -2432,7 +2478,7 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
     }
     }
     TACO_STAMP(5);
-    if (SPLIT && P.stamps && blockIdx.x == 0 && lane == 0) P.stamps[5 + wv] = __builtin_readcyclecounter();  // [6..8]: the role wavefronts' ends
+    if (SPLIT && P.stamps_on && P.stamps && blockIdx.x == 0 && lane == 0) P.stamps[5 + wv] = __builtin_readcyclecounter();  // [6..8]: the role wavefronts' ends
 #undef TACO_STAMP
 #undef TACO_ARG
 #undef MB_WAIT
@@ -2440,21 +2486,13 @@ TD void step_core(const StepParams &P, const FusedCtx &FX) {
 #undef MB_SEQ
 }
 
-// the launch-per-step forms: one step_core per launch
+// the launch-per-step forms: one step_core per launch (argument list: StepKernelArgs)
 template <int BLOCK, int LPE, bool SPLIT = false, bool CAP = false, bool OUT = false, bool RESET_ONLY = false, bool WIDE = false, bool LIN = false>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT || CAP) ? ((WIDE || BLOCK == 128) ? 2 : 4) : 1, CAP ? 4 : 8))) void taco_step_kernel(const StepParams P) {
-    // The kernel reads its ~370 bytes of arguments with scalar loads where the compiler's register allocation puts them: five to seven DEPENDENT
-    // groups (s_load ... s_waitcnt) ahead of the first state load, each a round trip to a cold scalar cache (a launch's argument block is fresh
-    // memory) -- 1 000 clocks of the latency-bound launch, and which build pays how many is an accident of SGPR pressure.  One dword of every
-    // 64-byte line up front, ONE wait: the groups behind it hit the cache.
-    if constexpr (LPE == 4) {
-        static_assert(sizeof(StepParams) > 320 && sizeof(StepParams) <= 384, "one touch per 64-byte line of the argument block");
-        const __attribute__((address_space(4))) char *ka = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
-        uint32_t t0, t1, t2, t3, t4, t5;
-        asm volatile("s_load_dword %0, %6, 0x0\n\ts_load_dword %1, %6, 0x40\n\ts_load_dword %2, %6, 0x80\n\ts_load_dword %3, %6, 0xc0\n\t"
-                     "s_load_dword %4, %6, 0x100\n\ts_load_dword %5, %6, 0x140\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5) : "s"(ka) : "memory");
-    }
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT || CAP) ? ((WIDE || BLOCK == 128) ? 2 : 4) : 1, CAP ? 4 : 8))) void taco_step_kernel(
+    float *S, long long *reset, const float *act_in, float *hist, uint32_t *wclk, int n, uint32_t flags, uint32_t early, int env_offset, const StepParams P0) {
+    StepParams P{};   // (the preloaded fields only; step_core reads the block P0 itself, behind its up-front loads)
+    P.S = S; P.reset = reset; P.act_in = act_in; P.hist = hist; P.wclk = wclk; P.n = n; P.flags = flags; P.env_offset = env_offset;
+    P.hh = (int)(early & 15u); P.hw_rows = (int)((early >> 8) & 7u); P.stamps_on = (int)((early >> 30) & 1u); P.use_ctl = (int)(early >> 31);
     step_core<BLOCK, LPE, SPLIT, CAP, OUT, RESET_ONLY, WIDE, false, LIN>(P, FusedCtx{});
 }
 
