@@ -6,8 +6,8 @@ hipcc cross-compiles without a GPU.  -ffp-contract=off is part of the kernel's n
 csrc/taco_math.hpp): fused multiply-adds appear only where the source writes fma().  -fno-slp-vectorize keeps the
 compiler from pairing scalar fp32 ops into v_pk_* (no faster on gfx950, costs ~30 VGPRs in register-pair shuffles).
 
--mllvm -amdgpu-kernarg-preload-count=9: gfx950 delivers the first user SGPRs' worth of kernel arguments in registers at wavefront start; the step
-kernel's nine leading scalar arguments (taco_step.hpp StepKernelArgs) are what its up-front loads need, so they are issued without the round
+-mllvm -amdgpu-kernarg-preload-count=11: gfx950 delivers the first user SGPRs' worth of kernel arguments in registers at wavefront start; the step
+kernel's eleven leading scalar arguments (taco_step.hpp StepKernelArgs) are what its up-front loads need, so they are issued without the round
 trip to the argument segment.  (On firmware without the feature the kernels' compatibility prologue loads the same registers: correct, no gain.)
 
 Every build embeds a hash of its sources (taco_source_hash()); `_lib.load()` compares it with the sources on disk, so an edited
@@ -31,7 +31,7 @@ SOURCES = ["taco_capi.hip"]
 DEPS = ["taco_capi.hip", "taco_step.hpp", "taco_math.hpp", "taco_rollout.hpp", "taco_policy.hpp", "taco_fused.hpp", os.path.join("..", "..", "include", "taco_env.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-falign-loops=64",
-         "-mllvm", "-amdgpu-kernarg-preload-count=9", "-Wall", "-Wno-unused-function"]
+         "-mllvm", "-amdgpu-kernarg-preload-count=11", "-Wall", "-Wno-unused-function"]
 
 
 def source_hash():

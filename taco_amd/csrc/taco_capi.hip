@@ -16,7 +16,7 @@
 #include "taco_step.hpp"
 // the argument list of taco_step_kernel (taco_step.hpp StepKernelArgs: the leading scalars arrive preloaded in registers)
 #define STEP_ARGS(P) uint32_t early_ = taco::pack_early((P).hh, (P).hw_rows, (P).stamps != nullptr, (P).use_ctl); \
-    void *args[] = {&(P).S, &(P).reset, &(P).act_in, &(P).hist, &(P).wclk, &(P).n, &(P).flags, &early_, &(P).env_offset, &(P)}
+    void *args[] = {&(P).S, &(P).reset, &(P).act_in, &(P).seed_lo, &(P).seed_hi, &(P).step, &(P).task_mode, &(P).n, &(P).flags, &early_, &(P).env_offset, &(P)}
 
 #include "taco_rollout.hpp"
 #include "taco_policy.hpp"

@@ -69,13 +69,16 @@ struct StepParams {
 
 // KERNEL-ARGUMENT PRELOAD.  gfx950 delivers the first user SGPRs' worth of kernel arguments IN REGISTERS when a wavefront starts (the build passes
 // -amdgpu-kernarg-preload-count; byref aggregates are not eligible, hence the leading scalars).  Everything the up-front loads of a step need -- the
-// state, flag, action and history pointers, the env count, the flags, the history row -- leads the argument list, so those loads are issued
+// state, flag and action pointers (history and device clock follow the state in the workspace), the env count, the flags, the history row --
+// and what the role wavefronts' reset draws need (Philox key, step, task) leads the argument list, so those loads and draws are issued
 // without the round trip to the argument segment (a launch's argument block is fresh memory) that every wavefront used to sit out first; the
 // parameter block behind them (a complete StepParams: the leading scalars repeat its fields) is read while the state loads are in flight.
 struct StepKernelArgs {   // (the layout of the kernel-argument segment: what lazy_arg and the line touches address)
-    float *S; long long *reset; const float *act_in; float *hist; uint32_t *wclk; int n; uint32_t flags; uint32_t early; int env_offset;
+    float *S; long long *reset; const float *act_in; uint32_t seed_lo, seed_hi, step; int task_mode, n; uint32_t flags; uint32_t early; int env_offset;
     StepParams P;
 };
+// (history and device clock are not among them: they lie at fixed offsets behind the state in the handle's workspace, taco_capi.hip taco_create)
+static_assert(sizeof(StepKernelArgs) - sizeof(StepParams) == 56, "fourteen dwords: what gfx950 preloads beside the segment pointer");
 constexpr size_t kParamsOffset = offsetof(StepKernelArgs, P);
 // `early`: hh | hw_rows << 8 | stamps bound << 30 | use_ctl << 31
 inline __host__ __device__ uint32_t pack_early(int hh, int hw_rows, bool stamps, int use_ctl) { return (uint32_t)(hh & 15) | ((uint32_t)(hw_rows & 7) << 8) | (stamps ? 1u << 30 : 0u) | (use_ctl ? 1u << 31 : 0u); }
@@ -908,6 +911,21 @@ TD void step_core(const StepParams &Pin, const FusedCtx &FX) {
         }
     };
     if constexpr (!FUSED) { if (!SPLIT || wv == 0) upfront_loads(); }   // (the rollout kernel, whose arguments are in registers anyway, keeps them where they were)
+    if constexpr (ROLES && LPE == 4 && !FUSED && !RESET_ONLY) {   // (= DRAWS_SERVED, defined below)
+        // The role wavefronts' reset draws (see rs_tab below): one Philox block per lane, from preloaded arguments too -- they run while the
+        // argument segment's round trip is under way instead of behind it (barrier 1 waits for them).
+        // (round 2 holds blocks 8 and 9 only: lane 2 of every quad draws the env's command block there, STREAM_CMD block 0 -- consumed by
+        // reset_command_idx of the rotate / flip envs, at a reset and at progress 500)
+        if (wv != 0) {
+            uint32_t step_e = Pin.step;
+            if (from_ctl) { uint32_t a = c_step; asm volatile("" : "+s"(a)); step_e = a; }   // (a captured launch waits for its pair of the device clock)
+            const bool cmd_lane = wv == 3 && sub == 2 && Pin.task_mode != TACO_TASK_POS;
+            if (((reset_blocks_wanted(fl) >> (4 * (wv - 1))) & 15u) || (wv == 3 && Pin.task_mode != TACO_TASK_POS)) {
+                const float4 u = uniform_block(Pin, step_e, Pin.env_offset + i, cmd_lane ? STREAM_CMD : STREAM_RESET, cmd_lane ? 0u : (uint32_t)(4 * (wv - 1) + sub));
+                ((__attribute__((address_space(3))) f32x4_t *)(lds_all + WAVE_LDS_WORDS))[(wv - 1) * 64 + lane] = f32x4_t{u.x, u.y, u.z, u.w};
+            }
+        }
+    }
     // ------------------------------------------------------------------ the parameter block
     // Read from HERE on, behind the loads above, through a copy of the argument-segment pointer the compiler cannot see through: as ordinary
     // kernel arguments its fields are loaded in the kernel's entry block, and the first use of any of them (or the first reuse of a register one
@@ -1988,15 +2006,7 @@ TD void step_core(const StepParams &Pin, const FusedCtx &FX) {
     } else {
         load_out_args();
         if (wv == 1 && lane < 8) mb_seq[lane] = 0;
-        if constexpr (DRAWS_SERVED) {   // the reset draws, round wv - 1 (see rs_tab)
-            // (round 2 holds blocks 8 and 9 only: lane 2 of every quad draws the env's command block there, STREAM_CMD block 0 -- consumed by
-            // reset_command_idx of the rotate / flip envs, at a reset and at progress 500)
-            const bool cmd_lane = wv == 3 && sub == 2 && P.task_mode != TACO_TASK_POS;
-            if (((reset_blocks_wanted(fl) >> (4 * (wv - 1))) & 15u) || (wv == 3 && P.task_mode != TACO_TASK_POS)) {
-                const float4 u = uniform_block(P, clk.step, gid, cmd_lane ? STREAM_CMD : STREAM_RESET, cmd_lane ? 0u : (uint32_t)(4 * (wv - 1) + sub));
-                rs_tab[(wv - 1) * 64 + lane] = f32x4_t{u.x, u.y, u.z, u.w};
-            }
-        }
+        // (DRAWS_SERVED: this wavefront's reset draws were made at the top of the kernel, "up-front loads")
         __syncthreads();  // barrier 1 of 2
         if constexpr (NOISE_TAB) {
             if (wv == (ROLES ? 2 : 1) && noise_served) {   // the step's 10 x EPW rotor-noise blocks -> rn_tab (first: wavefront 0 needs them at its first substep)
@@ -2489,9 +2499,13 @@ TD void step_core(const StepParams &Pin, const FusedCtx &FX) {
 // the launch-per-step forms: one step_core per launch (argument list: StepKernelArgs)
 template <int BLOCK, int LPE, bool SPLIT = false, bool CAP = false, bool OUT = false, bool RESET_ONLY = false, bool WIDE = false, bool LIN = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SPLIT || CAP) ? ((WIDE || BLOCK == 128) ? 2 : 4) : 1, CAP ? 4 : 8))) void taco_step_kernel(
-    float *S, long long *reset, const float *act_in, float *hist, uint32_t *wclk, int n, uint32_t flags, uint32_t early, int env_offset, const StepParams P0) {
+    float *S, long long *reset, const float *act_in, uint32_t seed_lo, uint32_t seed_hi, uint32_t step, int task_mode, int n, uint32_t flags, uint32_t early,
+    int env_offset, const StepParams P0) {
     StepParams P{};   // (the preloaded fields only; step_core reads the block P0 itself, behind its up-front loads)
-    P.S = S; P.reset = reset; P.act_in = act_in; P.hist = hist; P.wclk = wclk; P.n = n; P.flags = flags; P.env_offset = env_offset;
+    const size_t npad4 = (size_t)((n + 63) & ~63) * 4;   // floats per row of the workspace arrays (taco_capi.hip taco_create: S | hist | ring | wclk)
+    P.S = S; P.reset = reset; P.act_in = act_in; P.hist = S + (size_t)NUM_CHUNKS * npad4;
+    P.wclk = (uint32_t *)(S + (size_t)(NUM_CHUNKS + HIST_ROWS + TACO_RING_SLOTS) * npad4);
+    P.seed_lo = seed_lo; P.seed_hi = seed_hi; P.step = step; P.task_mode = task_mode; P.n = n; P.flags = flags; P.env_offset = env_offset;
     P.hh = (int)(early & 15u); P.hw_rows = (int)((early >> 8) & 7u); P.stamps_on = (int)((early >> 30) & 1u); P.use_ctl = (int)(early >> 31);
     step_core<BLOCK, LPE, SPLIT, CAP, OUT, RESET_ONLY, WIDE, false, LIN>(P, FusedCtx{});
 }
