@@ -944,8 +944,13 @@ TD void step_core(const StepParams &Pin, const FusedCtx &FX) {
     }
     const StepParams &P = *Pp;
     if (Pin.stamps_on && P.stamps && blockIdx.x == 0 && threadIdx.x == 0) P.stamps[0] = t_entry;
-    clk.step = FUSED ? FX.step : (from_ctl ? c_step : P.step); clk.head = FUSED ? FX.head : (from_ctl ? wclk_head(c_aux) : P.head);
-    clk.hh = FUSED ? FX.hh : (from_ctl ? wclk_hh(c_aux) : P.hh); clk.phase = from_ctl ? wclk_phase(c_aux) : P.st_phase;
+    // (the fields the code between here and barrier 1 consults, in ONE group of scalar loads: read where they are used, each was its own
+    // load-and-wait on the path to the barrier -- a dozen scalar-cache round trips of a wavefront with nothing else to issue.  What arrived
+    // preloaded -- step, history row, env offset, task, flags -- is taken from Pin)
+    const int b_head = P.head, b_phase = P.st_phase, b_substeps = P.substeps, b_mix1 = P.mix_n1, b_mix2 = P.mix_n2;
+    if constexpr (!FUSED) asm volatile("" : : "s"(b_head), "s"(b_phase), "s"(b_substeps), "s"(b_mix1), "s"(b_mix2));
+    clk.step = FUSED ? FX.step : (from_ctl ? c_step : Pin.step); clk.head = FUSED ? FX.head : (from_ctl ? wclk_head(c_aux) : b_head);
+    clk.hh = FUSED ? FX.hh : (from_ctl ? wclk_hh(c_aux) : Pin.hh); clk.phase = from_ctl ? wclk_phase(c_aux) : b_phase;
     // the next values, left in this wavefront's pairs (and, by workgroup 0, in the control block) when the step wavefront is done: by then every
     // wavefront of the workgroup has its copy (the role wavefronts wait for theirs ahead of barrier 2)
     auto publish_clock = [&]() {
@@ -1065,14 +1070,14 @@ TD void step_core(const StepParams &Pin, const FusedCtx &FX) {
     __shared__ float lin_ring[LIN_SERVED ? (10 * 3 + 1) * 64 : 4];   // [substep][0: q before the substep, 1: q after its first sub-iteration, 2: rf + swp(rf)][lane]
                                                                      // ([.][0] is written at the end of the substep BEFORE: the server starts on it one counter earlier)
     __shared__ float lin_init[LIN_SERVED ? 5 * 64 : 4];        // [p, v, drag coefficient, kt, keep mask][lane]: posted with counter value 1
-    const bool lin_served = LIN_SERVED && P.substeps == 2;     // (the server runs exactly two sub-iterations)
+    const bool lin_served = LIN_SERVED && b_substeps == 2;     // (the server runs exactly two sub-iterations)
     constexpr bool NOISE_TAB = SPLIT && !(WIDE && LPE == 4);
     constexpr bool NOISE_INLINE = !SPLIT;   // the one-wavefront instantiations have nobody to serve a table: their PLAIN forms draw the rotor noise themselves
     // (rn_tab lives in `hand`: the table is read by the substeps, the Carry is written after the last one and read after barrier 2; the
     // server writes the next table only after barrier 1 of the next step)
     static_assert(!NOISE_TAB || (64 / LPE) * 40 >= 10 * (64 / LPE) * 4, "rn_tab must fit in the Carry block");
     float *const rn_tab = hand;
-    const bool noise_served = NOISE_TAB && (P.flags & TACO_F_ROTOR_NOISE) != 0;
+    const bool noise_served = NOISE_TAB && (fl & TACO_F_ROTOR_NOISE) != 0;
     // The arrays are named directly at every use (macros, not lambdas or pointer parameters) so that the accesses stay LDS instructions;
     // through a generic pointer they become flat loads.  MB_WAIT is bounded, so a protocol bug can never hang the GPU; a wait that gives up
     // sets kStatusMailboxTimeout in the workspace's sticky status word (taco_check reports TACO_ERR_STATE) and poisons the voltage with NaN.
@@ -1086,7 +1091,8 @@ TD void step_core(const StepParams &Pin, const FusedCtx &FX) {
                                  __hip_atomic_store(&mb_seq[idx], (value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
     // (only while every wavefront of the launch has a SIMD to itself -- 1 024 on the MI355X -- or the server would take issue slots
     // from another workgroup's wavefront 0: 19.0 vs 18.4 us at 8 192 envs)
-    const bool bat_served = ROLES && LPE == 4 && (P.flags & TACO_F_BATTERY_CONSUMPTION) != 0 && (FUSED || TACO_AB_SERVE_ALWAYS || gridDim.x * 4u <= 1024u);   // (FUSED: one workgroup per CU)
+    const bool bat_served = ROLES && LPE == 4 && (fl & TACO_F_BATTERY_CONSUMPTION) != 0 && (FUSED || TACO_AB_SERVE_ALWAYS || (uint32_t)((Pin.n + EPW - 1) / EPW) * 4u <= 1024u);   // (FUSED: one workgroup per CU; the grid of a SPLIT launch
+                                                                                                                     // from the env count: gridDim is a load from the implicit arguments)
     const int euler_role = bat_served ? 3 : 1;   // which role wavefront serves the euler angles: the reward wavefront while it is idle (no battery to serve),
                                                  // otherwise the states wavefront (which may first have a stack history to move)
     Carry K;
@@ -1097,11 +1103,11 @@ TD void step_core(const StepParams &Pin, const FusedCtx &FX) {
     constexpr bool QUAD_POST = LPE == 4 && !FUSED && !ROLES;
     struct { float p, v, w, a, tp; } QF{};
     bool qf = false;
-    const int gid = P.env_offset + i;
+    const int gid = Pin.env_offset + i;
     const rsrc_t rR = make_rsrc(reinterpret_cast<const char *>(P.ring) + (size_t)tile_id * (TACO_RING_SLOTS * kRowBytes), TACO_RING_SLOTS * kRowBytes);
-    const int grp = (P.task_mode != TACO_TASK_MIX) ? P.task_mode
-                    : (gid < P.mix_n1 ? TACO_TASK_POS : (gid < P.mix_n2 ? TACO_TASK_ROTATE : TACO_TASK_FLIP));
-    const bool mix = P.task_mode == TACO_TASK_MIX;
+    const int grp = (Pin.task_mode != TACO_TASK_MIX) ? Pin.task_mode
+                    : (gid < b_mix1 ? TACO_TASK_POS : (gid < b_mix2 ? TACO_TASK_ROTATE : TACO_TASK_FLIP));
+    const bool mix = Pin.task_mode == TACO_TASK_MIX;
     // copter_rpy_continuous is consumed only by the flip command (FA:831, :930); other envs keep their reset-time value
     const bool track_rpy = grp == TACO_TASK_FLIP || (fl & TACO_F_TRACK_RPY) != 0;  // (record_flag: every env, as the reference does)
     // wave-uniform form of the same predicate: the euler/unwrap block runs for a whole wavefront or not at all (lanes of
