@@ -455,7 +455,12 @@ TD float quad_rotate(float qv, float w, float v) {
 // the linear lines of one sub-iteration of row I in the quad layout: v <- v + h (R(q) F / m + g), p <- p + h v, with q the attitude BEFORE the
 // sub-iteration's update (lane j = component j; gzq = (-0, -0, g, -0)).  Used by integrate_quad and, in the four-role quad forms, by the
 // wavefront that runs the linear chain behind the step wavefront (step_core: "linear chain served"): one definition, the same bits.
-TD void linear_iteration_quad(const StepParams &P, float qq, float Fq, float gzq, float &vq, float &pq) {
+// The integrator's step constants as the quad forms' loops take them: PINNED in scalar registers (pin_s).  Read through the parameter block's
+// reference they are loads the register allocator prefers to REPEAT inside the substep loop over keeping them (an invariant load is trivially
+// rematerialisable) -- a scalar-cache round trip per use per substep on the path of a wavefront that has nothing else to issue.
+struct QuadLoopP { float h, half_h, inv_m; int substeps; };
+TD float pin_s(float x) { asm volatile("" : "+s"(x)); return x; }
+template <class PT> TD void linear_iteration_quad(const PT &P, float qq, float Fq, float gzq, float &vq, float &pq) {
     const float ww = bc3(qq);
     const float q1 = rot1(qq), q2 = rot2(qq);
     float t = fma(q1, rot2(Fq), -(q2 * rot1(Fq)));
@@ -466,8 +471,8 @@ TD void linear_iteration_quad(const StepParams &P, float qq, float Fq, float gzq
 }
 // NOLIN: the angular lines only (pq, vq, Fq are not touched); q_mid <- the attitude after the FIRST sub-iteration (what the second one's
 // linear lines rotate the force with) -- the linear chain runs elsewhere, see linear_iteration_quad.
-template <int SUBS = 0, bool DEFER = false, bool NOLIN = false>
-TD bool integrate_quad(const StepParams &P, uint32_t k3, float &pq, float &qq, float &vq, float &bq, float Fq, float tqq, float Jq, float hJiq,
+template <int SUBS = 0, bool DEFER = false, bool NOLIN = false, class PT = StepParams>
+TD bool integrate_quad(const PT &P, uint32_t k3, float &pq, float &qq, float &vq, float &bq, float Fq, float tqq, float Jq, float hJiq,
                        float gzq, uint32_t sm3, float &q_mid) {
     bool any_big = false;
     uint64_t bad = 0;   // DEFER: the lanes that met a rare form (nothing was branched on; the caller redoes the call with DEFER = false)
@@ -1623,6 +1628,8 @@ TD void step_core(const StepParams &Pin, const FusedCtx &FX) {
 
     } else {
         // ---- quad layout: scatter (lane j keeps component j), run the ten substeps, gather back
+        const QuadLoopP LP{pin_s(P.h), pin_s(P.half_h), pin_s(P.inv_m), b_substeps};   // (see QuadLoopP)
+        const float dt_q = pin_s(P.dt), rdt_q = pin_s(P.rdt);
         float pq = pick4(sub, p.x, p.y, p.z, 0.0f), qq = pick4(sub, q.x, q.y, q.z, q.w), vq = pick4(sub, v.x, v.y, v.z, 0.0f);
         float bq = pick4(sub, wb.x, wb.y, wb.z, 0.0f);
         float ppq = pick4(sub, pid_prev[0], pid_prev[1], pid_prev[2], 0.0f), piq = pick4(sub, pid_int[0], pid_int[1], pid_int[2], 0.0f);
@@ -1657,7 +1664,7 @@ TD void step_core(const StepParams &Pin, const FusedCtx &FX) {
         auto redo_integrate = [&](int ks_of) {   // the PLAIN forms' rare case: see the end of `substep`; ks_of: that substep
             pq = fix_p; qq = fix_q; vq = fix_v; bq = fix_b;
             float q_mid = 0.0f;
-            integrate_quad<2, false, LIN_SERVED>(P, k3, pq, qq, vq, bq, fix_F, fix_t, Jq, hJiq, gzq, sm3, q_mid);
+            integrate_quad<2, false, LIN_SERVED>(LP, k3, pq, qq, vq, bq, fix_F, fix_t, Jq, hJiq, gzq, sm3, q_mid);
             if constexpr (LIN_SERVED) { lin_ring[(ks_of * 3 + 1) * 64 + lane] = q_mid; lin_ring[(ks_of * 3 + 3) * 64 + lane] = qq; }   // (not published yet: the counter follows at the top of the next substep)
             roundtrip();
         };
@@ -1706,7 +1713,7 @@ TD void step_core(const StepParams &Pin, const FusedCtx &FX) {
             const float d0 = bc0(dq);
             // angular_vel_control FA:637-650: lane j runs PID axis j on action component j + 1
             const float u0 = (d0 + 1.0f) / 2.0f * 1000.0f;
-            const float upid = pid_axis<FIN>(P.dt, P.rdt, kpq, dppf<QP(1, 2, 3, 3)>(dq) * 20.0f, bq, ppq, piq);
+            const float upid = pid_axis<FIN>(dt_q, rdt_q, kpq, dppf<QP(1, 2, 3, 3)>(dq) * 20.0f, bq, ppq, piq);
             // control_allocator CTRL/fpv_dynamics.py:35-46: lane k computes motor k
             const float u1 = bc0(upid), u2 = bc1(upid);
             float u3 = bc2(upid);
@@ -1744,7 +1751,7 @@ TD void step_core(const StepParams &Pin, const FusedCtx &FX) {
                     Pm = Pm + bc3(c3);
                 }
                 // Battery_Dynamics.sim_process CTRL/battery_dynamics.py:47-75 (replicated in the quad)
-                if (PLAIN || bat_on) bat_V = battery_step(P.dt, Pm, bat_E, bat_u1, bat_t);
+                if (PLAIN || bat_on) bat_V = battery_step(dt_q, Pm, bat_E, bat_u1, bat_t);
                 else bat_V = 4.35f * 6.0f;
             }
             // RotorDynamics.sim_process CTRL/thrust_dynamics.py:98-104: lane k = rotor k
@@ -1802,17 +1809,17 @@ TD void step_core(const StepParams &Pin, const FusedCtx &FX) {
                 // integrator from the substep's start values with the branching form (redo_integrate: same values as before, lane by lane).
                 fix_p = pq; fix_q = qq; fix_v = vq; fix_b = bq; fix_F = Fq; fix_t = tqq;
                 float q_mid = 0.0f;
-                rare = integrate_quad<2, true, LIN_SERVED>(P, k3, pq, qq, vq, bq, Fq, tqq, Jq, hJiq, gzq, sm3, q_mid);
+                rare = integrate_quad<2, true, LIN_SERVED>(LP, k3, pq, qq, vq, bq, Fq, tqq, Jq, hJiq, gzq, sm3, q_mid);
                 if constexpr (LIN_SERVED) { lin_ring[(ks * 3 + 1) * 64 + lane] = q_mid; lin_ring[(ks * 3 + 3) * 64 + lane] = qq; }   // (+ 3: the next substep's start attitude)
                 roundtrip();
                 asm volatile("" ::"v"(pq), "v"(qq), "v"(vq), "v"(bq));   // (or the compiler branches around the rest of the substep as soon as `rare` is known)
             } else {
                 float q_mid = 0.0f;
                 if (lin_off) {
-                    rare = integrate_quad<0, false, true>(P, k3, pq, qq, vq, bq, Fq, tqq, Jq, hJiq, gzq, sm3, q_mid);
+                    rare = integrate_quad<0, false, true>(LP, k3, pq, qq, vq, bq, Fq, tqq, Jq, hJiq, gzq, sm3, q_mid);
                     lin_ring[(ks * 3 + 1) * 64 + lane] = q_mid; lin_ring[(ks * 3 + 3) * 64 + lane] = qq;
                 } else {
-                    rare = integrate_quad<0>(P, k3, pq, qq, vq, bq, Fq, tqq, Jq, hJiq, gzq, sm3, q_mid);
+                    rare = integrate_quad<0>(LP, k3, pq, qq, vq, bq, Fq, tqq, Jq, hJiq, gzq, sm3, q_mid);
                 }
                 if (fl & TACO_F_WORLD_RATE_ROUNDTRIP) roundtrip();
             }
@@ -2083,6 +2090,7 @@ TD void step_core(const StepParams &Pin, const FusedCtx &FX) {
                 const uint32_t keep = bits(lin_init[256 + lane]);
                 const uint32_t k2 = (sub == 2) ? ~0u : 0u;
                 const float gzq = pick4(sub, -0.0f, -0.0f, P.g, -0.0f);
+                const QuadLoopP LP{pin_s(P.h), pin_s(P.half_h), pin_s(P.inv_m), 2};   // (see QuadLoopP; the server runs exactly two sub-iterations)
 #pragma unroll 1
                 for (int ks = 0; ks < 10; ++ks) {
                     // (the substep's start attitude came with the previous counter: body-frame velocity and drag are done when thrust and q1 arrive)
@@ -2094,8 +2102,8 @@ TD void step_core(const StepParams &Pin, const FusedCtx &FX) {
                     const float q1 = lin_ring[(ks * 3 + 1) * 64 + lane], psum = lin_ring[(ks * 3 + 2) * 64 + lane];
                     const float Fz = kvv + (bc2(psum) + bc0(psum));
                     const float Fq = from_bits(bits(selm(k2, Fz, dv)) & keep);
-                    linear_iteration_quad(P, q0, Fq, gzq, vq, pq);
-                    linear_iteration_quad(P, q1, Fq, gzq, vq, pq);
+                    linear_iteration_quad(LP, q0, Fq, gzq, vq, pq);
+                    linear_iteration_quad(LP, q1, Fq, gzq, vq, pq);
                 }
                 if (sub < 3) {   // lane j holds component j: the Carry's p and v, and their words of the state
                     hand[el * CARRY_WORDS + sub] = pq; hand[el * CARRY_WORDS + 4 + sub] = vq;
@@ -2113,6 +2121,7 @@ TD void step_core(const StepParams &Pin, const FusedCtx &FX) {
         if (bat_served && wv == 1) {  // battery server (the reward wavefront, idle until the post-phase): ten voltages, each one substep ahead of wavefront 0
             MB_WAIT(0, 1);
             float bE = mb_bs[el * 4], bu1 = mb_bs[el * 4 + 1], bt = mb_bs[el * 4 + 2];
+            const float dt_s = pin_s(P.dt);
             for (int ks = 0; ks < 10; ++ks) {
                 MB_WAIT(0, ks + 1);
                 float Pm;
@@ -2122,7 +2131,7 @@ TD void step_core(const StepParams &Pin, const FusedCtx &FX) {
                     b = TACO_DIVC(mb_om[el * 4 + 2] * 2.0f * kPi, 4500.0f); Pm = Pm + 400.0f * ((b * b) * b);
                     b = TACO_DIVC(mb_om[el * 4 + 3] * 2.0f * kPi, 4500.0f); Pm = Pm + 400.0f * ((b * b) * b);
                 }
-                const float V = battery_step(P.dt, Pm, bE, bu1, bt);
+                const float V = battery_step(dt_s, Pm, bE, bu1, bt);
 #ifdef TACO_TEST_HOOKS
                 if (P.flags & kDebugSlowServer) { for (int z = 0; z < 40; ++z) __builtin_amdgcn_s_sleep(100); }  // test hook: arrive late
 #endif
