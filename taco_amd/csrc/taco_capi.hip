@@ -14,6 +14,12 @@
 #include <new>
 
 #include "taco_step.hpp"
+// the kernel derives the history and device-clock pointers from the state pointer (StepKernelArgs): hold the layout of taco_create to it
+static bool step_layout_ok(const taco::StepParams &P) {
+    const size_t npad4 = (size_t)((P.n + 63) & ~63) * 4;
+    return P.hist == P.S + (size_t)taco::NUM_CHUNKS * npad4 &&
+           (const void *)P.wclk == (const void *)(P.S + (size_t)(taco::NUM_CHUNKS + taco::HIST_ROWS + TACO_RING_SLOTS) * npad4);
+}
 // the argument list of taco_step_kernel (taco_step.hpp StepKernelArgs: the leading scalars arrive preloaded in registers)
 #define STEP_ARGS(P) uint32_t early_ = taco::pack_early((P).hh, (P).hw_rows, (P).stamps != nullptr, (P).use_ctl); \
     void *args[] = {&(P).S, &(P).reset, &(P).act_in, &(P).seed_lo, &(P).seed_hi, &(P).step, &(P).task_mode, &(P).n, &(P).flags, &early_, &(P).env_offset, &(P)}
@@ -498,6 +504,7 @@ int launch_step(taco_env *e, const taco_rollout_io *io, void *stream) {
     P.hh = e->hh;
     int grid, block;
     P.stamps_on = P.stamps != nullptr;
+    if (!step_layout_ok(P)) return fail(TACO_ERR_WORKSPACE, "taco_step: the handle's workspace layout is not the one the step kernel derives its history / clock pointers from");
     STEP_ARGS(P);
     // (a handle created with a state stack launches the form chosen for stacks; the newest-frame-only launch of the same handle takes the
     // form its env count would get WITHOUT one -- the role wavefronts have no history to move -- unless the caller pinned a form)
@@ -537,6 +544,7 @@ int taco_reset_done(taco_env *e, int64_t *reset_buf, void *stream) {
     P.ctl = e->ctl; P.wclk = e->wclk; P.use_ctl = e->clock_on_device;
     P.step = (uint32_t)e->step_count; P.head = e->head; P.hh = e->hh;   // the clock of the NEXT step: it does not advance here
     P.stamps = nullptr; P.stamps_on = 0;
+    if (!step_layout_ok(P)) return fail(TACO_ERR_WORKSPACE, "taco_reset_done: the handle's workspace layout is not the one the step kernel derives its history / clock pointers from");
     STEP_ARGS(P);
     const void *fn = (const void *)taco::taco_step_kernel<64, 1, false, false, false, true>;
     hipError_t he = hipLaunchKernel(fn, dim3((unsigned)((e->cfg.num_envs + 63) / 64)), dim3(64), args, 0, (hipStream_t)stream);
