@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """ISA audit of the step kernel's substep loops.
 
-    python tools/isa_audit.py [--kernel _ZN4taco16taco_step_kernelILi256ELi1ELb0EEEvNS_10StepParamsE] [--out profiles/rNN_isa_audit.txt]
+    python tools/isa_audit.py [--kernel <prefix of the mangled name, e.g. _ZN4taco16taco_step_kernelILi64ELi4ELb0ELb0ELb0ELb0ELb0ELb0EEE>] [--out profiles/rNN_isa_audit.txt]
 
 Compiles taco_capi.hip to gfx950 assembly with the product flags (taco_amd/build.py FLAGS), cuts out one kernel, finds its natural
 loops (a backward branch to a label), and prints for every loop that contains VALU work an instruction census priced with the issue
@@ -47,7 +47,8 @@ def compile_asm():
 
 def cut_kernel(path, name):
     lines = open(path).read().split("\n")
-    start = next(i for i, l in enumerate(lines) if l.startswith(name + ":"))
+    # (a PREFIX of the mangled name is enough: the argument list behind the template arguments changes with the kernel's signature)
+    start = next(i for i, l in enumerate(lines) if l.startswith(name) and l.split(";")[0].rstrip().endswith(":"))
     end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
     return lines[start:end + 1]
 
@@ -124,7 +125,7 @@ def census(prog, lo, hi):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--kernel", default="_ZN4taco16taco_step_kernelILi64ELi1ELb0ELb1ELb0EEEvNS_10StepParamsE")
+    ap.add_argument("--kernel", default="_ZN4taco16taco_step_kernelILi64ELi1ELb0ELb1ELb0ELb0ELb0ELb0EEE")
     ap.add_argument("--asm", default=None, help="use this assembly file instead of compiling")
     ap.add_argument("--out", default=None)
     ap.add_argument("--min-valu", type=int, default=150, help="only report loops with at least this many VALU instructions")
