@@ -292,6 +292,37 @@ def philox(seed, c0, c1, c2, c3):
     return list(out)
 
 
+def uniform_block(seed, n_env, n_step, stream, n_idx, gid0=0, step0=0):
+    """[n_env, n_step, n_idx] uniforms of the build's generator: env gid0 + e, step step0 + t, stream, index k (tests/test_rng_distributions.py)"""
+    out = np.empty((n_env, n_step, n_idx), np.float32)
+    fn = lib().orc_uniform_block
+    fn.restype = None
+    fn.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_void_p]
+    fn(seed, gid0, n_env, step0, n_step, stream, n_idx, _p(out))
+    return out
+
+
+def rounded_normal(u, lim):
+    """round(N(0,1)) clamped to +-lim by inverse CDF on the uniforms u (the deploy / delay length draws, FA:324, :576)"""
+    u = _f32(u).ravel()
+    out = np.empty(u.size, np.int32)
+    fn = lib().orc_rounded_normal_vec
+    fn.restype = None
+    fn.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    fn(u.size, _p(u), lim, _p(out))
+    return out
+
+
+def obs_normals_block(seed, n_env, n_step, gid0=0, step0=0):
+    """[n_env, n_step, 12] observation-noise normals (Box-Muller on STREAM_OBS uniforms 4 .. 15, FA:402-410)"""
+    out = np.empty((n_env, n_step, 12), np.float32)
+    fn = lib().orc_obs_normals_block
+    fn.restype = None
+    fn.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_void_p]
+    fn(seed, gid0, n_env, step0, n_step, _p(out))
+    return out
+
+
 def vec(fn_name, *xs):
     """apply a scalar own-math function elementwise"""
     f = getattr(lib(), fn_name)

@@ -796,6 +796,23 @@ void orc_obs_normals(uint64_t seed, uint32_t gid, uint32_t step, float nrm[12]) 
     obs_normals(&D, nrm);
 }
 
+/* bulk hooks for tests/test_rng_distributions.py: the numbers the env consumes, by (env id, step, stream, index), without an env around them.
+ * out[(e * n_step + t) * n_idx + k] = uniform k of stream `stream` of env gid0 + e at step step0 + t */
+void orc_uniform_block(uint64_t seed, uint32_t gid0, int n_env, uint32_t step0, int n_step, uint32_t stream, int n_idx, float *out) {
+    for (int e = 0; e < n_env; ++e)
+        for (int t = 0; t < n_step; ++t) {
+            draw_ctx D = {seed, gid0 + (uint32_t)e, step0 + (uint32_t)t, stream, 0, {0, 0, 0, 0}, 0};
+            for (int k = 0; k < n_idx; ++k) out[((size_t)e * n_step + t) * n_idx + k] = draw_u(&D, k);
+        }
+}
+/* round(N(0,1)) clamped to +-lim of n uniforms: the deploy-length (lim 1, FA:324) and delay-length (lim 3, FA:576) draws */
+void orc_rounded_normal_vec(int n, const float *u, int lim, int32_t *out) { for (int i = 0; i < n; ++i) out[i] = rounded_normal(u[i], lim); }
+/* out[(e * n_step + t) * 12 + k]: the twelve observation-noise normals of env gid0 + e at step step0 + t */
+void orc_obs_normals_block(uint64_t seed, uint32_t gid0, int n_env, uint32_t step0, int n_step, float *out) {
+    for (int e = 0; e < n_env; ++e)
+        for (int t = 0; t < n_step; ++t) orc_obs_normals(seed, gid0 + (uint32_t)e, step0 + (uint32_t)t, out + ((size_t)e * n_step + t) * 12);
+}
+
 static void step_env(const orc_env *e, int i, const float *actions, float *obs_buf, float *states_buf, float *rew_buf,
                      int64_t *reset_buf, uint8_t *timeout_buf) {
     const orc_cfg *c = &e->cfg;
@@ -825,6 +842,7 @@ static void step_env(const orc_env *e, int i, const float *actions, float *obs_b
     /* ---- control_freq_inv x (mid_physics_step + simulate)  VT:309-313 */
     float wb[3];
     rotate_inv(s->q, s->w, wb); /* body-frame angular velocity of the root state (FA:350); carried by row I from here on */
+    const int roundtrip = e->world_rate_roundtrip || (fl & ORC_F_WORLD_RATE_ROUNDTRIP);
     for (int ks = 0; ks < c->control_freq_inv; ++ks) {
         /* refresh_state, the part the inner loop consumes (FA:339-350) */
         float rpy[3], vb[3];
@@ -869,10 +887,13 @@ static void step_env(const orc_env *e, int i, const float *actions, float *obs_b
             tq[2] = (ts[0] + ts[1]) + (ts[2] + ts[3]);
         }
         integrate_substep(&e->ip, s->p, s->q, s->v, wb, F, tq); /* gym.simulate VT:313 */
-        if (e->world_rate_roundtrip || (fl & ORC_F_WORLD_RATE_ROUNDTRIP)) { quat_sandwich(s->q, wb, s->w); rotate_inv(s->q, s->w, wb); }
+        /* the reference's data flow: simulate() leaves w = R(q) b in the root state, the next refresh_state re-derives b from it (FA:350).
+         * After the tenth simulate() the root state KEEPS that w (round 5: rounds 3-4 rebuilt it from the round-tripped b once more, one
+         * rotation pair too many: ~80 % of the world-frame rates were 1-4 ulp off the reference's, tests/golden/glue_*_ieee.npz) */
+        if (roundtrip) { quat_sandwich(s->q, wb, s->w); rotate_inv(s->q, s->w, wb); }
     }
 
-    quat_sandwich(s->q, wb, s->w); /* root state: world-frame angular velocity */
+    if (!roundtrip) quat_sandwich(s->q, wb, s->w); /* carried mode: the root state's world-frame angular velocity is rebuilt once */
 
     /* ---- post_physics_step FA:374-388 */
     s->progress += 1;

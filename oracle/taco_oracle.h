@@ -171,6 +171,10 @@ float orc_logf(float x);
 void orc_philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]);
 void orc_obs_normals(uint64_t seed, uint32_t gid, uint32_t step, float nrm[12]); /* STREAM_OBS Box-Muller normals of one env-step */
 float orc_uniform(uint32_t bits);
+/* bulk draws for tests/test_rng_distributions.py (see taco_oracle.c) */
+void orc_uniform_block(uint64_t seed, uint32_t gid0, int n_env, uint32_t step0, int n_step, uint32_t stream, int n_idx, float *out);
+void orc_rounded_normal_vec(int n, const float *u, int lim, int32_t *out);
+void orc_obs_normals_block(uint64_t seed, uint32_t gid0, int n_env, uint32_t step0, int n_step, float *out);
 
 #ifdef __cplusplus
 }

@@ -1440,6 +1440,10 @@ TD void step_core(const StepParams &Pin, const FusedCtx &FX) {
     // the target pose is consumed only after the loop; issuing the loads here hides their latency behind the substeps
     const float4 c_tp = CLD(C_TGT_POS), c_tq = CLD(C_TGT_QUAT);
     V3 wb = quat_rotate(conj(q), w);  // body-frame angular velocity of the root state (FA:350); row I carries it from here on
+    // Round-trip mode: the world-frame rate simulate() left in the root state, w = R(q) b -- what the NEXT refresh_state re-derives b from, and,
+    // after the tenth substep, what the root state keeps (rounds 3-4 rebuilt it once more from the round-tripped b: one rotation pair too many,
+    // ~80 % of the stored rates 1-4 ulp off the reference's own, tests/golden/glue_*_ieee.npz).  Every path through the loops below assigns it.
+    V3 w_rt{0.0f, 0.0f, 0.0f};
     // `fin` (wave-uniform): every value the rate PID and the allocator of the next substep consume -- the pending actions of this step,
     // the body rates, the PID memory -- is finite and below 1e30 in every lane.  Then no intermediate of that block can be a NaN or
     // overflow, and the selects that carry torch's NaN semantics (clamp pass-through, the NaN-propagating max) are dead: the block runs
@@ -1592,6 +1596,7 @@ TD void step_core(const StepParams &Pin, const FusedCtx &FX) {
             if (PLAIN || (fl & TACO_F_WORLD_RATE_ROUNDTRIP)) {  // the reference's data flow (FA:350): the rates pass through the root state
                 const V3 ww = quat_sandwich(q, wb);
                 wb = quat_rotate(conj(q), ww);
+                w_rt = ww;
             }
             return rare;
         };
@@ -1654,11 +1659,13 @@ TD void step_core(const StepParams &Pin, const FusedCtx &FX) {
         auto slot_of = [&](int k) { int r = (dlen - 1 < k) ? dlen - 1 : k; return r > 9 ? 9 : r; };
         float dq_next = slotsf[(slot_of(0) * EPW + el) * 4 + sub];
         float fix_p = 0.0f, fix_q = 0.0f, fix_v = 0.0f, fix_b = 0.0f, fix_F = 0.0f, fix_t = 0.0f;   // the integrator's inputs of the running substep (PLAIN forms)
+        float wq_rt = 0.0f;   // (w_rt in the quad layout)
         auto roundtrip = [&]() {  // FA:350 literally: w = R(q) b (quat_sandwich), b = quat_rotate(conj(q), w), lane j = component j
             const float ww = bc3(qq), q1 = rot1(qq), q2 = rot2(qq);
             float t = fma(q1, rot2(bq), -(q2 * rot1(bq)));
             t = t + t;
             const float wq = fma(q1, rot2(t), fma(-q2, rot1(t), fma(ww, t, bq)));
+            wq_rt = wq;
             bq = from_bits(bits(quad_rotate(-qq, ww, wq)) & ~k3);  // (lane 3 holds no rate component: kept at +0)
         };
         auto redo_integrate = [&](int ks_of) {   // the PLAIN forms' rare case: see the end of `substep`; ks_of: that substep
@@ -1903,6 +1910,7 @@ TD void step_core(const StepParams &Pin, const FusedCtx &FX) {
         q = Q4{bc0(qq), bc1(qq), bc2(qq), bc3(qq)};
         v = V3{bc0(vq), bc1(vq), bc2(vq)};
         wb = V3{bc0(bq), bc1(bq), bc2(bq)};
+        w_rt = V3{bc0(wq_rt), bc1(wq_rt), bc2(wq_rt)};
         pid_prev[0] = bc0(ppq); pid_prev[1] = bc1(ppq); pid_prev[2] = bc2(ppq);
         pid_int[0] = bc0(piq); pid_int[1] = bc1(piq); pid_int[2] = bc2(piq);
         omega[0] = bc0(omq); omega[1] = bc1(omq); omega[2] = bc2(omq); omega[3] = bc3(omq);
@@ -1920,7 +1928,8 @@ TD void step_core(const StepParams &Pin, const FusedCtx &FX) {
         if (lane == 0) atomicOr(&P.ctl[kCtlStatus], kStatusMailboxTimeout);
         bat_V = nanf32();
     }
-    w = quat_sandwich(q, wb);  // root state: world-frame angular velocity
+    // root state: world-frame angular velocity -- what the tenth simulate() left there (round trip), or rebuilt once from the carried body rates
+    if (fl & TACO_F_WORLD_RATE_ROUNDTRIP) w = w_rt; else w = quat_sandwich(q, wb);
 
     // ------------------------------------------------------------------ post_physics_step FA:374-388
     progress += 1;

@@ -197,7 +197,21 @@ def stabiliser(env):
     return a.numpy().astype(np.float32)
 
 
-def run_case(name, task, n, steps, seed, act_fn, **kw):
+class _TorchWithIEEESqrt:
+    """`torch` as control/battery_dynamics.py sees it in the `*_ieee` family: every attribute is torch's own except `sqrt`, which returns the
+    CORRECTLY ROUNDED fp32 square root (computed in fp64 and rounded once: 53 >= 2 * 24 + 2 bits make the double rounding innocuous).  That is
+    what the reference computes on its real platform (CUDA's sqrtf is IEEE) and what the oracle and the HIP kernel compute; this container's
+    CPU torch.sqrt is 1 ulp off on ~0.6 % of the battery's arguments (battery_dynamics.py:68)."""
+
+    def __getattr__(self, k):
+        return getattr(torch, k)
+
+    @staticmethod
+    def sqrt(x):
+        return torch.from_numpy(np.sqrt(x.detach().numpy().astype(np.float64)).astype(np.float32))
+
+
+def run_case(name, task, n, steps, seed, act_fn, ieee_sqrt=False, **kw):
     cfg = config.default_cfg(task, n, seed=seed, **{k: v for k, v in kw.items() if not k.startswith("_")})
     flat = config.flat_cfg(cfg)
     cls = {"pos": FA.FpvPos, "rotate": FA.FpvRotate, "flip": FA.FpvFlip, "mix": FA.FpvMix}[task]
@@ -406,6 +420,10 @@ def run_case(name, task, n, steps, seed, act_fn, **kw):
     FA.FpvBase.compute_observation_state = compute_observation_state
     cls.reset_copter_idx, cls.reset_command_idx = reset_copter_idx, reset_command_idx
     torch.normal, torch.rand = fake_normal, fake_rand
+    bd_torch = BD.torch
+    if ieee_sqrt:
+        BD.torch = _TorchWithIEEESqrt()   # inside battery_dynamics' namespace only
+        name += "_ieee"
     try:
         env = cls(cfg, "cpu", "cpu", -1, True, False, False)
         rec = {k: [] for k in ("step", "obs", "states", "rew", "reset", "timeout", "blob", "reset_vals")}
@@ -431,6 +449,7 @@ def run_case(name, task, n, steps, seed, act_fn, **kw):
                 rec["blob"].append(blob_of(env, n))
                 rec["reset_vals"].append(D.reset_vals)
     finally:
+        BD.torch = bd_torch
         VT.VecTask.__init__, FA.torch_rand_float, torch.normal, torch.rand, FA.FpvBase.reset_target_idx, FA.FpvBase.reset_env_idx = saved
         (BD.torch_rand_float, TD.torch_rand_float, FA.FpvBase.reset_controller_idx, FA.FpvBase.control_with_thrusts,
          FA.FpvBase.compute_observation_state) = saved2
@@ -491,28 +510,45 @@ def actions(seed, thrust_bias, crash_every=0, noise=0.3):
 
 
 if __name__ == "__main__":
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("ref", nargs="?")
+    ap.add_argument("--family", choices=["torch", "ieee", "both"], default="both",
+                    help="torch: glue_*.npz, the reference as it runs in this container; ieee: glue_*_ieee.npz, torch.sqrt inside "
+                         "battery_dynamics replaced by the correctly rounded fp32 square root (_TorchWithIEEESqrt)")
+    ap.add_argument("--only", default="", help="comma-separated case names")
+    args = ap.parse_args()
+    only = set(filter(None, args.only.split(",")))
+    families = {"torch": [False], "ieee": [True], "both": [False, True]}[args.family]
+
+    def case(name, *a, **kw):
+        if only and name not in only:
+            return
+        for ieee in families:
+            run_case(name, *a, ieee_sqrt=ieee, **kw)
+
     common = dict(random_voltage=False, random_rotor_speed=False, env_lenObservations=2, env_lenStates=3)
     # (1) pos task, every random_* of the pose on: reset dispatch / ordering / zeroing, delay line in the common regime, frame stacks,
     #     reward + done + time-outs (episodes of 70 steps), deaths
-    run_case("pos", "pos", 48, 170, 11, actions(1, 0.05, crash_every=5), env_maxEpisodeLength=70, **common)
+    case("pos", "pos", 48, 170, 11, actions(1, 0.05, crash_every=5), env_maxEpisodeLength=70, **common)
     # (2) delay-line overflow: delay_time = 85 (L + T > 100: truncated mask write, stale tail) ...
-    run_case("overflow", "pos", 32, 150, 12, actions(2, 0.05, crash_every=7), env_maxEpisodeLength=60, delay_time=85, **common)
+    case("overflow", "pos", 32, 150, 12, actions(2, 0.05, crash_every=7), env_maxEpisodeLength=60, delay_time=85, **common)
     # (3) ... and 75 ms with random deploy and delay lengths: the line random-walks into the overflow regime
-    run_case("deploy", "pos", 32, 220, 13, actions(3, 0.05, crash_every=6), env_maxEpisodeLength=90, delay_time=75, ramdom_deploy_time=True,
-             ramdom_delay_time=True, **common)
+    case("deploy", "pos", 32, 220, 13, actions(3, 0.05, crash_every=6), env_maxEpisodeLength=90, delay_time=75, ramdom_deploy_time=True,
+         ramdom_delay_time=True, **common)
     # (4) rotate with a random command, (5) flip and (6) mix across progress 500 (command re-draw; FpvMix thirds by global env id)
-    run_case("rotate", "rotate", 32, 160, 14, actions(4, 0.05, crash_every=5), env_maxEpisodeLength=75, **common)
+    case("rotate", "rotate", 32, 160, 14, actions(4, 0.05, crash_every=5), env_maxEpisodeLength=75, **common)
     around = lambda t: t < 40 or t % 50 == 0 or 495 <= t   # the first resets, a sparse middle, and the steps around progress 500
-    run_case("flip", "flip", 24, 520, 15, actions(5, -0.5, noise=0.05), env_maxEpisodeLength=1000, _hold=True, _record=around, **common)
-    run_case("mix", "mix", 36, 520, 16, actions(6, -0.5, crash_every=11, noise=0.05), env_maxEpisodeLength=1000, _hold=True, _record=around, **common)
+    case("flip", "flip", 24, 520, 15, actions(5, -0.5, noise=0.05), env_maxEpisodeLength=1000, _hold=True, _record=around, **common)
+    case("mix", "mix", 36, 520, 16, actions(6, -0.5, crash_every=11, noise=0.05), env_maxEpisodeLength=1000, _hold=True, _record=around, **common)
     # (7)-(10) the flag sets of BASELINE.json's configs 2 ... 5 (taco_amd/config.py baseline_config): configs 2-4 draw the battery's E_c and
     #     the rotors' initial speeds at every reset (random_voltage / random_rotor_speed are ON by default); config 5 adds rotor / aero
     #     coefficient and response-time randomisation, rotor noise per substep, observation noise, random delay / deploy lengths, 5 state frames
-    run_case("cfg2", "pos", 48, 170, 21, actions(7, 0.05, crash_every=5), env_maxEpisodeLength=70)
-    run_case("cfg3", "rotate", 32, 160, 22, actions(8, 0.05, crash_every=5), env_maxEpisodeLength=75)
-    run_case("cfg4", "flip", 24, 520, 23, actions(9, -0.5, noise=0.05), env_maxEpisodeLength=1000, _hold=True, _record=around)
+    case("cfg2", "pos", 48, 170, 21, actions(7, 0.05, crash_every=5), env_maxEpisodeLength=70)
+    case("cfg3", "rotate", 32, 160, 22, actions(8, 0.05, crash_every=5), env_maxEpisodeLength=75)
+    case("cfg4", "flip", 24, 520, 23, actions(9, -0.5, noise=0.05), env_maxEpisodeLength=1000, _hold=True, _record=around)
     cfg5 = dict(random_rotordynamic_coe=True, random_rotor_response=True, random_aerodynamic_coe=True, observation_noise=True, rotor_noise=True,
                 ramdom_delay_time=True, ramdom_deploy_time=True, env_lenStates=5)
-    run_case("cfg5", "mix", 36, 520, 24, actions(10, -0.5, crash_every=11, noise=0.05), env_maxEpisodeLength=1000, _hold=True, _record=around, **cfg5)
+    case("cfg5", "mix", 36, 520, 24, actions(10, -0.5, crash_every=11, noise=0.05), env_maxEpisodeLength=1000, _hold=True, _record=around, **cfg5)
     # (11) config 5's flags again with short episodes (many resets and time-outs with every draw live) and difficulty != 1
-    run_case("cfg5_short", "mix", 36, 200, 25, actions(11, 0.05, crash_every=4), env_maxEpisodeLength=60, difficulty=0.7, **cfg5)
+    case("cfg5_short", "mix", 36, 200, 25, actions(11, 0.05, crash_every=4), env_maxEpisodeLength=60, difficulty=0.7, **cfg5)

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O
-from util import GLUE_CASES, assert_bits_equal, assert_ulp
+from util import GLUE_CASES, GLUE_CASES_IEEE, assert_bits_equal, assert_ulp
 
 TWO_PI = np.float32(2 * np.pi)
 
@@ -312,10 +312,31 @@ class _OracleOneStep:
 @pytest.mark.parametrize("mode", ["roundtrip", "carried"])
 @pytest.mark.parametrize("case", GLUE_CASES)
 def test_one_step_from_the_references_own_state(case, mode, golden):
-    from util import ONE_STEP_TOL, ONE_STEP_TOL_CARRIED, glue_case, teacher_forced_one_step
+    from util import ONE_STEP_TOL, ONE_STEP_TOL_CARRIED, exact_table, glue_case, teacher_forced_one_step
     g = golden("glue_" + case)
     cfg, _, _ = glue_case(g)
+    exact = {}
     maxima, cnt = teacher_forced_one_step(g, _OracleOneStep(cfg, mode), f"glue_{case} [{mode}]",
-                                          ONE_STEP_TOL if mode == "roundtrip" else ONE_STEP_TOL_CARRIED)
+                                          ONE_STEP_TOL if mode == "roundtrip" else ONE_STEP_TOL_CARRIED, exact=exact)
     assert cnt["pairs"] >= 60
     print(f"one step, glue_{case} [{mode}] {cnt}: " + ", ".join(f"{k} {v:.1e}" for k, v in maxima.items()))
+    print(exact_table(f"glue_{case} [{mode}] (ABSOLUTE deviations in the last column)", exact))
+
+
+# The same against the IEEE-sqrt family (tests/util.py EXACT_GROUPS): with a correctly rounded square root in the reference's battery model
+# (battery_dynamics.py:68 -- its real platform's sqrtf) one step of the oracle from the reference's own state is BIT-EQUAL to the reference's
+# own step in root state, PID memory, battery, rotor speeds and every libm-free word of the obs / states stacks, for every env that did not
+# reset in the step; what sits behind a libm call of the reference (reset attitudes, euler angles, the flip command, the noised obs words,
+# the reward's asin) is reported in ulp.  Round-trip mode only: "carried" is not the reference's data flow.
+@pytest.mark.parametrize("case", GLUE_CASES_IEEE)
+def test_one_step_is_bit_exact_against_the_ieee_sqrt_reference(case, golden):
+    from util import ONE_STEP_TOL, exact_table, glue_case, teacher_forced_one_step
+    g = golden("glue_" + case)
+    cfg, _, _ = glue_case(g)
+    exact = {}
+    maxima, cnt = teacher_forced_one_step(g, _OracleOneStep(cfg, "roundtrip"), f"glue_{case}", ONE_STEP_TOL, exact=exact, assert_exact=True)
+    assert cnt["pairs"] >= 60
+    for name in ("root state", "PID memory", "battery state / voltage", "rotor speeds (~300 rev/s)", "obs stack, libm-free words", "states stack, libm-free words"):
+        assert exact[name]["differ (no reset)"] == 0 and exact[name]["words"] > 0
+    print(f"one step, glue_{case} {cnt}: " + ", ".join(f"{k} {v:.1e}" for k, v in maxima.items()))
+    print(exact_table(f"glue_{case}", exact))

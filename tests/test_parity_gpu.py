@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from taco_amd import config
-from util import GLUE_CASES, assert_bits_equal
+from util import GLUE_CASES, GLUE_CASES_IEEE, assert_bits_equal
 
 pytestmark = pytest.mark.gpu
 
@@ -434,14 +434,36 @@ class _HipOneStep:
 @pytest.mark.parametrize("mode", ["roundtrip", "carried"])
 @pytest.mark.parametrize("case", GLUE_CASES)
 def test_hip_one_step_from_the_references_own_state(case, mode, golden):
-    from util import ONE_STEP_TOL, ONE_STEP_TOL_CARRIED, glue_case, teacher_forced_one_step
+    from util import ONE_STEP_TOL, ONE_STEP_TOL_CARRIED, exact_table, glue_case, teacher_forced_one_step
     g = golden("glue_" + case)
     cfg, _, _ = glue_case(g)
     impl = _HipOneStep(cfg, mode)
-    maxima, cnt = teacher_forced_one_step(g, impl, f"HIP glue_{case} [{mode}]", ONE_STEP_TOL if mode == "roundtrip" else ONE_STEP_TOL_CARRIED)
+    exact = {}
+    maxima, cnt = teacher_forced_one_step(g, impl, f"HIP glue_{case} [{mode}]", ONE_STEP_TOL if mode == "roundtrip" else ONE_STEP_TOL_CARRIED, exact=exact)
     impl.env.check()
     assert cnt["pairs"] >= 60
     print(f"HIP one step, glue_{case} [{mode}] {cnt}: " + ", ".join(f"{k} {v:.1e}" for k, v in maxima.items()))
+    print(exact_table(f"HIP glue_{case} [{mode}] (ABSOLUTE deviations in the last column)", exact))
+
+
+# The same against the IEEE-sqrt family (tests/util.py EXACT_GROUPS; glue_*_ieee.npz: the reference with a correctly rounded square root in its
+# battery model, i.e. its real platform's sqrtf): ONE step of the HIP kernel from the reference's own state is BIT-EQUAL to the reference's own
+# step in root state, PID memory, battery, rotor speeds and every libm-free word of the obs / states stacks, for every env that did not reset
+# in the step; what sits behind a libm call of the reference is reported in ulp.  The table (incl. ABSOLUTE deviations) is printed with -s.
+@pytest.mark.parametrize("case", GLUE_CASES_IEEE)
+def test_hip_one_step_is_bit_exact_against_the_ieee_sqrt_reference(case, golden):
+    from util import ONE_STEP_TOL, exact_table, glue_case, teacher_forced_one_step
+    g = golden("glue_" + case)
+    cfg, _, _ = glue_case(g)
+    impl = _HipOneStep(cfg, "roundtrip")
+    exact = {}
+    maxima, cnt = teacher_forced_one_step(g, impl, f"HIP glue_{case}", ONE_STEP_TOL, exact=exact, assert_exact=True)
+    impl.env.check()
+    assert cnt["pairs"] >= 60
+    for name in ("root state", "PID memory", "battery state / voltage", "rotor speeds (~300 rev/s)", "obs stack, libm-free words", "states stack, libm-free words"):
+        assert exact[name]["differ (no reset)"] == 0 and exact[name]["words"] > 0
+    print(f"HIP one step, glue_{case} {cnt}: " + ", ".join(f"{k} {v:.1e}" for k, v in maxima.items()))
+    print(exact_table(f"HIP glue_{case}", exact))
 
 
 @pytest.mark.parametrize("form", ["quad_roles", "quad", "lane", "lane_roles", "lane_throughput", "quad_served"])
