@@ -253,8 +253,8 @@ def config_entry(idx, n, dev, torch, warm=0.1):
 
 
 def graph_entry(n, acts, dev, torch, steps_in_graph=64):
-    """the same workload as ONE HIP graph of `steps_in_graph` steps (each step = ONE kernel node: the step kernel reads the device-resident
-    clock and its last-ticket workgroup advances it), replayed back to back: what the per-step kernel boundary costs when the host is out of the loop"""
+    """the same workload as ONE HIP graph of `steps_in_graph` steps (each step = ONE kernel node: every step wavefront reads and rewrites the
+    device-resident clock pair of its 16 envs), replayed back to back: what the per-step kernel boundary costs when the host is out of the loop"""
     from taco_amd import config
     from taco_amd.vec_env import FpvBase
     env = FpvBase(config.baseline_config(1, num_envs=n), sim_device=str(dev), rl_device=str(dev), copy_outputs=False)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TACO_ABI_VERSION 6
+#define TACO_ABI_VERSION 7
 
 typedef enum taco_status {
     TACO_OK = 0,
@@ -167,11 +167,18 @@ void taco_destroy(taco_env *env);
  * clock and advancing it itself -- the workspace holds one copy of the clock per 16 envs, read and rewritten by the one wavefront that
  * steps those envs, so no synchronisation between workgroups exists: ONE graph node per step, no slower than an eager step, and the
  * captured graph can be replayed any number of times, continuing exactly where the eager steps (or earlier replays) stopped.
- * From the first capture on the clock lives on the device for good (the graph may be replayed at any time): every later launch of the handle
- * takes the device path, and taco_get_step_count / taco_set_step_count / taco_get_state / taco_set_state / taco_get_field /
- * taco_states_ring_row / taco_step_ring / an eager taco_rollout_run re-read it first (they block, device-wide). */
+ * GRAPH MODE: from the first capture on the clock lives on the device (the graph may be replayed at any time, and the host cannot see a
+ * replay that is enqueued but has not run): every later launch of the handle takes the device path, and taco_get_step_count /
+ * taco_set_step_count / taco_get_state / taco_set_state / taco_get_field / taco_states_ring_row / taco_step_ring / an eager taco_rollout_run
+ * re-read it first -- they BLOCK (hipDeviceSynchronize + a 16-byte copy), on EVERY call, for as long as the handle is in graph mode.
+ * taco_release_graphs ends it: the caller's word that no graph holding launches of this handle will be replayed any more (one last blocking
+ * re-read; afterwards eager launches take the clock from their arguments again and nothing synchronises).  A later capture re-enters graph
+ * mode.  A replay AFTER the release leaves the host's copy behind the device's; taco_check reports that (TACO_ERR_STATE).
+ * taco_graph_mode: 1 while in graph mode, 0 otherwise (never blocks). */
 int taco_step(taco_env *env, const float *actions, float *obs_buf, float *states_buf, float *rew_buf, int64_t *reset_buf,
               uint8_t *timeout_buf, void *stream);
+int taco_graph_mode(const taco_env *env);
+int taco_release_graphs(taco_env *env);
 
 /* ---- the replay buffer directly behind step() ------------------------------------------------
  * The reference's rollout loop (ppo_asymmetry.py:96-131) copies every step's obs / states / reward / done into
@@ -325,7 +332,7 @@ int taco_bind_gather_block(taco_env *env, float *block);
  * rows [ph, ph + len_states) ALWAYS hold the stack that step produced, oldest frame first: the reference's [num_envs][len_states][26] tensor is the
  * strided view ring[ph : ph + len_states] with the first two axes swapped (taco_amd/vec_env.py hands exactly that to the PPO loop).  104 B written
  * per env-step (+ (len_states - 1) / period of that for the twins) instead of (2 len_states - 1) x 104 B moved.  taco_states_ring_row = the
- * phase of the LAST step (the first row of its window; blocks after graph replays, -1 on error).  Binding resets the phase to 0 (blocks);
+ * phase of the LAST step (the first row of its window; blocks in graph mode, -1 on error).  Binding resets the phase to 0 (blocks);
  * NULL unbinds.  Calls with states_next != NULL are unaffected.  Finite clip_states: pass io->states_out = a SECOND ring of the same geometry;
  * it receives clamp(frame, +-clip_states) at the same rows -- the clamped copy VecTask.step returns (vec_task_asymmetry.py:332) is the same
  * view of that ring, since clamping a stack is clamping its frames. */
@@ -333,8 +340,8 @@ int taco_bind_states_ring(taco_env *env, float *ring, int rows);
 int taco_states_ring_row(taco_env *env);
 /* taco_step_rollout on the bound ring (io->states_next == NULL) that also reports the ring phase the launch uses: *phase = the first row of
  * the window this step fills -- what a host layer needs to hand out the right strided view without a second call.  Refuses a capturing
- * stream (TACO_ERR_STATE, nothing is enqueued: a replay's window cannot be told in advance; capture taco_step_rollout instead); after graph
- * replays it first re-reads the device clock (blocks once). */
+ * stream (TACO_ERR_STATE, nothing is enqueued: a replay's window cannot be told in advance; capture taco_step_rollout instead); in graph mode
+ * (see taco_step) it first re-reads the device clock: it blocks on every call until taco_release_graphs. */
 int taco_step_ring(taco_env *env, const taco_rollout_io *io, void *stream, int32_t *phase);
 
 /* env.difficulty = x (ppo_asymmetry.py:173-175, :376); takes effect at the next taco_step. */

@@ -50,13 +50,26 @@ def merge(state_dicts):
 
 def load_state_dict(env, sd, strict=True):
     """Restore `env` from a checkpoint that covers its env range (the same range, or a larger one: the env's columns are sliced out).
-    strict=False skips the check that the run's identity (task, stack lengths, seed, global env count) is the same."""
+    strict=False skips the check that the run's identity (task, stack lengths, seed, global env count) and its arithmetic (every task flag,
+    world_rate_roundtrip included; delay / episode length; dt; sub-iterations) are the same."""
     if sd.get("format") != FORMAT:
         raise ValueError(f"unknown checkpoint format {sd.get('format')}")
     if strict:
-        for k in ("num_envs_global", "task_mode", "len_obs", "len_states", "seed"):
-            if sd["flat_cfg"][k] != env._flat[k]:
-                raise ValueError(f"checkpoint was taken with {k}={sd['flat_cfg'][k]!r}, this env has {env._flat[k]!r}")
+        # the run's identity AND its arithmetic: every task flag (_lib.FLAG_BITS -- the randomisation switches and world_rate_roundtrip, the
+        # angular rate's data flow, whose default changed with ABI 6) decides what the next step computes; a key an older checkpoint does not
+        # carry is compared with the default it was written under (world_rate_roundtrip: False before ABI 6)
+        old_defaults = {"world_rate_roundtrip": sd.get("abi", 0) >= 6, "record_flag": False}
+        for k in ("num_envs_global", "task_mode", "len_obs", "len_states", "seed", "delay_time", "max_episode_length", "dt", "substeps") + tuple(_lib.FLAG_BITS):
+            if k == "record_flag" or k not in env._flat:   # (record_flag is bookkeeping only: which envs track rpy_continuous)
+                continue
+            have = sd["flat_cfg"].get(k, old_defaults.get(k))
+            if have != env._flat[k]:
+                raise ValueError(f"checkpoint was taken with {k}={have!r}, this env has {env._flat[k]!r} (strict=False loads it anyway: the run then "
+                                 f"continues under THIS env's settings and is no longer the one that was saved)")
+        if sd.get("abi") != _lib.ABI_VERSION:
+            import warnings
+            warnings.warn(f"checkpoint written by ABI {sd.get('abi')}, loading into ABI {_lib.ABI_VERSION}: the state layout is compatible (format {FORMAT}); "
+                          f"bit-exact continuation holds only if the arithmetic did not change in between (see DESIGN.md section 5)")
     lo = env._flat["env_offset"] - sd["flat_cfg"]["env_offset"]
     n = env._flat["num_envs"]
     if lo < 0 or lo + n > sd["flat_cfg"]["num_envs"]:

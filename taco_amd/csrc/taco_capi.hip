@@ -639,6 +639,20 @@ int64_t taco_get_step_count(taco_env *e) {
     return e->step_count;
 }
 int64_t taco_peek_step_count(const taco_env *e) { return e ? e->step_count : -1; }
+// Graph mode (clock_on_device): from the first captured launch every host-side use of the clock blocks (refresh_clock) -- a graph may have
+// been replayed behind the host's back, and no non-blocking scheme can know about a replay that is enqueued but has not run yet.  The way out
+// is the caller's word: taco_release_graphs = "no graph holding launches of this handle will be replayed from now on" (one last re-read, then
+// the handle is back on the eager path: kernel arguments, the host's own copy, no synchronisation anywhere).  A replay after that still
+// steps the envs correctly as far as IT goes (graphs read the device copy, which eager launches keep current) but leaves the host's copy
+// behind: taco_check reports exactly that (device clock ahead of the host's), it is never silent.
+int taco_graph_mode(const taco_env *e) { return e ? e->clock_on_device : TACO_ERR_INVALID_ARG; }
+int taco_release_graphs(taco_env *e) {
+    if (!e) return fail(TACO_ERR_INVALID_ARG, "env is null");
+    const int rc = refresh_clock(e);   // (refuses while a stream is still capturing launches of this handle)
+    if (rc != TACO_OK) return rc;
+    e->clock_on_device = 0;
+    return TACO_OK;
+}
 // The device-resident copy of the clock is set as well: a capture may be the very next launch (checkpoint restore -> capture -> replay), and a
 // captured step reads its Philox counter from there.  (Ring head and history row are not part of a checkpoint -- the blob is in logical
 // order -- and their device copies already equal the host's: every eager launch mirrors them.)
@@ -660,10 +674,16 @@ int taco_set_step_count(taco_env *e, int64_t n) {
 
 int taco_check(taco_env *e, void *stream) {
     if (!e) return fail(TACO_ERR_INVALID_ARG, "env is null");
-    uint32_t status = 0;
+    uint32_t status = 0, dev_step = 0;
     hipError_t he = hipMemcpyAsync(&status, e->ctl + taco::kCtlStatus, sizeof(status), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(&dev_step, e->ctl + taco::kCtlStep, sizeof(dev_step), hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (he == hipSuccess) he = hipStreamSynchronize((hipStream_t)stream);
     if (he != hipSuccess) return hip_fail(he, "taco_check");
+    // outside graph mode the host's copy of the clock leads the device's by the launches still in flight, never the other way round: a device
+    // clock AHEAD of it means a captured graph was replayed after taco_release_graphs (or by another handle on this workspace)
+    if (!e->clock_on_device && e->capture_stream == nullptr && (int32_t)(dev_step - (uint32_t)e->step_count) > 0)
+        return fail(TACO_ERR_STATE, "the device-resident step clock is ahead of the host's copy: a captured graph holding launches of this handle was "
+                                    "replayed after taco_release_graphs; eager steps since then used stale random-stream counters");
     if (status & taco::kStatusMailboxTimeout)
         return fail(TACO_ERR_STATE, "a step kernel gave up waiting on its battery mailbox (role wavefronts out of step): the affected envs' voltage "
                                     "was set to NaN; results since the last clean taco_check are suspect");

@@ -123,7 +123,8 @@ class FpvBase:
             self.set_kernel_form(kernel_form)
         if self._ring_on:
             front, row_bytes = self.len_states - 1, self.num_envs * self.num_states * 4
-            self._st_period = int(min(64, max(front + 1, (1 << 30) // row_bytes - front)))   # <= 1 GiB of ring, twins <= front / period of a frame per step
+            # <= 1 GiB of ring where that leaves period >= len_states + 1 (what step t returned survives step t + 1); twins cost front / period of a frame per step
+            self._st_period = int(min(64, max(front + 2, (1 << 30) // row_bytes - front)))
             self._st_ring = torch.zeros((self._st_period + front, self.num_envs, self.num_states), device=dev, dtype=torch.float32)
             with torch.cuda.device(dev):
                 torch.cuda.synchronize()   # (the bind resets the ring phase on the device, behind the workspace's initialisation)
@@ -178,15 +179,33 @@ class FpvBase:
 
     @property
     def states_buf(self):
-        """[num_envs, len_states, 26]; with the frame ring a STRIDED view (each frame contiguous, frames num_envs * 26 floats apart): reads,
-        copy_() into it, .cpu(), indexing all work; .view() needs .reshape() / .contiguous()"""
+        """[num_envs, len_states, 26]; with the frame ring a STRIDED, READ-ONLY view of the window the last step filled (each frame contiguous,
+        frames num_envs * 26 floats apart): reads, .cpu(), indexing work; .view() needs .reshape() / .contiguous().  Do NOT write into it: a
+        write reaches rows [ph, ph + len_states) only, never the twin rows the ring keeps for the wrap-around, so it is lost as soon as the
+        window wraps -- load_stacks(states=...) is the way to set the stack (it rebuilds the twins).  LIFETIME of a view handed out earlier
+        (by step() or this property): its oldest frame is overwritten period - len_states + 1 >= 2 steps later (the ring's period is at
+        least len_states + 1), i.e. what step t returned is intact while step t + 1 runs, as with the alternating obs buffers.
+        Outside graph mode (include/taco_env.h taco_graph_mode) this is a host-side lookup; in graph mode it asks the library, which blocks."""
         if self._ring_on:
-            ph = self.lib.taco_states_ring_row(self._h)   # (the library's word: graph replays advance the phase on the device)
+            if self.lib.taco_graph_mode(self._h) != 0:   # graph replays advance the phase on the device: the library re-reads it (device-wide sync)
+                ph = self.lib.taco_states_ring_row(self._h)
+                if ph < 0:
+                    raise _lib.TacoError(f"libtaco_env: {self.lib.taco_last_error().decode()}")
+                self._st_last = ph
+            return self._st_views[self._st_last]
+        return self._states_pp[self._pp]
+
+    def release_graphs(self):
+        """taco_release_graphs: the caller's word that no HIP graph holding launches of this env will be replayed any more.  From the first
+        captured launch on the env is in GRAPH MODE -- every step() / states_buf / step_count / get_state re-reads the device-resident clock
+        and blocks (a replay may have advanced it behind the host's back) --; this ends it (one last blocking re-read).  A replay after the
+        release is reported by check()."""
+        _lib.check(self.lib.taco_release_graphs(self._h), self.lib)
+        if self._ring_on:
+            ph = self.lib.taco_states_ring_row(self._h)
             if ph < 0:
                 raise _lib.TacoError(f"libtaco_env: {self.lib.taco_last_error().decode()}")
             self._st_last = ph
-            return self._st_views[ph]
-        return self._states_pp[self._pp]
 
     def load_stacks(self, obs=None, states=None):
         """make `obs` / `states` ([num_envs, len, 26]) the env's current frame stacks (checkpoint restore)"""

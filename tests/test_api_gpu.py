@@ -126,11 +126,18 @@ def test_full_size_parity_on_random_slices(idx, steps):
     assert (prog >= 1).all() and (prog <= flat["max_episode_length"]).all()
 
 
-@pytest.mark.parametrize("idx,n,steps,form", [(2, 16384, 60, "quad"), (3, 16384, 60, "quad_served"), (4, 32768, 40, "lane_roles"), (1, 65536, 25, "lane_throughput")])
+# (baseline_config index, envs per rank, steps, the kernel form the product picks there): BASELINE configs 2 ... 5 at the per-rank shapes of
+# N = 1, 2, 4, 8 ranks (DESIGN section 8 lists them): pos 4 096 / N; rotate 16 384 / N; flip 65 536 / N; mix 262 144 / N with every flag and 5 frames
+PER_RANK_SHAPES = [(2, 16384, 60, "quad"), (3, 16384, 60, "quad_served"), (4, 32768, 40, "lane_roles"), (1, 65536, 25, "lane_throughput"),
+                   (1, 512, 60, "quad_roles"), (2, 8192, 40, "quad_roles"), (2, 2048, 60, "quad_roles"), (3, 32768, 25, "lane_roles"),
+                   (3, 8192, 40, "quad_roles"), (4, 65536, 16, "lane_roles"), (4, 131072, 10, "lane_throughput")]
+
+
+@pytest.mark.parametrize("idx,n,steps,form", PER_RANK_SHAPES)
 def test_whole_batch_parity_at_the_per_rank_shapes(idx, n, steps, form):
-    """SURVEY 8(d)'s configs 3 / 4 / 5 at their per-GPU shapes (rotate 16 384, flip 16 384, mix 32 768 with every flag and 5 state frames)
-    and the first throughput-form size, in the kernel form the product picks there: EVERY env against the oracle (all host threads),
-    outputs each few steps and the whole state at the end, bit for bit."""
+    """SURVEY 8(d)'s configs 3 / 4 / 5 at their per-GPU shapes (rotate 16 384, flip 16 384, mix 32 768 with every flag and 5 state frames),
+    the first throughput-form size, and the shapes the same totals give on 2 / 4 / 8 ranks, in the kernel form the product picks there:
+    EVERY env against the oracle (all host threads), outputs each few steps and the whole state at the end, bit for bit."""
     from oracle import oracle as O
     from taco_amd.vec_env import FpvBase
     cfg = config.baseline_config(idx, num_envs=n)
@@ -523,6 +530,20 @@ def test_ring_backed_state_stack_through_capture_checkpoint_and_the_c_abi(tmp_pa
     assert torch.equal(twin.get_state().view(torch.int32), ref.get_state().view(torch.int32))
     assert torch.equal(_bits(twin.states_buf), _bits(ref.states_buf))
     env.check(); twin.check()
+    # GRAPH MODE and its end (include/taco_env.h taco_graph_mode / taco_release_graphs): since the capture every clock-reading call of `env`
+    # synchronises the device; release_graphs() puts the handle back on the eager path (host-side lookups, no sync), bit for bit the same run
+    assert env.lib.taco_graph_mode(env._h) == 1 and twin.lib.taco_graph_mode(twin._h) == 0
+    env.release_graphs()
+    assert env.lib.taco_graph_mode(env._h) == 0
+    for t3 in range(t2 + 1, t2 + 70):             # (more than a period of the ring)
+        d, *_ = env.step(acts[t3 % 8]); ref.step_raw(acts[t3 % 8])
+        assert torch.equal(_bits(d["states"]), _bits(ref.states_buf)) and torch.equal(_bits(env.states_buf), _bits(ref.states_buf))
+    assert torch.equal(env.get_state().view(torch.int32), ref.get_state().view(torch.int32)) and env.step_count == ref.step_count
+    env.check()
+    # ... and a replay AFTER the release is not silent: the device clock runs ahead of the host's copy, check() says so
+    graph.replay()
+    with pytest.raises(_lib.TacoError, match="replayed after taco_release_graphs"):
+        env.check()
 
 
 def _run_bench(extra, env_extra=None, timeout=420):

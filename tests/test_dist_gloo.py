@@ -1,4 +1,4 @@
-"""The N > 1 path on CPU: two `gloo` ranks, each stepping its contiguous slice of global env ids and publishing it with
+"""The N > 1 path on CPU: two (and eight) `gloo` ranks, each stepping its contiguous slice of global env ids and publishing it with
 ONE all-gather of the packed block.  There is no GPU here, so each rank's producer is the CPU oracle (a checker used as a
 stand-in data source inside tests/ only); what is under test is taco_amd.dist: shard bounds, block layout, the
 collective, and that the gathered result equals a single-process run of all envs (results independent of world size)."""
@@ -55,17 +55,19 @@ def _worker(rank, world, port, n_global, idx, steps, q):
         dist_.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_global,idx", [(64, 1), (75, 4)])   # equal shards; ragged shards + mix thirds + len_obs 1
-def test_two_rank_gather_equals_single_process(n_global, idx):
+# equal shards; ragged shards + mix thirds + len_obs 1; and the rank count the driver's scaling run ends with: EIGHT ranks, ragged (75 = 3 x 10 + 5 x 9
+# envs: the mix thirds 25 / 50 fall inside ranks 2 and 5)
+@pytest.mark.parametrize("n_global,idx,world", [(64, 1, 2), (75, 4, 2), (75, 4, 8)])
+def test_gather_over_gloo_ranks_equals_single_process(n_global, idx, world):
     from oracle import oracle as O
-    steps = 25
+    steps = 25 if world == 2 else 12
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_global, idx, steps, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_global, idx, steps, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = q.get(timeout=120)
+    got = q.get(timeout=240)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0

@@ -173,6 +173,18 @@ def test_checkpoint_merge_and_slice_by_global_env_id():
         checkpoint.load_state_dict(Env(3, 6, 12), checkpoint.state_dict(parts[0]))
     with pytest.raises(ValueError, match="num_envs_global"):
         checkpoint.load_state_dict(Env(0, 5, 13), merged)
+    # the arithmetic mode is part of the run's identity: a checkpoint written under the other data flow of the angular rate is refused, and so
+    # is one from before ABI 6 (which carries no such key: "carried" was the only arithmetic then) by an env on today's default
+    rt = Env(3, 6, 12)
+    rt._flat["world_rate_roundtrip"] = True
+    with pytest.raises(ValueError, match="world_rate_roundtrip=None|world_rate_roundtrip=False"):
+        checkpoint.load_state_dict(rt, dict(merged, abi=5))
+    sd = dict(merged, flat_cfg=dict(merged["flat_cfg"], world_rate_roundtrip=False))
+    with pytest.raises(ValueError, match="world_rate_roundtrip=False"):
+        checkpoint.load_state_dict(rt, sd)
+    checkpoint.load_state_dict(rt, sd, strict=False)
+    with pytest.warns(UserWarning, match="ABI"):
+        checkpoint.load_state_dict(rt, dict(merged, abi=_lib.ABI_VERSION - 1, flat_cfg=dict(merged["flat_cfg"], world_rate_roundtrip=True)))
 
 
 def test_replay_store_frame_ring_views_are_the_state_stacks():

@@ -1,5 +1,5 @@
-import sys, torch
-sys.path.insert(0,'/root/repo')
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from taco_amd import config
 from taco_amd.vec_env import FpvBase
