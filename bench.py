@@ -144,6 +144,32 @@ def pmc_traffic(n_envs):
     return d.get("derived", {}).get(f"hbm_bytes_per_launch_{n_envs}"), name
 
 
+# VALU issue roof.  One SIMD issues one wave64 VALU instruction per ~1.2 ns in a realistic mix at 2-4 wavefronts per SIMD (fma / fmac / mul / add
+# with VGPR operands 1.05-1.3 ns, SGPR-operand and VOP3 forms up to 2 ns, selects ~1.15 inside a mix: tools/ubench/intmul_cndmask.hip,
+# profiles/r05_b_ubench_intmul_cndmask.txt; the step loop's own census priced that way averages 1.23 ns, tools/isa_audit.py) -- so
+# floor = SQ_INSTS_VALU per launch / 1 024 SIMDs x 1.2 ns, the instruction count from the committed PMC summary of THIS build.
+VALU_NS_PER_INST = 1.2
+N_SIMDS = 1024
+
+
+def pmc_valu(n_envs, kernel_us):
+    import glob
+    from taco_amd import build
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    if d.get("source_hash") != build.source_hash():
+        return None
+    key = {262144: "sq_262144"}.get(n_envs)
+    insts = d.get(key, {}).get("SQ_INSTS_VALU", {}).get("mean_per_launch") if key else None
+    if not insts:
+        return None
+    floor_us = insts / N_SIMDS * VALU_NS_PER_INST * 1e-3
+    return {"insts_per_launch": insts, "ns_per_inst": VALU_NS_PER_INST, "simds": N_SIMDS, "floor_us": floor_us, "frac": floor_us / kernel_us,
+            "source": os.path.basename(files[-1]) + " (SQ_INSTS_VALU) x tools/ubench/intmul_cndmask (ns per instruction in a realistic mix)"}
+
+
 def cpu_sample(cfg, threads, budget_s):
     """the CPU oracle (oracle/, kind 'port') stepping `cfg` on `threads` OpenMP threads for about budget_s seconds"""
     import numpy as np
@@ -720,9 +746,13 @@ def main():
                          "traffic": traffic, "traffic_frac": (traffic / (k_avg_us * 1e-6) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                          "traffic_source": traffic_src, "kernel_avg_us": k_avg_us, "kernel_bracketed_median_us": k_med_us,
                          "algorithmic_bytes_per_env_step": nbytes,
+                         "binds": "neither roof: instruction LATENCY of the slowest wavefront (latency_floor) + the launch boundary",
                          "note": "frac = ALGORITHMIC bytes (SURVEY 8d) / kernel time / 8 TB/s; traffic_frac = counter-measured HBM bytes / kernel time / 8 TB/s. "
                                  "4096 envs = 256 step wavefronts (4 lanes per env, one per CU) + 3 post-phase role wavefronts each: instruction-latency "
-                                 "regime (SURVEY 8d), see latency_floor; the throughput regime is large_n"},
+                                 "regime (SURVEY 8d): what binds is the instruction stream of the slowest wavefront (latency_floor: ~8.5 us in-kernel, "
+                                 "+ ~0.7 us when some wavefront holds a resetting env, + ~1.6 us launch boundary incl. the write-back of 1.5 MB: "
+                                 "profiles/r05_b_ubench_launch_boundary.txt), not HBM (3-4 %) and not VALU issue (~13 %). The throughput regime is large_n, "
+                                 "where the VALU issue roof binds (large_n[].valu, binding_roof)"},
         }
         if multi:
             out.update(multi)
@@ -784,6 +814,7 @@ def main():
                     nb = ALGO_BYTES_PER_ENV_STEP if ring else algo_bytes(ls)
                     ach = nb * big_n / (b_med * 1e-6) / 1e9
                     tr, _ = pmc_traffic(big_n) if (ls == 1 and not ring) else (None, None)
+                    valu = pmc_valu(big_n, b_med) if (ls == 1 and not ring) else None
                     out["large_n"].append({"envs": big_n, "len_states": ls,
                                            "path": {True: "rollout (replay store's frame ring: one states frame written per step)",
                                                     "api": "VecTask.step() (frame ring behind states_buf: one states frame written per step, the stack a strided view)",
@@ -791,6 +822,9 @@ def main():
                                            "kernel_avg_us": b_med, "env_steps_per_s": big_n / (b_med * 1e-6),
                                            "algorithmic_bytes_per_env_step": nb, "achieved_GBps": ach, "frac_of_hbm_peak": ach / HBM_PEAK_GBPS,
                                            "traffic": tr, "traffic_frac_of_hbm_peak": (tr / (b_med * 1e-6) / 1e9 / HBM_PEAK_GBPS) if tr else None,
+                                           "valu": valu,
+                                           "binding_roof": ("valu" if (valu and tr and valu["frac"] > tr / (b_med * 1e-6) / 1e9 / HBM_PEAK_GBPS) else
+                                                            ("hbm" if (valu and tr) else None)),
                                            "kernel_form": benv.kernel_form, "grid": bg, "block": bb, "windows_us": b_ws,
                                            "first_100_launches_us": b_first,
                                            "protocol": "median of 5 windows of 200 back-to-back launches after 0.25 s of warm-up launches"})

@@ -218,8 +218,11 @@ struct U4 { uint32_t x, y, z, w; };
 TD U4 philox(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        // ONE 64-bit product per multiplier (v_mad_u64_u32) instead of a v_mul_hi_u32 + v_mul_lo_u32 pair: the same bits, half the
+        // quarter-rate multiplies -- a block 134 -> 104 ns per wavefront at 4 wavefronts per SIMD (tools/ubench/intmul_cndmask.hip,
+        // profiles/r05_b_ubench_intmul_cndmask.txt)
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0, h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
         c0 = h1 ^ c1 ^ k0;
         c1 = l1;
         c2 = h0 ^ c3 ^ k1;

@@ -41,8 +41,15 @@ class FpvBase:
 
     def __init__(self, cfg, rl_device="cuda:0", sim_device="cuda:0", graphics_device_id=-1, headless=True,
                  virtual_screen_capture=False, force_render=False, env_offset=0, num_envs_local=None, copy_outputs=True, kernel_form="auto",
-                 lib=None, states_ring=None):
+                 lib=None, states_ring=None, fresh_outputs=False):
         self.cfg = cfg
+        # fresh_outputs=True: step() returns NEWLY ALLOCATED obs / states tensors, as the reference does (vec_task_asymmetry.py:331-332:
+        # torch.clamp(...) allocates) -- for callers that keep observations across steps without cloning.  The default (False) hands out
+        # views of the env's alternating buffers / frame ring (see step(): ALIASING CONTRACT), which is what the PPO loop needs
+        # (ppo_asymmetry.py:326-329 copies at once) and costs nothing; the clones cost two copy kernels per step.
+        # rew / done / time_outs are the env's own buffers either way -- as in the reference (`.to(rl_device)` of a tensor already there
+        # returns the tensor itself, :329, :334).
+        self.fresh_outputs = bool(fresh_outputs)
         if self.task_mode is not None:
             cfg["task_mode"] = self.task_mode
         self.lib = lib or _lib.load()  # raises if libtaco_env.so is missing: no fallback
@@ -337,7 +344,8 @@ class FpvBase:
         ALIASING CONTRACT (differs from the reference's freshly allocated tensors): the obs / states tensors of step t are overwritten by
         step t + 2; rew / done / time_outs are the env's own buffers, overwritten by step t + 1.  The PPO loop copies them into its replay
         buffer straight away (ppo_asymmetry.py:326-329), which is the intended use; a caller that keeps observations across more than one
-        step must clone().  copy_outputs=False: everything in place, the returned tensors ARE the buffers."""
+        step must clone() -- or build the env with fresh_outputs=True, which returns newly allocated obs / states like the reference.
+        copy_outputs=False: everything in place, the returned tensors ARE the buffers."""
         if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.device != self.device:
             actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
         if actions.shape != (self.num_envs, self.num_acts):
@@ -377,6 +385,8 @@ class FpvBase:
             obs, st = self._obs_pp[nxt], self._st_views[self._st_last]
         else:
             obs, st = self._obs_pp[nxt], self._states_pp[nxt]
+        if self.fresh_outputs:
+            obs, st = obs.clone(), st.clone(memory_format=torch.contiguous_format)
         if self._same_device:
             self.obs_dict["obs"], self.obs_dict["states"], self.extras["time_outs"] = obs, st, self.timeout_buf
             return self.obs_dict, self.rew_buf, self.reset_buf, self.extras

@@ -467,6 +467,30 @@ def test_step_returns_kernel_written_buffers_without_a_copy(n, len_obs, len_stat
     env.check()
 
 
+@pytest.mark.parametrize("len_states,clip", [(1, math.inf), (5, math.inf), (5, 0.8)])
+def test_fresh_outputs_returns_newly_allocated_obs_and_states_like_the_reference(len_states, clip):
+    """FpvBase(..., fresh_outputs=True): step() returns NEW obs / states tensors every call (vec_task_asymmetry.py:331-332: torch.clamp allocates),
+    so a caller may keep them for any number of steps; same values as the default (aliasing) env, which hands out views of its buffers."""
+    from taco_amd.vec_env import FpvBase
+    n = 700
+    kw = dict(env_lenStates=len_states, env_maxEpisodeLength=30, observation_noise=True, env_clipObservations=clip, env_clipStates=clip)
+    env = FpvBase(config.default_cfg("mix", n, **kw), fresh_outputs=True)
+    ref = FpvBase(config.default_cfg("mix", n, **kw))
+    g = torch.Generator().manual_seed(2)
+    acts = (0.3 * torch.randn((6, n, 4), generator=g)).clamp(-1, 1).cuda()
+    kept = []
+    for t in range(2 * (ref._st_period if len_states > 1 else 4) + 3):
+        d, rew, done, info = env.step(acts[t % 6])
+        r, *_ = ref.step(acts[t % 6])
+        assert d["states"].is_contiguous() and tuple(d["states"].shape) == (n, len_states, 26)
+        assert torch.equal(_bits(d["obs"]), _bits(r["obs"])) and torch.equal(_bits(d["states"]), _bits(r["states"]))
+        assert all(d["obs"].data_ptr() != k[0].data_ptr() and d["states"].data_ptr() != k[1].data_ptr() for k in kept)
+        kept.append((d["obs"], d["states"], d["obs"].clone(), d["states"].clone()))
+    for o, s_, oc, sc in kept:   # every tensor ever returned still holds what it held when it was returned
+        assert torch.equal(_bits(o), _bits(oc)) and torch.equal(_bits(s_), _bits(sc))
+    env.check()
+
+
 def test_ring_backed_state_stack_through_capture_checkpoint_and_the_c_abi(tmp_path):
     """The frame ring behind the state stack (include/taco_env.h taco_bind_states_ring): (1) VecTask.step() refuses to be captured with it
     (every replay fills another window); (2) the C entry point itself IS capturable -- the ring phase is part of the device-resident clock, a
