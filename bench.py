@@ -390,6 +390,51 @@ def rollout_entry(n, horizon, dev, torch):
         cs.append(e0.elapsed_time(e1) * 1e-3 / 4)
     cs.sort()
     flops = 2 * rows * (T * 4 * hd2 * (26 + hd2) + 2 * hd2 * hd2 + hd2)
+    # OPT-IN (round 5): the same critic with the ring-form LSTM on the 16-bit matrix pipe, split-f16 operands (TACO_P_SPLIT_F16): alone, and the
+    # whole rollout with it; max |value difference| to the default kernel on this rollout's own frames
+    split = None
+    try:
+        pol16 = P.ActorCritic(sd, 1, env.len_states, critic_split="f16")
+        v32, v16 = pol.values_ring(st), pol16.values_ring(st)
+        dv = float((v32 - v16).abs().max())
+        vmax = float(v32.abs().max())
+        for _ in range(3):
+            pol16.values_ring(st)
+        torch.cuda.synchronize()
+        c16 = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(4):
+                pol16.values_ring(st)
+            e1.record()
+            torch.cuda.synchronize()
+            c16.append(e0.elapsed_time(e1) * 1e-3 / 4)
+        c16.sort()
+
+        def run16():
+            buf.reset()
+            last = buf.run(env, pol16)
+            buf.compute_returns_and_advantage(last)
+
+        for _ in range(2):
+            run16()
+        torch.cuda.synchronize()
+        r16 = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            for _ in range(4):
+                run16()
+            torch.cuda.synchronize()
+            r16.append((time.perf_counter() - t0) / 4)
+        r16.sort()
+        split = {"flag": "ActorCritic(critic_split='f16') / TACO_P_SPLIT_F16 (opt-in; default stays f32 MFMA)", "critic_ms": c16[2] * 1e3,
+                 "speedup_vs_default_critic": cs[2] / c16[2], "ms_per_rollout": r16[2] * 1e3, "env_steps_per_s": n * horizon / r16[2],
+                 "max_abs_value_difference_to_default": dv, "max_abs_value": vmax,
+                 "note": "every f32 operand of the LSTM's chains as two f16 halves (11 + 11 bits, low half scaled by 2^11), three v_mfma_f32_16x16x32_f16 "
+                         "chains per product chain, f32 accumulation; MLP and cells unchanged; trajectories / actions / log-probs / dones bit-identical"}
+    except Exception as e:  # noqa: BLE001
+        split = {"error": repr(e)[:300]}
     # what the kernels actually issue (v_mfma_f32_16x16x4_f32 = 2 048 flop): the paired-slot LSTM kernel runs blocks of 16 envs x 2 slots, per
     # wavefront 64 MFMAs at the first timestep (x chains only: h_-1 = 0) and 288 at each later one (shared input projection); the MLP 544 per
     # 16 rows.  K is padded 26 -> 32 in the x chains, so this is not a subset of the model count either; SQ_INSTS_MFMA in profiles/ agrees.
@@ -399,6 +444,7 @@ def rollout_entry(n, horizon, dev, torch):
             "per_step_chain": ("ONE persistent kernel (a workgroup owns 16 envs for the whole horizon; the actor's MFMAs run under the substeps): 4 launches per rollout"
                                if n <= 8192 else "actor launch + step launch per step (above 8 192 envs)"),
             "ms_per_rollout_launch_per_step": us[1] * 1e3,
+            "critic_split_f16": split,
             "critic": {"rows": rows, "ms": cs[2] * 1e3, "tflops": flops / cs[2] / 1e12, "frac_of_f32_mfma_peak": flops / cs[2] / 157.3e12,
                        "mfma_tflops_issued": issued / cs[2] / 1e12 if issued else None,
                        "frac_of_f32_mfma_peak_issued": issued / cs[2] / 157.3e12 if issued else None,

@@ -246,6 +246,14 @@ typedef struct taco_policy_cfg {
  * TACO_P_EXACT_CELL keeps the oracle's operations in those kernels (bit-identical to taco_policy_act and oracle/taco_policy_oracle.c; +23 %
  * critic time).  taco_policy_act itself always uses the exact cell. */
 #define TACO_P_EXACT_CELL 1
+/* OPT-IN, round 5: the batched critic's LSTM over a frame ring (taco_critic_values_ring, taco_rollout_run with a state stack) on the 16-bit
+ * matrix pipe with SPLIT operands -- every f32 operand as two 16-bit halves, three MFMA chains per product chain, f32 accumulation
+ * (taco_policy.hpp taco_critic_lstm_pair_split_kernel).  TACO_P_SPLIT_F16: f16 halves (11 + 11 significant bits): values within ~2e-7 of the
+ * default kernel's (asserted <= 2e-6, the fast cell's own bar; operands must stay below 65 504 in magnitude).  TACO_P_SPLIT_BF16: bf16
+ * halves (8 + 8 bits): ~5e-6, outside that bar -- kept for the A/B record only.  Other layouts (materialised stacks, one slot) ignore the
+ * bits.  Excludes TACO_P_EXACT_CELL. */
+#define TACO_P_SPLIT_F16 2
+#define TACO_P_SPLIT_BF16 4
 size_t taco_policy_blob_floats(const taco_policy_cfg *cfg);   /* 0 (and taco_last_error) for an unsupported configuration */
 int taco_policy_act(const taco_policy_cfg *cfg, const float *blob, int n, const float *obs, const float *states, uint64_t seed, uint32_t call,
                     int deterministic, int action_only, float *action, float *logp, float *value, float *mu, float *sigma, void *stream);

@@ -760,7 +760,10 @@ static int policy_cfg_ok(const taco_policy_cfg *c) {
     if (c->lstm_hidden < 0 || c->lstm_hidden > taco::POL_MAXW) return fail(TACO_ERR_INVALID_ARG, "policy: lstm_hidden must be 0..256");
     if (c->lstm_hidden > 0 && (c->states_len > taco::POL_MAXT || c->states_dim > 32)) return fail(TACO_ERR_INVALID_ARG, "policy: the LSTM critic takes at most 8 frames of at most 32 features");
     if (c->lstm_hidden == 0 && p16(c->states_len * c->states_dim) > taco::POL_MAXW) return fail(TACO_ERR_INVALID_ARG, "policy: states_len * states_dim must be <= 256 without an encoder");
-    if (c->flags & ~(int32_t)TACO_P_EXACT_CELL) return fail(TACO_ERR_INVALID_ARG, "policy: unknown bits in cfg.flags");
+    if (c->flags & ~(int32_t)(TACO_P_EXACT_CELL | TACO_P_SPLIT_F16 | TACO_P_SPLIT_BF16)) return fail(TACO_ERR_INVALID_ARG, "policy: unknown bits in cfg.flags");
+    if ((c->flags & TACO_P_EXACT_CELL) && (c->flags & (TACO_P_SPLIT_F16 | TACO_P_SPLIT_BF16)))
+        return fail(TACO_ERR_INVALID_ARG, "policy: TACO_P_EXACT_CELL (bit-exact critic) and TACO_P_SPLIT_* (16-bit matrix pipe) exclude each other");
+    if ((c->flags & TACO_P_SPLIT_F16) && (c->flags & TACO_P_SPLIT_BF16)) return fail(TACO_ERR_INVALID_ARG, "policy: choose ONE of TACO_P_SPLIT_F16 / TACO_P_SPLIT_BF16");
     return TACO_OK;
 }
 
@@ -865,6 +868,8 @@ static int launch_critic(const taco_policy_cfg *c, const float *blob, size_t row
             const size_t pw = (pb + cus - 1) / cus;
             const dim3 pg((unsigned)((pb + pw - 1) / pw));
             if (exact) hipLaunchKernelGGL(taco::taco_critic_lstm_pair_kernel<true>, pg, dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
+            else if (c->flags & TACO_P_SPLIT_F16) hipLaunchKernelGGL(taco::taco_critic_lstm_pair_split_kernel<1>, pg, dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
+            else if (c->flags & TACO_P_SPLIT_BF16) hipLaunchKernelGGL(taco::taco_critic_lstm_pair_split_kernel<2>, pg, dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
             else hipLaunchKernelGGL(taco::taco_critic_lstm_pair_kernel<false>, pg, dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
         } else if (ring_n > 0) {
             if (exact) hipLaunchKernelGGL((taco::taco_critic_lstm_kernel<true, true>), dim3(grid), dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);

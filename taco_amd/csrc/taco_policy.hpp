@@ -924,6 +924,244 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_kernel(cons
     flush_hT((int)blockIdx.x + (nb - 1) * (int)gridDim.x);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The pair kernel on the 16-BIT MATRIX PIPE with SPLIT operands (round 5; include/taco_env.h TACO_P_SPLIT_F16 / TACO_P_SPLIT_BF16 -- opt-in).
+// taco_critic_lstm_pair_kernel is MFMA time + the cells' VALU time, and its MFMA time is the f32 pipe's: v_mfma_f32_16x16x4_f32 delivers
+// 2 048 flop in 32 cycles, v_mfma_f32_16x16x32_{f16,bf16} 16 384 in 16 (MI355X_MICROARCH.md) -- 16 x per cycle.  Every f32 operand v is
+// split into two 16-bit halves, v = v1 + v2' / S with v1 = RN16(v) and v2' = RN16((v - v1) S) (v - v1 is exact in f32; S = 2^11 for f16,
+// 2^8 for bf16 keeps the low half in the format's normal range whatever the magnitude of v, so nothing depends on subnormal operands), and
+// a product chain is THREE MFMA chains,
+//     acc = bias + sum x1 w1  +  (sum x1 w2' + sum x2' w1) / S            (f32 accumulation inside the MFMA; x2' w2' / S^2 is dropped)
+// per-product relative error <= 3 * 2^-22 (f16: 11 + 11 significant bits) or 3 * 2^-16 (bf16: 8 + 8) instead of one f32 rounding.
+// MEASURED against the f32 kernels (tests/test_policy_gpu.py, tools/cell_ab.py; a numpy model of the same arithmetic predicted it):
+// f16 halves: |value difference| <= ~2e-7 on O(1) values -- inside the 2e-6 bar of the fast cell; bf16 halves with three terms: ~5e-6,
+// OUTSIDE that bar (six terms -- a three-way split -- would meet it at 1.5 x the weight registers, which this kernel does not have).
+// Operand range of the f16 form: frame words are clamped to +-65 504 (frames are O(1): normalised positions, rates, voltages -- the clamp
+// only keeps a diverged env's huge finite word from turning into inf - inf = NaN); h_t lies in [-1, 1]; bf16 has f32's range.
+// Layout (cdna_hip_programming.md section 3): lane (r = lane & 15, g = lane >> 4) holds A[row r][k = 32 S + 8 g + j] and
+// B[k = 32 S + 8 g + j][col r], j = 0 .. 7 (four VGPRs each); C / D as in the f32 form (row 4 g + i, col r).  Weights: both halves of the
+// wavefront's W_ih / W_hh columns resident (2 x 16 bit per weight: the 160 registers of the f32 form).  h_t travels through LDS as two
+// 16-bit planes written by the cells' producers (2 x ds_write_b16 instead of one b32), read back as ds_read_b128 per plane and K block,
+// row stride 272 B = 17 slots of 16 B -- row r's slot c on bank slot (r + c) mod 16 like the f32 tiles, so the same swizzle c ^ b(r)
+// keeps the reads conflict-free.  The last timestep's h_T leaves as f32 (the MLP kernel is unchanged).
+// Everything else -- persistent workgroups, pairs of consecutive slots sharing the input projection, LDS-DMA staging -- is the pair kernel's.
+template <int KIND> struct SplitKind;
+template <> struct SplitKind<1> {
+    typedef _Float16 T;
+    typedef _Float16 V8 __attribute__((ext_vector_type(8)));
+    static constexpr float S = 2048.0f, RS = 1.0f / 2048.0f;
+    static __device__ __forceinline__ pf32x4 mfma(V8 a, V8 b, pf32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct SplitKind<2> {
+    typedef __bf16 T;
+    typedef __bf16 V8 __attribute__((ext_vector_type(8)));
+    static constexpr float S = 256.0f, RS = 1.0f / 256.0f;
+    static __device__ __forceinline__ pf32x4 mfma(V8 a, V8 b, pf32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+constexpr int CR_HLD = 272;   // bytes per row of a 16-bit h plane (128 columns + one 16-byte slot of padding)
+
+template <int KIND>
+__global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_split_kernel(const PolicyParams P) {
+    typedef SplitKind<KIND> SK;
+    typedef typename SK::T HT;
+    typedef typename SK::V8 V8;
+    constexpr int FR = POL_MAXT + 1;
+    __shared__ __attribute__((aligned(16))) float xs[2][FR * 16 * 32];                 // [frame][env][sd] as they lie in the ring
+    __shared__ __attribute__((aligned(16))) unsigned char hs[2][2][CR_ROWS * CR_HLD];  // h_t: [buffer][high / low half][row][k], 16-bit
+    __shared__ __attribute__((aligned(16))) float hT[CR_ROWS * CR_LD];                 // h_T (f32, swizzled like the MLP's tiles) on its way out
+    constexpr int KSX = 2, KSH = 8, hp = 128, ip = 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int T = P.states_len, sd = P.states_dim, N = P.ring_n;
+    const int S = P.n / N;
+    const int groups = (N + 15) / 16, pairs = (S + 1) / 2, nblocks = groups * pairs;
+    const int nb = ((int)blockIdx.x < nblocks) ? (nblocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    if (nb == 0) return;
+    const float *w = P.blob;
+    {
+        int in_a = pad16(P.obs_len * P.obs_dim);
+        for (int l = 0; l <= P.n_actor_hidden; ++l) {
+            const int out = pad16(l == P.n_actor_hidden ? P.act_dim : P.actor_hidden[l]);
+            w += (size_t)out * in_a + out;
+            in_a = out;
+        }
+        w += 16;  // log_std
+    }
+    const float *Wih = w, *Whh = w + (size_t)4 * hp * ip, *bs = Whh + (size_t)4 * hp * hp;
+    const int col = wave * 16 + r;
+    // both halves of this wavefront's weights.  The blob is fragment-major for the f32 form: float4 ((wave KS + s) 64 + 16 g' + r) holds
+    // W[col][16 s + 4 g' .. + 3]; this lane's k = 32 Sb + 8 g + j lies in fragments s = 2 Sb + (g >> 1), g' = 2 (g & 1) + (j >> 2)
+    V8 wxh[4], wxl[4], whh[4][4], whl[4][4];
+    float bq[4];
+    auto halves = [](const float4 a, const float4 b, V8 &hi, V8 &lo) {
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const HT h = (HT)v[j]; hi[j] = h; lo[j] = (HT)((v[j] - (float)h) * SK::S); }
+    };
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        bq[q] = bs[q * hp + col];
+        {
+            const float4 *f = reinterpret_cast<const float4 *>(Wih + (size_t)q * hp * ip) + (size_t)(wave * KSX + (g >> 1)) * 64 + 32 * (g & 1) + r;
+            halves(f[0], f[16], wxh[q], wxl[q]);
+        }
+#pragma unroll
+        for (int sb = 0; sb < 4; ++sb) {
+            const float4 *f = reinterpret_cast<const float4 *>(Whh + (size_t)q * hp * hp) + (size_t)(wave * KSH + 2 * sb + (g >> 1)) * 64 + 32 * (g & 1) + r;
+            halves(f[0], f[16], whh[q][sb], whl[q][sb]);
+        }
+    }
+    const int ring_rows = S + T - 1;
+    const int piece_bytes = 16 * sd * (int)sizeof(float);
+    const bool dma_ok = (((size_t)N * sd * sizeof(float)) & 15u) == 0 && (piece_bytes & 15) == 0;
+    auto stage = [&](int blk, int half) {
+        const int pair = blk / groups, e0 = (blk - pair * groups) * 16, slot0 = 2 * pair;
+        const int per_piece = (piece_bytes / 16 + 63) / 64;
+        if (dma_ok && e0 + 16 <= N && slot0 + T < ring_rows) {
+            for (int j = wave; j < (T + 1) * per_piece; j += POL_NW) {
+                const int f = j / per_piece, off = ((j - f * per_piece) * 64 + lane) * 16;
+                const char *src = reinterpret_cast<const char *>(P.states) + ((size_t)(slot0 + f) * N + e0) * sd * sizeof(float);
+                if (off < piece_bytes)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off),
+                                                     (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(xs[half]) + f * piece_bytes + (j - f * per_piece) * 1024), 16, 0, 0);
+            }
+        } else {
+#pragma unroll 1
+            for (int e = tid; e < (T + 1) * 16 * sd; e += 64 * POL_NW) {
+                const int f = e / (16 * sd), rem = e - f * 16 * sd, env = rem / sd;
+                xs[half][e] = (slot0 + f < ring_rows && e0 + env < N) ? P.states[((size_t)(slot0 + f) * N + e0) * sd + rem] : 0.0f;
+            }
+        }
+    };
+    stage((int)blockIdx.x, 0);
+    const bool sd_even = (sd & 1) == 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // main / cross accumulators of the tile in flight.  Tile B's x part (combined) = tile A's start of the next timestep: parked in LDS
+    // (kp, 16 floats per lane: four b128 writes + reads per timestep) -- as 16 more registers it cost two spilled weight fragments,
+    // reloaded from scratch at every use
+    pf32x4 am[4], ac[4];
+    __shared__ __attribute__((aligned(16))) pf32x4 kp[POL_NW * 4 * 64];
+    pf32x4 *const kpl = kp + (size_t)wave * 4 * 64 + lane;
+    float cstA[4], cstB[4];
+    auto combine = [&]() __attribute__((always_inline)) {   // am += ac / S
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) am[q][i] = fma(ac[q][i], SK::RS, am[q][i]);
+    };
+    auto x_chain = [&](const float *xh, int f) __attribute__((always_inline)) {   // am = bias + W_ih x(frame f) (combined), rows = the block's 16 envs
+        const float *at = xh + (f * 16 + r) * sd + 8 * g;
+        float v[8];
+        if (sd_even) {
+#pragma unroll
+            for (int p2 = 0; p2 < 4; ++p2) { const float2 t2 = *reinterpret_cast<const float2 *>(at + 2 * p2); v[2 * p2] = t2.x; v[2 * p2 + 1] = t2.y; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = at[j];
+        }
+        V8 ah, al;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float xv = (8 * g + j < sd) ? v[j] : 0.0f;   // (beyond sd the row holds its neighbour's words)
+            if constexpr (KIND == 1) xv = xv > 65504.0f ? 65504.0f : (xv < -65504.0f ? -65504.0f : xv);   // f16's range: a huge finite frame word saturates instead of
+                                                                                                             // turning into inf - inf; a NaN stays a NaN (as in the f32 kernel)
+            const HT h = (HT)xv;
+            ah[j] = h; al[j] = (HT)((xv - (float)h) * SK::S);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { am[q] = pf32x4{bq[q], bq[q], bq[q], bq[q]}; ac[q] = pf32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) am[q] = SK::mfma(ah, wxh[q], am[q]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ac[q] = SK::mfma(ah, wxl[q], ac[q]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ac[q] = SK::mfma(al, wxh[q], ac[q]);
+        combine();
+    };
+    auto h_chain = [&](const unsigned char *hprev, int tile) __attribute__((always_inline)) {   // am (= the x part) += W_hh h_{t-1}
+        const unsigned char *rowh = hprev + (16 * tile + r) * CR_HLD, *rowl = rowh + CR_ROWS * CR_HLD;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ac[q] = pf32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int sb = 0; sb < 4; ++sb) {
+            const int pos = ((4 * sb + g) ^ cr_b(r)) << 4;
+            const V8 ah = *reinterpret_cast<const V8 *>(rowh + pos), al = *reinterpret_cast<const V8 *>(rowl + pos);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) am[q] = SK::mfma(ah, whh[q][sb], am[q]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ac[q] = SK::mfma(ah, whl[q][sb], ac[q]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ac[q] = SK::mfma(al, whh[q][sb], ac[q]);
+        }
+        combine();
+    };
+    auto cells = [&](int t, int tile, float (&cst)[4], bool first) __attribute__((always_inline)) {
+        const bool last = t + 1 >= T;
+        const int row0 = 16 * tile + 4 * g, bsw = cr_b(4 * g);   // rows 4 g + i: b(row) = b(4 g)
+        unsigned char *oh = hs[t & 1][0] + row0 * CR_HLD + (((col >> 3) ^ bsw) << 4) + (col & 7) * 2, *ol = oh + CR_ROWS * CR_HLD;
+        float *of = hT + row0 * CR_LD + (col ^ (bsw << 2));
+        float hv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float cn;
+            lstm_cell_fast(am[0][i], am[1][i], am[2][i], am[3][i], first ? 0.0f : cst[i], cn, hv[i]);
+            cst[i] = cn;
+        }
+        if (last) {   // (ONE wave-uniform branch per call: inside the loop above it became eight)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) of[i * CR_LD] = hv[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const HT h = (HT)hv[i];
+                *reinterpret_cast<HT *>(oh + i * CR_HLD) = h;
+                *reinterpret_cast<HT *>(ol + i * CR_HLD) = (HT)((hv[i] - (float)h) * SK::S);
+            }
+        }
+    };
+    auto flush_hT = [&](int blk) {
+        const int pair = blk / groups, e0 = (blk - pair * groups) * 16;
+#pragma unroll
+        for (int j = 0; j < CR_ROWS * (hp / 4) / (64 * POL_NW); ++j) {
+            const int e = tid + 64 * POL_NW * j, row = e >> 5, k4 = e & 31;
+            const int slot = 2 * pair + (row >> 4), env = e0 + (row & 15);
+            if (slot < S && env < N)
+                *reinterpret_cast<float4 *>(P.hT + ((size_t)slot * N + env) * hp + 4 * k4) = *reinterpret_cast<const float4 *>(hT + cr_sw4(row, k4));
+        }
+    };
+    for (int k = 0; k < nb; ++k) {
+        const int blk = (int)blockIdx.x + k * (int)gridDim.x;
+        const float *xh = xs[k & 1];
+        if (k + 1 < nb) stage(blk + (int)gridDim.x, (k + 1) & 1);
+        if (k > 0) flush_hT(blk - (int)gridDim.x);
+        // ---- timestep 0: x chains only (h_{-1} = 0)
+        x_chain(xh, 0);
+        cells(0, 0, cstA, true);
+        x_chain(xh, 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) kpl[q * 64] = am[q];
+        cells(0, 1, cstB, true);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next block's frames have landed
+        __syncthreads();
+        for (int t = 1; t < T; ++t) {
+            const unsigned char *hprev = hs[(t - 1) & 1][0];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) am[q] = kpl[q * 64];   // tile A: bias + W_ih x(frame t), computed for tile B a timestep ago
+            h_chain(hprev, 0);
+            cells(t, 0, cstA, false);
+            x_chain(xh, t + 1);                                // tile B: frame t + 1
+#pragma unroll
+            for (int q = 0; q < 4; ++q) kpl[q * 64] = am[q];
+            h_chain(hprev, 1);
+            cells(t, 1, cstB, false);
+            __syncthreads();
+        }
+    }
+    flush_hT((int)blockIdx.x + (nb - 1) * (int)gridDim.x);
+}
+
 // value = W3 relu(W2 relu(W1 h_T + b1) + b2) + b3 over the workspace rows (critic_body's dense layers; same chains, same bits)
 __global__ __launch_bounds__(64 * POL_NW, 4) void taco_critic_mlp_kernel(const PolicyParams P) {
     __shared__ __attribute__((aligned(16))) float xb[CR_MLP_ROWS * CR_LD];

@@ -24,6 +24,7 @@ class PolicyCfg(C.Structure):
 
 
 P_EXACT_CELL = 1   # TACO_P_EXACT_CELL
+P_SPLIT_F16, P_SPLIT_BF16 = 2, 4   # TACO_P_SPLIT_F16 / TACO_P_SPLIT_BF16
 
 
 MAX_WIDTH = 256
@@ -124,15 +125,22 @@ def pack_state_dict(cfg, sd):
 class ActorCritic:
     """Inference-side mirror of PPO_ActorCritic (nets_asymmetry.py:270-355) on the HIP policy kernel."""
 
-    def __init__(self, state_dict, obs_len, states_len, device="cuda:0", seed=0, obs_dim=26, states_dim=26, exact_critic=False):
+    def __init__(self, state_dict, obs_len, states_len, device="cuda:0", seed=0, obs_dim=26, states_dim=26, exact_critic=False, critic_split=None):
         """exact_critic: the batched critic (values / values_ring / RolloutBuffer.run) keeps the oracle's op-for-op LSTM cell, bit-identical
-        to act()'s `value`; default: the hardware's 2^x / reciprocal in the cell, 19 % faster, values within 2e-6 (TACO_P_EXACT_CELL)."""
+        to act()'s `value`; default: the hardware's 2^x / reciprocal in the cell, 19 % faster, values within 2e-6 (TACO_P_EXACT_CELL).
+        critic_split: None (default: f32 MFMA) | "f16" | "bf16" -- OPT-IN: the ring-form LSTM of the batched critic on the 16-bit matrix
+        pipe with split operands (include/taco_env.h TACO_P_SPLIT_F16 / TACO_P_SPLIT_BF16): "f16" stays within 2e-6 of the default kernel's
+        values, "bf16" does not (~5e-6; kept for the A/B record).  Excludes exact_critic."""
         self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.TacoError("the policy kernel runs on an MI355X; device must be a cuda:N (HIP) device")
         self.cfg = cfg_from_state_dict(state_dict, obs_len, states_len, obs_dim, states_dim)
-        self.cfg.flags = P_EXACT_CELL if exact_critic else 0
+        if critic_split not in (None, "f16", "bf16"):
+            raise ValueError("critic_split must be None, 'f16' or 'bf16'")
+        if exact_critic and critic_split:
+            raise ValueError("exact_critic and critic_split exclude each other")
+        self.cfg.flags = (P_EXACT_CELL if exact_critic else 0) | {None: 0, "f16": P_SPLIT_F16, "bf16": P_SPLIT_BF16}[critic_split]
         self.seed = int(seed)
         self.calls = 0  # Philox counter of the action noise: (seed, env index, call number); advanced by every SAMPLING call
         self.reuse_outputs = False  # True: act() returns the same five tensors every call (no allocations on the hot loop)

@@ -16,8 +16,9 @@ def child():
     sd = TP._random_policy(rng, 1, 5, [128, 128, 128], 128, [128, 128])
     fr = torch.from_numpy(rng.standard_normal((37, 4096, 26)).astype(np.float32) * float(os.environ.get("CELL_AB_SCALE", "1"))).cuda()
     res = {}
-    for exact in (True, False, True, False):
-        pol = P.ActorCritic(sd, 1, 5, exact_critic=exact)
+    kinds = (True, False, "f16", "bf16", True, False, "f16", "bf16") if os.environ.get("CELL_AB_SPLIT", "1") == "1" else (True, False, True, False)
+    for exact in kinds:
+        pol = P.ActorCritic(sd, 1, 5, exact_critic=exact is True, critic_split=exact if isinstance(exact, str) else None)
         v = pol.values_ring(fr)
         for _ in range(10):
             pol.values_ring(fr)
@@ -33,6 +34,11 @@ def child():
         res.setdefault(exact, []).append(sorted(ts)[3])
         res[("v", exact)] = v.cpu().numpy()
     ve, vf = res[("v", True)], res[("v", False)]
+    for kind in ("f16", "bf16"):
+        if kind in res:
+            vs = res[("v", kind)]
+            print(f"split {kind}: {min(res[kind]):.4f} ms per values_ring; max |difference| to the exact cell {np.abs(ve - vs).max():.3e}, to the hardware cell {np.abs(vf - vs).max():.3e}, "
+                  f"all finite: {bool(np.isfinite(vs).all())}")
     print(f"exact cell {min(res[True]):.4f} ms, hardware cell {min(res[False]):.4f} ms per values_ring(37 frames x 4096 envs); values in "
           f"[{ve.min():.3f}, {ve.max():.3f}], max |difference| {np.abs(ve - vf).max():.3e}, all finite: {bool(np.isfinite(vf).all())}")
 
