@@ -374,6 +374,23 @@ def rollout_entry(n, horizon, dev, torch):
         us.append((time.perf_counter() - t0) / 4)
     us.sort()
     env.set_rollout_fusion(True)
+    forced_ms = None
+    if n > 8192:   # the persistent kernel FORCED above its limit (its workgroups queue: 16 envs hold a whole CU): the record of why the limit stands
+        try:
+            env.set_rollout_fusion("force")
+            run()
+            torch.cuda.synchronize()
+            fs = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                for _ in range(2):
+                    run()
+                torch.cuda.synchronize()
+                fs.append((time.perf_counter() - t0) / 2)
+            fs.sort()
+            forced_ms = fs[1] * 1e3
+        finally:
+            env.set_rollout_fusion(True)
     rows, T, hd2 = (horizon + 1) * n, env.len_states, hd
     st = buf._frames   # the replay store's frame ring [horizon + T][n][26]: what taco_rollout_run's critic pass reads
     for _ in range(3):
@@ -444,6 +461,7 @@ def rollout_entry(n, horizon, dev, torch):
             "per_step_chain": ("ONE persistent kernel (a workgroup owns 16 envs for the whole horizon; the actor's MFMAs run under the substeps): 4 launches per rollout"
                                if n <= 8192 else "actor launch + step launch per step (above 8 192 envs)"),
             "ms_per_rollout_launch_per_step": us[1] * 1e3,
+            "ms_per_rollout_persistent_forced": forced_ms,
             "critic_split_f16": split,
             "critic": {"rows": rows, "ms": cs[2] * 1e3, "tflops": flops / cs[2] / 1e12, "frac_of_f32_mfma_peak": flops / cs[2] / 157.3e12,
                        "mfma_tflops_issued": issued / cs[2] / 1e12 if issued else None,

@@ -317,7 +317,9 @@ int taco_rollout_run(taco_env *env, const taco_policy_cfg *cfg, const float *blo
  * pinned) taco_rollout_run's per-step chain is ONE persistent launch: a workgroup owns 16 envs for all `horizon` steps, four of its eight
  * wavefronts run the actor on MFMA (weights register-resident) WHILE the step wavefront integrates the ten substeps -- the action of a step
  * enters the dynamics only delay_time later -- so a rollout is 4 launches (+ 1 when captured) instead of 2 * horizon + 3; same bits.
- * taco_set_rollout_fusion(env, 0) keeps the launch-per-step path (A/B measurements, tests); 1 (default) restores the choice above.
+ * taco_set_rollout_fusion(env, 0) keeps the launch-per-step path (A/B measurements, tests); 1 (default) restores the choice above; 2 takes
+ * the persistent kernel whatever the env count (A/B: a workgroup holds a whole CU for 16 envs, so above 8 192 envs its workgroups queue --
+ * 32 768 envs are eight rounds of the chip -- and the launch-per-step path with 64 envs per workgroup wins: bench.py records both).
  * taco_bind_rollout_stamps: profiling aid, DEVICE array of 136 + ceil(num_envs / 16) uint64 filled by the persistent kernel: workgroup 0: [w] = the SIMD
  * wavefront w runs on, [8 + 2 t] / [9 + 2 t] = shader clock of the step wavefront at the start / end of step t (t < 64); [136 + b] = clocks the step
  * wavefront of workgroup b spent in its loop.  NULL unbinds. */

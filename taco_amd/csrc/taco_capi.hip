@@ -63,6 +63,7 @@ struct taco_env {
     int form;  // TACO_FORM_* the step launches (never TACO_FORM_AUTO here: resolved by choose_form)
     int form_ring;    // ... and the form of a launch that writes only the newest states frame (taco_rollout_io.states_newest_only)
     int form_pinned;  // taco_set_kernel_form chose `form`: every launch uses it
+    int fusion_force; // taco_set_rollout_fusion(env, 2): the persistent kernel whatever the env count (A/B: its workgroups then queue, eight rounds of the chip at 32 768 envs)
     int fusion_off;   // taco_set_rollout_fusion(env, 0): taco_rollout_run launches the actor and the step per step even where the persistent kernel applies
     unsigned long long *rollout_stamps;  // optional profiling buffer of the persistent rollout kernel (taco_bind_rollout_stamps)
     uint32_t *ctl;        // control block (last 256 bytes of the workspace): device-resident step clock + sticky status word
@@ -329,6 +330,9 @@ FormInfo form_info(int form, bool out = false, bool wide = false, bool lin = fal
     if (lin && !wide && form == TACO_FORM_QUAD_ROLES)
         fn = out ? (const void *)taco::taco_step_kernel<kBlockLarge, 4, true, false, true, false, false, true>
                  : (const void *)taco::taco_step_kernel<kBlockLarge, 4, true, false, false, false, false, true>;
+    if (lin && form == TACO_FORM_QUAD_SERVED)
+        fn = out ? (const void *)taco::taco_step_kernel<kBlockPair, 4, true, false, true, false, false, true>
+                 : (const void *)taco::taco_step_kernel<kBlockPair, 4, true, false, false, false, false, true>;
     if (wide && form == TACO_FORM_QUAD_ROLES)
         fn = out ? (const void *)taco::taco_step_kernel<kBlockLarge, 4, true, false, true, false, true, true>
                  : (const void *)taco::taco_step_kernel<kBlockLarge, 4, true, false, false, false, true, true>;
@@ -353,7 +357,11 @@ bool wide_form(const taco_cfg &c, int form) {
            !(c.flags & (TACO_F_ROTOR_NOISE | TACO_F_TRACK_RPY));
 }
 // the four-role quad form with the linear chain served by the obs role wavefront: while at most two wavefronts share a SIMD (taco_step.hpp "LIN")
-bool lin_form(const taco_cfg &c, int form) { return form == TACO_FORM_QUAD_ROLES && c.num_envs <= 8192; }
+// ... and of the served pair (QUAD_SERVED) for launches without flip envs: its one serving wavefront then runs the linear chain (with flip envs it serves the euler angles)
+bool lin_form(const taco_cfg &c, int form) {
+    const bool euler = c.task_mode == TACO_TASK_FLIP || c.task_mode == TACO_TASK_MIX || (c.flags & TACO_F_TRACK_RPY) != 0;
+    return (form == TACO_FORM_QUAD_ROLES && c.num_envs <= 8192) || (form == TACO_FORM_QUAD_SERVED && !euler);
+}
 int choose_form(const taco_cfg &c) {
     const bool stacks = c.len_obs > 1 || c.len_states > 1;
     if (c.num_envs <= kQuadMaxEnvs) {
@@ -365,7 +373,10 @@ int choose_form(const taco_cfg &c) {
         // three helper wavefronts per 16 envs take over the post-phase: pays while every wavefront still has a SIMD to itself.  With
         // frame stacks the role wavefronts also move the stack history under the substeps, which pays up to the quad limit
         // (16 384 envs, 5 state frames: 19.2 us vs 22.1 us; 5 + 5 frames: 19.9 us vs 26.0 us; without stacks 18.0 us vs 17.5 us).
-        return c.num_envs <= (stacks ? kQuadMaxEnvs : kSplitMaxEnvs) ? TACO_FORM_QUAD_ROLES : TACO_FORM_QUAD;
+        // (round 5: without stacks above 8 192 envs the SERVED PAIR, whose serving wavefront runs the linear chain (taco_step.hpp LIN, lin_form):
+        // rotate 16 384 14.66 -> 14.51 us, pos 16 384 14.20 -> 14.08, 12 288 envs 14.46 -> 14.31 / 14.05 -> 13.82 against the one-wavefront quad form,
+        // profiles/r05_g_ab_pair_lin.txt -- 1 %: at two wavefronts per SIMD the server's issue slots come out of a step wavefront next to it)
+        return c.num_envs <= (stacks ? kQuadMaxEnvs : kSplitMaxEnvs) ? TACO_FORM_QUAD_ROLES : TACO_FORM_QUAD_SERVED;
     }
     // One lane per env, 16 385 ... 65 536 envs with frame stacks: the same four-role form (64 envs per workgroup) hides the stack
     // history, which a lone wavefront moves at only ~5 GB/s (tools/ubench/shift), under the substeps.  Likewise -- stacks or not -- when the
@@ -437,6 +448,7 @@ int taco_create(const taco_cfg *cfg, int device, void *workspace, size_t workspa
     { taco_cfg one = e->cfg; one.len_states = 1; e->form_ring = choose_form(one); }
     e->form_pinned = 0;
     e->fusion_off = 0;
+    e->fusion_force = 0;
     e->rollout_stamps = nullptr;
     std::memset(&e->P, 0, sizeof(e->P));
     derive(e);
@@ -941,7 +953,7 @@ int taco_policy_act(const taco_policy_cfg *c, const float *blob, int n, const fl
 constexpr int kFusedMaxEnvs = 8192;
 static bool fused_rollout_ok(const taco_env *e, const taco_policy_cfg *c) {
     auto p16 = [](int x) { return (x + 15) / 16 * 16; };
-    return !e->fusion_off && !e->form_pinned && e->gather == nullptr && e->cfg.num_envs <= kFusedMaxEnvs && e->cfg.len_obs == 1 && c->obs_len == 1 &&
+    return !e->fusion_off && !e->form_pinned && e->gather == nullptr && (e->cfg.num_envs <= kFusedMaxEnvs || e->fusion_force) && e->cfg.len_obs == 1 && c->obs_len == 1 &&
            c->obs_dim == 26 && c->act_dim == 4 && c->n_actor_hidden == 3 && p16(c->actor_hidden[0]) == 128 && p16(c->actor_hidden[1]) == 128 &&
            p16(c->actor_hidden[2]) == 128;
 }
@@ -1079,6 +1091,7 @@ int taco_test_slow_battery_server(taco_env *e, int on) {
 int taco_set_rollout_fusion(taco_env *e, int on) {
     if (!e) return fail(TACO_ERR_INVALID_ARG, "env is null");
     e->fusion_off = on ? 0 : 1;
+    e->fusion_force = on == 2 ? 1 : 0;
     return TACO_OK;
 }
 int taco_bind_rollout_stamps(taco_env *e, uint64_t *stamps) {

@@ -820,7 +820,7 @@ struct FusedCtx {
 };
 template <int BLOCK, int LPE, bool SPLIT, bool CAP, bool OUT, bool RESET_ONLY, bool WIDE, bool FUSED, bool LIN = false>
 TD void step_core(const StepParams &Pin, const FusedCtx &FX) {
-    static_assert(!LIN || (BLOCK == 256 && LPE == 4 && SPLIT), "LIN is a variant of the four-role quad form");
+    static_assert(!LIN || ((BLOCK == 256 || BLOCK == 128) && LPE == 4 && SPLIT), "LIN is a variant of the four-role quad form and of the served pair");
     static_assert(!FUSED || (BLOCK == 256 && LPE == 4 && SPLIT && !OUT && !RESET_ONLY && !CAP), "FUSED is the four-role quad form inside the rollout kernel");
     static_assert(!WIDE || (BLOCK == 256 && SPLIT && !RESET_ONLY), "WIDE is a variant of the four-role forms");
     static_assert(!RESET_ONLY || (BLOCK == 64 && LPE == 1 && !SPLIT && !CAP && !OUT), "RESET_ONLY exists in the plain one-lane form only");
@@ -1071,11 +1071,17 @@ TD void step_core(const StepParams &Pin, const FusedCtx &FX) {
     // 8 192), not beyond (at 12 288 the server's instructions cost the step wavefronts next to it more than they save: 15.6 -> 16.2 us), always in
     // the rollout kernel's own CU.  (A run-time switch inside one kernel -- both builds of every PLAIN form compiled in -- cost the 4 096-env launch
     // 0.3 us: profiles/r04_n_ab_linear_chain.txt.)
-    constexpr bool LIN_SERVED = ROLES && LPE == 4 && LIN;
+    // PAIR + LIN (round 5): the served pair's second wavefront runs the linear chain -- the one server a launch WITHOUT flip envs and rotor noise has
+    // work for (pos / rotate at 12 289 ... 16 384 envs: exactly two wavefronts per SIMD, the regime in which the server paid in the four-role form).
+    // Wavefront 0 runs the post-phase itself there, so it takes p and v back from the server (mb_seq[6], behind its own state stores).
+    constexpr bool LIN_SERVED = (ROLES || PAIR) && LPE == 4 && LIN;
     __shared__ float lin_ring[LIN_SERVED ? (10 * 3 + 1) * 64 : 4];   // [substep][0: q before the substep, 1: q after its first sub-iteration, 2: rf + swp(rf)][lane]
                                                                      // ([.][0] is written at the end of the substep BEFORE: the server starts on it one counter earlier)
     __shared__ float lin_init[LIN_SERVED ? 5 * 64 : 4];        // [p, v, drag coefficient, kt, keep mask][lane]: posted with counter value 1
-    const bool lin_served = LIN_SERVED && b_substeps == 2;     // (the server runs exactly two sub-iterations)
+    // (the server runs exactly two sub-iterations; in the pair form it is the ONLY serving wavefront: with flip envs it has the euler angles to serve
+    // instead -- the host never picks the LIN build of the pair for such a launch, and the PLAIN forms, which assume it, are then not taken)
+    const bool lin_served = LIN_SERVED && b_substeps == 2 &&
+                            !(PAIR && (Pin.task_mode == TACO_TASK_FLIP || Pin.task_mode == TACO_TASK_MIX || (Pin.flags & TACO_F_TRACK_RPY) != 0));
     constexpr bool NOISE_TAB = SPLIT && !(WIDE && LPE == 4);
     constexpr bool NOISE_INLINE = !SPLIT;   // the one-wavefront instantiations have nobody to serve a table: their PLAIN forms draw the rotor noise themselves
     // (rn_tab lives in `hand`: the table is read by the substeps, the Carry is written after the last one and read after barrier 2; the
@@ -1461,7 +1467,8 @@ TD void step_core(const StepParams &Pin, const FusedCtx &FX) {
     // The PLAIN forms are the DEFAULT arithmetic: the body rates make the reference's round trip through the root state after every simulate()
     // (TACO_F_WORLD_RATE_ROUNDTRIP, FA:350); the "carried" mode (flag cleared) runs the general forms.
     // (the instantiations without role wavefronts -- no one to serve a noise table -- draw the rotor noise inside their PLAIN forms, behind a launch-uniform branch)
-    const bool plain1 = (!(fl & TACO_F_ROTOR_NOISE) || noise_served || NOISE_INLINE) && (fl & TACO_F_WORLD_RATE_ROUNDTRIP) != 0 && P.substeps == 2 && (fl & TACO_F_BATTERY_CONSUMPTION) != 0;
+    const bool plain1 = (!(fl & TACO_F_ROTOR_NOISE) || noise_served || NOISE_INLINE) && (fl & TACO_F_WORLD_RATE_ROUNDTRIP) != 0 && P.substeps == 2 && (fl & TACO_F_BATTERY_CONSUMPTION) != 0 &&
+                        (!(PAIR && LIN_SERVED) || lin_served);
     // one lane per env: the PLAIN forms also carry the default airframe's constants as literals (kPlainConsts: the handle has exactly those)
     const bool plain = plain1 && (LPE != 1 || (fl & kPlainConsts) != 0);
     if constexpr (LPE == 1) {
@@ -2025,6 +2032,17 @@ TD void step_core(const StepParams &Pin, const FusedCtx &FX) {
     }
     publish_clock();
     if (ROLES) { TACO_STAMP(4); TACO_STAMP(5); return; }  // wave 0 is done; the roles below belong to the other three wavefronts
+    if constexpr (PAIR && LIN_SERVED) {
+        if (lin_served) {   // p and v of the step: from the wavefront that ran the linear chain (its last substep ends ~500 clocks after this wavefront's: under the stores above)
+            MB_WAIT(6, 1);
+            K.p = V3{hand[el * CARRY_WORDS], hand[el * CARRY_WORDS + 1], hand[el * CARRY_WORDS + 2]};
+            K.v = V3{hand[el * CARRY_WORDS + 4], hand[el * CARRY_WORDS + 5], hand[el * CARRY_WORDS + 6]};
+            if (__builtin_expect(mb_timeout, 0)) {
+                if (lane == 0) atomicOr(&P.ctl[kCtlStatus], kStatusMailboxTimeout);
+                K.p.x = nanf32();
+            }
+        }
+    }
     } else {
         load_out_args();
         if (wv == 1 && lane < 8) mb_seq[lane] = 0;
@@ -2092,7 +2110,7 @@ TD void step_core(const StepParams &Pin, const FusedCtx &FX) {
         }
         if (wv == 2 && (fl & TACO_F_OBSERVATION_NOISE)) { gen_obs_noise(); noise_ready = true; }
         if constexpr (LIN_SERVED) {
-            if (wv == 2 && lin_served) {   // the linear chain, behind wavefront 0 (see lin_ring)
+            if (wv == (ROLES ? 2 : 1) && lin_served) {   // the linear chain, behind wavefront 0 (see lin_ring)
                 MB_WAIT(5, 1);
                 float pq = lin_init[lane], vq = lin_init[64 + lane];
                 const float dragq = lin_init[128 + lane], kt_ = lin_init[192 + lane];
@@ -2125,6 +2143,7 @@ TD void step_core(const StepParams &Pin, const FusedCtx &FX) {
                     if (lane == 0) atomicOr(&P.ctl[kCtlStatus], kStatusMailboxTimeout);
                     if (sub < 3) hand[el * CARRY_WORDS + sub] = nanf32();
                 }
+                if constexpr (PAIR) MB_POST(6, 1);   // wavefront 0 runs the post-phase itself: p and v are in `hand`
             }
         }
         if (bat_served && wv == 1) {  // battery server (the reward wavefront, idle until the post-phase): ten voltages, each one substep ahead of wavefront 0

@@ -128,7 +128,7 @@ def test_full_size_parity_on_random_slices(idx, steps):
 
 # (baseline_config index, envs per rank, steps, the kernel form the product picks there): BASELINE configs 2 ... 5 at the per-rank shapes of
 # N = 1, 2, 4, 8 ranks (DESIGN section 8 lists them): pos 4 096 / N; rotate 16 384 / N; flip 65 536 / N; mix 262 144 / N with every flag and 5 frames
-PER_RANK_SHAPES = [(2, 16384, 60, "quad"), (3, 16384, 60, "quad_served"), (4, 32768, 40, "lane_roles"), (1, 65536, 25, "lane_throughput"),
+PER_RANK_SHAPES = [(2, 16384, 60, "quad_served"), (3, 16384, 60, "quad_served"), (4, 32768, 40, "lane_roles"), (1, 65536, 25, "lane_throughput"),
                    (1, 512, 60, "quad_roles"), (2, 8192, 40, "quad_roles"), (2, 2048, 60, "quad_roles"), (3, 32768, 25, "lane_roles"),
                    (3, 8192, 40, "quad_roles"), (4, 65536, 16, "lane_roles"), (4, 131072, 10, "lane_throughput")]
 

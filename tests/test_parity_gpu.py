@@ -196,16 +196,22 @@ def test_state_blob_roundtrip_and_restore():
     assert torch.equal(a.get_state().view(torch.int32), b.get_state().view(torch.int32))
 
 
-@pytest.mark.parametrize("task,n", [("pos", 1000), ("mix", 333), ("flip", 257), ("rotate", 4096), ("mix", 8232)])
+@pytest.mark.parametrize("task,n", [("pos", 1000), ("mix", 333), ("flip", 257), ("rotate", 4096), ("mix", 8232), ("rotate", 12500), ("posnoise", 777)])
 def test_quad_layout_equals_one_lane_per_env(task, n):
     """The six instantiations of the step kernel (4 lanes per env with and without the role wavefronts or with one serving wavefront / 1 lane per
     env with 64- and 256-thread workgroups and with role wavefronts) are the same function: every output and every state word bit-identical, all randomisation on, stacked frames.
     (Up to 8 192 envs the four-role quad form is the build whose obs role wavefront runs the linear chain, above it the build that keeps it in the
-    step wavefront -- taco_step.hpp LIN, taco_capi.hip lin_form: the 8 232-env case is the second.)"""
+    step wavefront -- taco_step.hpp LIN, taco_capi.hip lin_form: the 8 232-env case is the second.  The served pair pinned on a launch WITHOUT flip
+    envs runs the linear chain in its serving wavefront: the pos / rotate / posnoise cases.)"""
     from taco_amd.vec_env import FpvBase
     kw = dict(env_lenObservations=2, env_lenStates=3, env_maxEpisodeLength=40, seed=11)
     if task == "mix":
         kw.update(rotor_noise=True, observation_noise=True, ramdom_deploy_time=True, ramdom_delay_time=True)
+    if task == "posnoise":   # (pos / rotate in the served pair: its serving wavefront runs the LINEAR CHAIN, round 5 -- here behind the rotor-noise table)
+        task = "pos"
+        kw.update(rotor_noise=True, ramdom_deploy_time=True)
+    if n == 12500:           # (the size the product picks the pair for: no stacks)
+        kw.update(env_lenObservations=1, env_lenStates=1)
     envs = []
     for form, lpe, block in (("quad", 4, 64), ("lane", 1, 64), ("lane_throughput", 1, 64), ("quad_roles", 4, 256), ("lane_roles", 1, 256), ("quad_served", 4, 128)):
         e = FpvBase(config.default_cfg(task, n, **kw), copy_outputs=False, kernel_form=form)
