@@ -880,8 +880,8 @@ static int launch_critic(const taco_policy_cfg *c, const float *blob, size_t row
             const size_t pw = (pb + cus - 1) / cus;
             const dim3 pg((unsigned)((pb + pw - 1) / pw));
             if (exact) hipLaunchKernelGGL(taco::taco_critic_lstm_pair_kernel<true>, pg, dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
-            else if (c->flags & TACO_P_SPLIT_F16) hipLaunchKernelGGL(taco::taco_critic_lstm_pair_split_kernel<1>, pg, dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
-            else if (c->flags & TACO_P_SPLIT_BF16) hipLaunchKernelGGL(taco::taco_critic_lstm_pair_split_kernel<2>, pg, dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
+            else if ((c->flags & TACO_P_SPLIT_F16) && c->states_dim < 32) hipLaunchKernelGGL(taco::taco_critic_lstm_pair_split_kernel<1>, pg, dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
+            else if ((c->flags & TACO_P_SPLIT_BF16) && c->states_dim < 32) hipLaunchKernelGGL(taco::taco_critic_lstm_pair_split_kernel<2>, pg, dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
             else hipLaunchKernelGGL(taco::taco_critic_lstm_pair_kernel<false>, pg, dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
         } else if (ring_n > 0) {
             if (exact) hipLaunchKernelGGL((taco::taco_critic_lstm_kernel<true, true>), dim3(grid), dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);

@@ -936,6 +936,8 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_kernel(cons
 // MEASURED against the f32 kernels (tests/test_policy_gpu.py, tools/cell_ab.py; a numpy model of the same arithmetic predicted it):
 // f16 halves: |value difference| <= ~2e-7 on O(1) values -- inside the 2e-6 bar of the fast cell; bf16 halves with three terms: ~5e-6,
 // OUTSIDE that bar (six terms -- a three-way split -- would meet it at 1.5 x the weight registers, which this kernel does not have).
+// (Second form, same round: the frames are split ONCE per block into LDS planes, the product is taken transposed and the bias rides in an input
+// column -- see the kernel.)
 // Operand range of the f16 form: frame words are clamped to +-65 504 (frames are O(1): normalised positions, rates, voltages -- the clamp
 // only keeps a diverged env's huge finite word from turning into inf - inf = NaN); h_t lies in [-1, 1]; bf16 has f32's range.
 // Layout (cdna_hip_programming.md section 3): lane (r = lane & 15, g = lane >> 4) holds A[row r][k = 32 S + 8 g + j] and
@@ -960,13 +962,23 @@ template <> struct SplitKind<2> {
 };
 constexpr int CR_HLD = 272;   // bytes per row of a 16-bit h plane (128 columns + one 16-byte slot of padding)
 
+constexpr int CR_XROWS = (POL_MAXT + 1) * 16;   // rows of a block's frame planes: (T + 1) frames x 16 envs (a multiple of 16: the [k block][row] layout below is conflict-free)
+
 template <int KIND>
 __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_split_kernel(const PolicyParams P) {
     typedef SplitKind<KIND> SK;
     typedef typename SK::T HT;
     typedef typename SK::V8 V8;
+    typedef typename SK::T V4 __attribute__((ext_vector_type(4)));
+    typedef typename SK::T V2 __attribute__((ext_vector_type(2)));
     constexpr int FR = POL_MAXT + 1;
-    __shared__ __attribute__((aligned(16))) float xs[2][FR * 16 * 32];                 // [frame][env][sd] as they lie in the ring
+    // Frames: staged as f32 (LDS-DMA, as they lie in the ring) and split ONCE per block by the whole workgroup into two 16-bit planes -- in the
+    // first form every wavefront split every frame it consumed, eight-fold redundant: 46 of the kernel's 277 us (profiles/r05_e_critic_split_probe.txt).
+    // Plane layout [k block g][row][8 halves]: lane (r, g) of a B-operand read takes 16 B at slot g * CR_XROWS + row -- the 16 rows of a 16-lane
+    // service group are 16 consecutive slots, and the groups' other k block lies a multiple of 16 slots away on the complementary rows: no conflicts.
+    // Column sd of every row holds 1.0: the bias rides in the weights' column sd (sd <= 31; the host sends sd = 32 to the f32 kernel).
+    __shared__ __attribute__((aligned(16))) float xst[FR * 16 * 32];                   // staging: [frame][env][sd] f32
+    __shared__ __attribute__((aligned(16))) unsigned char xp[2][2][4 * CR_XROWS * 16]; // [block parity][high / low half][k block][row][8 x 16 bit]
     __shared__ __attribute__((aligned(16))) unsigned char hs[2][2][CR_ROWS * CR_HLD];  // h_t: [buffer][high / low half][row][k], 16-bit
     __shared__ __attribute__((aligned(16))) float hT[CR_ROWS * CR_LD];                 // h_T (f32, swizzled like the MLP's tiles) on its way out
     constexpr int KSX = 2, KSH = 8, hp = 128, ip = 32;
@@ -989,32 +1001,40 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_split_kerne
     }
     const float *Wih = w, *Whh = w + (size_t)4 * hp * ip, *bs = Whh + (size_t)4 * hp * hp;
     const int col = wave * 16 + r;
-    // both halves of this wavefront's weights.  The blob is fragment-major for the f32 form: float4 ((wave KS + s) 64 + 16 g' + r) holds
+    // The product is taken TRANSPOSED, D = W x^T: the weights are the A operand (lane (r, g): W[col 16 wave + r][k = 32 Sb + 8 g + j]), the
+    // activations the B operand (lane (r, g): x[env row r][k = 32 Sb + 8 g + j]), and lane (r, g) of D holds hidden columns 16 wave + 4 g + i,
+    // i = 0 .. 3, of env row r: a lane's four h values are ADJACENT in a row of h_t and leave as one 8-byte store per plane (the first form,
+    // D = x W^T, had them in four rows: eight 2-byte stores).
+    // Both halves of this wavefront's weights; the blob is fragment-major for the f32 form: float4 ((wave KS + s) 64 + 16 g' + r) holds
     // W[col][16 s + 4 g' .. + 3]; this lane's k = 32 Sb + 8 g + j lies in fragments s = 2 Sb + (g >> 1), g' = 2 (g & 1) + (j >> 2)
     V8 wxh[4], wxl[4], whh[4][4], whl[4][4];
-    float bq[4];
-    auto halves = [](const float4 a, const float4 b, V8 &hi, V8 &lo) {
-        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    auto halves = [](const float (&v)[8], V8 &hi, V8 &lo) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const HT h = (HT)v[j]; hi[j] = h; lo[j] = (HT)((v[j] - (float)h) * SK::S); }
     };
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        bq[q] = bs[q * hp + col];
         {
             const float4 *f = reinterpret_cast<const float4 *>(Wih + (size_t)q * hp * ip) + (size_t)(wave * KSX + (g >> 1)) * 64 + 32 * (g & 1) + r;
-            halves(f[0], f[16], wxh[q], wxl[q]);
+            const float4 a = f[0], b = f[16];
+            float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            const float bias = bs[q * hp + col];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (8 * g + j == sd) ? bias : v[j];   // the bias column (the frames' column sd is 1.0)
+            halves(v, wxh[q], wxl[q]);
         }
 #pragma unroll
         for (int sb = 0; sb < 4; ++sb) {
             const float4 *f = reinterpret_cast<const float4 *>(Whh + (size_t)q * hp * hp) + (size_t)(wave * KSH + 2 * sb + (g >> 1)) * 64 + 32 * (g & 1) + r;
-            halves(f[0], f[16], whh[q][sb], whl[q][sb]);
+            const float4 a = f[0], b = f[16];
+            const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            halves(v, whh[q][sb], whl[q][sb]);
         }
     }
     const int ring_rows = S + T - 1;
     const int piece_bytes = 16 * sd * (int)sizeof(float);
     const bool dma_ok = (((size_t)N * sd * sizeof(float)) & 15u) == 0 && (piece_bytes & 15) == 0;
-    auto stage = [&](int blk, int half) {
+    auto stage = [&](int blk) {   // the block's T + 1 frames -> xst (f32)
         const int pair = blk / groups, e0 = (blk - pair * groups) * 16, slot0 = 2 * pair;
         const int per_piece = (piece_bytes / 16 + 63) / 64;
         if (dma_ok && e0 + 16 <= N && slot0 + T < ring_rows) {
@@ -1023,19 +1043,36 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_split_kerne
                 const char *src = reinterpret_cast<const char *>(P.states) + ((size_t)(slot0 + f) * N + e0) * sd * sizeof(float);
                 if (off < piece_bytes)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off),
-                                                     (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(xs[half]) + f * piece_bytes + (j - f * per_piece) * 1024), 16, 0, 0);
+                                                     (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(xst) + f * piece_bytes + (j - f * per_piece) * 1024), 16, 0, 0);
             }
         } else {
 #pragma unroll 1
             for (int e = tid; e < (T + 1) * 16 * sd; e += 64 * POL_NW) {
                 const int f = e / (16 * sd), rem = e - f * 16 * sd, env = rem / sd;
-                xs[half][e] = (slot0 + f < ring_rows && e0 + env < N) ? P.states[((size_t)(slot0 + f) * N + e0) * sd + rem] : 0.0f;
+                xst[e] = (slot0 + f < ring_rows && e0 + env < N) ? P.states[((size_t)(slot0 + f) * N + e0) * sd + rem] : 0.0f;
             }
         }
     };
-    stage((int)blockIdx.x, 0);
-    const bool sd_even = (sd & 1) == 0;
+    auto split_frames = [&](int half) {   // xst -> the two planes of xp[half]: every thread pairs of adjacent columns (one 4-byte store per plane)
+#pragma unroll 1
+        for (int e = tid; e < (T + 1) * 16 * 16; e += 64 * POL_NW) {
+            const int row = e >> 4, k = (e & 15) * 2;
+            float v0 = k < sd ? xst[row * sd + k] : (k == sd ? 1.0f : 0.0f);
+            float v1 = k + 1 < sd ? xst[row * sd + k + 1] : (k + 1 == sd ? 1.0f : 0.0f);
+            if constexpr (KIND == 1) {   // f16's range: a huge finite frame word saturates instead of turning into inf - inf; a NaN stays a NaN (as in the f32 kernel)
+                v0 = v0 > 65504.0f ? 65504.0f : (v0 < -65504.0f ? -65504.0f : v0);
+                v1 = v1 > 65504.0f ? 65504.0f : (v1 < -65504.0f ? -65504.0f : v1);
+            }
+            const HT h0 = (HT)v0, h1 = (HT)v1;
+            const int at = (((k >> 3) * CR_XROWS + row) << 4) + (k & 7) * 2;
+            *reinterpret_cast<V2 *>(xp[half][0] + at) = V2{h0, h1};
+            *reinterpret_cast<V2 *>(xp[half][1] + at) = V2{(HT)((v0 - (float)h0) * SK::S), (HT)((v1 - (float)h1) * SK::S)};
+        }
+    };
+    stage((int)blockIdx.x);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    split_frames(0);
     __syncthreads();
 
     // main / cross accumulators of the tile in flight.  Tile B's x part (combined) = tile A's start of the next timestep: parked in LDS
@@ -1051,33 +1088,17 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_split_kerne
 #pragma unroll
             for (int i = 0; i < 4; ++i) am[q][i] = fma(ac[q][i], SK::RS, am[q][i]);
     };
-    auto x_chain = [&](const float *xh, int f) __attribute__((always_inline)) {   // am = bias + W_ih x(frame f) (combined), rows = the block's 16 envs
-        const float *at = xh + (f * 16 + r) * sd + 8 * g;
-        float v[8];
-        if (sd_even) {
+    auto x_chain = [&](const unsigned char *xh, int f) __attribute__((always_inline)) {   // am = bias + W_ih x(frame f) (combined), rows = the block's 16 envs
+        const int at = (g * CR_XROWS + f * 16 + r) << 4;
+        const V8 ah = *reinterpret_cast<const V8 *>(xh + at), al = *reinterpret_cast<const V8 *>(xh + 4 * CR_XROWS * 16 + at);
 #pragma unroll
-            for (int p2 = 0; p2 < 4; ++p2) { const float2 t2 = *reinterpret_cast<const float2 *>(at + 2 * p2); v[2 * p2] = t2.x; v[2 * p2 + 1] = t2.y; }
-        } else {
+        for (int q = 0; q < 4; ++q) { am[q] = pf32x4{0.0f, 0.0f, 0.0f, 0.0f}; ac[q] = pf32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = at[j];
-        }
-        V8 ah, al;
+        for (int q = 0; q < 4; ++q) am[q] = SK::mfma(wxh[q], ah, am[q]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float xv = (8 * g + j < sd) ? v[j] : 0.0f;   // (beyond sd the row holds its neighbour's words)
-            if constexpr (KIND == 1) xv = xv > 65504.0f ? 65504.0f : (xv < -65504.0f ? -65504.0f : xv);   // f16's range: a huge finite frame word saturates instead of
-                                                                                                             // turning into inf - inf; a NaN stays a NaN (as in the f32 kernel)
-            const HT h = (HT)xv;
-            ah[j] = h; al[j] = (HT)((xv - (float)h) * SK::S);
-        }
+        for (int q = 0; q < 4; ++q) ac[q] = SK::mfma(wxl[q], ah, ac[q]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { am[q] = pf32x4{bq[q], bq[q], bq[q], bq[q]}; ac[q] = pf32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) am[q] = SK::mfma(ah, wxh[q], am[q]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) ac[q] = SK::mfma(ah, wxl[q], ac[q]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) ac[q] = SK::mfma(al, wxh[q], ac[q]);
+        for (int q = 0; q < 4; ++q) ac[q] = SK::mfma(wxh[q], al, ac[q]);
         combine();
     };
     auto h_chain = [&](const unsigned char *hprev, int tile) __attribute__((always_inline)) {   // am (= the x part) += W_hh h_{t-1}
@@ -1089,19 +1110,19 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_split_kerne
             const int pos = ((4 * sb + g) ^ cr_b(r)) << 4;
             const V8 ah = *reinterpret_cast<const V8 *>(rowh + pos), al = *reinterpret_cast<const V8 *>(rowl + pos);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) am[q] = SK::mfma(ah, whh[q][sb], am[q]);
+            for (int q = 0; q < 4; ++q) am[q] = SK::mfma(whh[q][sb], ah, am[q]);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) ac[q] = SK::mfma(ah, whl[q][sb], ac[q]);
+            for (int q = 0; q < 4; ++q) ac[q] = SK::mfma(whl[q][sb], ah, ac[q]);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) ac[q] = SK::mfma(al, whh[q][sb], ac[q]);
+            for (int q = 0; q < 4; ++q) ac[q] = SK::mfma(whh[q][sb], al, ac[q]);
         }
         combine();
     };
+    // this lane's cells: env row 16 tile + r, hidden columns c0 .. c0 + 3
+    const int c0 = 16 * wave + 4 * g;
     auto cells = [&](int t, int tile, float (&cst)[4], bool first) __attribute__((always_inline)) {
         const bool last = t + 1 >= T;
-        const int row0 = 16 * tile + 4 * g, bsw = cr_b(4 * g);   // rows 4 g + i: b(row) = b(4 g)
-        unsigned char *oh = hs[t & 1][0] + row0 * CR_HLD + (((col >> 3) ^ bsw) << 4) + (col & 7) * 2, *ol = oh + CR_ROWS * CR_HLD;
-        float *of = hT + row0 * CR_LD + (col ^ (bsw << 2));
+        const int row = 16 * tile + r;
         float hv[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1109,16 +1130,15 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_split_kerne
             lstm_cell_fast(am[0][i], am[1][i], am[2][i], am[3][i], first ? 0.0f : cst[i], cn, hv[i]);
             cst[i] = cn;
         }
-        if (last) {   // (ONE wave-uniform branch per call: inside the loop above it became eight)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) of[i * CR_LD] = hv[i];
+        if (last) {   // (ONE wave-uniform branch per call)
+            *reinterpret_cast<float4 *>(hT + cr_sw4(row, c0 >> 2)) = float4{hv[0], hv[1], hv[2], hv[3]};
         } else {
+            unsigned char *oh = hs[t & 1][0] + row * CR_HLD + (((c0 >> 3) ^ cr_b(row)) << 4) + (c0 & 7) * 2;
+            V4 hi, lo;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const HT h = (HT)hv[i];
-                *reinterpret_cast<HT *>(oh + i * CR_HLD) = h;
-                *reinterpret_cast<HT *>(ol + i * CR_HLD) = (HT)((hv[i] - (float)h) * SK::S);
-            }
+            for (int i = 0; i < 4; ++i) { const HT h = (HT)hv[i]; hi[i] = h; lo[i] = (HT)((hv[i] - (float)h) * SK::S); }
+            *reinterpret_cast<V4 *>(oh) = hi;
+            *reinterpret_cast<V4 *>(oh + CR_ROWS * CR_HLD) = lo;
         }
     };
     auto flush_hT = [&](int blk) {
@@ -1133,8 +1153,8 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_split_kerne
     };
     for (int k = 0; k < nb; ++k) {
         const int blk = (int)blockIdx.x + k * (int)gridDim.x;
-        const float *xh = xs[k & 1];
-        if (k + 1 < nb) stage(blk + (int)gridDim.x, (k + 1) & 1);
+        const unsigned char *xh = xp[k & 1][0];
+        if (k + 1 < nb) stage(blk + (int)gridDim.x);   // (xst is free: its frames were split into xp[k & 1] a block ago)
         if (k > 0) flush_hT(blk - (int)gridDim.x);
         // ---- timestep 0: x chains only (h_{-1} = 0)
         x_chain(xh, 0);
@@ -1145,6 +1165,7 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_split_kerne
         cells(0, 1, cstB, true);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next block's frames have landed
         __syncthreads();
+        if (k + 1 < nb) split_frames((k + 1) & 1);        // ... and become its planes (read from the next block on: T - 1 >= 1 barriers lie in between)
         for (int t = 1; t < T; ++t) {
             const unsigned char *hprev = hs[(t - 1) & 1][0];
 #pragma unroll
