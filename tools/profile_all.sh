@@ -7,7 +7,8 @@
 #   5. kernel trace of VecTask.step() calls            -> gpurun_out/<tag>_step_api_kernel_stats.csv
 #   5b. kernel trace of taco_rollout_run                -> gpurun_out/<tag>_rollout_kernel_stats.csv
 #   5c. SQ counters of the rollout's kernels (2 passes) -> gpurun_out/<tag>_rollout_pmc.json (tools/pmc_kernels.py)
-#   6. bench.py --gpus 2 over gloo on this one GPU     -> gpurun_out/<tag>_bench_2ranks_gloo_one_gpu.json
+#   6. bench.py --gpus 2 / --gpus 4 over gloo on this one GPU -> gpurun_out/<tag>_bench_{2,4}ranks_gloo_one_gpu.json
+#   8. tools/cell_ab.py, tools/fresh_outputs_cost.py    -> gpurun_out/<tag>_cell_ab.txt, <tag>_fresh_outputs_cost.txt
 # --pmc is never combined with any trace domain other than --kernel-trace; python3 is the program right after `--`.
 set -eo pipefail
 TAG=${1:-r01_x}
@@ -44,3 +45,8 @@ python3 bench.py --steps 2000 --warmup 200 > "$O/${TAG}_bench_4096.json" 2> "$O/
 python3 tools/clock_path_ab.py > "$O/${TAG}_clock_path_ab.txt" 2>/dev/null || true
 # 6. the N > 1 code path end to end on this one GPU: 2 ranks over gloo (the driver runs the real thing over RCCL on 8 GPUs)
 TACO_BENCH_BACKEND=gloo TACO_BENCH_ONE_DEVICE=1 python3 bench.py --gpus 2 --steps 500 --warmup 100 --no-cpu-baseline --no-large-n --no-configs > "$O/${TAG}_bench_2ranks_gloo_one_gpu.json" 2> "$O/${TAG}_bench_2ranks.err" || true
+# 6b. ... and with FOUR ranks incl. the BASELINE-total legs (the pool's process guard allows six processes on a card: four ranks + the launcher fit, six ranks do not)
+TACO_BENCH_BACKEND=gloo TACO_BENCH_ONE_DEVICE=1 timeout -k 10 900 python3 bench.py --gpus 4 --steps 50 --warmup 10 --no-cpu-baseline --no-large-n > "$O/${TAG}_bench_4ranks_gloo_one_gpu.json" 2> "$O/${TAG}_bench_4ranks.err" || true
+# 8. the batched critic: exact cell / hardware cell / split f16 / split bf16 (ms per values_ring, value differences), and what fresh_outputs costs
+python3 tools/cell_ab.py > "$O/${TAG}_cell_ab.txt" 2>&1 || true
+python3 tools/fresh_outputs_cost.py > "$O/${TAG}_fresh_outputs_cost.txt" 2>&1 || true
