@@ -933,9 +933,10 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_kernel(cons
 // a product chain is THREE MFMA chains,
 //     acc = bias + sum x1 w1  +  (sum x1 w2' + sum x2' w1) / S            (f32 accumulation inside the MFMA; x2' w2' / S^2 is dropped)
 // per-product relative error <= 3 * 2^-22 (f16: 11 + 11 significant bits) or 3 * 2^-16 (bf16: 8 + 8) instead of one f32 rounding.
-// MEASURED against the f32 kernels (tests/test_policy_gpu.py, tools/cell_ab.py; a numpy model of the same arithmetic predicted it):
-// f16 halves: |value difference| <= ~2e-7 on O(1) values -- inside the 2e-6 bar of the fast cell; bf16 halves with three terms: ~5e-6,
-// OUTSIDE that bar (six terms -- a three-way split -- would meet it at 1.5 x the weight registers, which this kernel does not have).
+// MEASURED against the exact f32 critic (tests/test_policy_gpu.py, tools/cell_ab.py; a numpy model of the same arithmetic predicted the ranking):
+// f16 halves: |value difference| 3e-7 ... 1e-6 on O(1) values (the hardware cell alone: 7e-7) -- inside the 2e-6 bar of the fast cell; bf16
+// halves with three terms: 1e-5 ... 3e-5, OUTSIDE that bar (six terms -- a three-way split -- would meet it at 1.5 x the weight registers,
+// which this kernel does not have).
 // (Second form, same round: the frames are split ONCE per block into LDS planes, the product is taken transposed and the bias rides in an input
 // column -- see the kernel.)
 // Operand range of the f16 form: frame words are clamped to +-65 504 (frames are O(1): normalised positions, rates, voltages -- the clamp

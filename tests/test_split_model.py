@@ -1,0 +1,88 @@
+"""A numpy model of the split-precision critic arithmetic (taco_policy.hpp taco_critic_lstm_pair_split_kernel, include/taco_env.h TACO_P_SPLIT_F16 /
+TACO_P_SPLIT_BF16) on the reference's own weights (tests/golden/policy_documented.npz): every f32 operand v of the LSTM's product chains as two
+16-bit halves, v = v1 + v2' / S, v1 = RN16(v), v2' = RN16((v - v1) S); a chain = sum x1 w1 + (sum x1 w2' + sum x2' w1) / S.  CPU evidence for what
+the GPU tests measure (tests/test_policy_gpu.py::test_split_precision_critic_stays_within_its_bar_of_the_f32_kernel):
+  * f16 halves (S = 2^11) stay within 2e-6 of the f32 chain on O(1) inputs -- the fast cell's bar -- and need the scale: the same halves WITHOUT it,
+    on hardware that flushes subnormal operands, would lose the low half of every typical weight (1e-4);
+  * bf16 halves with three terms do not (1e-5): rejected; six terms (a three-way split) would, at 1.5 x the weight registers.
+"""
+import os
+
+import numpy as np
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _bf16(x):
+    u = np.asarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32).view(np.float32)
+
+
+def _f16(x):
+    return np.asarray(x, np.float32).astype(np.float16).astype(np.float32)
+
+
+def _ftz16(x):
+    y = _f16(x)
+    y[np.abs(y) < 6.103515625e-05] = 0      # what an f16 pipe that flushes subnormal operands would see
+    return y
+
+
+def _mm(x, W, mode):
+    x, W = np.asarray(x, np.float32), np.asarray(W, np.float32)
+    d = lambda a: a.astype(np.float64)
+    if mode == "f32":
+        return (d(x) @ d(W).T).astype(np.float32)
+    if mode in ("f16", "bf16"):        # the kernel's form: scaled low halves, cross terms accumulated apart and scaled back
+        cv, S = (_f16, 2048.0) if mode == "f16" else (_bf16, 256.0)
+        x1, w1 = cv(x), cv(W)
+        x2, w2 = cv((x - x1) * np.float32(S)), cv((W - w1) * np.float32(S))
+        if mode == "f16":
+            x2, w2 = _ftz16(x2), _ftz16(w2)   # (even flushed, a scaled low half loses at most 3e-8 of its operand)
+        cross = (d(x1) @ d(w2).T + d(x2) @ d(w1).T).astype(np.float32)
+        return (d(x1) @ d(w1).T + d(cross) / S).astype(np.float32)
+    if mode == "f16_unscaled_flushed":
+        x1, w1 = _ftz16(x), _ftz16(W)
+        x2, w2 = _ftz16(x - x1), _ftz16(W - w1)
+        return (d(x1) @ d(w1).T + d(x1) @ d(w2).T + d(x2) @ d(w1).T).astype(np.float32)
+    if mode == "bf16x6":               # three-way split, six terms
+        xs, ws, rx, rw = [], [], x.copy(), W.copy()
+        for _ in range(3):
+            h = _bf16(rx); xs.append(h); rx = (rx - h).astype(np.float32)
+            h = _bf16(rw); ws.append(h); rw = (rw - h).astype(np.float32)
+        return sum(d(xs[i]) @ d(ws[j]).T for i in range(3) for j in range(3) if i + j <= 2).astype(np.float32)
+    raise ValueError(mode)
+
+
+def _critic(g, states, mode):
+    sig = lambda a: 1 / (1 + np.exp(-a.astype(np.float64)))
+    Wih, Whh = g["sd.critic_encoder.layers.weight_ih_l0"], g["sd.critic_encoder.layers.weight_hh_l0"]
+    b = g["sd.critic_encoder.layers.bias_ih_l0"] + g["sd.critic_encoder.layers.bias_hh_l0"]
+    n = states.shape[0]
+    h, c = np.zeros((n, 128), np.float32), np.zeros((n, 128), np.float64)
+    for t in range(states.shape[1]):
+        a = _mm(states[:, t], Wih, mode).astype(np.float64) + _mm(h, Whh, mode) + b
+        i, f, gg, o = a[:, :128], a[:, 128:256], a[:, 256:384], a[:, 384:]
+        c = sig(f) * c + sig(i) * np.tanh(gg)
+        h = (sig(o) * np.tanh(c)).astype(np.float32)
+    y = h    # the MLP stays on f32 MFMA in the kernel
+    for k in (0, 2):
+        y = np.maximum(_mm(y, g[f"sd.critic_mlp.layers.{k}.weight"], "f32") + g[f"sd.critic_mlp.layers.{k}.bias"], 0)
+    return (_mm(y, g["sd.critic_mlp.layers.4.weight"], "f32") + g["sd.critic_mlp.layers.4.bias"])[:, 0]
+
+
+def test_split_f16_meets_the_fast_cells_bar_and_bf16_does_not():
+    g = np.load(os.path.join(GOLD, "policy_documented.npz"))
+    rng = np.random.default_rng(0)
+    worst = {}
+    for scale in (0.3, 1.0, 3.0):
+        S = np.concatenate([g["states"] * scale, (rng.standard_normal((1500, 5, 26)) * scale).astype(np.float32)]).astype(np.float32)
+        ref = _critic(g, S, "f32")
+        assert np.abs(ref[:100] - g["value"]).max() < 1e-5 or scale != 1.0     # (the model's f32 chain IS the reference's critic)
+        for mode in ("f16", "bf16", "bf16x6", "f16_unscaled_flushed"):
+            worst[mode] = max(worst.get(mode, 0.0), float(np.abs(_critic(g, S, mode) - ref).max()))
+    print("max |value - f32 chain| over inputs x 0.3 / 1 / 3: " + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
+    assert worst["f16"] < 5e-7                       # (GPU, incl. the hardware cell's own 7e-7: 3e-7 ... 1e-6)
+    assert 2e-6 < worst["bf16"] < 5e-5               # three bf16 terms: outside the bar -> rejected
+    assert worst["bf16x6"] < 2e-7                    # six terms would do, at 1.5 x the weight registers
+    assert worst["f16_unscaled_flushed"] > 5e-5      # why the low halves are scaled into the normal range
