@@ -928,10 +928,10 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_kernel(cons
 // The pair kernel on the 16-BIT MATRIX PIPE with SPLIT operands (round 5; include/taco_env.h TACO_P_SPLIT_F16 / TACO_P_SPLIT_BF16 -- opt-in).
 // taco_critic_lstm_pair_kernel is MFMA time + the cells' VALU time, and its MFMA time is the f32 pipe's: v_mfma_f32_16x16x4_f32 delivers
 // 2 048 flop in 32 cycles, v_mfma_f32_16x16x32_{f16,bf16} 16 384 in 16 (MI355X_MICROARCH.md) -- 16 x per cycle.  Every f32 operand v is
-// split into two 16-bit halves, v = v1 + v2' / S with v1 = RN16(v) and v2' = RN16((v - v1) S) (v - v1 is exact in f32; S = 2^11 for f16,
-// 2^8 for bf16 keeps the low half in the format's normal range whatever the magnitude of v, so nothing depends on subnormal operands), and
-// a product chain is THREE MFMA chains,
-//     acc = bias + sum x1 w1  +  (sum x1 w2' + sum x2' w1) / S            (f32 accumulation inside the MFMA; x2' w2' / S^2 is dropped)
+// split into two 16-bit halves, v = v1 + v2 with v1 = RN16(v) and v2 = RN16(v - v1) (v - v1 is exact in f32; the low half of a typical f16
+// operand is SUBNORMAL, which gfx950's 16-bit MFMAs keep: tools/ubench/mfma_f16_denorm -- the first two forms of this kernel scaled the low
+// halves by 2^11 into the normal range and carried the cross terms in accumulators of their own), and a product chain is THREE MFMA chains,
+//     acc = bias + sum x1 w1 + sum x1 w2 + sum x2 w1                      (f32 accumulation inside the MFMA; x2 w2 is dropped)
 // per-product relative error <= 3 * 2^-22 (f16: 11 + 11 significant bits) or 3 * 2^-16 (bf16: 8 + 8) instead of one f32 rounding.
 // MEASURED against the exact f32 critic (tests/test_policy_gpu.py, tools/cell_ab.py; a numpy model of the same arithmetic predicted the ranking):
 // f16 halves: |value difference| 3e-7 ... 1e-6 on O(1) values (the hardware cell alone: 7e-7) -- inside the 2e-6 bar of the fast cell; bf16
@@ -952,13 +952,11 @@ template <int KIND> struct SplitKind;
 template <> struct SplitKind<1> {
     typedef _Float16 T;
     typedef _Float16 V8 __attribute__((ext_vector_type(8)));
-    static constexpr float S = 2048.0f, RS = 1.0f / 2048.0f;
     static __device__ __forceinline__ pf32x4 mfma(V8 a, V8 b, pf32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 };
 template <> struct SplitKind<2> {
     typedef __bf16 T;
     typedef __bf16 V8 __attribute__((ext_vector_type(8)));
-    static constexpr float S = 256.0f, RS = 1.0f / 256.0f;
     static __device__ __forceinline__ pf32x4 mfma(V8 a, V8 b, pf32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 };
 constexpr int CR_HLD = 272;   // bytes per row of a 16-bit h plane (128 columns + one 16-byte slot of padding)
@@ -1011,7 +1009,7 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_split_kerne
     V8 wxh[4], wxl[4], whh[4][4], whl[4][4];
     auto halves = [](const float (&v)[8], V8 &hi, V8 &lo) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const HT h = (HT)v[j]; hi[j] = h; lo[j] = (HT)((v[j] - (float)h) * SK::S); }
+        for (int j = 0; j < 8; ++j) { const HT h = (HT)v[j]; hi[j] = h; lo[j] = (HT)(v[j] - (float)h); }
     };
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -1067,7 +1065,7 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_split_kerne
             const HT h0 = (HT)v0, h1 = (HT)v1;
             const int at = (((k >> 3) * CR_XROWS + row) << 4) + (k & 7) * 2;
             *reinterpret_cast<V2 *>(xp[half][0] + at) = V2{h0, h1};
-            *reinterpret_cast<V2 *>(xp[half][1] + at) = V2{(HT)((v0 - (float)h0) * SK::S), (HT)((v1 - (float)h1) * SK::S)};
+            *reinterpret_cast<V2 *>(xp[half][1] + at) = V2{(HT)(v0 - (float)h0), (HT)(v1 - (float)h1)};
         }
     };
     stage((int)blockIdx.x);
@@ -1076,48 +1074,35 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_split_kerne
     split_frames(0);
     __syncthreads();
 
-    // main / cross accumulators of the tile in flight.  Tile B's x part (combined) = tile A's start of the next timestep: parked in LDS
-    // (kp, 16 floats per lane: four b128 writes + reads per timestep) -- as 16 more registers it cost two spilled weight fragments,
-    // reloaded from scratch at every use
-    pf32x4 am[4], ac[4];
-    __shared__ __attribute__((aligned(16))) pf32x4 kp[POL_NW * 4 * 64];
-    pf32x4 *const kpl = kp + (size_t)wave * 4 * 64 + lane;
+    // ONE accumulator set for the three chains of a product chain (third form, same round: gfx950's 16-bit MFMAs KEEP subnormal operands --
+    // tools/ubench/mfma_f16_denorm, profiles/r05_l_ubench_mfma_f16_denorm.txt -- so the low halves need no scale, the cross terms no accumulators of
+    // their own and no "am += ac / S" pass: 32 VALU instructions per tile and timestep and 16 registers less, which is where tile B's x part
+    // -- tile A's start of the next timestep -- lives again instead of being parked in LDS).
+    pf32x4 am[4], keep[4];
     float cstA[4], cstB[4];
-    auto combine = [&]() __attribute__((always_inline)) {   // am += ac / S
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) am[q][i] = fma(ac[q][i], SK::RS, am[q][i]);
-    };
     auto x_chain = [&](const unsigned char *xh, int f) __attribute__((always_inline)) {   // am = bias + W_ih x(frame f) (combined), rows = the block's 16 envs
         const int at = (g * CR_XROWS + f * 16 + r) << 4;
         const V8 ah = *reinterpret_cast<const V8 *>(xh + at), al = *reinterpret_cast<const V8 *>(xh + 4 * CR_XROWS * 16 + at);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { am[q] = pf32x4{0.0f, 0.0f, 0.0f, 0.0f}; ac[q] = pf32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+        for (int q = 0; q < 4; ++q) am[q] = SK::mfma(wxl[q], ah, pf32x4{0.0f, 0.0f, 0.0f, 0.0f});   // (the small terms first)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) am[q] = SK::mfma(wxh[q], al, am[q]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) am[q] = SK::mfma(wxh[q], ah, am[q]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) ac[q] = SK::mfma(wxl[q], ah, ac[q]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) ac[q] = SK::mfma(wxh[q], al, ac[q]);
-        combine();
     };
     auto h_chain = [&](const unsigned char *hprev, int tile) __attribute__((always_inline)) {   // am (= the x part) += W_hh h_{t-1}
         const unsigned char *rowh = hprev + (16 * tile + r) * CR_HLD, *rowl = rowh + CR_ROWS * CR_HLD;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) ac[q] = pf32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int sb = 0; sb < 4; ++sb) {
             const int pos = ((4 * sb + g) ^ cr_b(r)) << 4;
             const V8 ah = *reinterpret_cast<const V8 *>(rowh + pos), al = *reinterpret_cast<const V8 *>(rowl + pos);
 #pragma unroll
+            for (int q = 0; q < 4; ++q) am[q] = SK::mfma(whl[q][sb], ah, am[q]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) am[q] = SK::mfma(whh[q][sb], al, am[q]);
+#pragma unroll
             for (int q = 0; q < 4; ++q) am[q] = SK::mfma(whh[q][sb], ah, am[q]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) ac[q] = SK::mfma(whl[q][sb], ah, ac[q]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) ac[q] = SK::mfma(whh[q][sb], al, ac[q]);
         }
-        combine();
     };
     // this lane's cells: env row 16 tile + r, hidden columns c0 .. c0 + 3
     const int c0 = 16 * wave + 4 * g;
@@ -1137,7 +1122,7 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_split_kerne
             unsigned char *oh = hs[t & 1][0] + row * CR_HLD + (((c0 >> 3) ^ cr_b(row)) << 4) + (c0 & 7) * 2;
             V4 hi, lo;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { const HT h = (HT)hv[i]; hi[i] = h; lo[i] = (HT)((hv[i] - (float)h) * SK::S); }
+            for (int i = 0; i < 4; ++i) { const HT h = (HT)hv[i]; hi[i] = h; lo[i] = (HT)(hv[i] - (float)h); }
             *reinterpret_cast<V4 *>(oh) = hi;
             *reinterpret_cast<V4 *>(oh + CR_ROWS * CR_HLD) = lo;
         }
@@ -1162,7 +1147,7 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_split_kerne
         cells(0, 0, cstA, true);
         x_chain(xh, 1);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) kpl[q * 64] = am[q];
+        for (int q = 0; q < 4; ++q) keep[q] = am[q];
         cells(0, 1, cstB, true);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next block's frames have landed
         __syncthreads();
@@ -1170,12 +1155,12 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_split_kerne
         for (int t = 1; t < T; ++t) {
             const unsigned char *hprev = hs[(t - 1) & 1][0];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) am[q] = kpl[q * 64];   // tile A: bias + W_ih x(frame t), computed for tile B a timestep ago
+            for (int q = 0; q < 4; ++q) am[q] = keep[q];        // tile A: bias + W_ih x(frame t), computed for tile B a timestep ago
             h_chain(hprev, 0);
             cells(t, 0, cstA, false);
             x_chain(xh, t + 1);                                // tile B: frame t + 1
 #pragma unroll
-            for (int q = 0; q < 4; ++q) kpl[q * 64] = am[q];
+            for (int q = 0; q < 4; ++q) keep[q] = am[q];
             h_chain(hprev, 1);
             cells(t, 1, cstB, false);
             __syncthreads();

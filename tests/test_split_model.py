@@ -1,9 +1,10 @@
 """A numpy model of the split-precision critic arithmetic (taco_policy.hpp taco_critic_lstm_pair_split_kernel, include/taco_env.h TACO_P_SPLIT_F16 /
 TACO_P_SPLIT_BF16) on the reference's own weights (tests/golden/policy_documented.npz): every f32 operand v of the LSTM's product chains as two
-16-bit halves, v = v1 + v2' / S, v1 = RN16(v), v2' = RN16((v - v1) S); a chain = sum x1 w1 + (sum x1 w2' + sum x2' w1) / S.  CPU evidence for what
+16-bit halves, v = v1 + v2, v1 = RN16(v), v2 = RN16(v - v1); a chain = sum x1 w1 + sum x1 w2 + sum x2 w1.  CPU evidence for what
 the GPU tests measure (tests/test_policy_gpu.py::test_split_precision_critic_stays_within_its_bar_of_the_f32_kernel):
-  * f16 halves (S = 2^11) stay within 2e-6 of the f32 chain on O(1) inputs -- the fast cell's bar -- and need the scale: the same halves WITHOUT it,
-    on hardware that flushes subnormal operands, would lose the low half of every typical weight (1e-4);
+  * f16 halves stay within 2e-6 of the f32 chain on O(1) inputs -- the fast cell's bar -- PROVIDED the pipe keeps subnormal operands (gfx950 does:
+    tools/ubench/mfma_f16_denorm); on hardware that flushed them the low half of every typical weight would be lost (1e-4), which is why the first
+    two forms of the kernel scaled the low halves by 2^11 (modelled too: same accuracy);
   * bf16 halves with three terms do not (1e-5): rejected; six terms (a three-way split) would, at 1.5 x the weight registers.
 """
 import os
@@ -33,12 +34,15 @@ def _mm(x, W, mode):
     d = lambda a: a.astype(np.float64)
     if mode == "f32":
         return (d(x) @ d(W).T).astype(np.float32)
-    if mode in ("f16", "bf16"):        # the kernel's form: scaled low halves, cross terms accumulated apart and scaled back
-        cv, S = (_f16, 2048.0) if mode == "f16" else (_bf16, 256.0)
+    if mode in ("f16", "bf16"):        # the kernel's form: v2 = RN16(v - v1), subnormal low halves KEPT (gfx950's 16-bit MFMAs keep them:
+        cv = _f16 if mode == "f16" else _bf16   # tools/ubench/mfma_f16_denorm), one accumulator for the three chains
         x1, w1 = cv(x), cv(W)
-        x2, w2 = cv((x - x1) * np.float32(S)), cv((W - w1) * np.float32(S))
-        if mode == "f16":
-            x2, w2 = _ftz16(x2), _ftz16(w2)   # (even flushed, a scaled low half loses at most 3e-8 of its operand)
+        x2, w2 = cv(x - x1), cv(W - w1)
+        return (d(x1) @ d(w1).T + d(x1) @ d(w2).T + d(x2) @ d(w1).T).astype(np.float32)
+    if mode == "f16_scaled":           # the first two forms: low halves scaled by 2^11 into the normal range, cross terms accumulated apart
+        S = 2048.0
+        x1, w1 = _f16(x), _f16(W)
+        x2, w2 = _ftz16((x - x1) * np.float32(S)), _ftz16((W - w1) * np.float32(S))   # (even flushed, a scaled low half loses at most 3e-8 of its operand)
         cross = (d(x1) @ d(w2).T + d(x2) @ d(w1).T).astype(np.float32)
         return (d(x1) @ d(w1).T + d(cross) / S).astype(np.float32)
     if mode == "f16_unscaled_flushed":
@@ -79,10 +83,10 @@ def test_split_f16_meets_the_fast_cells_bar_and_bf16_does_not():
         S = np.concatenate([g["states"] * scale, (rng.standard_normal((1500, 5, 26)) * scale).astype(np.float32)]).astype(np.float32)
         ref = _critic(g, S, "f32")
         assert np.abs(ref[:100] - g["value"]).max() < 1e-5 or scale != 1.0     # (the model's f32 chain IS the reference's critic)
-        for mode in ("f16", "bf16", "bf16x6", "f16_unscaled_flushed"):
+        for mode in ("f16", "f16_scaled", "bf16", "bf16x6", "f16_unscaled_flushed"):
             worst[mode] = max(worst.get(mode, 0.0), float(np.abs(_critic(g, S, mode) - ref).max()))
     print("max |value - f32 chain| over inputs x 0.3 / 1 / 3: " + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
-    assert worst["f16"] < 5e-7                       # (GPU, incl. the hardware cell's own 7e-7: 3e-7 ... 1e-6)
+    assert worst["f16"] < 5e-7 and worst["f16_scaled"] < 5e-7   # (GPU, incl. the hardware cell's own 7e-7: 3e-7 ... 1e-6)
     assert 2e-6 < worst["bf16"] < 5e-5               # three bf16 terms: outside the bar -> rejected
     assert worst["bf16x6"] < 2e-7                    # six terms would do, at 1.5 x the weight registers
-    assert worst["f16_unscaled_flushed"] > 5e-5      # why the low halves are scaled into the normal range
+    assert worst["f16_unscaled_flushed"] > 5e-5      # what a pipe that FLUSHED subnormal operands would make of the unscaled halves (gfx950 does not)
