@@ -248,7 +248,7 @@ typedef struct taco_policy_cfg {
 #define TACO_P_EXACT_CELL 1
 /* OPT-IN, round 5: the batched critic's LSTM over a frame ring (taco_critic_values_ring, taco_rollout_run with a state stack) on the 16-bit
  * matrix pipe with SPLIT operands -- every f32 operand as two 16-bit halves, three MFMA chains per product chain, f32 accumulation
- * (taco_policy.hpp taco_critic_lstm_pair_split_kernel; critic at 557 056 rows 3.22 -> 1.41 ms).  TACO_P_SPLIT_F16: f16 halves (11 + 11
+ * (taco_policy.hpp taco_critic_lstm_pair_split_kernel; critic at 557 056 rows 3.22 -> 1.31 ms).  TACO_P_SPLIT_F16: f16 halves (11 + 11
  * significant bits): values within ~1e-6 of the exact f32 critic's on O(1) frames (8.3e-7 measured, the fast cell alone 7.2e-7; asserted
  * <= 2e-6 x max(1, |value|), the fast cell's own bar; frame words beyond +-65 504 are clamped).  TACO_P_SPLIT_BF16: bf16 halves (8 + 8
  * bits): ~1.7e-5, outside that bar -- kept for the A/B record only.  Other layouts (materialised stacks, one slot, states_dim = 32)
