@@ -525,6 +525,8 @@ def test_ring_backed_state_stack_through_capture_checkpoint_and_the_c_abi(tmp_pa
         # (2) ... the C entry point without the window report is capturable: two steps on the action in `act`
         for _ in range(2):
             _lib.check(env.lib.taco_step_rollout(env._h, C.byref(io), C.c_void_p(s.cuda_stream)), env.lib)
+        with pytest.raises(_lib.TacoError, match="capturing"):
+            env.release_graphs()                  # (graph mode cannot be left while the capture is still open: that would synchronise into it)
         graph.capture_end()
     torch.cuda.current_stream().wait_stream(s)
     t = 11
