@@ -264,8 +264,7 @@ def test_policy_transcendentals_and_noise():
 GLUE_MAXIMA = {}
 
 
-@pytest.mark.parametrize("mode", ["roundtrip", "carried"])
-@pytest.mark.parametrize("case", GLUE_CASES)
+@pytest.mark.parametrize("case,mode", [(c, m) for c in GLUE_CASES for m in ("roundtrip", "carried")] + [(c, "roundtrip") for c in GLUE_CASES_IEEE])
 def test_task_glue_equals_the_references_own_step(case, mode, golden):
     from oracle import oracle as O
     from taco_amd import config
