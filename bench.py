@@ -333,7 +333,9 @@ def rollout_entry(n, horizon, dev, torch):
     """config 5's 'LSTM-critic rollout': one taco_rollout_run call = horizon x (actor forward -> clipped action -> env step writing the next
     replay slot), then the critic over all horizon + 1 slots in one batched pass + time-out bootstrap, then GAE.  Random-init weights of the
     documented architecture (actor MLP 26-128-128-128-4, critic LSTM 26->128 over 5 frames + MLP 128-128-128-1).  The critic is timed alone
-    as well (taco_critic_values over the same (horizon + 1) x n state stacks) and priced against the f32 MFMA peak."""
+    as well (over the replay store's frame ring) in BOTH of its forms: the host layer's default since round 5 -- the ring-form LSTM on the
+    16-bit matrix pipe with split-f16 operands (TACO_P_SPLIT_F16: values within 1e-6 of the f32 kernel's) -- and the
+    f32 MFMA kernel (ActorCritic(critic_split=None), the C ABI's own default), priced against the f32 MFMA peak."""
     import numpy as np
     from taco_amd import config, policy as P
     from taco_amd.rollout import RolloutBuffer
@@ -343,133 +345,85 @@ def rollout_entry(n, horizon, dev, torch):
     buf = RolloutBuffer(n, 26, 1, 26, env.len_states, 4, horizon, 4, 0.99, 0.95, str(dev))
     hd = 128
     sd = documented_policy(np.random.default_rng(0))
-    pol = P.ActorCritic(sd, 1, env.len_states)
+    pol = P.ActorCritic(sd, 1, env.len_states)                        # default: critic_split = "f16"
+    pol32 = P.ActorCritic(sd, 1, env.len_states, critic_split=None)   # the f32 MFMA critic
 
-    def run():
-        buf.reset()
-        last = buf.run(env, pol)
-        buf.compute_returns_and_advantage(last)
-
-    for _ in range(3):
-        run()
-    torch.cuda.synchronize()
-    ts = []
-    for _ in range(5):
-        t0 = time.perf_counter()
-        for _ in range(4):
+    def time_rollout(p, reps=5, inner=4):
+        def run():
+            buf.reset()
+            last = buf.run(env, p)
+            buf.compute_returns_and_advantage(last)
+        for _ in range(3):
             run()
         torch.cuda.synchronize()
-        ts.append((time.perf_counter() - t0) / 4)
-    ts.sort()
-    fused_ms = ts[2] * 1e3
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            for _ in range(inner):
+                run()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) / inner)
+        ts.sort()
+        return ts[len(ts) // 2]
+
+    def time_critic(p, st):
+        for _ in range(3):
+            p.values_ring(st)
+        torch.cuda.synchronize()
+        cs = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(4):
+                p.values_ring(st)
+            e1.record()
+            torch.cuda.synchronize()
+            cs.append(e0.elapsed_time(e1) * 1e-3 / 4)
+        cs.sort()
+        return cs[2]
+
+    fused_s = time_rollout(pol)
+    fused32_s = time_rollout(pol32)
     env.set_rollout_fusion(False)   # the launch-per-step path of the same call (2 x horizon + 3 launches), for comparison
-    run()
-    torch.cuda.synchronize()
-    us = []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        for _ in range(4):
-            run()
-        torch.cuda.synchronize()
-        us.append((time.perf_counter() - t0) / 4)
-    us.sort()
+    lps_s = time_rollout(pol, reps=3)
     env.set_rollout_fusion(True)
     forced_ms = None
     if n > 8192:   # the persistent kernel FORCED above its limit (its workgroups queue: 16 envs hold a whole CU): the record of why the limit stands
         try:
             env.set_rollout_fusion("force")
-            run()
-            torch.cuda.synchronize()
-            fs = []
-            for _ in range(3):
-                t0 = time.perf_counter()
-                for _ in range(2):
-                    run()
-                torch.cuda.synchronize()
-                fs.append((time.perf_counter() - t0) / 2)
-            fs.sort()
-            forced_ms = fs[1] * 1e3
+            forced_ms = time_rollout(pol, reps=3, inner=2) * 1e3
         finally:
             env.set_rollout_fusion(True)
     rows, T, hd2 = (horizon + 1) * n, env.len_states, hd
     st = buf._frames   # the replay store's frame ring [horizon + T][n][26]: what taco_rollout_run's critic pass reads
-    for _ in range(3):
-        pol.values_ring(st)
-    torch.cuda.synchronize()
-    cs = []
-    for _ in range(5):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(4):
-            pol.values_ring(st)
-        e1.record()
-        torch.cuda.synchronize()
-        cs.append(e0.elapsed_time(e1) * 1e-3 / 4)
-    cs.sort()
+    c16, c32 = time_critic(pol, st), time_critic(pol32, st)
+    v16, v32 = pol.values_ring(st), pol32.values_ring(st)
+    dv, vmax = float((v32 - v16).abs().max()), float(v32.abs().max())
     flops = 2 * rows * (T * 4 * hd2 * (26 + hd2) + 2 * hd2 * hd2 + hd2)
-    # OPT-IN (round 5): the same critic with the ring-form LSTM on the 16-bit matrix pipe, split-f16 operands (TACO_P_SPLIT_F16): alone, and the
-    # whole rollout with it; max |value difference| to the default kernel on this rollout's own frames
-    split = None
-    try:
-        pol16 = P.ActorCritic(sd, 1, env.len_states, critic_split="f16")
-        v32, v16 = pol.values_ring(st), pol16.values_ring(st)
-        dv = float((v32 - v16).abs().max())
-        vmax = float(v32.abs().max())
-        for _ in range(3):
-            pol16.values_ring(st)
-        torch.cuda.synchronize()
-        c16 = []
-        for _ in range(5):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(4):
-                pol16.values_ring(st)
-            e1.record()
-            torch.cuda.synchronize()
-            c16.append(e0.elapsed_time(e1) * 1e-3 / 4)
-        c16.sort()
-
-        def run16():
-            buf.reset()
-            last = buf.run(env, pol16)
-            buf.compute_returns_and_advantage(last)
-
-        for _ in range(2):
-            run16()
-        torch.cuda.synchronize()
-        r16 = []
-        for _ in range(5):
-            t0 = time.perf_counter()
-            for _ in range(4):
-                run16()
-            torch.cuda.synchronize()
-            r16.append((time.perf_counter() - t0) / 4)
-        r16.sort()
-        split = {"flag": "ActorCritic(critic_split='f16') / TACO_P_SPLIT_F16 (opt-in; default stays f32 MFMA)", "critic_ms": c16[2] * 1e3,
-                 "speedup_vs_default_critic": cs[2] / c16[2], "ms_per_rollout": r16[2] * 1e3, "env_steps_per_s": n * horizon / r16[2],
-                 "max_abs_value_difference_to_default": dv, "max_abs_value": vmax,
-                 "note": "every f32 operand of the LSTM's chains as two f16 halves (11 + 11 bits, low half scaled by 2^11), three v_mfma_f32_16x16x32_f16 "
-                         "chains per product chain, f32 accumulation; MLP and cells unchanged; trajectories / actions / log-probs / dones bit-identical"}
-    except Exception as e:  # noqa: BLE001
-        split = {"error": repr(e)[:300]}
-    # what the kernels actually issue (v_mfma_f32_16x16x4_f32 = 2 048 flop): the paired-slot LSTM kernel runs blocks of 16 envs x 2 slots, per
+    # what the f32 kernels actually issue (v_mfma_f32_16x16x4_f32 = 2 048 flop): the paired-slot LSTM kernel runs blocks of 16 envs x 2 slots, per
     # wavefront 64 MFMAs at the first timestep (x chains only: h_-1 = 0) and 288 at each later one (shared input projection); the MLP 544 per
     # 16 rows.  K is padded 26 -> 32 in the x chains, so this is not a subset of the model count either; SQ_INSTS_MFMA in profiles/ agrees.
     issued = 2048 * (((n + 15) // 16) * ((horizon + 2) // 2) * 8 * (64 + (T - 1) * 288) + ((rows + 15) // 16) * 544) if T >= 2 else None
     return {"config": 5, "what": "taco_rollout_run (actor forward + env step per step, replay store fused; critic batched over all slots afterwards) + GAE",
-            "envs": n, "horizon": horizon, "len_states": T, "ms_per_rollout": fused_ms, "env_steps_per_s": n * horizon / ts[2],
+            "envs": n, "horizon": horizon, "len_states": T, "ms_per_rollout": fused_s * 1e3, "env_steps_per_s": n * horizon / fused_s,
+            "ms_per_rollout_f32_critic": fused32_s * 1e3, "env_steps_per_s_f32_critic": n * horizon / fused32_s,
             "per_step_chain": ("ONE persistent kernel (a workgroup owns 16 envs for the whole horizon; the actor's MFMAs run under the substeps): 4 launches per rollout"
                                if n <= 8192 else "actor launch + step launch per step (above 8 192 envs)"),
-            "ms_per_rollout_launch_per_step": us[1] * 1e3,
+            "ms_per_rollout_launch_per_step": lps_s * 1e3,
             "ms_per_rollout_persistent_forced": forced_ms,
-            "critic_split_f16": split,
-            "critic": {"rows": rows, "ms": cs[2] * 1e3, "tflops": flops / cs[2] / 1e12, "frac_of_f32_mfma_peak": flops / cs[2] / 157.3e12,
-                       "mfma_tflops_issued": issued / cs[2] / 1e12 if issued else None,
-                       "frac_of_f32_mfma_peak_issued": issued / cs[2] / 157.3e12 if issued else None,
-                       "lstm_cell": "hardware 2^x / reciprocal (default; TACO_P_EXACT_CELL keeps the oracle's operations, +23 % critic time)",
-                       "note": "tflops / frac_of_f32_mfma_peak: MODEL flops 2 rows (T 4 H (26 + H) + 2 H H + H) over the LSTM + MLP kernels' time -- the "
-                               "kernels skip the h chain of the first timestep and share input projections between neighbouring slots, so the matrix "
-                               "pipe's own utilisation is the *_issued pair (MFMA instructions issued x 2 048 flop); peak 157.3 TFLOP/s (MI355X_MICROARCH.md)"}}
+            "critic": {"rows": rows, "ms": c16 * 1e3, "kernel": "ring-form LSTM on v_mfma_f32_16x16x32_f16 with split-f16 operands (the host layer's default, TACO_P_SPLIT_F16) + f32 MFMA MLP",
+                       "tflops_model": flops / c16 / 1e12, "speedup_vs_f32_critic": c32 / c16,
+                       "max_abs_value_difference_to_f32_critic": dv, "max_abs_value": vmax,
+                       "bound": "VALU issue (the cells' activations and the operand splits), not the matrix pipe: DESIGN.md section 4.3",
+                       "note": "every f32 operand of the LSTM's chains as two f16 halves (11 + 11 bits), three MFMA chains per product chain into one f32 accumulator; "
+                               "trajectories / actions / log-probs / dones bit-identical to the f32 critic's rollout"},
+            "critic_f32": {"rows": rows, "ms": c32 * 1e3, "tflops": flops / c32 / 1e12, "frac_of_f32_mfma_peak": flops / c32 / 157.3e12,
+                           "mfma_tflops_issued": issued / c32 / 1e12 if issued else None,
+                           "frac_of_f32_mfma_peak_issued": issued / c32 / 157.3e12 if issued else None,
+                           "lstm_cell": "hardware 2^x / reciprocal (TACO_P_EXACT_CELL keeps the oracle's operations, +23 % critic time)",
+                           "note": "ActorCritic(critic_split=None), the C ABI's default. tflops / frac_of_f32_mfma_peak: MODEL flops 2 rows (T 4 H (26 + H) + 2 H H + H) over the LSTM + MLP kernels' time -- the "
+                                   "kernels skip the h chain of the first timestep and share input projections between neighbouring slots, so the matrix "
+                                   "pipe's own utilisation is the *_issued pair (MFMA instructions issued x 2 048 flop); peak 157.3 TFLOP/s (MI355X_MICROARCH.md)"}}
 
 
 def shader_clock_mhz():

@@ -246,7 +246,7 @@ typedef struct taco_policy_cfg {
  * TACO_P_EXACT_CELL keeps the oracle's operations in those kernels (bit-identical to taco_policy_act and oracle/taco_policy_oracle.c; +23 %
  * critic time).  taco_policy_act itself always uses the exact cell. */
 #define TACO_P_EXACT_CELL 1
-/* OPT-IN, round 5: the batched critic's LSTM over a frame ring (taco_critic_values_ring, taco_rollout_run with a state stack) on the 16-bit
+/* OPT-IN at this boundary (the Python host layer, taco_amd/policy.py, sets TACO_P_SPLIT_F16 by default), round 5: the batched critic's LSTM over a frame ring (taco_critic_values_ring, taco_rollout_run with a state stack) on the 16-bit
  * matrix pipe with SPLIT operands -- every f32 operand as two 16-bit halves, three MFMA chains per product chain, f32 accumulation
  * (taco_policy.hpp taco_critic_lstm_pair_split_kernel; critic at 557 056 rows 3.22 -> 1.31 ms).  TACO_P_SPLIT_F16: f16 halves (11 + 11
  * significant bits): values within ~1e-6 of the exact f32 critic's on O(1) frames (8.3e-7 measured, the fast cell alone 7.2e-7; asserted

@@ -125,19 +125,23 @@ def pack_state_dict(cfg, sd):
 class ActorCritic:
     """Inference-side mirror of PPO_ActorCritic (nets_asymmetry.py:270-355) on the HIP policy kernel."""
 
-    def __init__(self, state_dict, obs_len, states_len, device="cuda:0", seed=0, obs_dim=26, states_dim=26, exact_critic=False, critic_split=None):
+    def __init__(self, state_dict, obs_len, states_len, device="cuda:0", seed=0, obs_dim=26, states_dim=26, exact_critic=False, critic_split="auto"):
         """exact_critic: the batched critic (values / values_ring / RolloutBuffer.run) keeps the oracle's op-for-op LSTM cell, bit-identical
         to act()'s `value`; default: the hardware's 2^x / reciprocal in the cell, 19 % faster, values within 2e-6 (TACO_P_EXACT_CELL).
-        critic_split: None (default: f32 MFMA) | "f16" | "bf16" -- OPT-IN: the ring-form LSTM of the batched critic on the 16-bit matrix
-        pipe with split operands (include/taco_env.h TACO_P_SPLIT_F16 / TACO_P_SPLIT_BF16): "f16" stays within 2e-6 of the default kernel's
-        values, "bf16" does not (~5e-6; kept for the A/B record).  Excludes exact_critic."""
+        critic_split: "auto" (default) | None | "f16" | "bf16" -- the ring-form LSTM of the batched critic (values_ring, RolloutBuffer.run) on
+        the 16-bit matrix pipe with split operands (include/taco_env.h TACO_P_SPLIT_F16 / TACO_P_SPLIT_BF16): 2.6 x the f32 MFMA kernel.
+        "f16": values within 1e-6 of the exact f32 critic's on O(1) frames -- the fast cell's own 2e-6 bar (the error table
+        this default rests on); "bf16": ~2e-5, outside it (kept for the A/B record); None: the f32 MFMA kernel.  "auto" = "f16" unless
+        exact_critic (which excludes a split).  The C ABI's own default (flags = 0) is the f32 kernel: the host layer opts in."""
         self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.TacoError("the policy kernel runs on an MI355X; device must be a cuda:N (HIP) device")
         self.cfg = cfg_from_state_dict(state_dict, obs_len, states_len, obs_dim, states_dim)
+        if critic_split == "auto":
+            critic_split = None if exact_critic else "f16"
         if critic_split not in (None, "f16", "bf16"):
-            raise ValueError("critic_split must be None, 'f16' or 'bf16'")
+            raise ValueError("critic_split must be 'auto', None, 'f16' or 'bf16'")
         if exact_critic and critic_split:
             raise ValueError("exact_critic and critic_split exclude each other")
         self.cfg.flags = (P_EXACT_CELL if exact_critic else 0) | {None: 0, "f16": P_SPLIT_F16, "bf16": P_SPLIT_BF16}[critic_split]

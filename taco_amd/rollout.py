@@ -141,7 +141,7 @@ class RolloutBuffer:
         action -> env step writing slot t + 1), then the critic over all H + 1 slots in one batched pass (nothing before GAE reads a
         value) + the time-out bootstrap: 2 H + 3 launches enqueued back to back with no host work in between.  Fills every buffer `store` fills; returns last_values [N, 1] for
         compute_returns_and_advantage.  Equivalent to the act()/collect() loop (tests/test_rollout_gpu.py): bit for bit with
-        ActorCritic(exact_critic=True); with the default LSTM cell the critic's values agree to 2e-6 and everything else stays bit-identical."""
+        ActorCritic(exact_critic=True); with the default critic (hardware LSTM cell, split-f16 operands on the 16-bit matrix pipe) the values agree to 2e-6 and everything else stays bit-identical."""
         if self.step != 0:
             raise AssertionError("run() fills a whole rollout: call reset() first")
         if math.isfinite(env.clip_obs) or math.isfinite(env.clip_states):
