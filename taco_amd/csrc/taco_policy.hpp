@@ -925,7 +925,8 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_kernel(cons
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
-// The pair kernel on the 16-BIT MATRIX PIPE with SPLIT operands (round 5; include/taco_env.h TACO_P_SPLIT_F16 / TACO_P_SPLIT_BF16 -- opt-in).
+// The pair kernel on the 16-BIT MATRIX PIPE with SPLIT operands (round 5; include/taco_env.h TACO_P_SPLIT_F16 / TACO_P_SPLIT_BF16: a flag at the C
+// boundary, which the Python host layer sets by default -- taco_amd/policy.py critic_split).
 // taco_critic_lstm_pair_kernel is MFMA time + the cells' VALU time, and its MFMA time is the f32 pipe's: v_mfma_f32_16x16x4_f32 delivers
 // 2 048 flop in 32 cycles, v_mfma_f32_16x16x32_{f16,bf16} 16 384 in 16 (MI355X_MICROARCH.md) -- 16 x per cycle.  Every f32 operand v is
 // split into two 16-bit halves, v = v1 + v2 with v1 = RN16(v) and v2 = RN16(v - v1) (v - v1 is exact in f32; the low half of a typical f16
@@ -937,16 +938,15 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_kernel(cons
 // f16 halves: |value difference| 3e-7 ... 1e-6 on O(1) values (the hardware cell alone: 7e-7) -- inside the 2e-6 bar of the fast cell; bf16
 // halves with three terms: 1e-5 ... 3e-5, OUTSIDE that bar (six terms -- a three-way split -- would meet it at 1.5 x the weight registers,
 // which this kernel does not have).
-// (Second form, same round: the frames are split ONCE per block into LDS planes, the product is taken transposed and the bias rides in an input
-// column -- see the kernel.)
 // Operand range of the f16 form: frame words are clamped to +-65 504 (frames are O(1): normalised positions, rates, voltages -- the clamp
 // only keeps a diverged env's huge finite word from turning into inf - inf = NaN); h_t lies in [-1, 1]; bf16 has f32's range.
 // Layout (cdna_hip_programming.md section 3): lane (r = lane & 15, g = lane >> 4) holds A[row r][k = 32 S + 8 g + j] and
-// B[k = 32 S + 8 g + j][col r], j = 0 .. 7 (four VGPRs each); C / D as in the f32 form (row 4 g + i, col r).  Weights: both halves of the
-// wavefront's W_ih / W_hh columns resident (2 x 16 bit per weight: the 160 registers of the f32 form).  h_t travels through LDS as two
-// 16-bit planes written by the cells' producers (2 x ds_write_b16 instead of one b32), read back as ds_read_b128 per plane and K block,
-// row stride 272 B = 17 slots of 16 B -- row r's slot c on bank slot (r + c) mod 16 like the f32 tiles, so the same swizzle c ^ b(r)
-// keeps the reads conflict-free.  The last timestep's h_T leaves as f32 (the MLP kernel is unchanged).
+// B[k = 32 S + 8 g + j][col r], j = 0 .. 7 (four VGPRs each); D: row 4 g + i, col r.  The product is taken TRANSPOSED (D = W x^T: the weights
+// are the A operand, the activations the B operand -- see the kernel).  Weights: both halves of the wavefront's W_ih / W_hh columns resident
+// (2 x 16 bit per weight: the 160 registers of the f32 form).  The frames are split ONCE per block into LDS planes; h_t travels through LDS as
+// two 16-bit planes (one 8-byte store per plane and lane), read back as ds_read_b128 per plane and K block, row stride 272 B = 17 slots of
+// 16 B -- row r's slot c on bank slot (r + c) mod 16 like the f32 tiles, so the same swizzle c ^ b(r) keeps the reads conflict-free.  The
+// bias rides in the weights' column sd against a 1.0 in the frames.  The last timestep's h_T leaves as f32 (the MLP kernel is unchanged).
 // Everything else -- persistent workgroups, pairs of consecutive slots sharing the input projection, LDS-DMA staging -- is the pair kernel's.
 template <int KIND> struct SplitKind;
 template <> struct SplitKind<1> {

@@ -35,7 +35,7 @@ def test_act_matches_reference_golden():
 @pytest.mark.parametrize("kind,bar", [("f16", 2e-6), ("bf16", 1e-4)])
 @pytest.mark.parametrize("slots,n,states_len,scale", [(8, 256, 5, 1.0), (33, 1000, 5, 1.0), (7, 90, 5, 3.0), (5, 70, 3, 0.2), (9, 333, 8, 1.0), (6, 64, 2, 20.0)])
 def test_split_precision_critic_stays_within_its_bar_of_the_f32_kernel(kind, bar, slots, n, states_len, scale):
-    """ActorCritic(critic_split=...) -- the ring-form LSTM on the 16-bit matrix pipe with split operands (TACO_P_SPLIT_F16 / _BF16, opt-in):
+    """ActorCritic(critic_split=...) -- the ring-form LSTM on the 16-bit matrix pipe with split operands (TACO_P_SPLIT_F16 / _BF16; "f16" is the host layer's default for the ring form):
     against the exact f32 critic on the same frame ring.  f16 halves: <= 2e-6 (the fast cell's own bar; measured ~2e-7); bf16 halves with
     three terms: measured 1e-5 ... 3e-5 (9e-5 on 20-sigma inputs) -- OUTSIDE 2e-6, which is why it is kept for the A/B record only; asserted
     against a loose 1e-4 so that the record stays reproducible.  (The bars scale with max(1, |value|): 20-sigma inputs give |value| ~ 2.)  Even / odd slot counts, ragged env groups, short and long stacks, small and 20-sigma inputs."""
