@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Golden traces of the reference's OWN task glue -- `fpv_asymmetry.py` + `vec_task_asymmetry.py` -- driven end to end on CPU.
 
-    python tests/golden/make_glue_golden.py [/root/reference]          (build container only; writes tests/golden/glue_*.npz)
+    python tests/golden/make_glue_golden.py [/root/reference] [--family torch|ieee|both] [--only case,case]
+                                                                       (build container only; writes tests/golden/glue_*.npz, glue_*_ieee.npz)
+
+Two families of the same eleven cases: `torch` = the reference as it runs in this container; `ieee` (round 5) = the same with `torch.sqrt` replaced,
+inside control/battery_dynamics.py's namespace only, by the correctly rounded fp32 square root (_TorchWithIEEESqrt) -- what the reference's real
+platform (CUDA's sqrtf) and both the oracle and the HIP kernel compute; against that family one step is bit-equal (tests/util.py EXACT_GROUPS).
 
 `fpv_asymmetry.py` cannot be imported as it stands (it needs the Isaac Gym binary, gym, matplotlib/TkAgg).  Here its module is loaded
 from the reference tree with in-memory STUB modules for those dependencies (no reference text is copied or stored):
