@@ -56,6 +56,23 @@ def test_split_precision_critic_stays_within_its_bar_of_the_f32_kernel(kind, bar
         P.ActorCritic(sd, 1, states_len, exact_critic=True, critic_split=kind)
 
 
+@pytest.mark.parametrize("states_dim", [17, 19, 30, 31, 32])
+def test_split_precision_critic_other_state_widths(states_dim):
+    """The split kernel stages the frames as they lie in the ring (LDS-DMA where 16-byte pieces allow, plain loads otherwise), splits them into its
+    LDS planes and puts the bias into the weights' column `states_dim`: odd and even widths, 31 (the last free column) -- and 32, which has no free
+    column: the host sends it to the f32 kernel (bit-identical to critic_split=None)."""
+    from taco_amd import policy as P
+    rng = np.random.default_rng(states_dim)
+    sd = _random_policy(rng, 1, 4, [32], 128, [128, 128], states_dim=states_dim)
+    frames = torch.from_numpy(rng.standard_normal((9, 123, states_dim)).astype(np.float32)).cuda()
+    ref = P.ActorCritic(sd, 1, 4, seed=3, states_dim=states_dim, exact_critic=True).values_ring(frames).cpu().numpy()
+    got = P.ActorCritic(sd, 1, 4, seed=3, states_dim=states_dim, critic_split="f16").values_ring(frames).cpu().numpy()
+    assert np.isfinite(got).all() and np.abs(got - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max())
+    if states_dim == 32:
+        f32 = P.ActorCritic(sd, 1, 4, seed=3, states_dim=states_dim, critic_split=None).values_ring(frames).cpu().numpy()
+        assert_bits_equal(got, f32, "states_dim = 32: the split flag falls back to the f32 kernel")
+
+
 def test_split_precision_critic_matches_reference_golden_and_rollout_trajectories_do_not_move():
     """policy_documented.npz through the split-f16 critic: inside the 1e-5 bar to the reference's own numbers (a ring built from the fixture's
     stacks); and a rollout with critic_split='f16' produces bit-identical observations / actions / log-probs / rewards / dones -- only
