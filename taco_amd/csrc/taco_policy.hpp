@@ -960,6 +960,16 @@ template <> struct SplitKind<2> {
     static __device__ __forceinline__ pf32x4 mfma(V8 a, V8 b, pf32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 };
 constexpr int CR_HLD = 272;   // bytes per row of a 16-bit h plane (128 columns + one 16-byte slot of padding)
+// The two halves of an f32 value: hi = RN16(v), lo = RN16(v - hi).  The value is PINNED first: left to itself hipcc folds "(half)(a * b)" into
+// v_fma_mixlo_f16 -- which rounds the EXACT product once, where a conversion of the f32 product rounds twice: one f16 ulp apart in 5e-5 of the
+// cases, tools/ubench/mixlo_rounding -- and it does so at some uses of the value and not at others (also under -ffp-contract=off).  Two builds of
+// this kernel stored a "hi" converted from the f32 value and subtracted a "hi" folded into the producing multiply: a rare one-ulp mismatch
+// between an operand's halves, 2e-5 on the critic's value, with f16 only (bf16 has no such instruction).  Behind the pin every use sees ONE value.
+template <typename HT> __device__ __forceinline__ void split16(float v, HT &hi, HT &lo) {
+    asm volatile("" : "+v"(v));
+    hi = (HT)v;
+    lo = (HT)(v - (float)hi);
+}
 
 constexpr int CR_XROWS = (POL_MAXT + 1) * 16;   // rows of a block's frame planes: (T + 1) frames x 16 envs (a multiple of 16: the [k block][row] layout below is conflict-free)
 
@@ -1009,7 +1019,7 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_split_kerne
     V8 wxh[4], wxl[4], whh[4][4], whl[4][4];
     auto halves = [](const float (&v)[8], V8 &hi, V8 &lo) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const HT h = (HT)v[j]; hi[j] = h; lo[j] = (HT)(v[j] - (float)h); }
+        for (int j = 0; j < 8; ++j) { HT h, l; split16(v[j], h, l); hi[j] = h; lo[j] = l; }
     };
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -1062,10 +1072,12 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_split_kerne
                 v0 = v0 > 65504.0f ? 65504.0f : (v0 < -65504.0f ? -65504.0f : v0);
                 v1 = v1 > 65504.0f ? 65504.0f : (v1 < -65504.0f ? -65504.0f : v1);
             }
-            const HT h0 = (HT)v0, h1 = (HT)v1;
+            HT h0, h1, l0, l1;
+            split16(v0, h0, l0);
+            split16(v1, h1, l1);
             const int at = (((k >> 3) * CR_XROWS + row) << 4) + (k & 7) * 2;
             *reinterpret_cast<V2 *>(xp[half][0] + at) = V2{h0, h1};
-            *reinterpret_cast<V2 *>(xp[half][1] + at) = V2{(HT)(v0 - (float)h0), (HT)(v1 - (float)h1)};
+            *reinterpret_cast<V2 *>(xp[half][1] + at) = V2{l0, l1};
         }
     };
     stage((int)blockIdx.x);
@@ -1122,7 +1134,7 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_split_kerne
             unsigned char *oh = hs[t & 1][0] + row * CR_HLD + (((c0 >> 3) ^ cr_b(row)) << 4) + (c0 & 7) * 2;
             V4 hi, lo;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { const HT h = (HT)hv[i]; hi[i] = h; lo[i] = (HT)(hv[i] - (float)h); }
+            for (int i = 0; i < 4; ++i) { HT h, l; split16(hv[i], h, l); hi[i] = h; lo[i] = l; }
             *reinterpret_cast<V4 *>(oh) = hi;
             *reinterpret_cast<V4 *>(oh + CR_ROWS * CR_HLD) = lo;
         }
