@@ -34,7 +34,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${TAG}_rollout" -- p
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_INSTS_LDS --output-format csv -d "$O/${TAG}_rollout_pmc/a" -- python3 "$R/tools/prof_rollout.py" >> "$O/${TAG}_pmc.log" 2>&1
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d "$O/${TAG}_rollout_pmc/b" -- python3 "$R/tools/prof_rollout.py" >> "$O/${TAG}_pmc.log" 2>&1
 cd "$R"
-python3 tools/pmc_kernels.py "$O/${TAG}_rollout_pmc" "$O/${TAG}_rollout_pmc.json" taco_rollout_kernel taco_critic_lstm_pair_kernel taco_critic_mlp > /dev/null
+python3 tools/pmc_kernels.py "$O/${TAG}_rollout_pmc" "$O/${TAG}_rollout_pmc.json" taco_rollout_kernel taco_critic_lstm_pair_split_kernel taco_critic_lstm_pair_kernel taco_critic_mlp > /dev/null
 python3 tools/pmc_summary.py "$TAG"
 cp "$O/${TAG}_rollout"/*/*kernel_stats.csv "$O/${TAG}_rollout_kernel_stats.csv"
 cp "$O/${TAG}_step_api"/*/*kernel_stats.csv "$O/${TAG}_step_api_kernel_stats.csv"
