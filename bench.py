@@ -411,7 +411,7 @@ def rollout_entry(n, horizon, dev, torch):
                                if n <= 8192 else "actor launch + step launch per step (above 8 192 envs)"),
             "ms_per_rollout_launch_per_step": lps_s * 1e3,
             "ms_per_rollout_persistent_forced": forced_ms,
-            "critic": {"rows": rows, "ms": c16 * 1e3, "kernel": "ring-form LSTM on v_mfma_f32_16x16x32_f16 with split-f16 operands (the host layer's default, TACO_P_SPLIT_F16) + f32 MFMA MLP",
+            "critic": {"rows": rows, "ms": c16 * 1e3, "kernel": "ring-form LSTM on v_mfma_f32_16x16x32_f16 with split-f16 operands (the host layer's default, TACO_P_SPLIT_F16) + the MLP's two hidden layers likewise (f32 head on the VALU)",
                        "tflops_model": flops / c16 / 1e12, "speedup_vs_f32_critic": c32 / c16,
                        "max_abs_value_difference_to_f32_critic": dv, "max_abs_value": vmax,
                        "bound": "VALU issue (the cells' activations and the operand splits), not the matrix pipe: DESIGN.md section 4.3",

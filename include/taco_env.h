@@ -248,8 +248,8 @@ typedef struct taco_policy_cfg {
 #define TACO_P_EXACT_CELL 1
 /* OPT-IN at this boundary (the Python host layer, taco_amd/policy.py, sets TACO_P_SPLIT_F16 by default), round 5: the batched critic's LSTM over a frame ring (taco_critic_values_ring, taco_rollout_run with a state stack) on the 16-bit
  * matrix pipe with SPLIT operands -- every f32 operand as two 16-bit halves, three MFMA chains per product chain, f32 accumulation
- * (taco_policy.hpp taco_critic_lstm_pair_split_kernel; critic at 557 056 rows 3.22 -> 1.31 ms).  TACO_P_SPLIT_F16: f16 halves (11 + 11
- * significant bits): values within ~1e-6 of the exact f32 critic's on O(1) frames (8.3e-7 measured, the fast cell alone 7.2e-7; asserted
+ * (taco_policy.hpp taco_critic_lstm_pair_split_kernel, and the MLP's two hidden layers behind it: taco_critic_mlp_split_kernel; critic at 557 056 rows 3.22 -> 1.06 ms).  TACO_P_SPLIT_F16: f16 halves (11 + 11
+ * significant bits): values within ~1e-6 of the exact f32 critic's on O(1) frames (1.25e-6 measured on values up to 1.5, the fast cell alone 7.2e-7; asserted
  * <= 2e-6 x max(1, |value|), the fast cell's own bar; frame words beyond +-65 504 are clamped).  TACO_P_SPLIT_BF16: bf16 halves (8 + 8
  * bits): ~1.7e-5, outside that bar -- kept for the A/B record only.  Other layouts (materialised stacks, one slot, states_dim = 32)
  * ignore the bits.  Excludes TACO_P_EXACT_CELL. */

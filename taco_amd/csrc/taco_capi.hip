@@ -870,6 +870,7 @@ static int launch_critic(const taco_policy_cfg *c, const float *blob, size_t row
         if (((uintptr_t)states & 15u) != 0) return fail(TACO_ERR_INVALID_ARG, "critic: the batched form needs 16-byte aligned state stacks");
         const int cus = cu_limit > 0 ? cu_limit : device_cus();
         const bool exact = (c->flags & TACO_P_EXACT_CELL) != 0;
+        int split = 0;   // 1 / 2: the split-f16 / split-bf16 kernels (TACO_P_SPLIT_*: the pair form of the ring LSTM with states_dim < 32, and the MLP behind it)
         // a persistent workgroup per CU walking blocks b, b + grid, ...: shrink the grid to the smallest that keeps the longest walk as short
         const size_t nblocks = (rows + taco::CR_ROWS - 1) / taco::CR_ROWS;
         const size_t walk = (nblocks + cus - 1) / cus;
@@ -879,9 +880,10 @@ static int launch_critic(const taco_policy_cfg *c, const float *blob, size_t row
             const size_t pb = (((size_t)ring_n + 15) / 16) * ((rows / (size_t)ring_n + 1) / 2);
             const size_t pw = (pb + cus - 1) / cus;
             const dim3 pg((unsigned)((pb + pw - 1) / pw));
+            split = (exact || c->states_dim >= 32) ? 0 : ((c->flags & TACO_P_SPLIT_F16) ? 1 : ((c->flags & TACO_P_SPLIT_BF16) ? 2 : 0));
             if (exact) hipLaunchKernelGGL(taco::taco_critic_lstm_pair_kernel<true>, pg, dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
-            else if ((c->flags & TACO_P_SPLIT_F16) && c->states_dim < 32) hipLaunchKernelGGL(taco::taco_critic_lstm_pair_split_kernel<1>, pg, dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
-            else if ((c->flags & TACO_P_SPLIT_BF16) && c->states_dim < 32) hipLaunchKernelGGL(taco::taco_critic_lstm_pair_split_kernel<2>, pg, dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
+            else if (split == 1) hipLaunchKernelGGL(taco::taco_critic_lstm_pair_split_kernel<1>, pg, dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
+            else if (split == 2) hipLaunchKernelGGL(taco::taco_critic_lstm_pair_split_kernel<2>, pg, dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
             else hipLaunchKernelGGL(taco::taco_critic_lstm_pair_kernel<false>, pg, dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
         } else if (ring_n > 0) {
             if (exact) hipLaunchKernelGGL((taco::taco_critic_lstm_kernel<true, true>), dim3(grid), dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
@@ -894,7 +896,10 @@ static int launch_critic(const taco_policy_cfg *c, const float *blob, size_t row
         if (he != hipSuccess) return hip_fail(he, "taco_critic_lstm_kernel launch");
         const size_t nchunks = (rows + taco::CR_MLP_ROWS - 1) / taco::CR_MLP_ROWS;
         const size_t cap = (size_t)2 * cus;
-        hipLaunchKernelGGL(taco::taco_critic_mlp_kernel, dim3((unsigned)(nchunks < cap ? nchunks : cap)), dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
+        const dim3 mg((unsigned)(nchunks < cap ? nchunks : cap));
+        if (split == 1) hipLaunchKernelGGL(taco::taco_critic_mlp_split_kernel<1>, mg, dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);   // (the forms the split LSTM ran in)
+        else if (split == 2) hipLaunchKernelGGL(taco::taco_critic_mlp_split_kernel<2>, mg, dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
+        else hipLaunchKernelGGL(taco::taco_critic_mlp_kernel, mg, dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
     } else {
         hipLaunchKernelGGL(taco::taco_policy_kernel, dim3((unsigned)((rows + taco::POL_ROWS - 1) / taco::POL_ROWS), 1), dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
     }

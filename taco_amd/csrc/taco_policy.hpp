@@ -946,7 +946,7 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_kernel(cons
 // (2 x 16 bit per weight: the 160 registers of the f32 form).  The frames are split ONCE per block into LDS planes; h_t travels through LDS as
 // two 16-bit planes (one 8-byte store per plane and lane), read back as ds_read_b128 per plane and K block, row stride 272 B = 17 slots of
 // 16 B -- row r's slot c on bank slot (r + c) mod 16 like the f32 tiles, so the same swizzle c ^ b(r) keeps the reads conflict-free.  The
-// bias rides in the weights' column sd against a 1.0 in the frames.  The last timestep's h_T leaves as f32 (the MLP kernel is unchanged).
+// bias rides in the weights' column sd against a 1.0 in the frames.  The last timestep's h_T leaves as f32 (taco_critic_mlp_split_kernel splits it again: same bytes as two 16-bit planes would be).
 // Everything else -- persistent workgroups, pairs of consecutive slots sharing the input projection, LDS-DMA staging -- is the pair kernel's.
 template <int KIND> struct SplitKind;
 template <> struct SplitKind<1> {
@@ -1261,6 +1261,164 @@ __global__ __launch_bounds__(64 * POL_NW, 4) void taco_critic_mlp_kernel(const P
             }
         }
         __syncthreads();
+    }
+}
+
+// The same MLP on the 16-bit matrix pipe with split operands (TACO_P_SPLIT_F16 / _BF16: the split LSTM kernel's companion).  After the LSTM moved to
+// v_mfma_f32_16x16x32_f16 the f32 MLP above was a quarter of the critic's time (88 of 330 us at 135 168 rows, 101 TFLOP/s of f32 MFMA); here every
+// product chain of the two hidden layers is three 16-bit chains into one f32 accumulator, as in taco_critic_lstm_pair_split_kernel: 12 MFMAs of 16
+// cycles per 16-row tile and layer where the f32 form issues 32 of 32 cycles.  The product is taken TRANSPOSED (D = W x^T: weights = A operand,
+// activations = B operand), so a lane's four outputs are adjacent columns of one row and leave as one 8-byte store per plane; activations travel
+// from layer 1 to layer 2 as two 16-bit planes laid out like the LSTM's h_t (row stride CR_HLD, slot c of row r at c ^ b(r): conflict-free
+// ds_read_b128).  Every value is split behind split16's pin.  ReLU outputs are clamped to f16's largest finite value in the f16 form (they are O(1);
+// the clamp only keeps inf - inf out of the low half).  The 128 -> 1 head stays in f32 on the VALU, straight from layer 2's accumulators (a lane holds
+// four columns of a row: four fma, two cross-lane adds, one partial sum per wavefront and row through LDS) -- layer 2's output is neither split nor
+// stored, and the head costs no MFMA tile of which one row in sixteen is real.
+template <int KIND>
+__global__ __launch_bounds__(64 * POL_NW, 4) void taco_critic_mlp_split_kernel(const PolicyParams P) {
+    typedef SplitKind<KIND> SK;
+    typedef typename SK::T HT;
+    typedef typename SK::V8 V8;
+    typedef typename SK::T V4 __attribute__((ext_vector_type(4)));
+    constexpr int hp = 128, ip = 32, ROWS = CR_MLP_ROWS, PLANE = ROWS * CR_HLD;
+    __shared__ __attribute__((aligned(16))) unsigned char ap[2][2][PLANE];   // [h_T / layer 1's output][high / low half][row][k], 16-bit
+    __shared__ float part[POL_NW][ROWS];                                      // the head's partial sums: [wavefront = 16 columns][row]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const float *w = P.blob;
+    {
+        int in_a = pad16(P.obs_len * P.obs_dim);
+        for (int l = 0; l <= P.n_actor_hidden; ++l) {
+            const int out = pad16(l == P.n_actor_hidden ? P.act_dim : P.actor_hidden[l]);
+            w += (size_t)out * in_a + out;
+            in_a = out;
+        }
+        w += 16 + (size_t)4 * hp * ip + (size_t)4 * hp * hp + (size_t)4 * hp;
+    }
+    const float *W1 = w, *b1 = W1 + hp * hp, *W2 = b1 + hp, *b2 = W2 + hp * hp, *W3 = b2 + hp, *b3 = W3 + 16 * hp;
+    // this wavefront's weights as A operands: lane (r, g) holds W[out 16 wave + r][k = 32 sb + 8 g + j] (the blob is fragment-major for the f32 form:
+    // float4 ((tile 8 + s) 64 + 16 g' + r) = W[16 s + 4 g' .. + 3][out 16 tile + r]; see the split LSTM kernel)
+    V8 w1h[4], w1l[4], w2h[4], w2l[4];
+    auto frag = [&](const float *W, int tile, int sb, V8 &hi, V8 &lo) {
+        const float4 *f = reinterpret_cast<const float4 *>(W) + (size_t)(tile * 8 + 2 * sb + (g >> 1)) * 64 + 32 * (g & 1) + r;
+        const float4 a = f[0], b = f[16];
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { HT h, l; split16(v[j], h, l); hi[j] = h; lo[j] = l; }
+    };
+#pragma unroll
+    for (int sb = 0; sb < 4; ++sb) { frag(W1, wave, sb, w1h[sb], w1l[sb]); frag(W2, wave, sb, w2h[sb], w2l[sb]); }
+    const int c0 = 16 * wave + 4 * g;   // this lane's output columns c0 .. c0 + 3 (of env row r of a tile)
+    float c1[4], c2[4], hw[4];          // biases of its columns; the head's weights W3[k = c0 + i][column 0] (fragment s = c0 / 16 = wave, g' = g, r = 0)
+    {
+        const float4 h4 = reinterpret_cast<const float4 *>(W3)[(size_t)wave * 64 + 16 * g];
+        hw[0] = h4.x; hw[1] = h4.y; hw[2] = h4.z; hw[3] = h4.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { c1[i] = b1[c0 + i]; c2[i] = b2[c0 + i]; }
+    const float hb = b3[0];
+    // HEAD false: relu, split, store the two planes of the next layer's input.  HEAD true: relu, this lane's share of the head, reduced over the
+    // wavefront's sixteen columns (lanes r, 16 + r, 32 + r, 48 + r), one partial per row
+    auto layer = [&](auto head_c, const unsigned char *in, unsigned char *out, const V8 (&wh)[4], const V8 (&wl)[4], const float (&bias)[4]) __attribute__((always_inline)) {
+        constexpr bool HEAD = decltype(head_c)::value;
+        constexpr int TG = 2;   // row tiles in flight per wavefront (independent accumulator chains)
+#pragma unroll
+        for (int r0 = 0; r0 < ROWS / 16; r0 += TG) {
+            pf32x4 acc[TG];
+#pragma unroll
+            for (int u = 0; u < TG; ++u) acc[u] = pf32x4{bias[0], bias[1], bias[2], bias[3]};
+#pragma unroll
+            for (int sb = 0; sb < 4; ++sb) {
+                const int pos = ((4 * sb + g) ^ cr_b(r)) << 4;
+                V8 ah[TG], al[TG];
+#pragma unroll
+                for (int u = 0; u < TG; ++u) {
+                    ah[u] = *reinterpret_cast<const V8 *>(in + (16 * (r0 + u) + r) * CR_HLD + pos);
+                    al[u] = *reinterpret_cast<const V8 *>(in + PLANE + (16 * (r0 + u) + r) * CR_HLD + pos);
+                }
+#pragma unroll
+                for (int u = 0; u < TG; ++u) acc[u] = SK::mfma(wl[sb], ah[u], acc[u]);   // (the small terms first)
+#pragma unroll
+                for (int u = 0; u < TG; ++u) acc[u] = SK::mfma(wh[sb], al[u], acc[u]);
+#pragma unroll
+                for (int u = 0; u < TG; ++u) acc[u] = SK::mfma(wh[sb], ah[u], acc[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < TG; ++u) {
+                const int row = 16 * (r0 + u) + r;
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = acc[u][i] < 0.0f ? 0.0f : acc[u][i];
+                if constexpr (HEAD) {
+                    float ps = v[0] * hw[0];
+                    ps = fma(v[1], hw[1], ps); ps = fma(v[2], hw[2], ps); ps = fma(v[3], hw[3], ps);
+                    ps += __shfl_xor(ps, 16);
+                    ps += __shfl_xor(ps, 32);
+                    if (g == 0) part[wave][row] = ps;
+                } else {
+                    unsigned char *oh = out + row * CR_HLD + (((c0 >> 3) ^ cr_b(row)) << 4) + (c0 & 7) * 2;
+                    V4 hi, lo;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float x = v[i];
+                        if constexpr (KIND == 1) x = x > 65504.0f ? 65504.0f : x;
+                        HT h, l;
+                        split16(x, h, l);
+                        hi[i] = h; lo[i] = l;
+                    }
+                    *reinterpret_cast<V4 *>(oh) = hi;
+                    *reinterpret_cast<V4 *>(oh + PLANE) = lo;
+                }
+            }
+        }
+    };
+    // a pass = 64 rows of h_T: every thread two pieces of eight columns (32 coalesced bytes each), fetched a pass ahead into registers
+    const int nchunks = (P.n + ROWS - 1) / ROWS;
+    float4 pre[4];
+    auto fetch = [&](int c) {
+        const size_t row0 = (size_t)c * ROWS;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int e = tid + 64 * POL_NW * j, row = e >> 4, slot = e & 15;
+            const bool ok = row0 + row < (size_t)P.n;
+            const float4 *src = reinterpret_cast<const float4 *>(P.hT + (row0 + row) * hp + 8 * slot);
+            pre[2 * j] = ok ? src[0] : float4{0.0f, 0.0f, 0.0f, 0.0f};
+            pre[2 * j + 1] = ok ? src[1] : float4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+    };
+    auto put = [&]() {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int e = tid + 64 * POL_NW * j, row = e >> 4, slot = e & 15;
+            const float v[8] = {pre[2 * j].x, pre[2 * j].y, pre[2 * j].z, pre[2 * j].w, pre[2 * j + 1].x, pre[2 * j + 1].y, pre[2 * j + 1].z, pre[2 * j + 1].w};
+            V8 hi, lo;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { HT h, l; split16(v[q], h, l); hi[q] = h; lo[q] = l; }
+            unsigned char *at = ap[0][0] + row * CR_HLD + ((slot ^ cr_b(row)) << 4);
+            *reinterpret_cast<V8 *>(at) = hi;
+            *reinterpret_cast<V8 *>(at + PLANE) = lo;
+        }
+    };
+    if ((int)blockIdx.x < nchunks) fetch((int)blockIdx.x);
+    for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const size_t row0 = (size_t)c * ROWS;
+        put();            // (ap[0] was last read by layer 1 of the previous pass: two barriers ago)
+        __syncthreads();
+        if (c + (int)gridDim.x < nchunks) fetch(c + (int)gridDim.x);
+        layer(std::false_type{}, ap[0][0], ap[1][0], w1h, w1l, c1);
+        __syncthreads();
+        layer(std::true_type{}, ap[1][0], nullptr, w2h, w2l, c2);
+        __syncthreads();
+        if (tid < ROWS) {   // value = b3 + the eight wavefronts' partial sums, in wavefront order (`part` is next written behind the next pass's second barrier)
+            float val = hb;
+#pragma unroll
+            for (int wv_ = 0; wv_ < POL_NW; ++wv_) val += part[wv_][tid];
+            const size_t row = row0 + tid;
+            if (row < (size_t)P.n) {
+                if (row < (size_t)P.value_split) P.value[row] = val;
+                else P.value_tail[row - (size_t)P.value_split] = val;
+            }
+        }
     }
 }
 

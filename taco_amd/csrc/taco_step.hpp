@@ -555,6 +555,8 @@ TD float4 uniform_block(const StepParams &P, uint32_t step, int gid, uint32_t st
 // this lane's block of round `rnd` of the quad layout's share-out (block 4 rnd + sub)
 TD float4 reset_block_quad(const StepParams &P, uint32_t step, int gid, int rnd, int sub) { return uniform_block(P, step, gid, STREAM_RESET, (uint32_t)(4 * rnd + sub)); }
 // `drawn` (LPE == 4, optional): the three rounds' blocks, [rnd * 64 + lane], drawn ahead by the role wavefronts (step_core: "reset draws")
+// `drawn_shared` (LPE == 1, wave-uniform; a flag, not a null test: the wavefront's scratch may sit at LDS address 0): the env's blocks 0..15 are at drawn[drawn_row * 16 + b], drawn by sixteen lanes of the wavefront
+// at once (step_core: "shared reset draws")
 // FL: the randomisation flags this build of the function is for, or ~0u = read them from the handle.  A resetting env puts ~700 issue slots on
 // the path of the wavefront that decides most launches' time, a good third of them the tests and selects of the dozen flags reset_idx consults
 // (launch-uniform, but run-time: a scalar branch around every few instructions) -- the four-role quad forms call a build with the flags of the
@@ -568,7 +570,7 @@ constexpr uint32_t kResetFlagsAll = kResetFlagMask;
 template <int LPE, uint32_t FL = ~0u>
 TD void reset_env(const StepParams &P, uint32_t step, rsrc_t rS, uint32_t voff, uint32_t row_bytes, int gid, int grp, bool mix, bool store, int sub,
                   float4 &c_pos, float4 &c_quat, float4 &c_lin, float4 &c_ang, float4 &c_pp, float4 &c_pi, float4 &c_om, float4 &c_misc, float4 &c_tau,
-                  float4 &c_op, float4 &c_a0, float4 &c_a1, const __attribute__((address_space(3))) f32x4_t *drawn = nullptr) {
+                  float4 &c_op, float4 &c_a0, float4 &c_a1, const __attribute__((address_space(3))) f32x4_t *drawn = nullptr, bool drawn_shared = false, int drawn_row = 0) {
     const uint32_t fl = FL == ~0u ? P.flags : ((P.flags & ~kResetFlagMask) | (FL & kResetFlagMask));
     const bool rc = (fl & TACO_F_RANDOM_ROTORDYNAMIC_COE) != 0, ra = (fl & TACO_F_RANDOM_AERODYNAMIC_COE) != 0;
     const bool rtau = (fl & TACO_F_ROTOR_RESPONSE) && (fl & TACO_F_RANDOM_ROTOR_RESPONSE), rspd = (fl & TACO_F_RANDOM_ROTOR_SPEED) != 0;
@@ -598,6 +600,9 @@ TD void reset_env(const StepParams &P, uint32_t step, rsrc_t rS, uint32_t voff, 
             if constexpr (LPE == 4) {
                 const int rnd = (int)(b >> 2), k = (int)(b & 3u);
                 u0 = from_lane(qu[rnd][0], k); u1 = from_lane(qu[rnd][1], k); u2 = from_lane(qu[rnd][2], k); u3 = from_lane(qu[rnd][3], k);
+            } else if (drawn_shared) {  // (wave-uniform) LPE == 1, few lanes reset: the wavefront drew this env's blocks together (step_core: "shared reset draws")
+                const f32x4_t d = drawn[drawn_row * 16 + (int)b];
+                u0 = d.x; u1 = d.y; u2 = d.z; u3 = d.w;
             } else {
                 U4 r = philox(P.seed_lo, P.seed_hi, (uint32_t)gid, step, STREAM_RESET, b);
                 u0 = uniform(r.x); u1 = uniform(r.y); u2 = uniform(r.z); u3 = uniform(r.w);
@@ -1172,10 +1177,46 @@ TD void step_core(const StepParams &Pin, const FusedCtx &FX) {
     if constexpr (DRAWS_SERVED) __syncthreads();   // barrier 1 of 2 (here in these forms: the role wavefronts' reset draws are in rs_tab, see below)
     if (P.stamps_on) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TACO_STAMP(1); }  // all up-front loads have landed
     if (wave_has_reset) {
+        // Shared reset draws (LPE == 1).  A resetting env draws from up to ten Philox blocks, and in these forms the lane that holds it evaluated
+        // them one after the other with the wavefront's other 63 lanes switched off: ~100 VALU instructions per block in every wavefront that
+        // holds a resetting env -- half of them at the benchmark's 1.1 % resets per step.  With at most four resetting lanes in the wavefront
+        // (else every lane draws for itself, as before) the sixteen lanes [16 j, 16 j + 16) evaluate blocks 0..15 of the j-th resetting lane's
+        // env in ONE Philox pass and leave the uniforms in the wavefront's scratch (the slot table is not built yet); the resetting lane reads
+        // the blocks it wants.  Same counters, same bits.  Steady state at 262 144 envs: 28.63 M -> 28.01 M VALU instructions per launch,
+        // 42.6 -> 42.4 us; one wavefront per SIMD (32 768 envs) 20.5 -> 20.2 us, flip 65 536 29.4 -> 28.9 (profiles/r05_x_*).  The quad forms
+        // keep their own share-out (three blocks per lane of the quad): three independent Philox chains interleave at the issue rate, one chain
+        // runs at its dependent latency, and with the hop through LDS the shared pass came out 0.15-0.3 us SLOWER there (same profile).
+        const __attribute__((address_space(3))) f32x4_t *coop_tab = nullptr;
+        int coop_row = 0;
+        bool coop = false;
+        if constexpr (LPE == 1 && !FUSED) {
+            const uint64_t rm = __builtin_amdgcn_ballot_w64(is_reset);
+            if (__builtin_popcountll(rm) <= 4) {   // (wave-uniform)
+                uint64_t m = rm;
+                int src[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {   // the k-th resetting lane (the last one again when there are fewer)
+                    src[k] = (int)__builtin_ctzll(m);
+                    const uint64_t m2 = m & (m - 1);
+                    if (m2) m = m2;
+                }
+                const int i0 = __builtin_amdgcn_readlane(i, src[0]), i1 = __builtin_amdgcn_readlane(i, src[1]);
+                const int i2 = __builtin_amdgcn_readlane(i, src[2]), i3 = __builtin_amdgcn_readlane(i, src[3]);
+                const int jg = lane >> 4;
+                const int i_src = jg == 0 ? i0 : (jg == 1 ? i1 : (jg == 2 ? i2 : i3));
+                const float4 u = uniform_block(P, clk.step, Pin.env_offset + i_src, STREAM_RESET, (uint32_t)(lane & 15));
+                __attribute__((address_space(3))) f32x4_t *tab = (__attribute__((address_space(3))) f32x4_t *)tile;
+                tab[lane] = f32x4_t{u.x, u.y, u.z, u.w};
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                coop_tab = tab;
+                coop = true;
+                coop_row = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(rm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rm, 0u));   // resetting lanes below this one
+            }
+        }
         if (is_reset) {
             auto do_reset = [&](auto fl_c) {
                 reset_env<LPE, decltype(fl_c)::value>(P, clk.step, rS, voff, row_bytes, gid, grp, mix, active, sub, c_pos, c_quat, c_lin, c_ang, c_pp, c_pi, c_om, c_misc, c_tau, c_op,
-                                                      c_a0, c_a1, DRAWS_SERVED ? rs_tab : nullptr);
+                                                      c_a0, c_a1, DRAWS_SERVED ? rs_tab : coop_tab, coop, coop_row);
             };
             if constexpr (!RESET_ONLY) {   // (see reset_env's FL)
                 if ((fl & kResetFlagMask) == kResetFlagsBaseline) do_reset(std::integral_constant<uint32_t, kResetFlagsBaseline>{});

@@ -11,7 +11,10 @@ import sys
 
 tag = sys.argv[1]
 O = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
-DROP = 3  # reset-all launch + warm-up
+DROP = 3            # short passes (the one-wavefront instruction count at 4 096 envs): reset-all launch + warm-up
+STEADY_DROP = 500   # long passes (>= 600 launches): everything before the steady state -- 1.1 % of the envs reset in every step from ~ step 300 on, and a
+                    # resetting env costs its wavefront instructions and stores that the first dozen launches of a fresh env never show (round 5: 26.8 M
+                    # VALU instructions per launch at 262 144 envs in launches 3..11, 28.0 M in the steady state)
 
 
 def counters(d):
@@ -24,7 +27,8 @@ def counters(d):
             per.setdefault(r["Counter_Name"], {}).setdefault(int(r["Dispatch_Id"]), 0.0)
             per[r["Counter_Name"]][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
         for name, by in per.items():
-            vals = [by[k] for k in sorted(by)][DROP:]
+            vals = [by[k] for k in sorted(by)]
+            vals = vals[STEADY_DROP if len(vals) >= 600 else DROP:]
             out[name] = {"launches_averaged": len(vals), "mean_per_launch": sum(vals) / max(len(vals), 1)}
     return out
 
@@ -34,7 +38,8 @@ for n in (262144, 4096):
     S[f"fetch_{n}"] = counters(f"{tag}_pmc_FETCH_SIZE_{n}")
     S[f"write_{n}"] = counters(f"{tag}_pmc_WRITE_SIZE_{n}")
 der = {"note": "FETCH_SIZE/WRITE_SIZE are in KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of "
-               "16-B-per-lane coalesced reads); separate --pmc passes, first 3 launches (reset-all + warm-up) dropped"}
+               "16-B-per-lane coalesced reads); separate --pmc passes; launches 500..699 of a fresh env (the steady state: 1.1 % of the envs reset per step) "
+               "except per_wave_4096_quad (launches 3..39: the reset-free instruction count of one step wavefront)"}
 for n in (262144, 4096):
     try:
         rd = S[f"fetch_{n}"]["FETCH_SIZE"]["mean_per_launch"] * 1024 * 2

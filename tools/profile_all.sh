@@ -18,10 +18,10 @@ mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${TAG}_stats" -- python3 "$R/bench.py" --steps 2000 --warmup 200 --no-cpu-baseline > "$O/${TAG}_bench_prof.json" 2> "$O/${TAG}_bench_prof.err"
 SQ="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_WAIT_ANY"
-rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d "$O/${TAG}_pmc_sq_262144" -- python3 "$R/tools/prof_step.py" --envs 262144 --steps 12 > "$O/${TAG}_pmc.log" 2>&1
+rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d "$O/${TAG}_pmc_sq_262144" -- python3 "$R/tools/prof_step.py" --envs 262144 --steps 700 > "$O/${TAG}_pmc.log" 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/${TAG}_pmc_${c}_262144" -- python3 "$R/tools/prof_step.py" --envs 262144 --steps 12 >> "$O/${TAG}_pmc.log" 2>&1
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/${TAG}_pmc_${c}_4096" -- python3 "$R/tools/prof_step.py" --envs 4096 --steps 40 >> "$O/${TAG}_pmc.log" 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/${TAG}_pmc_${c}_262144" -- python3 "$R/tools/prof_step.py" --envs 262144 --steps 700 >> "$O/${TAG}_pmc.log" 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/${TAG}_pmc_${c}_4096" -- python3 "$R/tools/prof_step.py" --envs 4096 --steps 700 >> "$O/${TAG}_pmc.log" 2>&1
 done
 # 3b. instructions of ONE wavefront that runs a whole step (the quad form without role wavefronts: every wavefront is a step wavefront) at 4 096 envs:
 #     the count behind bench.py's latency_floor
