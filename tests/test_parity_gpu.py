@@ -232,6 +232,44 @@ def test_quad_layout_equals_one_lane_per_env(task, n):
     assert int(envs[1].reset_buf.sum()) >= 0
 
 
+@pytest.mark.parametrize("form", ["lane", "lane_throughput", "lane_roles"])
+def test_shared_reset_draws_match_the_oracle_for_every_count_of_resetting_lanes(form):
+    """The one-lane forms draw a resetting env's Philox blocks with sixteen lanes at once when at most four lanes of the wavefront reset, and lane
+    by lane otherwise (taco_step.hpp "shared reset draws"): planted reset flags -- 1, 2, 3, 4 (shared pass), 5, 17, 64 (own draws) resetting lanes in
+    a wavefront, none in another, and the ragged last wavefront's last lanes (whose tail lanes shadow env n - 1) -- against the CPU oracle, every
+    randomisation on (all ten blocks drawn), state blob and outputs bit for bit."""
+    from oracle import oracle as O
+    from taco_amd.vec_env import FpvBase
+    n = 64 * 8 + 37
+    cfg = config.default_cfg("mix", n, env_lenObservations=1, env_lenStates=3, env_maxEpisodeLength=400, seed=23, rotor_noise=True, observation_noise=True,
+                             ramdom_deploy_time=True, ramdom_delay_time=True, random_rotordynamic_coe=True, random_rotor_response=True,
+                             random_aerodynamic_coe=True)
+    flat = config.flat_cfg(cfg)
+    env = FpvBase(cfg, copy_outputs=False, kernel_form=form)
+    assert env.kernel_form == form
+    orc = O.OracleEnv(flat, threads=8)
+    acts = action_stream(n, 12, 6)
+    acts_d = torch.from_numpy(acts).cuda()
+    rng = np.random.default_rng(2)
+    counts = {0: 1, 1: 2, 2: 3, 3: 4, 4: 5, 5: 17, 6: 64, 7: 0}
+    for t in range(12):
+        if t in (3, 6, 9):   # (every step 0 resets all envs: the own-draws path with 64 lanes)
+            plant = np.zeros(n, np.int64)
+            for wv, c in counts.items():
+                plant[64 * wv + rng.choice(64, c, replace=False)] = 1
+            plant[n - 2:] = 1   # the last wavefront: 37 live lanes, lanes 35 and 36 reset, 27 tail lanes shadow env n - 1
+            keep = orc.reset_buf.astype(bool)
+            orc.reset_buf[:] = np.where(keep, 1, plant)
+            env.reset_buf.copy_(torch.from_numpy(orc.reset_buf.copy()))
+        env.step_raw(acts_d[t])
+        orc.step(acts[t])
+        for name in ("obs_buf", "states_buf", "rew_buf", "reset_buf"):
+            assert_bits_equal(getattr(env, name).cpu().numpy(), getattr(orc, name), f"{form} step {t} {name}")
+        gb, ob = env.get_state().cpu().numpy(), orc.get_state().view(np.float32)
+        assert_bits_equal(gb[:20], ob[:20], f"{form} step {t} state fields 0..19")
+        assert_bits_equal(gb[26:], ob[26:], f"{form} step {t} state fields 26..")
+
+
 def test_battery_mailbox_wait_path():
     """The role-wavefront battery server normally posts each voltage long before wavefront 0 needs it; with the server delayed on purpose
     (taco_test_slow_battery_server of the -DTACO_TEST_HOOKS build; the product library has no such hook) wavefront 0 has to take the
