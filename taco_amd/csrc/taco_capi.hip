@@ -836,7 +836,7 @@ static int launch_policy(const taco_policy_cfg *c, const float *blob, int n, con
     const bool actor_throughput = action_only && n > 8192 && !stamps && c->act_dim == 4 && p16(c->obs_len * c->obs_dim) == 32 && c->n_actor_hidden == 3 &&
                                   p16(c->actor_hidden[0]) == 128 && p16(c->actor_hidden[1]) == 128 && p16(c->actor_hidden[2]) == 128;
     if (actor_throughput) {
-        const int npass = (n + taco::CR_MLP_ROWS - 1) / taco::CR_MLP_ROWS, cap = 2 * device_cus();
+        const int npass = (n + taco::ACT_ROWS - 1) / taco::ACT_ROWS, cap = 2 * device_cus();
         hipLaunchKernelGGL(taco::taco_actor_kernel, dim3((unsigned)(npass < cap ? npass : cap)), dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
     } else {
         hipLaunchKernelGGL(taco::taco_policy_kernel, dim3((n + taco::POL_ROWS - 1) / taco::POL_ROWS, action_only ? 1 : 2), dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);

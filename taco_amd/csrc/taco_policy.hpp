@@ -1428,9 +1428,14 @@ __global__ __launch_bounds__(64 * POL_NW, 4) void taco_critic_mlp_split_kernel(c
 // fragments of all four layers in registers (tile = wave; 8 + 32 + 32 + 32 float4), takes 64 rows per pass (four 16-row MFMA tiles per
 // weight fragment) and walks passes b, b + grid, ...  Same chains in the same k order as dense_tile: same bits.
 // requirements (host): the documented actor -- pad16(obs_len * obs_dim) == 32, three hidden layers padded to 128, act_dim == 4
-__global__ __launch_bounds__(64 * POL_NW) void taco_actor_kernel(const PolicyParams P) {
-    __shared__ __attribute__((aligned(16))) float xb[CR_MLP_ROWS * CR_LD];
-    __shared__ __attribute__((aligned(16))) float yb[CR_MLP_ROWS * CR_LD];
+// (End of round 5: at most 128 registers, so that TWO workgroups share a CU and one's staging / sampling / barrier waits lie under the other's MFMAs.  The
+// first build kept all four layers' fragments in registers -- 104 + working set = 193, one workgroup per CU -- although its launches give a workgroup one
+// or two passes: 33.1 us at 32 768 rows = 49 % of the f32 MFMA peak, a quarter of config 5's rollout at its per-rank shape.  Here a layer's fragments are
+// fetched (from L2: 26 KB per wavefront and pass) behind the layer before it, ahead of the barrier: the other workgroup's MFMAs cover the fetch.)
+constexpr int ACT_ROWS = CR_MLP_ROWS;   // rows per pass of taco_actor_kernel (32-row passes, four workgroups per CU wanted, two resident at 128 registers: 37.6 us against 31.2)
+__global__ __launch_bounds__(64 * POL_NW, 4) void taco_actor_kernel(const PolicyParams P) {
+    __shared__ __attribute__((aligned(16))) float xb[ACT_ROWS * CR_LD];
+    __shared__ __attribute__((aligned(16))) float yb[ACT_ROWS * CR_LD];
     constexpr int hp = 128, ip = 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
@@ -1438,19 +1443,17 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_actor_kernel(const PolicyPar
     const float *W0 = P.blob, *b0 = W0 + hp * ip, *W1 = b0 + hp, *b1 = W1 + hp * hp, *W2 = b1 + hp, *b2 = W2 + hp * hp, *W3 = b2 + hp, *b3 = W3 + 16 * hp;
     const float *log_std = b3 + 16;
     const int col = wave * 16 + r;
-    float4 w0[2], w1[8], w2[8], w3[8];
+    float4 w0[2], wA[8];
+    auto fetch8 = [&](float4 (&w)[8], const float *W, int tile) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) w[s] = *reinterpret_cast<const float4 *>(W + ((size_t)(tile * 8 + s) * 64 + lane) * 4);
+    };
 #pragma unroll
     for (int s = 0; s < 2; ++s) w0[s] = *reinterpret_cast<const float4 *>(W0 + ((size_t)(wave * 2 + s) * 64 + lane) * 4);
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        w1[s] = *reinterpret_cast<const float4 *>(W1 + ((size_t)(wave * 8 + s) * 64 + lane) * 4);
-        w2[s] = *reinterpret_cast<const float4 *>(W2 + ((size_t)(wave * 8 + s) * 64 + lane) * 4);
-        w3[s] = *reinterpret_cast<const float4 *>(W3 + ((size_t)s * 64 + lane) * 4);
-    }
     const float c0 = b0[col], c1 = b1[col], c2 = b2[col], c3 = b3[r];
     auto layer = [&](const float *in, float *out, const float4 *wf, int ks, float bias) {
 #pragma unroll
-        for (int rt = 0; rt < CR_MLP_ROWS / 16; ++rt) {
+        for (int rt = 0; rt < ACT_ROWS / 16; ++rt) {
             const float *arow = in + (16 * rt + r) * CR_LD + 4 * (g ^ cr_b(r));   // (swizzled tiles: cr_sw4)
             pf32x4 acc = {bias, bias, bias, bias};
 #pragma unroll
@@ -1468,21 +1471,25 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_actor_kernel(const PolicyPar
         }
     };
     const int kin = P.obs_len * P.obs_dim;
-    const int npass = (P.n + CR_MLP_ROWS - 1) / CR_MLP_ROWS;
+    const int npass = (P.n + ACT_ROWS - 1) / ACT_ROWS;
     for (int c = blockIdx.x; c < npass; c += gridDim.x) {
-        const int row0 = c * CR_MLP_ROWS;
-        for (int e = tid; e < CR_MLP_ROWS * ip; e += 64 * POL_NW) {  // obs [row][kin] -> xb[row][32], zero beyond kin and beyond the last row
+        const int row0 = c * ACT_ROWS;
+        for (int e = tid; e < ACT_ROWS * ip; e += 64 * POL_NW) {  // obs [row][kin] -> xb[row][32], zero beyond kin and beyond the last row
             const int row = e >> 5, k = e & 31;
             xb[cr_sw4(row, k >> 2) + (k & 3)] = (row0 + row < P.n && k < kin) ? P.obs[(size_t)(row0 + row) * kin + k] : 0.0f;
         }
+        fetch8(wA, W1, wave);
         __syncthreads();
         layer(xb, yb, w0, 2, c0);
         __syncthreads();
-        layer(yb, xb, w1, 8, c1);
+        layer(yb, xb, wA, 8, c1);
+        fetch8(wA, W2, wave);
         __syncthreads();
-        layer(xb, yb, w2, 8, c2);
+        layer(xb, yb, wA, 8, c2);
+        fetch8(wA, W3, 0);
         __syncthreads();
-        if (wave < CR_MLP_ROWS / 16) {  // the 128 -> 4 head (one 16-column tile) with its tanh: wavefront w takes row tile w
+        const float4 (&w3)[8] = wA;
+        if (wave < ACT_ROWS / 16) {  // the 128 -> 4 head (one 16-column tile) with its tanh: wavefront w takes row tile w
             const float *arow = yb + (16 * wave + r) * CR_LD + 4 * (g ^ cr_b(r));
             pf32x4 acc = {c3, c3, c3, c3};
 #pragma unroll
@@ -1497,7 +1504,7 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_actor_kernel(const PolicyPar
             for (int i = 0; i < 4; ++i) xb[(16 * wave + 4 * g + i) * CR_LD + r] = tanh_own(acc[i]);   // (the head's output, read by sample4: plain rows)
         }
         __syncthreads();
-        if (tid < 4 * CR_MLP_ROWS) sample4(P, xb, CR_LD, row0, tid >> 2, tid & 3, log_std, call);
+        if (tid < 4 * ACT_ROWS) sample4(P, xb, CR_LD, row0, tid >> 2, tid & 3, log_std, call);
         __syncthreads();  // xb is staged again by the next pass
     }
 }

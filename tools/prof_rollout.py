@@ -1,4 +1,5 @@
-"""Minimal driver to put under rocprofv3: `reps` taco_rollout_run rollouts (+ reset + GAE) of config 5's flags.  --unfused: launch-per-step path."""
+"""Minimal driver to put under rocprofv3: `reps` taco_rollout_run rollouts (+ reset + GAE) of config 5's flags.  --unfused: launch-per-step path.
+--envs=N --horizon=H: another shape (default 4 096 x 32; above 8 192 envs the rollout is launch-per-step: actor kernel + step kernel per step)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -9,7 +10,8 @@ from taco_amd.rollout import RolloutBuffer
 from taco_amd.vec_env import FpvBase
 import test_policy_gpu as TP
 
-n, H, reps = 4096, 32, 20
+_o = {a.split("=")[0]: a.split("=")[1] for a in sys.argv[1:] if a.startswith("--") and "=" in a}
+n, H, reps = int(_o.get("--envs", 4096)), int(_o.get("--horizon", 32)), int(_o.get("--reps", 20))
 cfg = config.baseline_config(4, num_envs=n)
 env = FpvBase(cfg, copy_outputs=False)
 env.set_rollout_fusion("--unfused" not in sys.argv)
