@@ -830,7 +830,7 @@ static int launch_policy(const taco_policy_cfg *c, const float *blob, int n, con
     P.n = n; P.deterministic = deterministic ? 1 : 0;
     P.seed_lo = (uint32_t)seed; P.seed_hi = (uint32_t)(seed >> 32); P.call = call;
     P.role0 = 0; P.value_tail = nullptr; P.value_split = INT_MAX;
-    // the actor alone above 8 192 rows, documented architecture: the throughput form (weights resident, 64 rows per pass); otherwise the
+    // the actor alone above 8 192 rows, documented architecture: the throughput form (64 rows per pass, two workgroups per CU); otherwise the
     // 16-rows-per-workgroup form, which is the faster one while its workgroups fit the chip in two rounds
     auto p16 = [](int x) { return (x + 15) / 16 * 16; };
     const bool actor_throughput = action_only && n > 8192 && !stamps && c->act_dim == 4 && p16(c->obs_len * c->obs_dim) == 32 && c->n_actor_hidden == 3 &&

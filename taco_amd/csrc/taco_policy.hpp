@@ -1424,8 +1424,8 @@ __global__ __launch_bounds__(64 * POL_NW, 4) void taco_critic_mlp_split_kernel(c
 
 
 // The actor alone at LARGE N (taco_policy_act / taco_rollout_run above 8 192 envs): the 16-row form above is built for latency (256
-// workgroups at 4 096 envs, one per CU: 9.6 us) and runs at 25 % of the f32 MFMA peak from 16 384 envs on; this form keeps the weight
-// fragments of all four layers in registers (tile = wave; 8 + 32 + 32 + 32 float4), takes 64 rows per pass (four 16-row MFMA tiles per
+// workgroups at 4 096 envs, one per CU: 9.6 us) and runs at 25 % of the f32 MFMA peak from 16 384 envs on; this form gives a wavefront
+// 16 output columns of every layer (tile = wave; fragments of 2 + 8 + 8 + 8 float4), takes 64 rows per pass (four 16-row MFMA tiles per
 // weight fragment) and walks passes b, b + grid, ...  Same chains in the same k order as dense_tile: same bits.
 // requirements (host): the documented actor -- pad16(obs_len * obs_dim) == 32, three hidden layers padded to 128, act_dim == 4
 // (End of round 5: at most 128 registers, so that TWO workgroups share a CU and one's staging / sampling / barrier waits lie under the other's MFMAs.  The

@@ -319,7 +319,7 @@ def test_batched_critic_other_state_widths(states_dim, exact):
 
 @pytest.mark.parametrize("n", [8193, 20000, 65536 + 3])
 def test_actor_throughput_form_equals_the_latency_form_and_oracle(n):
-    """Above 8 192 rows act(action_only=True) runs taco_actor_kernel (weights resident, 64 rows per pass): same actions, log-probs, means as
+    """Above 8 192 rows act(action_only=True) runs taco_actor_kernel (64 rows per pass, two workgroups per CU): same actions, log-probs, means as
     the 16-row form (which a full act() still uses) and as the oracle, bit for bit, sampled and deterministic."""
     from oracle import oracle as O
     from taco_amd import policy as P
