@@ -747,7 +747,9 @@ TD void reset_env(const StepParams &P, uint32_t step, rsrc_t rS, uint32_t voff, 
                            ra ? 0.05f * (P.dr_sc * g0 + P.dr_lo) : ae0.z, ra ? -0.386f * (P.dr_sc * g1 + P.dr_lo) : ae0.w);
         c_a1 = make_float4(ra ? -0.53f * (P.dr_sc * g2 + P.dr_lo) : ae1.x, ra ? 0.009f * (P.dr_sc * g3 + P.dr_lo) : ae1.y, 0.0f, 0.0f);
     }
-    if (store) {  // the parameter chunks are only ever written here
+    if (store && !(P.flags & kUniformParams)) {  // the parameter chunks are only ever written here -- and not even here while they hold the same nominal
+        // values in every env (kUniformParams: nothing randomises them, init_state_kernel wrote what this would write, nobody loads them):
+        // four 16-byte stores of a lone lane less per reset (partial lines: each a read-modify-write somewhere below L2)
         CST(C_TAU, c_tau); CST(C_OPARA, c_op); CST(C_AERO0, c_a0); CST(C_AERO1, c_a1);
     }
     // the ring is NOT zeroed (FA:574): the delay-line word marks every pending slot as an implied zero
