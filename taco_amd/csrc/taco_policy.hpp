@@ -12,6 +12,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "taco_math.hpp"
 
 namespace taco {
