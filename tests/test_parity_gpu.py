@@ -289,11 +289,11 @@ def test_random_configurations():
     import fuzz
     rng = np.random.default_rng(2024)
     for i in range(40):
-        cfg, steps = fuzz.draw_case(rng)
+        cfg, steps, form = fuzz.draw_case(rng)   # (a quarter of the small cases pin a one-lane kernel form)
         try:
-            run_pair(cfg, steps, seed=i, check_every=1 if steps > 8 else 2, hover_bias=bool(i & 1), api=cfg["env"]["numEnvs"] <= 20000)   # (+ what VecTask.step() returns)
+            run_pair(cfg, steps, seed=i, check_every=1 if steps > 8 else 2, hover_bias=bool(i & 1), api=cfg["env"]["numEnvs"] <= 20000, form=form)   # (+ what VecTask.step() returns)
         except AssertionError as e:
-            raise AssertionError(f"case {i}: {fuzz.describe(cfg)}: {e}") from e
+            raise AssertionError(f"case {i}: form={form} {fuzz.describe(cfg)}: {e}") from e
 
 
 @pytest.mark.slow
@@ -306,11 +306,11 @@ def test_full_fuzz_run():
     cases, seed = int(os.environ["TACO_FUZZ_CASES"]), int(os.environ.get("TACO_FUZZ_SEED", "0"))
     rng = np.random.default_rng(seed)
     for i in range(cases):
-        cfg, steps = fuzz.draw_case(rng)
+        cfg, steps, form = fuzz.draw_case(rng)
         try:
-            run_pair(cfg, steps, seed=i, check_every=1 if steps > 8 else 2, hover_bias=bool(i & 1))
+            run_pair(cfg, steps, seed=i, check_every=1 if steps > 8 else 2, hover_bias=bool(i & 1), form=form)
         except AssertionError as e:
-            raise AssertionError(f"seed {seed} case {i}: {fuzz.describe(cfg)}: {e}") from e
+            raise AssertionError(f"seed {seed} case {i}: form={form} {fuzz.describe(cfg)}: {e}") from e
         if i % 50 == 49:
             print(f"fuzz: {i + 1} / {cases} cases clean", flush=True)
 

@@ -45,7 +45,7 @@ def main():
         from oracle import oracle as O
         from taco_amd import config
     for i in range(args.cases):
-        cfg, _ = fuzz.draw_case(rng)
+        cfg, _, _ = fuzz.draw_case(rng)
         env_c = cfg["env"]
         env_c["numEnvs"] = int(rng.integers(6000, 8193)) if rng.random() < 0.125 else int(rng.integers(1, 6000) if rng.random() < 0.5 else rng.integers(1, 400))
         env_c["lenObservations"] = 1
