@@ -161,7 +161,7 @@ def pmc_valu(n_envs, kernel_us):
     d = json.load(open(files[-1]))
     if d.get("source_hash") != build.source_hash():
         return None
-    key = {262144: "sq_262144"}.get(n_envs)
+    key = {262144: "sq_262144", 4096: "sq_4096"}.get(n_envs)
     insts = d.get(key, {}).get("SQ_INSTS_VALU", {}).get("mean_per_launch") if key else None
     if not insts:
         return None
@@ -764,12 +764,13 @@ def main():
                          "traffic": traffic, "traffic_frac": (traffic / (k_avg_us * 1e-6) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                          "traffic_source": traffic_src, "kernel_avg_us": k_avg_us, "kernel_bracketed_median_us": k_med_us,
                          "algorithmic_bytes_per_env_step": nbytes,
+                         "valu": pmc_valu(n_local, k_avg_us) if (world == 1 and n_local == 4096) else None,   # the other roof: SQ_INSTS_VALU of this launch (steady state) / 1 024 SIMDs x the mix's issue cost
                          "binds": "neither roof: instruction LATENCY of the slowest wavefront (latency_floor) + the launch boundary",
                          "note": "frac = ALGORITHMIC bytes (SURVEY 8d) / kernel time / 8 TB/s; traffic_frac = counter-measured HBM bytes / kernel time / 8 TB/s. "
                                  "4096 envs = 256 step wavefronts (4 lanes per env, one per CU) + 3 post-phase role wavefronts each: instruction-latency "
                                  "regime (SURVEY 8d): what binds is the instruction stream of the slowest wavefront (latency_floor: ~8.5 us in-kernel, "
                                  "+ ~0.7 us when some wavefront holds a resetting env, + ~1.6 us launch boundary incl. the write-back of 1.5 MB: "
-                                 "profiles/r05_b_ubench_launch_boundary.txt), not HBM (3-4 %) and not VALU issue (~13 %). The throughput regime is large_n, "
+                                 "profiles/r05_b_ubench_launch_boundary.txt), not HBM (3-4 %) and not VALU issue (roofline.valu: ~15 %). The throughput regime is large_n, "
                                  "where the VALU issue roof binds (large_n[].valu, binding_roof)"},
         }
         if multi:

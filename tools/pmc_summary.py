@@ -33,7 +33,7 @@ def counters(d):
     return out
 
 
-S = {"sq_262144": counters(f"{tag}_pmc_sq_262144"), "sq_4096_quad": counters(f"{tag}_pmc_sq_4096_quad")}
+S = {"sq_262144": counters(f"{tag}_pmc_sq_262144"), "sq_4096": counters(f"{tag}_pmc_sq_4096"), "sq_4096_quad": counters(f"{tag}_pmc_sq_4096_quad")}
 for n in (262144, 4096):
     S[f"fetch_{n}"] = counters(f"{tag}_pmc_FETCH_SIZE_{n}")
     S[f"write_{n}"] = counters(f"{tag}_pmc_WRITE_SIZE_{n}")

@@ -23,6 +23,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/${TAG}_pmc_${c}_262144" -- python3 "$R/tools/prof_step.py" --envs 262144 --steps 700 >> "$O/${TAG}_pmc.log" 2>&1
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/${TAG}_pmc_${c}_4096" -- python3 "$R/tools/prof_step.py" --envs 4096 --steps 700 >> "$O/${TAG}_pmc.log" 2>&1
 done
+# 3a. the headline launch's own instruction counts (4 096 envs, the form the product picks, steady state): bench.py's roofline.valu
+rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d "$O/${TAG}_pmc_sq_4096" -- python3 "$R/tools/prof_step.py" --envs 4096 --steps 700 >> "$O/${TAG}_pmc.log" 2>&1
 # 3b. instructions of ONE wavefront that runs a whole step (the quad form without role wavefronts: every wavefront is a step wavefront) at 4 096 envs:
 #     the count behind bench.py's latency_floor
 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d "$O/${TAG}_pmc_sq_4096_quad" -- python3 "$R/tools/prof_step.py" --envs 4096 --steps 40 --form quad >> "$O/${TAG}_pmc.log" 2>&1
