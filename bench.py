@@ -9,11 +9,14 @@ the children's status.  Under torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE /
 
 A "step" is one VecTask.step() of the whole batch = ONE taco_step launch through the C ABI.  Workload at N = 1: BASELINE configs[1]
 (task_mode=pos, 4 096 envs, rotor_response_time=0.017).  For N > 1 every rank holds 4 096 envs (weak scaling; global env ids are disjoint
-contiguous slices) and the timed region holds no collective (envs are independent); value = N * 4096 * K / max-over-ranks time (every
-rank: W warm-up steps, synchronize + barrier + synchronize, t0, K steps, synchronize, t1, barrier; before the warm-up a twin env is stepped
-for 0.2 s so that a short region does not time the process's first calls).  The
-north-star's single RCCL all-gather of the packed obs|reward|done|time-out block per step is timed right after ("with_allgather": the
-serial form a single learner needs, and the overlapped form with the gather of step t running under step t + 1), then a strong-scaling
+contiguous slices) and EVERY timed step carries north_star's collective: one RCCL all-gather of the kernel-filled [obs|reward|done|time-out]
+block per step, overlapped as SURVEY 8(e) prescribes (ShardedEnv.step_async: the gather of step t runs on the process group's stream
+under the launch of step t + 1 and is waited for right after it; the last gather is waited for inside the timed region).
+value = N * 4096 * K / max-over-ranks time (every rank: W warm-up steps, synchronize + barrier + synchronize, t0, K steps + the drain of
+the last gather, synchronize, t1, barrier; before the warm-up a twin env is stepped for 0.2 s so that a short region does not time the
+process's first calls).  Reported beside it: "without_allgather" (the gather-free ShardedEnv.step_local of the same K steps: what a
+data-parallel learner that never needs the global view pays) and "with_allgather_serial" (step + gather waited for before the next step: a
+single learner that needs obs(t) before action(t + 1)); --no-gather makes the gather-free leg the headline instead.  Then a strong-scaling
 leg (4 096 envs in TOTAL).  Inputs (the action stream a_t = clamp(0.3 N(0,1) + (-0.45,0,0,0), -1, 1)) are resident in HBM before any
 timed region.
 
@@ -520,8 +523,9 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
                     help="which BASELINE.json config (1-based) the MAIN timed leg runs: 2 = pos, 4 096 envs per GPU (weak scaling, the metric's config); "
                          "3 = rotate 16 384 / 4 = flip 65 536 / 5 = mix 262 144 envs IN TOTAL, sharded over the N ranks (strong scaling)")
-    ap.add_argument("--gather", action="store_true", help="N > 1: put the per-step RCCL all-gather inside the main timed region "
-                    "(default: the sharded path alone is timed, the gathered variants are timed separately and reported as with_allgather)")
+    ap.add_argument("--gather", action="store_true", help="(the default since round 6; kept so that old command lines still parse)")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the per-step all-gather out of the main timed region (the gather-free "
+                    "sharded path becomes the headline; the gathered variants are still timed and reported)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall-time budget of the all-cores CPU baseline sample of config 1")
     ap.add_argument("--no-large-n", action="store_true")
@@ -553,13 +557,28 @@ def main():
     weak = args.config == 2
     n_global = args.envs * world if weak else total
     cfg = config.baseline_config(cfg_idx, num_envs=n_global)
+    gathered_main = world > 1 and not args.no_gather and not solo   # north_star: "a single RCCL all-gather of the (obs, reward, done) buffers per step"
+    finish_main = None
     if world > 1:
         from taco_amd.dist import ShardedEnv
-        env = ShardedEnv(cfg, rank=rank, world_size=world, device=dev, gather=args.gather and not solo)
-        # without --gather the timed leg needs no global view: every rank makes the launch a single-GPU VecTask.step() makes (no gather
-        # block bound: filling it costs 0.4 us per step at 4 096 envs, tools/host_cost.py); the gathered variants are timed right after
-        step = env.step_gathered if (args.gather and not solo) else env.step_local
+        env = ShardedEnv(cfg, rank=rank, world_size=world, device=dev, gather=gathered_main)
         n_local = env.hi - env.lo
+        pend = []
+
+        def step_overlapped(a):   # the gather of step t is waited for only after step t + 1 has been launched (two alternating blocks)
+            pend.append(env.step_async(a))
+            if len(pend) > 1:
+                pend.pop(0).wait()
+
+        def finish_overlapped():  # ... and the last one inside the timed region
+            while pend:
+                pend.pop(0).wait()
+            env.drain()
+
+        # --no-gather: no global view, every rank makes the launch a single-GPU VecTask.step() makes (no gather block bound: filling it
+        # costs 0.4 us per step at 4 096 envs, tools/host_cost.py)
+        step = step_overlapped if gathered_main else env.step_local
+        finish_main = finish_overlapped if gathered_main else None
     else:
         env = FpvBase(cfg, sim_device=str(dev), rl_device=str(dev))   # copy_outputs=True: VecTask.step() as the PPO loop calls it
         step = env.step
@@ -637,11 +656,12 @@ def main():
     # ---- the main timed leg.  It holds no data-path collective (envs are independent); a failure inside it still yields a line.
     main_error = None
     try:
-        elapsed = timed(step, acts, args.steps, args.warmup)
+        elapsed = timed(step, acts, args.steps, args.warmup, finish_main)
     except Exception as e:  # noqa: BLE001
         main_error = repr(e)[:300]
         dist = None
         solo = world > 1
+        gathered_main = False
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for t in range(args.steps):
@@ -668,34 +688,26 @@ def main():
         ids = [torch.zeros(1, dtype=torch.int64, device=ids_dev) for _ in range(world)]
         dist.all_gather(ids, torch.tensor([rank], device=ids_dev, dtype=torch.int64))
         multi["ranks_seen"] = sorted(int(x.item()) for x in ids)
-        if not args.gather:
-            # The same K steps with the north-star's single all-gather of [obs|rew|done|timeout] per step (one learner sees all envs).
-            # The headline above is already measured: a failure of this optional leg is reported, it does not cost the result line.
-            try:
-                env.gather = True
-                el_serial = timed(env.step_gathered, acts, args.steps, min(args.warmup, 50))
-                pend = []
-
-                def step_overlapped(a):   # the gather of step t is waited for only after step t + 1 has been launched
-                    pend.append(env.step_async(a))
-                    if len(pend) > 1:
-                        pend.pop(0).wait()
-
-                def finish():
-                    while pend:
-                        pend.pop(0).wait()
-                    env.drain()
-
-                el_over = timed(step_overlapped, acts, args.steps, min(args.warmup, 50), finish)
-                multi["with_allgather"] = {
-                    "value": n_global * args.steps / el_serial, "unit": "env-steps/s", "ms_per_step": el_serial / args.steps * 1e3,
-                    "overlapped": {"value": n_global * args.steps / el_over, "ms_per_step": el_over / args.steps * 1e3,
-                                   "what": "step t + 1 is launched before the gather of step t is waited for (two alternating blocks)"},
-                    "collective": "1 all_gather_into_tensor of the kernel-filled [obs|rew|done|timeout] block per step",
-                    "bytes_per_rank": int(env.block.numel() * 4)}
-            except Exception as e:  # noqa: BLE001
-                multi["with_allgather"] = {"error": repr(e)[:300]}
-            env.gather = False
+        # The same K steps in the two other forms (the headline above is already measured: a failure of these legs is reported, it does not cost
+        # the result line): gather-free (step_local), and with the gather waited for before the next step (serial: one learner sees all envs)
+        try:
+            if gathered_main:
+                el_local = timed(env.step_local, acts, args.steps, min(args.warmup, 50))
+                multi["without_allgather"] = {"value": n_global * args.steps / el_local, "unit": "env-steps/s", "ms_per_step": el_local / args.steps * 1e3,
+                                              "what": "ShardedEnv.step_local: every rank steps its own slice, no gather block bound, no collective"}
+            env.gather = True
+            el_serial = timed(env.step_gathered, acts, args.steps, min(args.warmup, 50))
+            multi["with_allgather_serial"] = {"value": n_global * args.steps / el_serial, "unit": "env-steps/s", "ms_per_step": el_serial / args.steps * 1e3,
+                                              "what": "step + gather, waited for before the next step is launched"}
+            if not gathered_main:
+                el_over = timed(step_overlapped, acts, args.steps, min(args.warmup, 50), finish_overlapped)
+                multi["with_allgather"] = {"value": n_global * args.steps / el_over, "unit": "env-steps/s", "ms_per_step": el_over / args.steps * 1e3,
+                                           "what": "overlapped: step t + 1 is launched before the gather of step t is waited for (two alternating blocks)"}
+            multi["allgather"] = {"collective": "1 all_gather_into_tensor of the kernel-filled [obs|rew|done|timeout] block per step",
+                                  "bytes_per_rank": int(env.block.numel() * 4), "backend": backend_used}
+        except Exception as e:  # noqa: BLE001
+            multi["allgather_legs_error"] = repr(e)[:300]
+        env.gather = gathered_main
         short = max(50, min(args.steps, 300))
         if weak:
             # strong scaling: BASELINE's "4 096 envs" spread over the N GPUs (512-2 048 envs per rank: the latency regime, expected to lose)
@@ -753,10 +765,12 @@ def main():
             "config": {"workload": f"BASELINE configs[{args.config - 1}]: " + what,
                        "envs_per_gpu": n_local, "envs_total": n_global, "parallelism": f"env-sharded x{world}",
                        "api": "VecTask.step() (taco_amd.vec_env: returns the reference's (obs dict, rew, done, extras))" if world == 1 else
-                              ("ShardedEnv.step_gathered() (taco_step on this rank's slice + the all-gather)" if (args.gather and not solo) else
-                               "ShardedEnv.step_local() = VecTask.step() on this rank's slice"),
-                       "collective": ("1 RCCL all-gather of [obs|rew|done|timeout] per step" if (world > 1 and args.gather) else
-                                      "none in the timed region: envs are independent, each rank steps its own slice"),
+                              ("ShardedEnv.step_async() (taco_step on this rank's slice, which fills the gather block, + the all-gather; waited for after the next launch)"
+                               if gathered_main else "ShardedEnv.step_local() = VecTask.step() on this rank's slice"),
+                       "collective": ("none" if world == 1 else
+                                      (f"1 {'RCCL' if backend_used == 'nccl' else backend_used} all_gather_into_tensor of the [obs|rew|done|timeout] block per step, inside the timed "
+                                       "region, overlapped with the next step's launch" if gathered_main else
+                                       "none in the timed region (--no-gather, or the collective could not be set up: see collective_init_error / main_leg_error)")),
                        "kernel": base.lib.taco_step_kernel_name().decode(), "kernel_form": base.kernel_form, "grid": grid, "block": block,
                        "pre_warm": pre_warm,
                        "timing": "per rank: W warm-up steps, synchronize + barrier + synchronize, t0, K steps, synchronize, t1, barrier; elapsed = MAX over ranks of t1 - t0"},

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TACO_ABI_VERSION 7
+#define TACO_ABI_VERSION 8
 
 typedef enum taco_status {
     TACO_OK = 0,
@@ -173,7 +173,9 @@ void taco_destroy(taco_env *env);
  * re-read it first -- they BLOCK (hipDeviceSynchronize + a 16-byte copy), on EVERY call, for as long as the handle is in graph mode.
  * taco_release_graphs ends it: the caller's word that no graph holding launches of this handle will be replayed any more (one last blocking
  * re-read; afterwards eager launches take the clock from their arguments again and nothing synchronises).  A later capture re-enters graph
- * mode.  A replay AFTER the release leaves the host's copy behind the device's; taco_check reports that (TACO_ERR_STATE).
+ * mode.  A replay AFTER the release leaves the host's copy behind the device's; taco_check reports that (TACO_ERR_STATE) and KEEPS reporting it
+ * whatever eager steps follow (launches that take their clock from the device count themselves in a workspace word eager launches never
+ * write; the release latches the count) -- those steps reused random-stream counters and a stale delay-ring head.
  * taco_graph_mode: 1 while in graph mode, 0 otherwise (never blocks). */
 int taco_step(taco_env *env, const float *actions, float *obs_buf, float *states_buf, float *rew_buf, int64_t *reset_buf,
               uint8_t *timeout_buf, void *stream);
@@ -250,7 +252,10 @@ typedef struct taco_policy_cfg {
  * matrix pipe with SPLIT operands -- every f32 operand as two 16-bit halves, three MFMA chains per product chain, f32 accumulation
  * (taco_policy.hpp taco_critic_lstm_pair_split_kernel, and the MLP's two hidden layers behind it: taco_critic_mlp_split_kernel; critic at 557 056 rows 3.22 -> 1.06 ms).  TACO_P_SPLIT_F16: f16 halves (11 + 11
  * significant bits): values within ~1e-6 of the exact f32 critic's on O(1) frames (1.25e-6 measured on values up to 1.5, the fast cell alone 7.2e-7; asserted
- * <= 2e-6 x max(1, |value|), the fast cell's own bar; frame words beyond +-65 504 are clamped).  TACO_P_SPLIT_BF16: bf16 halves (8 + 8
+ * <= 2e-6 x max(1, |value|), the fast cell's own bar).  Frame words outside f16's range are NOT silent (ABI 8): +-inf becomes NaN and NaN stays NaN (the
+ * value of a diverged env is NaN, as in the f32 kernels); a FINITE word beyond +-65 504 saturates there -- the gates it feeds are saturated either
+ * way -- and is counted: taco_critic_clamped_words reads the count of the last call, and inside taco_rollout_run the env's sticky status word is
+ * set as well, so taco_check returns TACO_ERR_STATE.  TACO_P_SPLIT_BF16: bf16 halves (8 + 8
  * bits): ~1.7e-5, outside that bar -- kept for the A/B record only.  Other layouts (materialised stacks, one slot, states_dim = 32)
  * ignore the bits.  Excludes TACO_P_EXACT_CELL. */
 #define TACO_P_SPLIT_F16 2
@@ -272,7 +277,10 @@ int taco_policy_act_stamped(const taco_policy_cfg *cfg, const float *blob, int n
  * 32-row blocks, W_ih / W_hh register-resident, the SIMD's two wavefronts one phase apart so one's MFMAs run beside the other's gate
  * activations) writing h_T to `workspace`, then the MLP with resident weights; other geometries run the critic role of the policy kernel
  * (workspace unused).  This is what takes the critic off the rollout's serial chain (taco_rollout_run). */
-size_t taco_critic_workspace_bytes(const taco_policy_cfg *cfg, int64_t rows);   /* the LSTM's h_T between the two kernels: rows x 128 floats */
+size_t taco_critic_workspace_bytes(const taco_policy_cfg *cfg, int64_t rows);   /* the LSTM's h_T between the two kernels: rows x 128 floats, + a 256-byte tail (ABI 8) */
+/* ABI 8.  BLOCKS on `stream`: *count = how many times the LAST batched-critic call on (`workspace`, `rows`) saturated a finite frame word beyond +-65 504
+ * (TACO_P_SPLIT_F16 only; 0 for every other form).  Clamp EVENTS: a frame of a ring is staged once per block of two slots whose stacks hold it. */
+int taco_critic_clamped_words(const taco_policy_cfg *cfg, int64_t rows, const void *workspace, uint32_t *count, void *stream);
 int taco_critic_values(const taco_policy_cfg *cfg, const float *blob, int64_t rows, const float *states, float *value, void *workspace,
                        uint64_t *stamps, void *stream);   /* stamps: NULL, or a DEVICE array of 259 uint64 (profiling; taco_policy.hpp) */
 
@@ -370,8 +378,9 @@ int taco_set_step_count(taco_env *env, int64_t n);   /* also writes the device-r
 int64_t taco_peek_step_count(const taco_env *env);
 
 /* Health check (BLOCKS on `stream`): TACO_ERR_STATE if any step kernel since taco_create recorded a sticky error in the workspace's status
- * word -- today one condition: a bounded wait of the four-role form's battery mailbox gave up (the voltage of the affected envs was set to
- * NaN instead of a stale value).  Never observed; the steps themselves return TACO_OK because they never synchronise. */
+ * word -- a bounded wait of the four-role form's battery mailbox gave up (the voltage of the affected envs was set to NaN instead of a stale
+ * value; never observed), or the split-f16 critic of a taco_rollout_run saturated finite frame words beyond +-65 504 (ABI 8) -- or if a captured
+ * graph was replayed after taco_release_graphs (see taco_step).  The steps themselves return TACO_OK because they never synchronise. */
 int taco_check(taco_env *env, void *stream);
 
 /* One row of the state blob (TACO_S_* except actions_old) for every env -> DEVICE array out[num_envs]; e.g. TACO_S_PROGRESS = progress_buf. */

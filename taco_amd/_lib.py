@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TACO_ENV_LIB", os.path.join(HERE, "libtaco_env.so"))  # override = A/B builds of the same ABI (taken as it is, never rebuilt)
 SKIP_ABI_CHECK = os.environ.get("TACO_ENV_LIB_SKIP_ABI", "") == "1"   # explicit opt-out for A/B runs ACROSS ABI revisions (missing symbols are stubbed)
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 NUM_FIELDS = 67
 RING_SLOTS = 100
 BLOB_ROWS = NUM_FIELDS + 4 * RING_SLOTS
@@ -25,7 +25,7 @@ FLAG_BITS = {
 EXPORTS = ["taco_abi_version", "taco_source_hash", "taco_last_error", "taco_workspace_bytes", "taco_create", "taco_destroy", "taco_step",
            "taco_gather_row_floats", "taco_bind_gather_block", "taco_set_difficulty", "taco_get_step_count", "taco_set_step_count", "taco_get_state", "taco_set_state",
            "taco_step_kernel_name", "taco_launch_geometry", "taco_set_kernel_form", "taco_get_kernel_form", "taco_check", "taco_get_field", "taco_step_rollout", "taco_reset_done", "taco_gae_workspace_bytes", "taco_gae", "taco_occupancy", "taco_bind_phase_stamps", "taco_policy_blob_floats", "taco_policy_act", "taco_rollout_run", "taco_policy_act_stamped", "taco_critic_values", "taco_critic_workspace_bytes", "taco_peek_step_count", "taco_critic_values_ring", "taco_set_rollout_fusion", "taco_bind_rollout_stamps", "taco_bind_states_ring",
-           "taco_states_ring_row", "taco_step_ring", "taco_graph_mode", "taco_release_graphs"]
+           "taco_states_ring_row", "taco_step_ring", "taco_graph_mode", "taco_release_graphs", "taco_critic_clamped_words"]
 
 
 class TacoCfg(C.Structure):
@@ -124,6 +124,8 @@ def _declare(lib, ab_build=False):
     lib.taco_critic_values_ring.restype = C.c_int
     lib.taco_critic_workspace_bytes.argtypes = [C.c_void_p, C.c_int64]
     lib.taco_critic_workspace_bytes.restype = C.c_size_t
+    lib.taco_critic_clamped_words.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p]
+    lib.taco_critic_clamped_words.restype = C.c_int
     lib.taco_rollout_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(RolloutBufs), C.c_int, C.c_uint64, C.c_uint32, C.c_double,
                                      C.c_double, C.c_double, C.c_void_p, C.c_void_p]
     lib.taco_rollout_run.restype = C.c_int

@@ -70,6 +70,7 @@ struct taco_env {
     uint32_t *wclk;       // the same clock per 16 envs, where captured kernels take it from (taco_step.hpp "wclk"): in front of the control block
     int clock_on_device;  // a launch of this handle has been captured into a HIP graph (sticky): replays advance the device clock only, so from
                           // then on every launch reads the device clock and every host-side use of the fields above re-reads them first
+    uint32_t dev_steps_seen;  // ctl[kCtlDevSteps] as of the last refresh_clock (latched for good by taco_release_graphs): see taco_check
     void *capture_stream; // the stream a launch of this handle was last seen CAPTURING on (refresh_clock refuses to synchronise while it still is)
     int params_imported;  // taco_set_state has been called: rotor / aero parameters may differ per env from now on (see kUniformParams)
     float *gather;  // optional per-rank all-gather block, see taco_bind_gather_block
@@ -436,6 +437,7 @@ int taco_create(const taco_cfg *cfg, int device, void *workspace, size_t workspa
     e->wclk = (uint32_t *)(e->ring + (size_t)TACO_RING_SLOTS * e->npad * 4);
     e->ctl = (uint32_t *)((char *)e->wclk + (taco::wclk_words(e->npad) * sizeof(uint32_t) + 255) / 256 * 256);
     e->clock_on_device = 0;
+    e->dev_steps_seen = 0;
     e->capture_stream = nullptr;
     e->step_count = 0;
     e->head = 0;
@@ -626,7 +628,7 @@ int refresh_clock(taco_env *e, void *stream = nullptr) {
         e->capture_stream = nullptr;
     }
     if (!e->clock_on_device) return TACO_OK;
-    uint32_t c[4];
+    uint32_t c[8];
     hipError_t he;
     // (the whole device, whatever stream the caller named: the replays that advanced the clock may have run on ANOTHER stream the caller's has
     // not waited for -- adopting a stale clock would corrupt the Philox counters and the delay ring's head silently; this path is rare)
@@ -638,6 +640,7 @@ int refresh_clock(taco_env *e, void *stream = nullptr) {
     e->head = (int)c[taco::kCtlHead];
     e->hh = (int)c[taco::kCtlHh];
     if (e->st_period > 0) e->st_phase = (int)(c[taco::kCtlPhase] % (uint32_t)e->st_period);
+    e->dev_steps_seen = c[taco::kCtlDevSteps];
     // clock_on_device stays set: a graph captured from this handle may be replayed again at any time, behind the host's back -- from the first
     // capture on every launch takes its clock from the device and every host-side read of it comes here (rounds 2-3 went back to the host's
     // copy after one re-read: a replay after that left it stale, silently)
@@ -656,7 +659,9 @@ int64_t taco_peek_step_count(const taco_env *e) { return e ? e->step_count : -1;
 // is the caller's word: taco_release_graphs = "no graph holding launches of this handle will be replayed from now on" (one last re-read, then
 // the handle is back on the eager path: kernel arguments, the host's own copy, no synchronisation anywhere).  A replay after that still
 // steps the envs correctly as far as IT goes (graphs read the device copy, which eager launches keep current) but leaves the host's copy
-// behind: taco_check reports exactly that (device clock ahead of the host's), it is never silent.
+// behind: taco_check reports exactly that, and keeps reporting it -- every launch that takes its clock from the device counts itself in
+// ctl[kCtlDevSteps], a word eager launches outside graph mode never write, and the release latches its value: a later eager step overwrites
+// kCtlStep (so "device clock ahead of the host's" alone would go quiet again, round 5's advisor), never the count.
 int taco_graph_mode(const taco_env *e) { return e ? e->clock_on_device : TACO_ERR_INVALID_ARG; }
 int taco_release_graphs(taco_env *e) {
     if (!e) return fail(TACO_ERR_INVALID_ARG, "env is null");
@@ -686,16 +691,20 @@ int taco_set_step_count(taco_env *e, int64_t n) {
 
 int taco_check(taco_env *e, void *stream) {
     if (!e) return fail(TACO_ERR_INVALID_ARG, "env is null");
-    uint32_t status = 0, dev_step = 0;
-    hipError_t he = hipMemcpyAsync(&status, e->ctl + taco::kCtlStatus, sizeof(status), hipMemcpyDeviceToHost, (hipStream_t)stream);
-    if (he == hipSuccess) he = hipMemcpyAsync(&dev_step, e->ctl + taco::kCtlStep, sizeof(dev_step), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    uint32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hipError_t he = hipMemcpyAsync(c, e->ctl, sizeof(c), hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (he == hipSuccess) he = hipStreamSynchronize((hipStream_t)stream);
     if (he != hipSuccess) return hip_fail(he, "taco_check");
-    // outside graph mode the host's copy of the clock leads the device's by the launches still in flight, never the other way round: a device
-    // clock AHEAD of it means a captured graph was replayed after taco_release_graphs (or by another handle on this workspace)
-    if (!e->clock_on_device && e->capture_stream == nullptr && (int32_t)(dev_step - (uint32_t)e->step_count) > 0)
+    const uint32_t status = c[taco::kCtlStatus], dev_step = c[taco::kCtlStep];
+    // outside graph mode (a) the host's copy of the clock leads the device's by the launches still in flight, never the other way round, and
+    // (b) no launch takes its clock from the device, so ctl[kCtlDevSteps] stands where taco_release_graphs found it.  Either one broken means
+    // a captured graph was replayed after the release (or by another handle on this workspace); (b) stays broken whatever eager steps follow
+    if (!e->clock_on_device && e->capture_stream == nullptr && ((int32_t)(dev_step - (uint32_t)e->step_count) > 0 || c[taco::kCtlDevSteps] != e->dev_steps_seen))
         return fail(TACO_ERR_STATE, "the device-resident step clock is ahead of the host's copy: a captured graph holding launches of this handle was "
                                     "replayed after taco_release_graphs; eager steps since then used stale random-stream counters");
+    if (status & taco::kStatusCriticClamped)
+        return fail(TACO_ERR_STATE, "the split-f16 critic of a taco_rollout_run saturated finite frame words beyond +-65 504 (values of those rows are approximate): "
+                                    "normalise the states, or run the critic in f32 (taco_policy_cfg.flags without TACO_P_SPLIT_F16; ActorCritic(critic_split=None))");
     if (status & taco::kStatusMailboxTimeout)
         return fail(TACO_ERR_STATE, "a step kernel gave up waiting on its battery mailbox (role wavefronts out of step): the affected envs' voltage "
                                     "was set to NaN; results since the last clean taco_check are suspect");
@@ -855,8 +864,11 @@ static bool critic_batched_form(const taco_policy_cfg *c) {
 }
 // cu_limit > 0: the persistent LSTM kernel uses at most that many workgroups (a stream that owns fewer CUs than the device has)
 // ring_n > 0: `states` is a frame ring [slots + states_len - 1][ring_n][states_dim] and row = slot * ring_n + env (taco_policy.hpp, PolicyParams.ring_n)
+static_assert(taco::kStatusCriticClamped == taco::kStatusCriticClampedBit, "the policy header's copy of the status bit");
+// the batched critic's workspace: h_T [rows][128] f32, then a 256-byte tail whose first word counts the split-f16 form's clamp events of the LAST call
+static uint32_t *critic_ws_tail(float *workspace, size_t rows) { return (uint32_t *)(workspace + rows * 128); }
 static int launch_critic(const taco_policy_cfg *c, const float *blob, size_t rows, const float *states, float *value, float *value_tail, size_t split,
-                         float *workspace, int cu_limit, void *stream, uint64_t *stamps = nullptr, int ring_n = 0) {
+                         float *workspace, int cu_limit, void *stream, uint64_t *stamps = nullptr, int ring_n = 0, uint32_t *env_status = nullptr) {
     if (rows > (size_t)INT_MAX - 64) return fail(TACO_ERR_INVALID_ARG, "critic: too many rows for one launch");
     taco::PolicyParams P{};
     P.obs_len = c->obs_len; P.obs_dim = c->obs_dim; P.states_len = c->states_len; P.states_dim = c->states_dim; P.act_dim = c->act_dim;
@@ -881,6 +893,11 @@ static int launch_critic(const taco_policy_cfg *c, const float *blob, size_t row
             const size_t pw = (pb + cus - 1) / cus;
             const dim3 pg((unsigned)((pb + pw - 1) / pw));
             split = (exact || c->states_dim >= 32) ? 0 : ((c->flags & TACO_P_SPLIT_F16) ? 1 : ((c->flags & TACO_P_SPLIT_BF16) ? 2 : 0));
+            if (split == 1) {   // the f16 form counts what it saturates: the tail word starts every call at zero (a memset node when captured)
+                P.clamped = critic_ws_tail(workspace, rows); P.env_status = env_status;
+                const hipError_t me = hipMemsetAsync(P.clamped, 0, sizeof(uint32_t), (hipStream_t)stream);
+                if (me != hipSuccess) return hip_fail(me, "critic: zeroing the clamp counter");
+            }
             if (exact) hipLaunchKernelGGL(taco::taco_critic_lstm_pair_kernel<true>, pg, dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
             else if (split == 1) hipLaunchKernelGGL(taco::taco_critic_lstm_pair_split_kernel<1>, pg, dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
             else if (split == 2) hipLaunchKernelGGL(taco::taco_critic_lstm_pair_split_kernel<2>, pg, dim3(64 * taco::POL_NW), 0, (hipStream_t)stream, P);
@@ -910,7 +927,19 @@ static int launch_critic(const taco_policy_cfg *c, const float *blob, size_t row
 
 size_t taco_critic_workspace_bytes(const taco_policy_cfg *c, int64_t rows) {
     if (policy_cfg_ok(c) != TACO_OK || rows < 1) return 0;
-    return critic_batched_form(c) ? (size_t)rows * 128 * sizeof(float) : 16;
+    return critic_batched_form(c) ? (size_t)rows * 128 * sizeof(float) + 256 : 16;
+}
+
+int taco_critic_clamped_words(const taco_policy_cfg *c, int64_t rows, const void *workspace, uint32_t *count, void *stream) {
+    const int rc = policy_cfg_ok(c);
+    if (rc != TACO_OK) return rc;
+    if (!workspace || !count || rows < 1) return fail(TACO_ERR_INVALID_ARG, "taco_critic_clamped_words: bad argument");
+    *count = 0;
+    if (!critic_batched_form(c) || !(c->flags & TACO_P_SPLIT_F16) || (c->flags & TACO_P_EXACT_CELL)) return TACO_OK;   // (only the split-f16 form saturates anything)
+    hipError_t he = hipMemcpyAsync(count, critic_ws_tail((float *)const_cast<void *>(workspace), (size_t)rows), sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (he == hipSuccess) he = hipStreamSynchronize((hipStream_t)stream);
+    if (he != hipSuccess) return hip_fail(he, "taco_critic_clamped_words");
+    return TACO_OK;
 }
 
 int taco_critic_values(const taco_policy_cfg *c, const float *blob, int64_t rows, const float *states, float *value, void *workspace, uint64_t *stamps,
@@ -1024,7 +1053,8 @@ int taco_rollout_run(taco_env *e, const taco_policy_cfg *c, const float *blob, c
     }
     // the values of all H + 1 state stacks (:311 value of slot t, :341 of the final state) in one launch: slots 0..H-1 -> value_buf, H -> last_value
     const size_t count = (size_t)horizon * n;
-    rc = launch_critic(c, blob, count + n, b->states_store, b->value_buf, b->last_value, count, b->critic_ws, 0, stream, nullptr, ec.len_states > 1 ? (int)n : 0);
+    rc = launch_critic(c, blob, count + n, b->states_store, b->value_buf, b->last_value, count, b->critic_ws, 0, stream, nullptr, ec.len_states > 1 ? (int)n : 0,
+                       e->ctl + taco::kCtlStatus);
     if (rc != TACO_OK) return rc;
     hipLaunchKernelGGL(taco::timeout_bootstrap_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, b->rew_buf, b->value_buf, b->done_buf,
                        b->timeout_buf, count, (float)gamma);

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(FU_THREADS) void taco_rollout_kernel(const RolloutP
         const int nhead = (head0 + 10 * H) % TACO_RING_SLOTS, nhh = (hh0 + H) % HIST_ROWS;
         uint32_t *w = R.S.wclk + (size_t)blockIdx.x * kWclkWordsPerGroup;
         w[0] = nstep; w[1] = wclk_aux(nhead, nhh, phase0);
-        if (blockIdx.x == 0) { R.S.ctl[kCtlStep] = nstep; R.S.ctl[kCtlHead] = (uint32_t)nhead; R.S.ctl[kCtlHh] = (uint32_t)nhh; }
+        if (blockIdx.x == 0) { R.S.ctl[kCtlStep] = nstep; R.S.ctl[kCtlHead] = (uint32_t)nhead; R.S.ctl[kCtlHh] = (uint32_t)nhh; if (R.S.use_ctl) atomicAdd(&R.S.ctl[kCtlDevSteps], 1u); }
     }
 }
 

@@ -46,7 +46,10 @@ struct PolicyParams {
                         // instead of a shifted stack per slot; include/taco_env.h taco_rollout_bufs)
     const uint32_t *clock;  // optional: the env's device-resident step word (taco_step.hpp, kCtlStep).  Non-NULL: the noise counter is
     uint32_t call_delta;    // *clock + call_delta instead of `call` -- what makes a captured rollout draw fresh noise at every replay
+    uint32_t *clamped;      // split-f16 critic: counts the finite frame words beyond +-65 504 it saturated (the workspace's tail word, zeroed per call)
+    uint32_t *env_status;   // ... and, inside taco_rollout_run, the env's sticky status word receives kStatusCriticClamped (taco_check reports it)
 };
+constexpr uint32_t kStatusCriticClampedBit = 2u;   // (= taco_step.hpp kStatusCriticClamped; this header does not include that one)
 
 typedef float pf32x4 __attribute__((ext_vector_type(4)));
 TD int pad16(int x) { return (x + 15) / 16 * 16; }
@@ -939,8 +942,9 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_kernel(cons
 // f16 halves: |value difference| 3e-7 ... 1e-6 on O(1) values (the hardware cell alone: 7e-7) -- inside the 2e-6 bar of the fast cell; bf16
 // halves with three terms: 1e-5 ... 3e-5, OUTSIDE that bar (six terms -- a three-way split -- would meet it at 1.5 x the weight registers,
 // which this kernel does not have).
-// Operand range of the f16 form: frame words are clamped to +-65 504 (frames are O(1): normalised positions, rates, voltages -- the clamp
-// only keeps a diverged env's huge finite word from turning into inf - inf = NaN); h_t lies in [-1, 1]; bf16 has f32's range.
+// Operand range of the f16 form: finite frame words beyond +-65 504 saturate there AND ARE COUNTED (frames are O(1): normalised positions, rates,
+// voltages -- the clamp keeps a huge finite word from turning into inf - inf; the gates it feeds are saturated either way); +-inf becomes NaN, NaN
+// stays NaN (a diverged env poisons its value as in the f32 kernel); h_t lies in [-1, 1]; bf16 has f32's range.
 // Layout (cdna_hip_programming.md section 3): lane (r = lane & 15, g = lane >> 4) holds A[row r][k = 32 S + 8 g + j] and
 // B[k = 32 S + 8 g + j][col r], j = 0 .. 7 (four VGPRs each); D: row 4 g + i, col r.  The product is taken TRANSPOSED (D = W x^T: the weights
 // are the A operand, the activations the B operand -- see the kernel).  Weights: both halves of the wavefront's W_ih / W_hh columns resident
@@ -1069,9 +1073,20 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_split_kerne
             const int row = e >> 4, k = (e & 15) * 2;
             float v0 = k < sd ? xst[row * sd + k] : (k == sd ? 1.0f : 0.0f);
             float v1 = k + 1 < sd ? xst[row * sd + k + 1] : (k + 1 == sd ? 1.0f : 0.0f);
-            if constexpr (KIND == 1) {   // f16's range: a huge finite frame word saturates instead of turning into inf - inf; a NaN stays a NaN (as in the f32 kernel)
-                v0 = v0 > 65504.0f ? 65504.0f : (v0 < -65504.0f ? -65504.0f : v0);
-                v1 = v1 > 65504.0f ? 65504.0f : (v1 < -65504.0f ? -65504.0f : v1);
+            if constexpr (KIND == 1) {
+                // f16's range.  NaN stays NaN and +-inf BECOMES NaN (the f32 kernel propagates both: a diverged env must not come out with a
+                // plausible value -- round 5's advisor); a huge FINITE word saturates at +-65 504 (it would otherwise turn into inf - inf) and
+                // is COUNTED: the workspace's tail word (taco_critic_clamped_words) and, in a rollout, the env's status word (taco_check)
+                const float a0 = __builtin_fabsf(v0), a1 = __builtin_fabsf(v1);
+                if (a0 > 65504.0f || a1 > 65504.0f) {   // (false for NaN)
+                    const uint32_t n0 = a0 > 65504.0f && a0 < __builtin_inff(), n1 = a1 > 65504.0f && a1 < __builtin_inff();
+                    if (a0 > 65504.0f) v0 = n0 ? __builtin_copysignf(65504.0f, v0) : __builtin_nanf("");
+                    if (a1 > 65504.0f) v1 = n1 ? __builtin_copysignf(65504.0f, v1) : __builtin_nanf("");
+                    if (n0 | n1) {   // (clamp EVENTS: a frame is staged by every block of two slots whose stacks hold it, up to (T + 2) / 2 of them)
+                        if (P.clamped) atomicAdd(P.clamped, n0 + n1);
+                        if (P.env_status) atomicOr(P.env_status, kStatusCriticClampedBit);
+                    }
+                }
             }
             HT h0, h1, l0, l1;
             split16(v0, h0, l0);

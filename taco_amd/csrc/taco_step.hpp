@@ -116,7 +116,10 @@ constexpr int HIST_ROWS = 16;  // action history: hist[tile][k][64] float4, the 
 // control block: the last 256 bytes of the workspace.  Words: 0 step count, 1 ring head, 2 history row, 3 phase of the states frame ring
 // (taco_bind_states_ring) -- the step CLOCK as the host reads it back (refresh_clock): workgroup 0 of every launch leaves the NEXT values
 // here --, 4 sticky status bits.
-enum : uint32_t { kCtlStep = 0, kCtlHead = 1, kCtlHh = 2, kCtlPhase = 3, kCtlStatus = 4, kCtlBytes = 256 };
+// kCtlDevSteps counts the launches that took their clock from the DEVICE (use_ctl: every launch of a handle in graph mode, and every replay of a
+// graph captured from it, whenever that happens); eager launches outside graph mode never touch it -- what lets taco_check see a replay made after
+// taco_release_graphs even once later eager steps have overwritten kCtlStep
+enum : uint32_t { kCtlStep = 0, kCtlHead = 1, kCtlHh = 2, kCtlPhase = 3, kCtlStatus = 4, kCtlDevSteps = 5, kCtlBytes = 256 };
 // wclk: the same clock where the KERNELS take it from when their arguments are frozen in a HIP graph: one {step, aux} pair per 16 envs
 // (aux = ring head | history row << 8 | frame-ring phase << 16), all pairs equal between launches.  A step wavefront reads the pair of its own
 // envs and leaves the next values there when it is done -- every word has ONE reader-writer per launch, so a captured step advances the clock
@@ -131,6 +134,7 @@ __host__ __device__ constexpr int wclk_hh(uint32_t aux) { return (int)((aux >> 8
 __host__ __device__ constexpr int wclk_phase(uint32_t aux) { return (int)(aux >> 16); }
 __host__ __device__ constexpr size_t wclk_words(int npad) { return (size_t)(npad / 16) * kWclkWordsPerGroup; }
 constexpr uint32_t kStatusMailboxTimeout = 1u;  // a battery-mailbox wait gave up (the affected envs' voltage was poisoned with NaN)
+constexpr uint32_t kStatusCriticClamped = 2u;   // taco_rollout_run's split-f16 critic saturated a finite frame word beyond +-65 504 (taco_policy.hpp split_frames)
 constexpr uint32_t kRowBytes = 1024;  // one row (chunk, history row or ring slot) of one tile: 64 lanes x 16 B
 // float index of word 0 of (row r, env i) in an array with `rows` rows per tile (host-side kernels of taco_capi.hip)
 __host__ __device__ constexpr size_t tile_word(int rows, int r, int i) { return (((size_t)(i >> 6) * rows + r) * 64 + (size_t)(i & 63)) * 4; }
@@ -976,6 +980,7 @@ TD void step_core(const StepParams &Pin, const FusedCtx &FX) {
                 for (int gq = 0; gq < (64 / LPE) / 16; ++gq) { w[2 * gq] = nstep; w[2 * gq + 1] = naux; }
                 if (blockIdx.x == 0 && threadIdx.x == 0) {
                     P.ctl[kCtlStep] = nstep; P.ctl[kCtlHead] = (uint32_t)nhead; P.ctl[kCtlHh] = (uint32_t)nhh; P.ctl[kCtlPhase] = (uint32_t)nphase;
+                    if (from_ctl) atomicAdd(&P.ctl[kCtlDevSteps], 1u);
                 }
             }
         }

@@ -150,6 +150,7 @@ class ActorCritic:
         self.reuse_outputs = False  # True: act() returns the same five tensors every call (no allocations on the hot loop)
         self.stamps = None          # profiling: a [16] int64 device tensor that workgroup 0 of every act() launch fills with shader-clock stamps
         self._out = None
+        self._last_critic_rows = 0
         n = self.lib.taco_policy_blob_floats(C.byref(self.cfg))
         if n == 0:
             raise _lib.TacoError(f"unsupported policy configuration: {self.lib.taco_last_error().decode()}")
@@ -227,9 +228,27 @@ class ActorCritic:
         slots, n = fr.shape[0] - T + 1, fr.shape[1]
         out = torch.empty(slots * n, device=self.device)
         ws = self.critic_workspace(slots * n)
+        self._last_critic_rows = slots * n
         s = _lib.stream_ptr(self.device)
         _lib.check(self.lib.taco_critic_values_ring(C.byref(self.cfg), self._blob.data_ptr(), slots, n, fr.data_ptr(), out.data_ptr(), ws.data_ptr(), s), self.lib)
         return out.view(slots, n, 1)
+
+    def clamped_words(self, rows=None):
+        """BLOCKS.  How many finite frame words beyond +-65 504 the LAST batched split-f16 critic call (values_ring / RolloutBuffer.run; `rows` = its row
+        count, default: that of the last values_ring call) saturated; 0 for every other critic form.  +-inf / NaN words are not counted: they poison the
+        row's value with NaN, as in the f32 kernels.  (include/taco_env.h taco_critic_clamped_words)"""
+        rows = self._last_critic_rows if rows is None else int(rows)
+        if not rows or getattr(self, "_critic_ws", None) is None:
+            return 0
+        n = C.c_uint32(0)
+        _lib.check(self.lib.taco_critic_clamped_words(C.byref(self.cfg), rows, self._critic_ws.data_ptr(), C.byref(n), _lib.stream_ptr(self.device)), self.lib)
+        return int(n.value)
+
+    def check(self, rows=None):
+        """raise if the last batched critic call saturated frame words (states not normalised: use critic_split=None / exact_critic=True)"""
+        n = self.clamped_words(rows)
+        if n:
+            raise _lib.TacoError(f"the split-f16 critic saturated {n} finite frame words beyond +-65 504: normalise the states or construct ActorCritic(critic_split=None)")
 
     def critic_workspace(self, rows):
         """the batched critic's workspace for `rows` state stacks (kept and reused while it is large enough)"""

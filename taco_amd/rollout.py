@@ -158,6 +158,7 @@ class RolloutBuffer:
                              self.rew_buf.data_ptr(), self.done_buf.data_ptr(), self.value_buf.data_ptr(), self.logp_buf.data_ptr(),
                              self.mu_buf.data_ptr(), self.sigma_buf.data_ptr(), self._timeouts.data_ptr(), self._last_value.data_ptr(),
                              policy.critic_workspace((H + 1) * N).data_ptr())
+        policy._last_critic_rows = (H + 1) * N      # (what policy.clamped_words() / policy.check() look at afterwards)
         # The actor's noise counter is (env step word) + call_delta on a capturing stream (taco_rollout_run), so replays of a captured rollout
         # consume counters the Python-side policy.calls never sees: the first EAGER run() after replays re-derives it from the env's clock.
         if torch.cuda.is_current_stream_capturing():

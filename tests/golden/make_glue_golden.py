@@ -202,6 +202,26 @@ def stabiliser(env):
     return a.numpy().astype(np.float32)
 
 
+def station_keeper(env):
+    """the long cases' stabilising law (round 6): as `stabiliser`, but the axis body z is turned towards leans against the horizontal position
+    error and velocity (so that an env neither drifts out of the 10 m death radius nor sinks below z = 0.1 within 1 000 steps), and the thrust
+    word holds the target's height.  Computed from the REFERENCE's own state inside the generator; what is stored is the resulting action
+    stream, which the tests replay open loop."""
+    q, n = env.copter_quat, env.copter_quat.shape[0]
+    err = env.target_pos - env.copter_pos
+    a_des = torch.clamp(1.2 * err - 1.6 * env.copter_linvel, -4.0, 4.0)
+    z_des = torch.stack((a_des[:, 0], a_des[:, 1], torch.full((n,), 9.81)), dim=1)
+    z_des = z_des / z_des.norm(dim=1, keepdim=True)
+    z_des_b = FA.quat_rotate(FA.quat_conjugate(q), z_des)
+    e3 = torch.tensor([[0.0, 0.0, 1.0]]).expand(n, 3)
+    rate = 7.0 * torch.cross(e3, z_des_b, dim=1)
+    rate = torch.where((z_des_b[:, 2:3] < 0) & (rate.norm(dim=1, keepdim=True) < 1.0), torch.tensor([[7.0, 0.0, 0.0]]).expand(n, 3), rate)  # upside down: roll out of it
+    a = torch.zeros((n, 4))
+    a[:, 1:] = rate / 20.0
+    a[:, 0] = 0.5 * torch.clamp(err[:, 2], -2.0, 2.0) - 0.35 * env.copter_linvel[:, 2]
+    return a.numpy().astype(np.float32)
+
+
 class _TorchWithIEEESqrt:
     """`torch` as control/battery_dynamics.py sees it in the `*_ieee` family: every attribute is torch's own except `sqrt`, which returns the
     CORRECTLY ROUNDED fp32 square root (computed in fp64 and rounded once: 53 >= 2 * 24 + 2 bits make the double rounding innocuous).  That is
@@ -432,6 +452,8 @@ def run_case(name, task, n, steps, seed, act_fn, ieee_sqrt=False, **kw):
     try:
         env = cls(cfg, "cpu", "cpu", -1, True, False, False)
         rec = {k: [] for k in ("step", "obs", "states", "rew", "reset", "timeout", "blob", "reset_vals")}
+        slim = kw.get("_slim", False)   # long cases: the rows of SLIM_ROWS, the newest obs / states frame, reward and flags after EVERY step
+        srec = {k: [] for k in ("rows_t", "obs_t", "states_t", "rew_t", "reset_t", "timeout_t")}
         record = kw.get("_record", lambda t: True)   # long cases keep the steps around the events of interest only (all actions are kept)
         n_resets = n_tmo = 0
         acts = act_fn(n, steps)
@@ -440,7 +462,10 @@ def run_case(name, task, n, steps, seed, act_fn, ieee_sqrt=False, **kw):
             D.step, D.substep = t, 0
             D.reset_vals = np.full((n, 5), np.nan, np.float32)
             if hold:  # a crude attitude / altitude stabiliser on top of the noise, so that envs live long enough to reach progress 500
-                acts[t] = np.clip(acts[t] + stabiliser(env), -1, 1)
+                cut = acts[t][:, 0] <= -1.0
+                acts[t] = np.clip(acts[t] + (station_keeper(env) if hold == "station" else stabiliser(env)), -1, 1)
+                if hold == "station":
+                    acts[t][cut, 0] = -1.0   # (the long cases' throttle cuts are not to be held against)
             # reset_command_idx draws the "flips to add" vector only if some env sits at progress 500 (FA:888-890); otherwise the first
             # torch.rand it makes is the unused one
             D.flip_first_is_time = bool(torch.isin(env.progress_buf, env.time_index).any()) if hasattr(env, "time_index") else False
@@ -453,6 +478,11 @@ def run_case(name, task, n, steps, seed, act_fn, ieee_sqrt=False, **kw):
                 rec["timeout"].append(info["time_outs"].numpy().astype(np.uint8))
                 rec["blob"].append(blob_of(env, n))
                 rec["reset_vals"].append(D.reset_vals)
+            if slim:
+                srec["rows_t"].append(blob_of(env, n)[SLIM_ROWS])
+                srec["obs_t"].append(env.obs_buf.numpy()[:, -1, :].copy()); srec["states_t"].append(env.states_buf.numpy()[:, -1, :].copy())
+                srec["rew_t"].append(rew.numpy().copy()); srec["reset_t"].append(done.numpy().astype(np.uint8))
+                srec["timeout_t"].append(info["time_outs"].numpy().astype(np.uint8))
     finally:
         BD.torch = bd_torch
         VT.VecTask.__init__, FA.torch_rand_float, torch.normal, torch.rand, FA.FpvBase.reset_target_idx, FA.FpvBase.reset_env_idx = saved
@@ -462,6 +492,11 @@ def run_case(name, task, n, steps, seed, act_fn, ieee_sqrt=False, **kw):
             setattr(cls, k, v)
     out = {k: np.stack(v) for k, v in rec.items()}
     out["actions"] = acts
+    if slim:
+        out.update({k: np.stack(v) for k, v in srec.items()})
+        if np.array_equal(out["states_t"], out["obs_t"], equal_nan=True):
+            del out["states_t"]          # no observation noise: the newest states frame IS the newest obs frame (the loader falls back to obs_t)
+        out["rows_index"] = SLIM_ROWS
     out["cfg_task"] = np.array(task)
     out["cfg_n"] = np.array(n)
     out["cfg_seed"] = np.array(seed)
@@ -469,6 +504,11 @@ def run_case(name, task, n, steps, seed, act_fn, ieee_sqrt=False, **kw):
     np.savez_compressed(HERE / f"glue_{name}.npz", **out)
     print(f"glue_{name}.npz: {steps} steps x {n} envs ({len(rec['step'])} recorded), {n_resets} resets, {n_tmo} time-outs, "
           f"max delay length {int(out['blob'][:, 66].view(np.int32).max())}, max progress {int(out['blob'][:, 65].view(np.int32).max())}")
+
+
+# rows of the state blob a long case keeps after every step: root state, rpy_old / rpy_continuous, PID memory, battery state + voltage,
+# rotor speeds, command / flip_radian, progress_buf, actions_remained_length
+SLIM_ROWS = np.r_[0:13, 20:26, 26:32, 32:36, 36:40, 48:51, 65:67]
 
 
 def blob_of(env, n):
@@ -501,15 +541,15 @@ def blob_of(env, n):
     return b
 
 
-def actions(seed, thrust_bias, crash_every=0, noise=0.3):
+def actions(seed, thrust_bias, crash_every=0, noise=0.3, crash_t0=15, crash_stride=7, by_rank=False, crash_len=60):
     def f(n, steps):
         rng = np.random.default_rng(seed)
         a = noise * rng.standard_normal((steps, n, 4)).astype(np.float32)
         a[:, :, 0] += thrust_bias
         if crash_every:  # a few envs cut the throttle for a while: they fall below z = 0.1 and die
             for e in range(0, n, crash_every):
-                t0 = 15 + 7 * (e % 9)
-                a[t0:t0 + 60, e, 0] = -1.0
+                t0 = crash_t0 + crash_stride * ((e // crash_every if by_rank else e) % 9)
+                a[t0:t0 + crash_len, e, 0] = -1.0
         return np.clip(a, -1, 1).astype(np.float32)
     return f
 
@@ -529,8 +569,9 @@ if __name__ == "__main__":
     def case(name, *a, **kw):
         if only and name not in only:
             return
-        for ieee in families:
-            run_case(name, *a, ieee_sqrt=ieee, **kw)
+        for ieee in kw.pop("_families", families):
+            if ieee in families:
+                run_case(name, *a, ieee_sqrt=ieee, **kw)
 
     common = dict(random_voltage=False, random_rotor_speed=False, env_lenObservations=2, env_lenStates=3)
     # (1) pos task, every random_* of the pose on: reset dispatch / ordering / zeroing, delay line in the common regime, frame stacks,
@@ -557,3 +598,15 @@ if __name__ == "__main__":
     case("cfg5", "mix", 36, 520, 24, actions(10, -0.5, crash_every=11, noise=0.05), env_maxEpisodeLength=1000, _hold=True, _record=around, **cfg5)
     # (11) config 5's flags again with short episodes (many resets and time-outs with every draw live) and difficulty != 1
     case("cfg5_short", "mix", 36, 200, 25, actions(11, 0.05, crash_every=4), env_maxEpisodeLength=60, difficulty=0.7, **cfg5)
+    # (12)-(15) round 6, north_star's "1 000 steps": 1 060 steps with episodes of 1 200, a station-keeping action stream computed from the
+    #     reference's own state (most envs live through the whole trace; a few cut the throttle and die, so resets and their successors are
+    #     in it too).  Stored: the FULL task state + stacks at the anchors (step 0 = right after every env's first reset, step 530, the last
+    #     step) and the rows of SLIM_ROWS + newest obs / states frame + reward + flags after EVERY step.  tests/util.py::long_replay loads the
+    #     reference's state at an anchor and replays the stored actions open loop.  (`ieee` family only is committed: the bit-exact one.)
+    anchors = lambda t: t in (0, 530, 1059)
+    long_kw = dict(env_maxEpisodeLength=1200, _hold="station", _record=anchors, _slim=True, _families=[True])
+    cut = dict(crash_every=7, noise=0.04, crash_t0=120, crash_stride=95, by_rank=True, crash_len=170)   # every seventh env cuts its throttle for 170 steps somewhere in 120 ... 880
+    case("long_pos", "pos", 64, 1060, 31, actions(12, -0.5, **cut), **long_kw)
+    case("long_rotate", "rotate", 48, 1060, 32, actions(13, -0.5, **cut), **long_kw)
+    case("long_mix", "mix", 36, 1060, 33, actions(14, -0.5, **cut), env_lenStates=5, **long_kw)
+    case("long_cfg5", "mix", 36, 1060, 34, actions(15, -0.5, **cut), **dict(cfg5, **long_kw))

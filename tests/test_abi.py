@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported(lib):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/taco_env.h but not exported"
     assert sorted(_lib.EXPORTS) == names, "binding list out of sync with the header"
-    assert lib.taco_abi_version() == _lib.ABI_VERSION == 7
+    assert lib.taco_abi_version() == _lib.ABI_VERSION == 8
     assert lib.taco_step_kernel_name() == b"taco_step_kernel"
 
 

@@ -570,6 +570,12 @@ def test_ring_backed_state_stack_through_capture_checkpoint_and_the_c_abi(tmp_pa
     graph.replay()
     with pytest.raises(_lib.TacoError, match="replayed after taco_release_graphs"):
         env.check()
+    # ... and STAYS reported once eager steps have overwritten the device clock's step word (round 5's advisor: the comparison of the two clocks
+    # alone went quiet after one env.step()): launches that read the device clock count themselves, the release latched the count
+    for t4 in range(3):
+        env.step(acts[t4 % 8])
+    with pytest.raises(_lib.TacoError, match="replayed after taco_release_graphs"):
+        env.check()
 
 
 def _run_bench(extra, env_extra=None, timeout=420):
@@ -636,8 +642,11 @@ def test_bench_launches_its_own_ranks():
     d = _run_bench(["--gpus", "2", "--steps", "60", "--warmup", "10"], {"TACO_BENCH_BACKEND": "gloo", "TACO_BENCH_ONE_DEVICE": "1"})
     assert d["n_gpus"] == 2 and d["ranks_seen"] == [0, 1] and d["config"]["envs_total"] == 8192 and d["scaling"] == "weak"
     assert abs(d["value"] - 8192 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
-    w = d["with_allgather"]
-    assert "error" not in w and w["value"] > 0 and w["overlapped"]["value"] > 0 and w["bytes_per_rank"] == 4096 * 32 * 4
+    # the headline of N > 1 carries north_star's per-step all-gather (overlapped); the gather-free and the serial figures sit beside it
+    assert d["config"]["collective"] != "none" and "all_gather" in d["config"]["collective"] and "step_async" in d["config"]["api"]
+    assert "allgather_legs_error" not in d and d["without_allgather"]["value"] > 0 and d["with_allgather_serial"]["value"] > 0
+    assert d["without_allgather"]["value"] >= 0.8 * d["value"], "the gather-free leg cannot be much slower than the gathered one"
+    assert d["allgather"]["bytes_per_rank"] == 4096 * 32 * 4 and d["allgather"]["backend"] == "gloo"
     assert len(d["kernel_us_per_rank"]) == 2 and d["envs_per_rank"] == [4096.0, 4096.0] and d["n1_on_rank0"]["value"] > 0
     bc = d["baseline_configs"]      # BASELINE configs 3-5 at their real totals, sharded over the two ranks; config 5 with its rollout
     assert [(x["config"], x["envs_total"], x["envs_per_rank"]) for x in bc] == [(3, 16384, 8192), (4, 65536, 32768), (5, 262144, 131072), (5, 262144, 131072)], bc
@@ -653,6 +662,14 @@ def test_bench_main_leg_on_another_baseline_config_and_backend_fallback():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["envs_total"] == 65536 and d["config"]["envs_per_gpu"] == 32768
     assert "configs[3]" in d["metric"] and abs(d["value"] - 65536 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     assert d["backend"] == "gloo" and "ucc" in d["collective_init_error"] and d["ranks_seen"] == [0, 1]
+    assert "all_gather" in d["config"]["collective"] and d["without_allgather"]["value"] > 0
+
+
+def test_bench_no_gather_flag_keeps_the_gather_free_headline():
+    """`--no-gather`: the main timed leg of N > 1 is the gather-free ShardedEnv.step_local; the gathered forms are still timed beside it"""
+    d = _run_bench(["--gpus", "2", "--steps", "40", "--warmup", "10", "--no-gather", "--no-configs"], {"TACO_BENCH_BACKEND": "gloo", "TACO_BENCH_ONE_DEVICE": "1"})
+    assert d["config"]["collective"].startswith("none in the timed region") and "step_local" in d["config"]["api"]
+    assert d["with_allgather"]["value"] > 0 and d["with_allgather_serial"]["value"] > 0 and "without_allgather" not in d
 
 
 def test_yaml_launcher_equals_the_python_built_config(tmp_path):

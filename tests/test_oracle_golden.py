@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O
-from util import GLUE_CASES, GLUE_CASES_IEEE, assert_bits_equal, assert_ulp
+from util import GLUE_CASES, GLUE_CASES_IEEE, GLUE_CASES_LONG, assert_bits_equal, assert_ulp
 
 TWO_PI = np.float32(2 * np.pi)
 
@@ -339,3 +339,18 @@ def test_one_step_is_bit_exact_against_the_ieee_sqrt_reference(case, golden):
         assert exact[name]["differ (no reset)"] == 0 and exact[name]["words"] > 0
     print(f"one step, glue_{case} {cnt}: " + ", ".join(f"{k} {v:.1e}" for k, v in maxima.items()))
     print(exact_table(f"glue_{case}", exact))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# north_star's parity sentence ("state trajectories within 1e-5 fp32 over 1 000 steps") against the reference's OWN 1 060-step runs
+# (glue_long_*_ieee.npz; tests/util.py::long_replay states what is bit-equal and what is held to 1e-5).  Here: the oracle; the HIP kernel
+# takes the same test in tests/test_parity_gpu.py.
+# ---------------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case,anchor", [(c, a) for c in GLUE_CASES_LONG for a in (0, 530)])
+def test_thousand_steps_from_the_references_own_state(case, anchor, golden):
+    from util import glue_case, long_replay, long_table
+    g = golden("glue_" + case)
+    cfg, acts, _ = glue_case(g)
+    st, tab, summary = long_replay(g, _OracleOneStep(cfg, "roundtrip"), f"glue_{case} from step {anchor}", anchor_step=anchor)
+    assert summary["steps"] >= (1000 if anchor == 0 else 500)
+    print(long_table(f"glue_{case} from step {anchor}", st, tab, summary))

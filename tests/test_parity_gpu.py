@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from taco_amd import config
-from util import GLUE_CASES, GLUE_CASES_IEEE, assert_bits_equal
+from util import GLUE_CASES, GLUE_CASES_IEEE, GLUE_CASES_LONG, assert_bits_equal
 
 pytestmark = pytest.mark.gpu
 
@@ -561,3 +561,22 @@ def test_ducted_airframe_preset():
     assert abs(config.flat_cfg(cfg)["mass"] - 0.5700008) < 1e-9
     for form in ("auto", "lane", "lane_throughput"):
         run_pair(cfg, steps=150, check_every=10, form=form)
+
+
+# north_star's parity sentence -- "state trajectories within 1e-5 fp32 over 1 000 steps" -- against the reference's OWN 1 060-step runs
+# (glue_long_*_ieee.npz, tests/golden/make_glue_golden.py cases 12-15: pos, rotate, mix with 5 state frames, mix with every flag of BASELINE config 5):
+# the reference's task state at an anchor step loaded through the C ABI (taco_set_state / taco_set_step_count), the stored actions replayed open loop
+# through taco_step, and after EVERY step root state, PID memory, battery, rotor speeds, bookkeeping, flags and every libm-free word of the newest
+# obs / states frame BIT-EQUAL to what the reference held, for every env that has not reset since the anchor; euler-angle rows, the flip command,
+# noised obs words and the reward (behind libm calls of the reference) within tests/util.py::LONG_TOL; the envs that did reset tabulated apart
+# (reset step: what libm's sin / cos costs; afterwards: the closed loop).  Printed with -s.
+@pytest.mark.parametrize("case,anchor", [(c, a) for c in GLUE_CASES_LONG for a in (0, 530)])
+def test_hip_thousand_steps_from_the_references_own_state(case, anchor, golden):
+    from util import glue_case, long_replay, long_table
+    g = golden("glue_" + case)
+    cfg, _, _ = glue_case(g)
+    impl = _HipOneStep(cfg, "roundtrip")
+    st, tab, summary = long_replay(g, impl, f"HIP glue_{case} from step {anchor}", anchor_step=anchor)
+    impl.env.check()
+    assert summary["steps"] >= (1000 if anchor == 0 else 500)
+    print(long_table(f"HIP glue_{case} from step {anchor}", st, tab, summary))

@@ -73,6 +73,76 @@ def test_split_precision_critic_other_state_widths(states_dim):
         assert_bits_equal(got, f32, "states_dim = 32: the split flag falls back to the f32 kernel")
 
 
+def test_split_precision_critic_does_not_hide_out_of_range_frames():
+    """include/taco_env.h TACO_P_SPLIT_F16 (ABI 8), round 5's verdict / advisor: the split-f16 critic (the host layer's default) must not turn a diverged
+    env into a plausible value, nor clamp silently.  (a) a +-inf or NaN frame word -> the value of every stack holding it is NaN, exactly the rows the f32
+    kernel poisons; (b) FINITE words of magnitude 1e5 (states that were never normalised) saturate at +-65 504 and are COUNTED
+    (ActorCritic.clamped_words / .check; the gates they feed are saturated either way: the values stay within 2e-6 of the f32 kernel's);
+    (c) in-range frames count nothing."""
+    from taco_amd import _lib, policy as P
+    rng = np.random.default_rng(77)
+    T, slots, n = 5, 8, 96
+    sd = _random_policy(rng, 1, T, [32], 128, [128, 128])
+    base = rng.standard_normal((slots + T - 1, n, 26)).astype(np.float32)
+    f32, split = P.ActorCritic(sd, 1, T, seed=3, critic_split=None), P.ActorCritic(sd, 1, T, seed=3)
+    assert split.cfg.flags & P.P_SPLIT_F16
+    # (c)
+    fr = torch.from_numpy(base).cuda()
+    split.values_ring(fr)
+    assert split.clamped_words() == 0
+    split.check()
+    # (a) poison: frame 6 of env 10 is +inf, frame 3 of env 20 is -inf, frame 9 of env 30 NaN
+    bad = base.copy()
+    bad[6, 10, 4], bad[3, 20, 17], bad[9, 30, 0] = np.inf, -np.inf, np.nan
+    fr = torch.from_numpy(bad).cuda()
+    v_ref, v = f32.values_ring(fr).cpu().numpy()[:, :, 0], split.values_ring(fr).cpu().numpy()[:, :, 0]
+    # every stack holding a poisoned frame, and no other row (the f32 kernel poisons a subset: an inf word can saturate all four gates to finite values there)
+    assert np.isnan(v[2:7, 10]).all() and np.isnan(v[0:4, 20]).all() and np.isnan(v[5:8, 30]).all() and np.isnan(v).sum() == 5 + 4 + 3
+    assert not (np.isnan(v_ref) & ~np.isnan(v)).any() and np.isnan(v_ref[5:8, 30]).all()
+    ok = ~np.isnan(v)
+    assert np.abs(v[ok] - v_ref[ok]).max() <= 2e-6 * max(1.0, np.abs(v_ref[ok]).max())
+    assert split.clamped_words() == 0, "inf / NaN words poison, they are not counted as clamps"
+    # (b) huge finite words
+    big = base.copy()
+    big[2, 5, 1], big[7, 40, 20], big[7, 41, 3] = 1.0e5, -3.0e5, 7.0e4
+    fr = torch.from_numpy(big).cuda()
+    v_ref, v = f32.values_ring(fr).cpu().numpy(), split.values_ring(fr).cpu().numpy()
+    assert np.isfinite(v).all() and np.abs(v - v_ref).max() <= 2e-6 * max(1.0, np.abs(v_ref).max())
+    cnt = split.clamped_words()
+    assert 3 <= cnt <= 3 * ((T + 2) // 2 + 1), cnt          # three words; each staged by every two-slot block whose stacks hold its frame
+    with pytest.raises(_lib.TacoError, match="saturated"):
+        split.check()
+    assert f32.clamped_words() == 0
+    split.values_ring(torch.from_numpy(base).cuda())
+    assert split.clamped_words() == 0, "the count is per call"
+
+
+def test_split_precision_critic_large_magnitude_weights():
+    """round 5's advisor: the 2e-6 bar was measured on random-init weights only.  Weights scaled up (x 4 / x 8 on the LSTM: saturated gates; x 3 / x 6 on
+    the MLP: hidden activations of tens, |value| up to hundreds): the error relative to max(1, |value|) grows with the weights' magnitude -- the value is a
+    sum of terms larger than itself, and the split operands carry 22 bits against f32's 24.  Printed next to the f32 fast cell's own distance from the exact
+    cell (same weights), and asserted against the bar scaled by the weights' gain; random-init scale (1, 1) holds the plain 2e-6.  DESIGN.md section 4.3 quotes this table."""
+    from taco_amd import policy as P
+    for seed, lstm_scale, mlp_scale in ((0, 1.0, 1.0), (1, 4.0, 3.0), (2, 8.0, 1.0), (3, 1.0, 6.0)):
+        rng = np.random.default_rng(seed)
+        sd = _random_policy(rng, 1, 5, [32], 128, [128, 128])
+        for k in sd:
+            if k.startswith("critic_encoder."):
+                sd[k] = (sd[k] * lstm_scale).astype(np.float32)
+            elif k.startswith("critic_mlp."):
+                sd[k] = (sd[k] * mlp_scale).astype(np.float32)
+        frames = torch.from_numpy(rng.standard_normal((12, 200, 26)).astype(np.float32)).cuda()
+        ref = P.ActorCritic(sd, 1, 5, seed=3, exact_critic=True).values_ring(frames).cpu().numpy()
+        fast = P.ActorCritic(sd, 1, 5, seed=3, critic_split=None).values_ring(frames).cpu().numpy()
+        pol = P.ActorCritic(sd, 1, 5, seed=3, critic_split="f16")
+        got = pol.values_ring(frames).cpu().numpy()
+        rel = lambda x: (np.abs(x.astype(np.float64) - ref) / np.maximum(1.0, np.abs(ref))).max()
+        print(f"weights x ({lstm_scale}, {mlp_scale}): values in [{ref.min():.2f}, {ref.max():.2f}]; |difference| / max(1, |value|) from the exact f32 critic: "
+              f"split f16 {rel(got):.2e}, f32 fast cell {rel(fast):.2e}")
+        assert np.isfinite(got).all() and pol.clamped_words() == 0
+        assert rel(got) <= 2e-6 * max(1.0, lstm_scale) * max(1.0, mlp_scale), "the bar scaled by the gain of the weights"
+
+
 def test_split_precision_critic_matches_reference_golden_and_rollout_trajectories_do_not_move():
     """policy_documented.npz through the split-f16 critic: inside the 1e-5 bar to the reference's own numbers (a ring built from the fixture's
     stacks); and a rollout with critic_split='f16' produces bit-identical observations / actions / log-probs / rewards / dones -- only
