@@ -121,7 +121,7 @@ def test_split_precision_critic_large_magnitude_weights():
     """round 5's advisor: the 2e-6 bar was measured on random-init weights only.  Weights scaled up (x 4 / x 8 on the LSTM: saturated gates; x 3 / x 6 on
     the MLP: hidden activations of tens, |value| up to hundreds): the error relative to max(1, |value|) grows with the weights' magnitude -- the value is a
     sum of terms larger than itself, and the split operands carry 22 bits against f32's 24.  Printed next to the f32 fast cell's own distance from the exact
-    cell (same weights), and asserted against the bar scaled by the weights' gain; random-init scale (1, 1) holds the plain 2e-6.  DESIGN.md section 4.3 quotes this table."""
+    cell (same weights): the growth is the MLP's gain on the cell's error, not the split -- asserted: split <= 4 x the fast cell's distance; random-init scale (1, 1) holds the plain 2e-6.  DESIGN.md section 4.3 quotes this table."""
     from taco_amd import policy as P
     for seed, lstm_scale, mlp_scale in ((0, 1.0, 1.0), (1, 4.0, 3.0), (2, 8.0, 1.0), (3, 1.0, 6.0)):
         rng = np.random.default_rng(seed)
@@ -140,7 +140,11 @@ def test_split_precision_critic_large_magnitude_weights():
         print(f"weights x ({lstm_scale}, {mlp_scale}): values in [{ref.min():.2f}, {ref.max():.2f}]; |difference| / max(1, |value|) from the exact f32 critic: "
               f"split f16 {rel(got):.2e}, f32 fast cell {rel(fast):.2e}")
         assert np.isfinite(got).all() and pol.clamped_words() == 0
-        assert rel(got) <= 2e-6 * max(1.0, lstm_scale) * max(1.0, mlp_scale), "the bar scaled by the gain of the weights"
+        # measured (round 6, r06_a): (1, 1) split 6.9e-7 / fast cell 4.8e-7; (4, 3) 1.8e-5 / 1.3e-5; (8, 1) 2.8e-6 / 9.6e-7; (1, 6) 3.2e-5 / 3.7e-5:
+        # the MLP's gain amplifies the cell's ~1e-6 on h_T; the split operands add at most 3 x on top of what the f32 fast cell already differs by
+        assert rel(got) <= 4.0 * max(rel(fast), 7e-7), "the split form stays within 4 x the f32 fast cell's own distance from the exact cell"
+        if lstm_scale == mlp_scale == 1.0:
+            assert rel(got) <= 2e-6
 
 
 def test_split_precision_critic_matches_reference_golden_and_rollout_trajectories_do_not_move():
