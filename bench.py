@@ -131,20 +131,54 @@ def steady_windows(step_fn, acts, torch, warm_seconds, windows, steps_per_window
     return ws[len(ws) // 2], ws, first
 
 
+def pmc_summary():
+    """-> (summary dict or None, file name or reason).  The committed rocprofv3 PMC summary (profiles/r*_pmc_summary.json) whose `source_hash` is
+    THIS build's -- chosen by hash, not by file name (round 5's advisor: the lexicographically last file happened to be the right one) -- newest first
+    among several.  No match: the reason is reported on the line instead of a silent None."""
+    import glob
+    from taco_amd import build
+    want = build.source_hash()
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), key=os.path.getmtime, reverse=True)
+    seen = []
+    for f in files:
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if d.get("source_hash") == want:
+            return d, os.path.basename(f)
+        seen.append(d.get("source_hash"))
+    return None, (f"no profiles/r*_pmc_summary.json carries this build's source hash {want} ({len(files)} summaries of other builds: run tools/profile_all.sh)"
+                  if files else "no PMC summary under profiles/")
+
+
 def pmc_traffic(n_envs):
     """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC summary (FETCH_SIZE x2 per the gfx950 note in
     MI355X_MICROARCH.md + WRITE_SIZE, separate passes; profiles/README.md).  bench.py cannot run rocprofv3 on itself, so the figure is
     the one measured for the build that produced the summary: it is reported only if that build's source hash is THIS build's."""
-    import glob
-    from taco_amd import build
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
-    if not files:
-        return None, None
-    d = json.load(open(files[-1]))
-    name = os.path.basename(files[-1])
-    if d.get("source_hash") != build.source_hash():
-        return None, f"{name} is from another build ({d.get('source_hash')} != {build.source_hash()})"
+    d, name = pmc_summary()
+    if d is None:
+        return None, name
     return d.get("derived", {}).get(f"hbm_bytes_per_launch_{n_envs}"), name
+
+
+def rocprof_row(shape, needle="taco_step_kernel"):
+    """the size-isolated `rocprofv3 --kernel-trace --stats` table of this build for one shape (tools/profile_all.sh step 5d:
+    profiles/<tag>_kernel_stats_<shape>.csv, <tag> = the PMC summary's): the row of the kernel that dominates it -- what the figure next to it
+    can be checked against.  None if this build has not been profiled."""
+    import csv
+    d, name = pmc_summary()
+    if d is None:
+        return None
+    f = os.path.join(ROOT, "profiles", name.replace("_pmc_summary.json", f"_kernel_stats_{shape}.csv"))
+    if not os.path.exists(f):
+        return None
+    rows = [r for r in csv.DictReader(open(f)) if needle in r["Name"]]
+    if not rows:
+        return None
+    r = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+    return {"csv": os.path.relpath(f, ROOT), "kernel": r["Name"][:120], "calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) * 1e-3,
+            "min_us": float(r["MinNs"]) * 1e-3}
 
 
 # VALU issue roof.  One SIMD issues one wave64 VALU instruction per ~1.2 ns in a realistic mix at 2-4 wavefronts per SIMD (fma / fmac / mul / add
@@ -156,21 +190,16 @@ N_SIMDS = 1024
 
 
 def pmc_valu(n_envs, kernel_us):
-    import glob
-    from taco_amd import build
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
-    if not files:
-        return None
-    d = json.load(open(files[-1]))
-    if d.get("source_hash") != build.source_hash():
-        return None
+    d, name = pmc_summary()
+    if d is None:
+        return {"missing": name}
     key = {262144: "sq_262144", 4096: "sq_4096"}.get(n_envs)
     insts = d.get(key, {}).get("SQ_INSTS_VALU", {}).get("mean_per_launch") if key else None
     if not insts:
-        return None
+        return {"missing": f"{name} holds no SQ_INSTS_VALU for {n_envs} envs"}
     floor_us = insts / N_SIMDS * VALU_NS_PER_INST * 1e-3
     return {"insts_per_launch": insts, "ns_per_inst": VALU_NS_PER_INST, "simds": N_SIMDS, "floor_us": floor_us, "frac": floor_us / kernel_us,
-            "source": os.path.basename(files[-1]) + " (SQ_INSTS_VALU) x tools/ubench/intmul_cndmask (ns per instruction in a realistic mix)"}
+            "source": name + " (SQ_INSTS_VALU) x tools/ubench/intmul_cndmask (ns per instruction in a realistic mix)"}
 
 
 def cpu_sample(cfg, threads, budget_s):
@@ -210,7 +239,11 @@ def cpu_baseline(budget_s=12.0):
     main = cpu_sample(config.baseline_config(1, num_envs=4096), threads, budget_s)
     out = {"value": main["value"], "unit": "env-steps/s", "cores": threads, "kind": "port",
            "sample": f"{main['sample']} of the same workload through the CPU oracle (OpenMP over envs) on {model or 'host CPU'}",
-           "single_thread": cpu_sample(config.baseline_config(1, num_envs=4096), 1, min(3.0, budget_s)), "configs": []}
+           "single_thread": cpu_sample(config.baseline_config(1, num_envs=4096), 1, min(3.0, budget_s)), "configs": [],
+           # context, NOT measured in this run: the reference's OWN torch modules (rows C-H'', O, P: no rigid-body integrate, no glue) timed by the survey in the
+           # build container (48.1 ms per step at 4 096 envs on 8 cores) -- the reference cannot travel to the GPU box
+           "reference_torch_partial_path_in_build_container": {"value": 85e3, "unit": "env-steps/s", "envs": 4096, "cores": 8, "ms_per_step": 48.1,
+                                                               "source": "BASELINE.md section 2 (survey's measurement; partial path, not this run)"}}
     side = max(1.0, min(3.0, budget_s / 4))
     for label, idx, n in ((1, 0, 64), (3, 2, 16384)):   # SURVEY 8(d) numbering: 1 = pos @ 64 (plumbing), 2 = the headline above, 3 = rotate @ 16 384
         cfg = config.baseline_config(idx, num_envs=n)
@@ -278,7 +311,8 @@ def config_entry(idx, n, dev, torch, warm=0.1):
                          "ramdom_delay_time", "ramdom_deploy_time", "random_command") if cfg.get(k)]
     return {"config": idx + 1, "task_mode": cfg["task_mode"], "envs": n, "len_states": env.len_states, "flags_on": flags, "kernel_us": med,
             "env_steps_per_s": n / (med * 1e-6), "algorithmic_bytes_per_env_step": b, "achieved_GBps": b * n / (med * 1e-6) / 1e9,
-            "frac_of_hbm_peak": b * n / (med * 1e-6) / 1e9 / HBM_PEAK_GBPS, "kernel_form": env.kernel_form, "grid": grid, "block": block, **extra}
+            "frac_of_hbm_peak": b * n / (med * 1e-6) / 1e9 / HBM_PEAK_GBPS, "kernel_form": env.kernel_form, "grid": grid, "block": block,
+            "rocprof": rocprof_row({(1, 16384): "rotate_16384", (2, 16384): "flip_16384", (3, 32768): "mix_32768x5"}.get((idx, n), "none")), **extra}
 
 
 def graph_entry(n, acts, dev, torch, steps_in_graph=64):
@@ -414,7 +448,7 @@ def rollout_entry(n, horizon, dev, torch):
                                if n <= 8192 else "actor launch + step launch per step (above 8 192 envs)"),
             "ms_per_rollout_launch_per_step": lps_s * 1e3,
             "ms_per_rollout_persistent_forced": forced_ms,
-            "critic": {"rows": rows, "ms": c16 * 1e3, "kernel": "ring-form LSTM on v_mfma_f32_16x16x32_f16 with split-f16 operands (the host layer's default, TACO_P_SPLIT_F16) + the MLP's two hidden layers likewise (f32 head on the VALU)",
+            "critic": {"rows": rows, "ms": c16 * 1e3, "rocprof": rocprof_row(f"critic_{rows}", "critic_lstm"), "kernel": "ring-form LSTM on v_mfma_f32_16x16x32_f16 with split-f16 operands (the host layer's default, TACO_P_SPLIT_F16) + the MLP's two hidden layers likewise (f32 head on the VALU)",
                        "tflops_model": flops / c16 / 1e12, "speedup_vs_f32_critic": c32 / c16,
                        "max_abs_value_difference_to_f32_critic": dv, "max_abs_value": vmax,
                        "bound": "VALU issue (the cells' activations and the operand splits), not the matrix pipe: DESIGN.md section 4.3",
@@ -779,7 +813,11 @@ def main():
                          "traffic_source": traffic_src, "kernel_avg_us": k_avg_us, "kernel_bracketed_median_us": k_med_us,
                          "algorithmic_bytes_per_env_step": nbytes,
                          "valu": pmc_valu(n_local, k_avg_us) if (world == 1 and n_local == 4096) else None,   # the other roof: SQ_INSTS_VALU of this launch (steady state) / 1 024 SIMDs x the mix's issue cost
-                         "binds": "neither roof: instruction LATENCY of the slowest wavefront (latency_floor) + the launch boundary",
+                         "bound_is": "the roof SURVEY 8(d) prescribes for this path and `frac` is priced against; see `regime` for what limits THIS launch",
+                         "regime": "latency" if n_local <= 16384 else "valu-issue",
+                         "binds": ("at 4 096 envs per GPU neither roof is reached: instruction LATENCY of the slowest wavefront (latency_floor) + the launch boundary; "
+                                   "the HBM roof prices the throughput regime (large_n: >= 60 % of it at 262 144 envs, where VALU issue is the nearer roof)"),
+                         "rocprof": rocprof_row("bench_4096"),
                          "note": "frac = ALGORITHMIC bytes (SURVEY 8d) / kernel time / 8 TB/s; traffic_frac = counter-measured HBM bytes / kernel time / 8 TB/s. "
                                  "4096 envs = 256 step wavefronts (4 lanes per env, one per CU) + 3 post-phase role wavefronts each: instruction-latency "
                                  "regime (SURVEY 8d): what binds is the instruction stream of the slowest wavefront (latency_floor: ~8.5 us in-kernel, "
@@ -856,8 +894,9 @@ def main():
                                            "algorithmic_bytes_per_env_step": nb, "achieved_GBps": ach, "frac_of_hbm_peak": ach / HBM_PEAK_GBPS,
                                            "traffic": tr, "traffic_frac_of_hbm_peak": (tr / (b_med * 1e-6) / 1e9 / HBM_PEAK_GBPS) if tr else None,
                                            "valu": valu,
-                                           "binding_roof": ("valu" if (valu and tr and valu["frac"] > tr / (b_med * 1e-6) / 1e9 / HBM_PEAK_GBPS) else
-                                                            ("hbm" if (valu and tr) else None)),
+                                           "binding_roof": ("valu" if (valu and "frac" in valu and tr and valu["frac"] > tr / (b_med * 1e-6) / 1e9 / HBM_PEAK_GBPS) else
+                                                            ("hbm" if (valu and "frac" in valu and tr) else None)),
+                                           "rocprof": rocprof_row(str(big_n)) if (ls == 1 and not ring) else None,
                                            "kernel_form": benv.kernel_form, "grid": bg, "block": bb, "windows_us": b_ws,
                                            "first_100_launches_us": b_first,
                                            "protocol": "median of 5 windows of 200 back-to-back launches after 0.25 s of warm-up launches"})

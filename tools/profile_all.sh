@@ -7,6 +7,8 @@
 #   5. kernel trace of VecTask.step() calls            -> gpurun_out/<tag>_step_api_kernel_stats.csv
 #   5b. kernel trace of taco_rollout_run                -> gpurun_out/<tag>_rollout_kernel_stats.csv
 #   5c. SQ counters of the rollout's kernels (2 passes) -> gpurun_out/<tag>_rollout_pmc.json (tools/pmc_kernels.py)
+#   5d. size-isolated kernel-trace tables (262 144 / 1 M envs, rotate / flip 16 384, mix 32 768 x 5 and 262 144 x 5, the critic at 557 056 / 135 168 rows,
+#       the rollout at 32 768 x 16)                     -> gpurun_out/<tag>_kernel_stats_<shape>.csv
 #   6. bench.py --gpus 2 / --gpus 4 over gloo on this one GPU -> gpurun_out/<tag>_bench_{2,4}ranks_gloo_one_gpu.json
 #   8. tools/cell_ab.py, tools/fresh_outputs_cost.py    -> gpurun_out/<tag>_cell_ab.txt, <tag>_fresh_outputs_cost.txt
 # --pmc is never combined with any trace domain other than --kernel-trace; python3 is the program right after `--`.
@@ -35,6 +37,22 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${TAG}_rollout" -- p
 # 5c. where the rollout's kernels spend their SIMD time: MFMA vs VALU instructions, busy cycles, LDS
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_INSTS_LDS --output-format csv -d "$O/${TAG}_rollout_pmc/a" -- python3 "$R/tools/prof_rollout.py" >> "$O/${TAG}_pmc.log" 2>&1
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d "$O/${TAG}_rollout_pmc/b" -- python3 "$R/tools/prof_rollout.py" >> "$O/${TAG}_pmc.log" 2>&1
+# 5d. (round 6) SIZE-ISOLATED kernel-trace rows: every figure bench.py's large_n[] / configs[] quotes has a CSV whose AverageNs it can be checked against
+#     (the bench run's own table lumps all launches of an instantiation: 262 144- and 1 M-env launches of <64,1,false,true,...> share one row)
+iso() { # iso <name> <program> <args...>
+  local name=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${TAG}_iso_${name}" -- python3 "$@" >> "$O/${TAG}_pmc.log" 2>&1
+  cp "$O/${TAG}_iso_${name}"/*/*kernel_stats.csv "$O/${TAG}_kernel_stats_${name}.csv"
+}
+iso 262144 "$R/tools/prof_step.py" --envs 262144 --steps 3000
+iso 1048576 "$R/tools/prof_step.py" --envs 1048576 --steps 1000
+iso rotate_16384 "$R/tools/prof_step.py" --config 2 --envs 16384 --steps 6000
+iso flip_16384 "$R/tools/prof_step.py" --config 3 --envs 16384 --steps 6000
+iso mix_32768x5 "$R/tools/prof_step.py" --config 4 --envs 32768 --steps 6000 --api
+iso mix_262144x5 "$R/tools/prof_step.py" --config 4 --envs 262144 --steps 2000 --api
+iso critic_557056 "$R/tools/prof_critic.py" --slots=17 --envs=32768 --reps=60
+iso critic_135168 "$R/tools/prof_critic.py" --slots=33 --envs=4096 --reps=200
+iso rollout_32768x16 "$R/tools/prof_rollout.py" --envs=32768 --horizon=16 --reps=20
 cd "$R"
 python3 tools/pmc_kernels.py "$O/${TAG}_rollout_pmc" "$O/${TAG}_rollout_pmc.json" taco_rollout_kernel taco_critic_lstm_pair_split_kernel taco_critic_lstm_pair_kernel taco_critic_mlp > /dev/null
 python3 tools/pmc_summary.py "$TAG"
