@@ -63,7 +63,7 @@ struct taco_env {
     int form;  // TACO_FORM_* the step launches (never TACO_FORM_AUTO here: resolved by choose_form)
     int form_ring;    // ... and the form of a launch that writes only the newest states frame (taco_rollout_io.states_newest_only)
     int form_pinned;  // taco_set_kernel_form chose `form`: every launch uses it
-    int fusion_force; // taco_set_rollout_fusion(env, 2): the persistent kernel whatever the env count (A/B: its workgroups then queue, eight rounds of the chip at 32 768 envs)
+    int fusion_force; // taco_set_rollout_fusion(env, 2 / 3): the persistent kernel's quad / one-lane form whatever the env count (A/B: the quad form's workgroups queue, eight rounds of the chip at 32 768 envs)
     int fusion_off;   // taco_set_rollout_fusion(env, 0): taco_rollout_run launches the actor and the step per step even where the persistent kernel applies
     unsigned long long *rollout_stamps;  // optional profiling buffer of the persistent rollout kernel (taco_bind_rollout_stamps)
     uint32_t *ctl;        // control block (last 256 bytes of the workspace): device-resident step clock + sticky status word
@@ -984,7 +984,14 @@ int taco_policy_act(const taco_policy_cfg *c, const float *blob, int n, const fl
 // The persistent actor + step kernel (taco_fused.hpp) covers the documented rollout: one observation frame per step (len_obs = 1), the actor MLP
 // 26-128-128-128-4 (widths padded to 32 / 128 / 16), launches of at most kFusedMaxEnvs envs (16 envs per workgroup, one workgroup per CU at a
 // time: 512 workgroups are two rounds of the chip).  Anything else runs the launch-per-step path, same results.
-constexpr int kFusedMaxEnvs = 8192;
+// Round 6 built the same kernel with ONE LANE PER ENV (taco_rollout_kernel<1>: 64 envs per workgroup, the actor over four row tiles; 32 768 envs = 512
+// workgroups = two rounds of the chip instead of the quad form's eight) for the range above kFusedMaxEnvs: bit-identical (tests/test_rollout_gpu.py runs
+// every case in both forms), and SLOWER than the launch-per-step path -- 2.39-2.40 vs 2.04-2.05 ms per rollout at 32 768 x 16, 9.2 vs 6.8 at 131 072 x 16
+// (profiles/r06_b_rollout_ab_lane.txt): its step takes 71 k clocks = 29.7 us because the actor's f32 MFMAs of 64 rows (77.8 k MFMA cycles per step) have the
+// TWO SIMDs the step and battery wavefronts leave them, i.e. >= 16.2 us even at full rate, where the stand-alone actor kernel has all four of every CU
+// (28.8 us for 32 768 rows).  The per-step chain above 8 192 envs is bound by the f32 matrix pipe, not by launches: taco_set_rollout_fusion(env, 3) keeps the
+// form reachable for the A/B record, the host's choice stays launch-per-step there.
+constexpr int kFusedMaxEnvs = 8192;          // the quad form (16 envs per workgroup): the host's choice up to here
 static bool fused_rollout_ok(const taco_env *e, const taco_policy_cfg *c) {
     auto p16 = [](int x) { return (x + 15) / 16 * 16; };
     return !e->fusion_off && !e->form_pinned && e->gather == nullptr && (e->cfg.num_envs <= kFusedMaxEnvs || e->fusion_force) && e->cfg.len_obs == 1 && c->obs_len == 1 &&
@@ -1028,7 +1035,10 @@ int taco_rollout_run(taco_env *e, const taco_policy_cfg *c, const float *blob, c
         R.obs_store = b->obs_store; R.frames = b->states_store; R.act_buf = b->act_buf; R.mu_buf = b->mu_buf; R.sigma_buf = b->sigma_buf;
         R.logp_buf = b->logp_buf; R.rew_buf = b->rew_buf; R.done_buf = b->done_buf; R.timeout_buf = b->timeout_buf;
         R.horizon = horizon; R.len_states = ec.len_states; R.stamps = e->rollout_stamps;
-        hipLaunchKernelGGL(taco::taco_rollout_kernel, dim3((unsigned)((n + taco::POL_ROWS - 1) / taco::POL_ROWS)), dim3(taco::FU_THREADS), 0, (hipStream_t)stream, R);
+        // fusion_force: 2 = the quad form whatever the env count (round 5's A/B), 3 = the one-lane form whatever the env count
+        const bool lane_form = e->fusion_force == 3;
+        if (lane_form) hipLaunchKernelGGL(taco::taco_rollout_kernel<1>, dim3((unsigned)((n + 63) / 64)), dim3(taco::FU_THREADS), 0, (hipStream_t)stream, R);
+        else hipLaunchKernelGGL(taco::taco_rollout_kernel<4>, dim3((unsigned)((n + taco::POL_ROWS - 1) / taco::POL_ROWS)), dim3(taco::FU_THREADS), 0, (hipStream_t)stream, R);
         hipError_t he = hipGetLastError();
         if (he != hipSuccess) return hip_fail(he, "taco_rollout_kernel launch");
         e->step_count += horizon;   // (the kernel left the clock after `horizon` steps on the device itself)
@@ -1126,7 +1136,7 @@ int taco_test_slow_battery_server(taco_env *e, int on) {
 int taco_set_rollout_fusion(taco_env *e, int on) {
     if (!e) return fail(TACO_ERR_INVALID_ARG, "env is null");
     e->fusion_off = on ? 0 : 1;
-    e->fusion_force = on == 2 ? 1 : 0;
+    e->fusion_force = (on == 2 || on == 3) ? on : 0;   // 2: the quad form whatever the env count, 3: the one-lane form whatever the env count
     return TACO_OK;
 }
 int taco_bind_rollout_stamps(taco_env *e, uint64_t *stamps) {

@@ -18,6 +18,14 @@
 // overflow regime of the delay line, make their step wavefront wait for the actor first (step_core `fetch_action`).
 // Same arithmetic as the launch-per-step path -- step_core IS the step kernel's body, the MFMA chains are dense_tile's in the same k order,
 // sample4 is shared -- so a rollout is bit-identical to taco_policy_act / taco_step_rollout per step (tests/test_rollout_gpu.py).
+//
+// Round 6, LPE = 1 (`taco_rollout_kernel<1>`; opt-in: taco_set_rollout_fusion(env, 3)): the same kernel with ONE LANE PER ENV -- a workgroup owns 64 envs, its
+// step wavefront is the one-lane four-role form's (step_core<256, 1, true, ..., FUSED>: battery inline, rotor-noise table and euler angles served by the role
+// wavefronts), and the actor runs FOUR 16-row tiles per layer against the same register-resident weights; each actor wavefront samples one row tile (the
+// 128 -> 4 head's weights are resident in all four), so the action mailbox is complete after four posts.  Built for launches above 8 192 envs (512 workgroups
+// at 32 768 envs: two rounds of the chip instead of the quad form's eight), bit-identical to the other paths -- and measured SLOWER than launch-per-step there
+// (2.40 vs 2.05 ms per rollout at 32 768 x 16): a step takes 71 k clocks because 64 rows of f32 MFMAs (77.8 k matrix-pipe cycles) share the two SIMDs the
+// step and battery wavefronts leave free.  Not the host's choice anywhere; kept for the A/B record (profiles/r06_b_rollout_ab_lane.txt, tools/rollout_ab.py).
 #pragma once
 #include "taco_policy.hpp"
 #include "taco_step.hpp"
@@ -45,14 +53,17 @@ struct RolloutParams {
                                  // wavefront at the start / end of step t (t < 64); [136 + b] = clocks workgroup b's step wavefront spent in its loop
 };
 
+template <int LPE>
 __global__ __launch_bounds__(FU_THREADS) void taco_rollout_kernel(const RolloutParams R) {
-    __shared__ __attribute__((aligned(16))) float xin[POL_ROWS * FU_XLD];   // the actor's input: obs_t of the 16 envs
-    __shared__ __attribute__((aligned(16))) float xa[POL_ROWS * FU_LD];
-    __shared__ __attribute__((aligned(16))) float xb[POL_ROWS * FU_LD];
-    __shared__ float act_lds[POL_ROWS * 4];
-    __shared__ int act_seq, a_cnt, reset_seq, reset_lds[POL_ROWS];
+    static_assert(LPE == 4 || LPE == 1, "four lanes per env (16 envs per workgroup) or one (64 envs)");
+    constexpr int ROWS = 64 / LPE, RT = ROWS / 16;   // envs per workgroup, 16-row tiles of the actor
+    __shared__ __attribute__((aligned(16))) float xin[ROWS * FU_XLD];   // the actor's input: obs_t of the workgroup's envs
+    __shared__ __attribute__((aligned(16))) float xa[ROWS * FU_LD];
+    __shared__ __attribute__((aligned(16))) float xb[ROWS * FU_LD];
+    __shared__ float act_lds[ROWS * 4];
+    __shared__ int act_seq, a_cnt, reset_seq, reset_lds[ROWS];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = R.S.n, row0 = blockIdx.x * POL_ROWS;
+    const int n = R.S.n, row0 = blockIdx.x * ROWS;
     if (row0 >= n) return;
     const int role = wave == 0 ? 0 : wave == 1 ? 1 : wave == 5 ? 2 : wave == 4 ? 3 : -1;          // step_core role of this wavefront, or
     const int actor = wave == 2 ? 0 : wave == 6 ? 1 : wave == 3 ? 2 : wave == 7 ? 3 : -1;        // which of the four actor wavefronts it is
@@ -60,7 +71,7 @@ __global__ __launch_bounds__(FU_THREADS) void taco_rollout_kernel(const RolloutP
     // the step clock, as the step kernel takes it: kernel arguments, or the device-resident copy when this launch was captured into a graph
     // (the workgroup's own pair of the per-16-env clock, taco_step.hpp "wclk": read here, rewritten by this workgroup when the rollout is done)
     const __attribute__((address_space(4))) uint32_t *wc =
-        (const __attribute__((address_space(4))) uint32_t *)(R.S.wclk + (size_t)blockIdx.x * kWclkWordsPerGroup);
+        (const __attribute__((address_space(4))) uint32_t *)(R.S.wclk + (size_t)blockIdx.x * RT * kWclkWordsPerGroup);   // (one pair per 16 envs: the first of this workgroup's)
     const bool from_ctl = R.S.use_ctl != 0;
     const uint32_t c_step = wc[0], c_aux = wc[1];
     const uint32_t step0 = from_ctl ? c_step : R.S.step;
@@ -69,7 +80,7 @@ __global__ __launch_bounds__(FU_THREADS) void taco_rollout_kernel(const RolloutP
     const int H = R.horizon;
     const size_t frame = (size_t)n * 26;
     // the starting observation -> the actor's input rows (columns 26..31 stay zero: the weights' k range is padded to 32)
-    for (int e = tid; e < POL_ROWS * 32; e += FU_THREADS) {
+    for (int e = tid; e < ROWS * 32; e += FU_THREADS) {
         const int r = e >> 5, k = e & 31;
         xin[r * FU_XLD + k] = (row0 + r < n && k < 26) ? R.obs_store[(size_t)(row0 + r) * 26 + k] : 0.0f;
     }
@@ -102,26 +113,29 @@ __global__ __launch_bounds__(FU_THREADS) void taco_rollout_kernel(const RolloutP
         // out[16][128] = relu(in[16][K] W^T + b) for this wavefront's two tiles: dense_tile's chain (bias, then k ascending), two independent
         // accumulators interleaved so that one's MFMA latency hides under the other's
         auto layer = [&](const float *in, int ld, float *out, const float4 *wa, const float4 *wb, int ks, float ba, float bb) __attribute__((always_inline)) {
-            const float *arow = in + r * ld + 4 * g;
-            pf32x4 acc_a = {ba, ba, ba, ba}, acc_b = {bb, bb, bb, bb};
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                if (s < ks) {
-                    const float4 a4 = *reinterpret_cast<const float4 *>(arow + 16 * s);
-                    acc_a = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, wa[s].x, acc_a, 0, 0, 0);
-                    acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, wb[s].x, acc_b, 0, 0, 0);
-                    acc_a = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, wa[s].y, acc_a, 0, 0, 0);
-                    acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, wb[s].y, acc_b, 0, 0, 0);
-                    acc_a = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, wa[s].z, acc_a, 0, 0, 0);
-                    acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, wb[s].z, acc_b, 0, 0, 0);
-                    acc_a = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wa[s].w, acc_a, 0, 0, 0);
-                    acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wb[s].w, acc_b, 0, 0, 0);
+            for (int rt = 0; rt < RT; ++rt) {   // (LPE = 1: four 16-row tiles against the same resident weights)
+                const float *arow = in + (rt * 16 + r) * ld + 4 * g;
+                pf32x4 acc_a = {ba, ba, ba, ba}, acc_b = {bb, bb, bb, bb};
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    if (s < ks) {
+                        const float4 a4 = *reinterpret_cast<const float4 *>(arow + 16 * s);
+                        acc_a = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, wa[s].x, acc_a, 0, 0, 0);
+                        acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, wb[s].x, acc_b, 0, 0, 0);
+                        acc_a = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, wa[s].y, acc_a, 0, 0, 0);
+                        acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, wb[s].y, acc_b, 0, 0, 0);
+                        acc_a = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, wa[s].z, acc_a, 0, 0, 0);
+                        acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, wb[s].z, acc_b, 0, 0, 0);
+                        acc_a = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wa[s].w, acc_a, 0, 0, 0);
+                        acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wb[s].w, acc_b, 0, 0, 0);
+                    }
                 }
-            }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {   // C/D layout: col = lane & 15, row = 4 (lane >> 4) + i
-                out[(4 * g + i) * FU_LD + tl[0] * 16 + r] = acc_a[i] < 0.0f ? 0.0f : acc_a[i];
-                out[(4 * g + i) * FU_LD + tl[1] * 16 + r] = acc_b[i] < 0.0f ? 0.0f : acc_b[i];
+                for (int i = 0; i < 4; ++i) {   // C/D layout: col = lane & 15, row = 4 (lane >> 4) + i
+                    out[(rt * 16 + 4 * g + i) * FU_LD + tl[0] * 16 + r] = acc_a[i] < 0.0f ? 0.0f : acc_a[i];
+                    out[(rt * 16 + 4 * g + i) * FU_LD + tl[1] * 16 + r] = acc_b[i] < 0.0f ? 0.0f : acc_b[i];
+                }
             }
         };
         // the four actor wavefronts meet at an LDS counter (the workgroup's barrier belongs to the step: its other wavefronts are in the middle of
@@ -144,12 +158,15 @@ __global__ __launch_bounds__(FU_THREADS) void taco_rollout_kernel(const RolloutP
         // what the sampling does not need the MLP for: the distribution's scale (step-invariant) and, per step, the standard normal of (env, call) --
         // drawn by the sampling wavefront AHEAD of barrier 1, where it idles (Philox, log, sqrt, sincos: ~1 000 clocks off the path between the
         // head's last MFMA and the action a step wavefront with fewer than ten pending slots is waiting for: the tail of the kernel)
+        // (LPE = 1: every actor wavefront samples ONE of the four row tiles -- the head's weights are resident in all of them)
+        const bool sampler = RT == 1 ? actor == 0 : true;
+        const int stile = RT == 1 ? 0 : actor;           // the row tile this wavefront's head + sampling works on
         float scale_pre = 0.0f, ls_pre = 0.0f;
-        if (actor == 0) { const float e = expf_own(log_std[lane & 3]); scale_pre = e * e; ls_pre = log(scale_pre); }
+        if (sampler) { const float e = expf_own(log_std[lane & 3]); scale_pre = e * e; ls_pre = log(scale_pre); }
 #pragma unroll 1
         for (int t = 0; t < H; ++t) {
             float eps_pre = 0.0f;
-            if (actor == 0) eps_pre = sample_eps(PP, row0 + (lane >> 2), lane & 3, call_base + (uint32_t)t);
+            if (sampler) eps_pre = sample_eps(PP, row0 + stile * 16 + (lane >> 2), lane & 3, call_base + (uint32_t)t);
             __syncthreads();   // barrier 1 of the step: obs_t is in xin
             layer(xin, FU_XLD, xa, w0[0], w0[1], 2, c0[0], c0[1]);
             meet();
@@ -157,8 +174,8 @@ __global__ __launch_bounds__(FU_THREADS) void taco_rollout_kernel(const RolloutP
             meet();
             layer(xb, FU_LD, xa, w2[0], w2[1], 8, c2[0], c2[1]);
             meet();
-            if (actor == 0) {   // the 128 -> 4 head (one 16-column tile) with its tanh, then the distribution (nets_asymmetry.py:333-345)
-                const float *arow = xa + r * FU_LD + 4 * g;
+            if (sampler) {   // the 128 -> 4 head (one 16-column tile) with its tanh, then the distribution (nets_asymmetry.py:333-345)
+                const float *arow = xa + (stile * 16 + r) * FU_LD + 4 * g;
                 pf32x4 acc = {c3, c3, c3, c3};
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
@@ -168,13 +185,17 @@ __global__ __launch_bounds__(FU_THREADS) void taco_rollout_kernel(const RolloutP
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, w3[s].z, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, w3[s].w, acc, 0, 0, 0);
                 }
+                // (xb: every actor wavefront is past its last read of it -- with four samplers each writes ITS tile's rows only, and the others' reads of xb
+                // ended at the meet() above)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) xb[(4 * g + i) * FU_LD + r] = tanh_own(acc[i]);   // (xb: every actor wavefront is past its last read of it)
+                for (int i = 0; i < 4; ++i) xb[(stile * 16 + 4 * g + i) * FU_LD + r] = tanh_own(acc[i]);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // same wavefront writes and reads: in order
                 PP.action = R.act_buf + (size_t)t * n * 4; PP.mu = R.mu_buf + (size_t)t * n * 4; PP.sigma = R.sigma_buf + (size_t)t * n * 4;
                 PP.logp = R.logp_buf + (size_t)t * n;
-                sample4(PP, xb, FU_LD, row0, lane >> 2, lane & 3, log_std, call_base + (uint32_t)t, (lds_f32 *)act_lds, &eps_pre, scale_pre, ls_pre,
-                        (lds_i32 *)&act_seq, t + 1);   // (posts act_seq = t + 1 as soon as the action of step t is in act_lds, ahead of the log-prob and the stores)
+                // posts the action mailbox as soon as the tile's actions are in act_lds, ahead of the log-prob and the stores: RT == 1: act_seq = t + 1;
+                // RT == 4: one increment per tile, complete at 4 (t + 1)
+                sample4(PP, xb + stile * 16 * FU_LD, FU_LD, row0 + stile * 16, lane >> 2, lane & 3, log_std, call_base + (uint32_t)t, (lds_f32 *)act_lds + stile * 64, &eps_pre,
+                        scale_pre, ls_pre, (lds_i32 *)&act_seq, RT == 1 ? t + 1 : -1);
             }
             __syncthreads();   // barrier 2 of the step
         }
@@ -194,9 +215,10 @@ __global__ __launch_bounds__(FU_THREADS) void taco_rollout_kernel(const RolloutP
             Q.rew = R.rew_buf + (size_t)t * n; Q.done_f32 = R.done_buf + (size_t)t * n; Q.timeout = R.timeout_buf + (size_t)t * n;
             FusedCtx FX;
             FX.role = role; FX.step = step0 + (uint32_t)t; FX.head = (head0 + 10 * t) % TACO_RING_SLOTS; FX.hh = (hh0 + t) % HIST_ROWS;
-            FX.act_lds = (lds_f32 *)act_lds; FX.act_seq = (lds_i32 *)&act_seq; FX.act_want = t + 1; FX.xin = (lds_f32 *)xin; FX.xin_ld = FU_XLD;
+            FX.act_lds = (lds_f32 *)act_lds; FX.act_seq = (lds_i32 *)&act_seq; FX.act_want = RT * (t + 1); FX.xin = (lds_f32 *)xin; FX.xin_ld = FU_XLD;
             FX.reset_lds = (lds_i32 *)reset_lds; FX.reset_seq = (lds_i32 *)&reset_seq; FX.reset_want = t;
-            step_core<256, 4, true, false, false, false, false, true, true>(Q, FX);   // (its two barriers are the step's two)
+            if constexpr (LPE == 4) step_core<256, 4, true, false, false, false, false, true, true>(Q, FX);   // (its two barriers are the step's two)
+            else step_core<256, 1, true, false, false, false, true, true, false>(Q, FX);                       // (the one-lane four-role form, no register cap)
             if (R.stamps && blockIdx.x == 0 && tid == 0 && t < 64) R.stamps[9 + 2 * t] = __builtin_readcyclecounter();
         }
         if (R.stamps && tid == 0) R.stamps[136 + blockIdx.x] = __builtin_readcyclecounter() - loop_t0;
@@ -206,8 +228,9 @@ __global__ __launch_bounds__(FU_THREADS) void taco_rollout_kernel(const RolloutP
     if (wave == 0 && lane == 0) {
         const uint32_t nstep = step0 + (uint32_t)H;
         const int nhead = (head0 + 10 * H) % TACO_RING_SLOTS, nhh = (hh0 + H) % HIST_ROWS;
-        uint32_t *w = R.S.wclk + (size_t)blockIdx.x * kWclkWordsPerGroup;
-        w[0] = nstep; w[1] = wclk_aux(nhead, nhh, phase0);
+        uint32_t *w = R.S.wclk + (size_t)blockIdx.x * RT * kWclkWordsPerGroup;
+#pragma unroll
+        for (int gq = 0; gq < RT; ++gq) { w[2 * gq] = nstep; w[2 * gq + 1] = wclk_aux(nhead, nhh, phase0); }
         if (blockIdx.x == 0) { R.S.ctl[kCtlStep] = nstep; R.S.ctl[kCtlHead] = (uint32_t)nhead; R.S.ctl[kCtlHh] = (uint32_t)nhh; if (R.S.use_ctl) atomicAdd(&R.S.ctl[kCtlDevSteps], 1u); }
     }
 }

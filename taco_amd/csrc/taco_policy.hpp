@@ -215,7 +215,10 @@ TD void sample4(const PolicyParams &P, const float *x, int ld, int row0, int er,
         env_lds[er * 4 + a] = clampf(act, P.act_lo, P.act_hi);
         if (env_seq) {   // (one wavefront's LDS operations execute in order: the action words before the counter)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            if ((threadIdx.x & 63) == 0) __hip_atomic_store(env_seq, env_seq_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((threadIdx.x & 63) == 0) {   // (env_seq_val < 0: one of several posting wavefronts -- each adds one)
+                if (env_seq_val >= 0) __hip_atomic_store(env_seq, env_seq_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else __hip_atomic_fetch_add(env_seq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
     }
     const float zz = (act - mean) / scale;

@@ -832,7 +832,7 @@ struct FusedCtx {
 template <int BLOCK, int LPE, bool SPLIT, bool CAP, bool OUT, bool RESET_ONLY, bool WIDE, bool FUSED, bool LIN = false>
 TD void step_core(const StepParams &Pin, const FusedCtx &FX) {
     static_assert(!LIN || ((BLOCK == 256 || BLOCK == 128) && LPE == 4 && SPLIT), "LIN is a variant of the four-role quad form and of the served pair");
-    static_assert(!FUSED || (BLOCK == 256 && LPE == 4 && SPLIT && !OUT && !RESET_ONLY && !CAP), "FUSED is the four-role quad form inside the rollout kernel");
+    static_assert(!FUSED || (BLOCK == 256 && SPLIT && !OUT && !RESET_ONLY && !CAP), "FUSED is a four-role form (quad, or one lane per env) inside the rollout kernel");
     static_assert(!WIDE || (BLOCK == 256 && SPLIT && !RESET_ONLY), "WIDE is a variant of the four-role forms");
     static_assert(!RESET_ONLY || (BLOCK == 64 && LPE == 1 && !SPLIT && !CAP && !OUT), "RESET_ONLY exists in the plain one-lane form only");
     static_assert(!SPLIT || BLOCK == 256 || (BLOCK == 128 && LPE == 4 && !WIDE && !FUSED),
@@ -1657,9 +1657,26 @@ TD void step_core(const StepParams &Pin, const FusedCtx &FX) {
         };
         // the FIN form of the loop runs while `fin` holds (normally all ten substeps), the exact form takes over at the first rare form
         int ks = 0;
+        // FUSED, 0..9 pending slots somewhere in the wavefront: the actor's action arrives at the top of the substep that reads slot min(dlen) (see the
+        // quad loop's late_patch below: the same protocol, a float4 per env and slot here).  A non-finite action hands over to the exact form.
+        bool force_exact = false;
+        auto late_patch = [&]() {
+            fetch_action();
+            act[0] = clampf(a_in.x, -P.clip_act, P.clip_act); act[1] = clampf(a_in.y, -P.clip_act, P.clip_act);
+            act[2] = clampf(a_in.z, -P.clip_act, P.clip_act); act[3] = clampf(a_in.w, -P.clip_act, P.clip_act);
+            act4 = make_float4(act[0], act[1], act[2], act[3]);
+            if (active) buf_st4(rH, act4, voff, (uint32_t)(clk.hh & (HIST_ROWS - 1)) * row_bytes);  // this step's action, row hh
+#pragma unroll
+            for (int sl = 0; sl < 10; ++sl)
+                if (sl >= dlen0) slots[sl * EPW + el] = act4;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // (same wavefront writes and reads the table: in order)
+            const float mag = (absf(act[0]) + absf(act[1])) + (absf(act[2]) + absf(act[3]));
+            force_exact = __builtin_amdgcn_ballot_w64(!(mag < 1e30f)) != 0;
+        };
         if (fin && plain && (CAP || !wave_tracks_rpy)) {
     #pragma unroll 1
             while (ks < 10) {
+                if constexpr (FUSED) { if (ks == patch_at) { late_patch(); if (force_exact) break; } }
                 const bool rare = substep(std::integral_constant<int, 2>{}, ks);
                 ++ks;
                 if (rare) break;
@@ -1667,6 +1684,7 @@ TD void step_core(const StepParams &Pin, const FusedCtx &FX) {
         } else if (!CAP && fin && plain) {  // (the throughput instantiation keeps two forms: a third costs it 28 spilled VGPRs)
     #pragma unroll 1
             while (ks < 10) {
+                if constexpr (FUSED) { if (ks == patch_at) { late_patch(); if (force_exact) break; } }
                 const bool rare = substep(std::integral_constant<int, 10>{}, ks);
                 ++ks;
                 if (rare) break;
@@ -1680,7 +1698,10 @@ TD void step_core(const StepParams &Pin, const FusedCtx &FX) {
             }
         }
     #pragma unroll 1
-        for (; ks < 10; ++ks) substep(std::integral_constant<int, 0>{}, ks);
+        for (; ks < 10; ++ks) {
+            if constexpr (FUSED) { if (ks == patch_at && !have_act) late_patch(); }
+            substep(std::integral_constant<int, 0>{}, ks);
+        }
         if (euler_served) {   // the attitude after the tenth substep (refresh_state of post_physics_step, FA:382)
             reinterpret_cast<float4 *>(eq_tab)[10 * 64 + lane] = make_float4(q.x, q.y, q.z, q.w);
             MB_POST(3, 11);

@@ -147,9 +147,10 @@ class FpvBase:
         _lib.check(self.lib.taco_set_kernel_form(self._h, _lib.FORMS[name]), self.lib)
 
     def set_rollout_fusion(self, on=True):
-        """taco_rollout_run's persistent actor + step kernel (taco_fused.hpp) on / off for this env (on by default where it applies: at most
-        8 192 envs); on="force": the persistent kernel whatever the env count (A/B measurements: above 8 192 envs its workgroups queue)"""
-        _lib.check(self.lib.taco_set_rollout_fusion(self._h, 2 if on == "force" else (1 if on else 0)), self.lib)
+        """taco_rollout_run's persistent actor + step kernel (taco_fused.hpp) on / off for this env (on by default where it applies: the quad form -- 16
+        envs per workgroup -- up to 8 192 envs, the one-lane form -- 64 envs per workgroup, round 6 -- above); on="quad" (= "force") / "lane": that form
+        whatever the env count (A/B measurements: above 8 192 envs the quad form's workgroups queue)"""
+        _lib.check(self.lib.taco_set_rollout_fusion(self._h, {"force": 2, "quad": 2, "lane": 3}.get(on, 1 if on else 0) if isinstance(on, str) else (1 if on else 0)), self.lib)
 
     def bind_rollout_stamps(self, stamps):
         """profiling: a [136 + ceil(num_envs / 16)] int64 device tensor workgroup 0 of the persistent rollout kernel fills (SIMD of its 8 wavefronts, per-step clocks); None unbinds"""

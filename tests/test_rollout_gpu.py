@@ -229,11 +229,13 @@ def test_rollout_run_is_graph_capturable_and_replays_are_the_next_rollouts():
     (500, "rotate", 2, dict(delay_time=85, ramdom_deploy_time=True)),   # the delay line's overflow regime: DENSE envs take the early path
     (600, "mix", 5, dict(battery_consumption=False)),         # no battery server
 ])
-def test_persistent_rollout_kernel_equals_the_launch_per_step_path(n, task, len_states, kw):
+@pytest.mark.parametrize("fused_form", ["quad", "lane"])
+def test_persistent_rollout_kernel_equals_the_launch_per_step_path(n, task, len_states, kw, fused_form):
     """taco_rollout_run with the persistent actor + step kernel (one workgroup owns 16 envs for the whole horizon, the actor's MFMAs run
     under the substeps) against the same call with fusion switched off (2 H launches): every replay-buffer array, the env's whole state and
     reset_buf bit for bit, over three rollouts with episode ends; and the hardware really places the eight wavefronts two per SIMD in
-    launch order, which is what keeps the actor off the step wavefront's SIMD."""
+    launch order, which is what keeps the actor off the step wavefront's SIMD.  fused_form: "quad" = 16 envs per workgroup (what the host picks up to
+    8 192 envs), "lane" = round 6's one-lane form, 64 envs per workgroup, the actor over four row tiles (what it picks above) -- both forced here."""
     from taco_amd import policy as P
     from taco_amd.vec_env import FpvBase
     import test_policy_gpu as TP
@@ -245,7 +247,7 @@ def test_persistent_rollout_kernel_equals_the_launch_per_step_path(n, task, len_
     outs = []
     for fused in (True, False):
         env = FpvBase(cfg, copy_outputs=False)
-        env.set_rollout_fusion(fused)
+        env.set_rollout_fusion(fused_form if fused else False)
         stamps = torch.zeros(136 + (n + 15) // 16, dtype=torch.int64, device="cuda")
         env.bind_rollout_stamps(stamps)
         pol = P.ActorCritic(sd, 1, len_states, seed=21)
@@ -282,6 +284,11 @@ def test_persistent_rollout_kernel_equals_the_launch_per_step_path(n, task, len_
                                 rotor_noise=True, ramdom_delay_time=True, ramdom_deploy_time=True)),
     (333, "flip", 3, True, dict(delay_time=5)),        # the late-patch path of the persistent kernel (2..9 pending slots)
     (700, "mix", 5, False, dict(observation_noise=True, rotor_noise=True)),   # the launch-per-step chain
+    # round 6: the persistent kernel's ONE-LANE form (64 envs per workgroup), forced at small env counts: config 5's flags, the late patch, no battery
+    (1000, "mix", 5, "lane", dict(random_rotordynamic_coe=True, random_rotor_response=True, random_aerodynamic_coe=True, observation_noise=True,
+                                  rotor_noise=True, ramdom_delay_time=True, ramdom_deploy_time=True)),
+    (333, "flip", 3, "lane", dict(delay_time=5)),
+    (650, "rotate", 2, "lane", dict(delay_time=1, ramdom_delay_time=True, battery_consumption=False)),
 ])
 def test_rollout_run_equals_the_oracle_rollout(n, task, len_states, fused, kw):
     """taco_rollout_run DIRECTLY against the CPU oracle's orc_rollout (actor forward + clip + env step + store + time-out bootstrap per step,
@@ -329,5 +336,5 @@ def test_rollout_run_equals_the_oracle_rollout(n, task, len_states, fused, kw):
         assert np.array_equal(env.reset_buf.cpu().numpy(), orc.reset_buf)
         n_tmo += int(exp["timeout"].sum()); n_done += int(exp["done"].sum())
     assert n_tmo > 0 and n_done >= n_tmo and (task != "mix" or n_done > n_tmo)
-    assert (stamps[8:8 + 2 * H].min() > 0) == fused, "the persistent kernel ran / did not run as asked"
+    assert (stamps[8:8 + 2 * H].min() > 0) == bool(fused), "the persistent kernel ran / did not run as asked"
     env.check()

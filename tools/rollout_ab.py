@@ -1,5 +1,6 @@
 """taco_rollout_run with the persistent actor + step kernel vs the launch-per-step path: ms per rollout (median of 5 x 4), the critic alone,
-and the persistent kernel's in-kernel step clocks.  `python tools/rollout_ab.py [n] [horizon] [config index]`"""
+and the persistent kernel's in-kernel step clocks.  `python tools/rollout_ab.py [n] [horizon] [config index] [forms]`; forms: comma-separated
+from quad, lane (the persistent kernel's two forms, forced), auto (the host's choice), off (launch per step); default auto,off,auto,off"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -14,7 +15,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 ci = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 rng = np.random.default_rng(0)
-for fused in (True, False, True, False):
+forms = [{"auto": True, "off": False}.get(f, f) for f in (sys.argv[4].split(",") if len(sys.argv) > 4 else ["auto", "off", "auto", "off"])]
+for fused in forms:
     cfg = config.baseline_config(ci, num_envs=n)
     env = FpvBase(cfg, copy_outputs=False)
     env.set_rollout_fusion(fused)
@@ -24,6 +26,7 @@ for fused in (True, False, True, False):
     buf = RolloutBuffer(n, 26, 1, 26, T, 4, H, 4, 0.99, 0.95, "cuda:0")
     stamps = torch.zeros(136 + (n + 15) // 16, dtype=torch.int64, device="cuda")
     env.bind_rollout_stamps(stamps)
+    nwg = (n + 63) // 64 if (fused == "lane" or (fused is True and n > 8192)) else (n + 15) // 16
 
     def run():
         buf.reset()
@@ -57,5 +60,5 @@ for fused in (True, False, True, False):
         st = stamps.cpu().numpy()
         per = (st[9:9 + 2 * min(H, 64):2] - st[8:8 + 2 * min(H, 64):2])
         gap = (st[10:8 + 2 * min(H, 64):2] - st[9:7 + 2 * min(H, 64):2])
-        line += f"; in-kernel step ticks (step wavefront, workgroup 0): median {int(np.median(per))}, max {int(per.max())}, total {int(st[7 + 2 * min(H, 64)] - st[8])}; simd {st[:8].tolist()}; per-workgroup loop ticks: min {int(st[136:].min())} median {int(np.median(st[136:]))} max {int(st[136:].max())}"
+        line += f"; in-kernel step ticks (step wavefront, workgroup 0): median {int(np.median(per))}, max {int(per.max())}, total {int(st[7 + 2 * min(H, 64)] - st[8])}; simd {st[:8].tolist()}; per-workgroup loop ticks ({nwg} workgroups): min {int(st[136:136 + nwg].min())} median {int(np.median(st[136:136 + nwg]))} max {int(st[136:136 + nwg].max())}"
     print(line, flush=True)
