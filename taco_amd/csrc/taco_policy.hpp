@@ -1293,8 +1293,11 @@ __global__ __launch_bounds__(64 * POL_NW, 4) void taco_critic_mlp_kernel(const P
 // the clamp only keeps inf - inf out of the low half).  The 128 -> 1 head stays in f32 on the VALU, straight from layer 2's accumulators (a lane holds
 // four columns of a row: four fma, two cross-lane adds, one partial sum per wavefront and row through LDS) -- layer 2's output is neither split nor
 // stored, and the head costs no MFMA tile of which one row in sixteen is real.
+#ifndef TACO_AB_MLP_MINW
+#define TACO_AB_MLP_MINW 4
+#endif
 template <int KIND>
-__global__ __launch_bounds__(64 * POL_NW, 4) void taco_critic_mlp_split_kernel(const PolicyParams P) {
+__global__ __launch_bounds__(64 * POL_NW, TACO_AB_MLP_MINW) void taco_critic_mlp_split_kernel(const PolicyParams P) {
     typedef SplitKind<KIND> SK;
     typedef typename SK::T HT;
     typedef typename SK::V8 V8;
@@ -1452,7 +1455,10 @@ __global__ __launch_bounds__(64 * POL_NW, 4) void taco_critic_mlp_split_kernel(c
 // or two passes: 33.1 us at 32 768 rows = 49 % of the f32 MFMA peak, a quarter of config 5's rollout at its per-rank shape.  Here a layer's fragments are
 // fetched (from L2: 26 KB per wavefront and pass) behind the layer before it, ahead of the barrier: the other workgroup's MFMAs cover the fetch.)
 constexpr int ACT_ROWS = CR_MLP_ROWS;   // rows per pass of taco_actor_kernel (32-row passes, four workgroups per CU wanted, two resident at 128 registers: 37.6 us against 31.2)
-__global__ __launch_bounds__(64 * POL_NW, 4) void taco_actor_kernel(const PolicyParams P) {
+#ifndef TACO_AB_ACTOR_MINW
+#define TACO_AB_ACTOR_MINW 4
+#endif
+__global__ __launch_bounds__(64 * POL_NW, TACO_AB_ACTOR_MINW) void taco_actor_kernel(const PolicyParams P) {
     __shared__ __attribute__((aligned(16))) float xb[ACT_ROWS * CR_LD];
     __shared__ __attribute__((aligned(16))) float yb[ACT_ROWS * CR_LD];
     constexpr int hp = 128, ip = 32;

@@ -194,13 +194,16 @@ class FpvBase:
         window wraps -- load_stacks(states=...) is the way to set the stack (it rebuilds the twins).  LIFETIME of a view handed out earlier
         (by step() or this property): its oldest frame is overwritten period - len_states + 1 >= 2 steps later (the ring's period is at
         least len_states + 1), i.e. what step t returned is intact while step t + 1 runs, as with the alternating obs buffers.
-        Outside graph mode (include/taco_env.h taco_graph_mode) this is a host-side lookup; in graph mode it asks the library, which blocks."""
+        Outside graph mode (include/taco_env.h taco_graph_mode) the library answers from the host's copy of the clock (no sync); in graph mode it blocks."""
         if self._ring_on:
-            if self.lib.taco_graph_mode(self._h) != 0:   # graph replays advance the phase on the device: the library re-reads it (device-wide sync)
-                ph = self.lib.taco_states_ring_row(self._h)
-                if ph < 0:
-                    raise _lib.TacoError(f"libtaco_env: {self.lib.taco_last_error().decode()}")
-                self._st_last = ph
+            # the LIBRARY is the source of truth for the window (round 5's advisor: a cached phase goes stale when something other than step() advances the
+            # ring -- a direct taco_step_rollout with states_next = NULL on the bound ring, as tools do).  Outside graph mode taco_states_ring_row is a
+            # host-side lookup (it never synchronises there); in graph mode it re-reads the device-resident clock (device-wide sync).  step() itself does
+            # not come here: taco_step_ring hands it the phase.
+            ph = self.lib.taco_states_ring_row(self._h)
+            if ph < 0:
+                raise _lib.TacoError(f"libtaco_env: {self.lib.taco_last_error().decode()}")
+            self._st_last = ph
             return self._st_views[self._st_last]
         return self._states_pp[self._pp]
 

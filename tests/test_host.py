@@ -185,6 +185,33 @@ def test_checkpoint_merge_and_slice_by_global_env_id():
     checkpoint.load_state_dict(rt, sd, strict=False)
     with pytest.warns(UserWarning, match="ABI"):
         checkpoint.load_state_dict(rt, dict(merged, abi=_lib.ABI_VERSION - 1, flat_cfg=dict(merged["flat_cfg"], world_rate_roundtrip=True)))
+    # round 5's advisor: (a) an ABI-6 checkpoint (arithmetic revision 1: the stored world-frame rate was rebuilt once more) is refused under strict;
+    good = dict(merged, flat_cfg=dict(merged["flat_cfg"], world_rate_roundtrip=True))
+    with pytest.raises(ValueError, match="arithmetic revision 1"):
+        checkpoint.load_state_dict(rt, {k: v for k, v in dict(good, abi=6).items() if k != "arith_rev"})
+    checkpoint.load_state_dict(rt, {k: v for k, v in dict(good, abi=6).items() if k != "arith_rev"}, strict=False)
+    # (b) the numeric cfg values the arithmetic reads are compared;
+    rt._flat["rotor_response_time"] = 0.017
+    with pytest.raises(ValueError, match="rotor_response_time=0.02"):
+        checkpoint.load_state_dict(rt, dict(good, flat_cfg=dict(good["flat_cfg"], rotor_response_time=0.02)))
+    rt._flat["inertia"] = (1.0, 2.0, 3.0)
+    with pytest.raises(ValueError, match="inertia"):
+        checkpoint.load_state_dict(rt, dict(good, flat_cfg=dict(good["flat_cfg"], rotor_response_time=0.017, inertia=[1.0, 2.0, 3.5])))
+    checkpoint.load_state_dict(rt, dict(good, flat_cfg=dict(good["flat_cfg"], rotor_response_time=0.017, inertia=[1.0, 2.0, 3.0])))
+    # (c) a recording env does not take over the stale rpy rows of a checkpoint taken without record_flag (the other direction is fine);
+    rt._flat["record_flag"] = True
+    full = dict(good, flat_cfg=dict(good["flat_cfg"], rotor_response_time=0.017, inertia=[1.0, 2.0, 3.0]))
+    with pytest.raises(ValueError, match="record_flag=False"):
+        checkpoint.load_state_dict(rt, full)
+    checkpoint.load_state_dict(rt, dict(full, flat_cfg=dict(full["flat_cfg"], record_flag=True)))
+    rt._flat["record_flag"] = False
+    checkpoint.load_state_dict(rt, dict(full, flat_cfg=dict(full["flat_cfg"], record_flag=True)))
+    # (d) merge() refuses shards taken under different flags / constants (it compared five identity keys only)
+    a, b = checkpoint.state_dict(parts[0]), checkpoint.state_dict(parts[1])
+    b["flat_cfg"] = dict(b["flat_cfg"], rotor_noise=True)
+    a["flat_cfg"] = dict(a["flat_cfg"], rotor_noise=False)
+    with pytest.raises(ValueError, match="rotor_noise"):
+        checkpoint.merge([a, b])
 
 
 def test_replay_store_frame_ring_views_are_the_state_stacks():
