@@ -59,7 +59,7 @@ python3 tools/pmc_summary.py "$TAG"
 cp "$O/${TAG}_rollout"/*/*kernel_stats.csv "$O/${TAG}_rollout_kernel_stats.csv"
 cp "$O/${TAG}_step_api"/*/*kernel_stats.csv "$O/${TAG}_step_api_kernel_stats.csv"
 # 1. the un-profiled bench line, with this build's PMC summary where bench.py looks for it (profiles/, newest matching source hash)
-cp "$O/${TAG}_pmc_summary.json" profiles/
+cp "$O/${TAG}_pmc_summary.json" "$O/${TAG}"_kernel_stats_*.csv profiles/   # (the size-isolated tables too: bench.py names them beside its figures, rocprof_row)
 python3 bench.py --steps 2000 --warmup 200 > "$O/${TAG}_bench_4096.json" 2> "$O/${TAG}_bench.err"
 # 7. eager (clock in the kernel arguments / on the device) vs HIP-graph replays of 1, 16, 64 steps: what the device-resident clock costs
 python3 tools/clock_path_ab.py > "$O/${TAG}_clock_path_ab.txt" 2>/dev/null || true
