@@ -162,7 +162,7 @@ def pmc_traffic(n_envs):
     return d.get("derived", {}).get(f"hbm_bytes_per_launch_{n_envs}"), name
 
 
-def rocprof_row(shape, needle="taco_step_kernel"):
+def rocprof_row(shape, needle="taco_step_kernel", by="TotalDurationNs"):
     """the size-isolated `rocprofv3 --kernel-trace --stats` table of this build for one shape (tools/profile_all.sh step 5d:
     profiles/<tag>_kernel_stats_<shape>.csv, <tag> = the PMC summary's): the row of the kernel that dominates it -- what the figure next to it
     can be checked against.  None if this build has not been profiled."""
@@ -176,7 +176,7 @@ def rocprof_row(shape, needle="taco_step_kernel"):
     rows = [r for r in csv.DictReader(open(f)) if needle in r["Name"]]
     if not rows:
         return None
-    r = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+    r = max(rows, key=lambda r: float(r[by]))
     return {"csv": os.path.relpath(f, ROOT), "kernel": r["Name"][:120], "calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) * 1e-3,
             "min_us": float(r["MinNs"]) * 1e-3}
 
@@ -817,7 +817,8 @@ def main():
                          "regime": "latency" if n_local <= 16384 else "valu-issue",
                          "binds": ("at 4 096 envs per GPU neither roof is reached: instruction LATENCY of the slowest wavefront (latency_floor) + the launch boundary; "
                                    "the HBM roof prices the throughput regime (large_n: >= 60 % of it at 262 144 envs, where VALU issue is the nearer roof)"),
-                         "rocprof": rocprof_row("bench_4096"),
+                         # (the bench run's table holds every instantiation: the headline's is the <block, lanes per env, ...> one with the most calls)
+                         "rocprof": rocprof_row("bench_4096", f"taco_step_kernel<{block}, {4 if base.kernel_form.startswith('quad') else 1}, ", by="Calls"),
                          "note": "frac = ALGORITHMIC bytes (SURVEY 8d) / kernel time / 8 TB/s; traffic_frac = counter-measured HBM bytes / kernel time / 8 TB/s. "
                                  "4096 envs = 256 step wavefronts (4 lanes per env, one per CU) + 3 post-phase role wavefronts each: instruction-latency "
                                  "regime (SURVEY 8d): what binds is the instruction stream of the slowest wavefront (latency_floor: ~8.5 us in-kernel, "
