@@ -981,6 +981,20 @@ template <typename HT> __device__ __forceinline__ void split16(float v, HT &hi, 
 
 constexpr int CR_XROWS = (POL_MAXT + 1) * 16;   // rows of a block's frame planes: (T + 1) frames x 16 envs (a multiple of 16: the [k block][row] layout below is conflict-free)
 
+// TACO_LSTM_SYNC (round 6, an A/B switch; the product builds 0): how the eight wavefronts of the split LSTM kernel meet between timesteps.
+//   0  one workgroup barrier per timestep: every wavefront is in its MFMA chains, then in its cells, at the same time -- the two wavefronts of a SIMD run
+//      at roughly the SUM of both phases (2.9 us per timestep against 2.4 priced serially and 1.5 if both pipes were always busy);
+//   1  per-tile LDS counters instead (h_t of tile X is complete when its counter says so): no barrier inside the timestep loop;
+//   2  = 1 + the cooperative VALU work of a block (splitting the next block's frames, flushing h_T) done by wavefronts 4-7 alone, which puts them one
+//      segment BEHIND wavefronts 0-3, so that a SIMD's two wavefronts are in opposite phases.
+// Why it was tried: tools/ubench/mfma16_cross_wave (profiles/r06_f_ubench_mfma16_cross_wave.txt) -- unlike f32 MFMAs, 1 024 v_mfma_f32_16x16x32_f16 of one
+// wavefront and 4 096 v_fma of its SIMD partner finish in 29.1 k cycles, not in the 40.0 k of their sum (17.4 + 22.6): the partner's VALU issues under the
+// 16-bit MFMAs at ~60 % of its own rate.  What the kernel did with it: bit-identical values, 0.287 (1) and 0.291 ms (2) per values_ring(37 x 4 096) against
+// 0.278 (0), 1.195 / 1.235 against 1.163 ms at 557 056 rows (profiles/r06_g_ab_lstm_sync.txt): the counters' polling and the lost lock-step of the LDS
+// traffic cost more than the overlap returns -- round 5's two schedules (barrier-separated ping-pong, in-wave interleave) had lost the same way.
+#ifndef TACO_LSTM_SYNC
+#define TACO_LSTM_SYNC 0
+#endif
 template <int KIND>
 __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_split_kernel(const PolicyParams P) {
     typedef SplitKind<KIND> SK;
@@ -998,10 +1012,31 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_split_kerne
     __shared__ __attribute__((aligned(16))) unsigned char xp[2][2][4 * CR_XROWS * 16]; // [block parity][high / low half][k block][row][8 x 16 bit]
     __shared__ __attribute__((aligned(16))) unsigned char hs[2][2][CR_ROWS * CR_HLD];  // h_t: [buffer][high / low half][row][k], 16-bit
     __shared__ __attribute__((aligned(16))) float hT[CR_ROWS * CR_LD];                 // h_T (f32, swizzled like the MLP's tiles) on its way out
+    __shared__ int tile_cnt[2];   // TACO_LSTM_SYNC >= 1: cells() calls completed on tile A / B, summed over the wavefronts (monotonic over the kernel)
     constexpr int KSX = 2, KSH = 8, hp = 128, ip = 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
     const int T = P.states_len, sd = P.states_dim, N = P.ring_n;
+    if (tid < 2) tile_cnt[tid] = 0;   // (ordered ahead of every use by the barriers of the first block's staging)
+    // One wavefront's LDS operations execute in order (h_t before the increment on the writer's side, the counter before h_t on the reader's), so the
+    // fences only have to stop the compiler.  Bounded: a protocol bug ends in wrong values, never in a hang.
+    auto post_tile = [&](int tile) __attribute__((always_inline)) {
+        if constexpr (TACO_LSTM_SYNC >= 1) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            if (lane == 0) __hip_atomic_fetch_add(&tile_cnt[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    auto wait_tile = [&](int tile, int want) __attribute__((always_inline)) {
+        if constexpr (TACO_LSTM_SYNC >= 1) {
+            int spins = 0;
+            while (__hip_atomic_load(&tile_cnt[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(0);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    };
+    // the threads that do a block's cooperative work (frame split, h_T flush): all of them, or wavefronts 4-7 (SYNC 2)
+    constexpr int COOP_T = TACO_LSTM_SYNC == 2 ? 64 * POL_NW / 2 : 64 * POL_NW;
+    const bool coop = TACO_LSTM_SYNC == 2 ? wave >= POL_NW / 2 : true;
+    const int ctid = TACO_LSTM_SYNC == 2 ? tid - 64 * POL_NW / 2 : tid;
     const int S = P.n / N;
     const int groups = (N + 15) / 16, pairs = (S + 1) / 2, nblocks = groups * pairs;
     const int nb = ((int)blockIdx.x < nblocks) ? (nblocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
@@ -1070,9 +1105,11 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_split_kerne
             }
         }
     };
-    auto split_frames = [&](int half) {   // xst -> the two planes of xp[half]: every thread pairs of adjacent columns (one 4-byte store per plane)
+    auto split_frames = [&](int half, bool everyone) {   // xst -> the two planes of xp[half]: every thread pairs of adjacent columns (one 4-byte store per plane)
+        if (!everyone && !coop) return;
+        const int e0_ = everyone ? tid : ctid, stride_ = everyone ? 64 * POL_NW : COOP_T;
 #pragma unroll 1
-        for (int e = tid; e < (T + 1) * 16 * 16; e += 64 * POL_NW) {
+        for (int e = e0_; e < (T + 1) * 16 * 16; e += stride_) {
             const int row = e >> 4, k = (e & 15) * 2;
             float v0 = k < sd ? xst[row * sd + k] : (k == sd ? 1.0f : 0.0f);
             float v1 = k + 1 < sd ? xst[row * sd + k + 1] : (k + 1 == sd ? 1.0f : 0.0f);
@@ -1102,7 +1139,7 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_split_kerne
     stage((int)blockIdx.x);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    split_frames(0);
+    split_frames(0, true);
     __syncthreads();
 
     // ONE accumulator set for the three chains of a product chain (third form, same round: gfx950's 16-bit MFMAs KEEP subnormal operands --
@@ -1158,11 +1195,13 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_split_kerne
             *reinterpret_cast<V4 *>(oh + CR_ROWS * CR_HLD) = lo;
         }
     };
-    auto flush_hT = [&](int blk) {
+    auto flush_hT = [&](int blk, bool everyone) {
+        if (!everyone && !coop) return;
         const int pair = blk / groups, e0 = (blk - pair * groups) * 16;
-#pragma unroll
-        for (int j = 0; j < CR_ROWS * (hp / 4) / (64 * POL_NW); ++j) {
-            const int e = tid + 64 * POL_NW * j, row = e >> 5, k4 = e & 31;
+        const int e0_ = everyone ? tid : ctid, stride_ = everyone ? 64 * POL_NW : COOP_T;
+#pragma unroll 1
+        for (int e = e0_; e < CR_ROWS * (hp / 4); e += stride_) {
+            const int row = e >> 5, k4 = e & 31;
             const int slot = 2 * pair + (row >> 4), env = e0 + (row & 15);
             if (slot < S && env < N)
                 *reinterpret_cast<float4 *>(P.hT + ((size_t)slot * N + env) * hp + 4 * k4) = *reinterpret_cast<const float4 *>(hT + cr_sw4(row, k4));
@@ -1172,32 +1211,44 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_split_kerne
         const int blk = (int)blockIdx.x + k * (int)gridDim.x;
         const unsigned char *xh = xp[k & 1][0];
         if (k + 1 < nb) stage(blk + (int)gridDim.x);   // (xst is free: its frames were split into xp[k & 1] a block ago)
-        if (k > 0) flush_hT(blk - (int)gridDim.x);
+        if constexpr (TACO_LSTM_SYNC >= 1) {
+            // the previous block is COMPLETE in every wavefront (its last cells wrote h_T, and its last chains read the h planes timestep 0 is about to
+            // overwrite): what the barrier behind its last timestep said
+            if (k > 0) { wait_tile(0, 8 * k * T); wait_tile(1, 8 * k * T); }
+        }
+        if (k > 0) flush_hT(blk - (int)gridDim.x, TACO_LSTM_SYNC != 2);
         // ---- timestep 0: x chains only (h_{-1} = 0)
         x_chain(xh, 0);
         cells(0, 0, cstA, true);
+        post_tile(0);
         x_chain(xh, 1);
 #pragma unroll
         for (int q = 0; q < 4; ++q) keep[q] = am[q];
         cells(0, 1, cstB, true);
+        post_tile(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next block's frames have landed
         __syncthreads();
-        if (k + 1 < nb) split_frames((k + 1) & 1);        // ... and become its planes (read from the next block on: T - 1 >= 1 barriers lie in between)
+        if (k + 1 < nb) split_frames((k + 1) & 1, TACO_LSTM_SYNC != 2);   // ... and become its planes (read from the next block on: T - 1 >= 1 barriers / counter waits lie in between)
         for (int t = 1; t < T; ++t) {
             const unsigned char *hprev = hs[(t - 1) & 1][0];
 #pragma unroll
             for (int q = 0; q < 4; ++q) am[q] = keep[q];        // tile A: bias + W_ih x(frame t), computed for tile B a timestep ago
+            wait_tile(0, 8 * (k * T + t));                       // h_{t-1} of tile A is complete (all eight wavefronts' columns)
             h_chain(hprev, 0);
             cells(t, 0, cstA, false);
+            post_tile(0);
             x_chain(xh, t + 1);                                // tile B: frame t + 1
 #pragma unroll
             for (int q = 0; q < 4; ++q) keep[q] = am[q];
+            wait_tile(1, 8 * (k * T + t));
             h_chain(hprev, 1);
             cells(t, 1, cstB, false);
-            __syncthreads();
+            post_tile(1);
+            if constexpr (TACO_LSTM_SYNC == 0) __syncthreads();
         }
     }
-    flush_hT((int)blockIdx.x + (nb - 1) * (int)gridDim.x);
+    if constexpr (TACO_LSTM_SYNC >= 1) { wait_tile(0, 8 * nb * T); wait_tile(1, 8 * nb * T); }
+    flush_hT((int)blockIdx.x + (nb - 1) * (int)gridDim.x, true);
 }
 
 // value = W3 relu(W2 relu(W1 h_T + b1) + b2) + b3 over the workspace rows (critic_body's dense layers; same chains, same bits)
