@@ -312,7 +312,7 @@ def config_entry(idx, n, dev, torch, warm=0.1):
     return {"config": idx + 1, "task_mode": cfg["task_mode"], "envs": n, "len_states": env.len_states, "flags_on": flags, "kernel_us": med,
             "env_steps_per_s": n / (med * 1e-6), "algorithmic_bytes_per_env_step": b, "achieved_GBps": b * n / (med * 1e-6) / 1e9,
             "frac_of_hbm_peak": b * n / (med * 1e-6) / 1e9 / HBM_PEAK_GBPS, "kernel_form": env.kernel_form, "grid": grid, "block": block,
-            "rocprof": rocprof_row({(1, 16384): "rotate_16384", (2, 16384): "flip_16384", (3, 32768): "mix_32768x5"}.get((idx, n), "none")), **extra}
+            "rocprof": rocprof_row({(2, 16384): "rotate_16384", (3, 16384): "flip_16384", (4, 32768): "mix_32768x5"}.get((idx, n), "none")), **extra}
 
 
 def graph_entry(n, acts, dev, torch, steps_in_graph=64):
@@ -929,6 +929,7 @@ def sharded_config_leg(number, rank, world, dev, torch, timed, gather_floats, st
         k_us, _ = time_kernel_launches(senv.env, sacts, min(steps, 200), torch)
         entry = {"config": number, "task_mode": task, "envs_total": total, "envs_per_rank": n_local, "len_states": senv.env.len_states, "steps": steps,
                  "value": total * steps / el, "unit": "env-steps/s", "ms_per_step": el / steps * 1e3, "kernel_us_per_rank": gather_floats(k_us),
+                 "rocprof": rocprof_row({(5, 262144): "mix_262144x5", (3, 16384): "rotate_16384"}.get((number, n_local), "none")) if rank == 0 else None,
                  "kernel_form": senv.env.kernel_form, "states_path": "frame ring (one frame per env-step)" if senv.env._ring_on else "in place",
                  # (a state stack lives in the frame ring: the algorithmic 820 B; SURVEY 8d's + 104 B per frame is for a MATERIALISED stack)
                  "frac_of_hbm_peak_per_gpu": (ALGO_BYTES_PER_ENV_STEP if senv.env._ring_on else algo_bytes(senv.env.len_states)) * n_local / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBPS}
