@@ -1,7 +1,7 @@
 """Rollout fuzz: taco_rollout_run with the persistent actor + step kernel vs the launch-per-step path of the same call, bit for bit, over random
 configurations (tools/fuzz.py's generator restricted to what the persistent form takes: one obs frame, at most 8 192 envs, unclamped stacks).
 
-    python tools/fuzz_rollout.py [--cases 200] [--seed 0] [--oracle]
+    python tools/fuzz_rollout.py [--cases 200] [--seed 0] [--oracle] [--form auto|quad|lane]
 
 --oracle: both paths run with the exact LSTM cell, and every case of at most 20 000 env-steps per rollout is ALSO held against the CPU oracle's
 orc_rollout (oracle/taco_policy_oracle.c) directly: every replay-buffer array, the final value, the env's state, bit for bit.
@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--only", type=int, default=-1, help="run only this case of the sequence (the draws of the earlier ones are replayed)")
     ap.add_argument("--oracle", action="store_true", help="exact LSTM cell; small cases are also compared with the CPU oracle's orc_rollout")
+    ap.add_argument("--form", default="auto", choices=["auto", "quad", "lane"], help="the persistent kernel's form: auto (the host's choice: quad at these sizes), "
+                    "quad, or lane (round 6's one-lane form, 64 envs per workgroup, forced)")
     args = ap.parse_args()
     import torch
     import fuzz
@@ -58,7 +60,7 @@ def main():
             continue
         sd = TP._random_policy(np.random.default_rng(1000 + i), 1, T, [128, 128, 128], 128, [128, 128])
         outs = []
-        for fused in (True, False):
+        for fused in (True if args.form == "auto" else args.form, False):
             env = FpvBase(cfg, copy_outputs=False)
             env.set_rollout_fusion(fused)
             stamps = torch.zeros(136 + (n + 15) // 16, dtype=torch.int64, device="cuda")
@@ -96,7 +98,7 @@ def main():
                                                                              "state": env.get_state().view(torch.int32).clone()})
             torch.cuda.synchronize()
             ran = bool(stamps[8:8 + 2 * min(H, 64)].min() > 0)
-            assert ran == fused, f"case {i}: persistent kernel ran = {ran} with fusion = {fused}: {fuzz.describe(cfg)}"
+            assert ran == bool(fused), f"case {i}: persistent kernel ran = {ran} with fusion = {fused}: {fuzz.describe(cfg)}"
             outs.append(snaps)
         failed = []
         for epoch in range(2):
