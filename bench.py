@@ -11,7 +11,7 @@ A "step" is one VecTask.step() of the whole batch = ONE taco_step launch through
 (task_mode=pos, 4 096 envs, rotor_response_time=0.017).  For N > 1 every rank holds 4 096 envs (weak scaling; global env ids are disjoint
 contiguous slices) and EVERY timed step carries north_star's collective: one RCCL all-gather of the kernel-filled [obs|reward|done|time-out]
 block per step, overlapped as SURVEY 8(e) prescribes (ShardedEnv.step_async: the gather of step t runs on the process group's stream
-under the launch of step t + 1 and is waited for right after it; the last gather is waited for inside the timed region).
+under the kernel of step t + 1 and is waited for right after that launch, before gather t + 1 is issued; the last gather is waited for inside the timed region).
 value = N * 4096 * K / max-over-ranks time (every rank: W warm-up steps, synchronize + barrier + synchronize, t0, K steps + the drain of
 the last gather, synchronize, t1, barrier; before the warm-up a twin env is stepped for 0.2 s so that a short region does not time the
 process's first calls).  Reported beside it: "without_allgather" (the gather-free ShardedEnv.step_local of the same K steps: what a
@@ -599,10 +599,12 @@ def main():
         n_local = env.hi - env.lo
         pend = []
 
-        def step_overlapped(a):   # the gather of step t is waited for only after step t + 1 has been launched (two alternating blocks)
-            pend.append(env.step_async(a))
-            if len(pend) > 1:
+        def wait_previous():
+            while pend:
                 pend.pop(0).wait()
+
+        def step_overlapped(a):   # the gather of step t is waited for once the KERNEL of step t + 1 is in flight, then gather t + 1 is issued (two alternating blocks)
+            pend.append(env.step_async(a, before_gather=wait_previous))
 
         def finish_overlapped():  # ... and the last one inside the timed region
             while pend:

@@ -14,7 +14,9 @@ shards make that the global env order; ragged shards (numEnvs not a multiple of 
 Overlap (the gather of ~12-25 us is comparable to the step itself): `ShardedEnv.step_async` issues the
 collective with async_op=True -- RCCL runs it on the process group's own stream, ordered behind the step kernel -- and
 returns a handle; the next step's launch does not wait for it.  Two block / result buffers alternate, and a step that
-is about to refill a block first waits (stream-side) for the gather that last read it.  `step_gathered` = step_async +
+is about to refill a block first waits (stream-side) for the gather that last read it.  An overlapped loop passes
+`before_gather` = "wait for the previous step's gather": the wait then sits between this step's kernel launch and this
+step's collective, so the kernel runs under the previous gather and at most one collective is outstanding when the next is issued.  `step_gathered` = step_async +
 wait is the serial form a single learner that needs obs(t) before action(t+1) uses.
 """
 import torch
@@ -143,9 +145,11 @@ class ShardedEnv:
         self._bind(None)
         return self.env.step(local_actions)
 
-    def step_async(self, local_actions):
+    def step_async(self, local_actions, before_gather=None):
         """One step of this rank's envs + the all-gather of its block, issued without waiting for it: returns a GatheredBlocks whose
-        `wait()` orders the current stream behind the collective.  (gather off / one rank: the local block, nothing pending)"""
+        `wait()` orders the current stream behind the collective.  (gather off / one rank: the local block, nothing pending)
+        before_gather: called between the kernel launch and the collective -- where an overlapped loop waits for the PREVIOUS step's gather
+        (the step kernel is already in flight under it; at most one collective of this env is outstanding when the next is issued)."""
         k = self.k
         if self.pending[k] is not None:  # the gather that last read this block / wrote this result must be done before both are reused
             self.pending[k].wait()
@@ -154,6 +158,8 @@ class ShardedEnv:
         self._bind(self.block)
         self.env.step_raw(local_actions)
         self.k = 1 - k
+        if before_gather is not None:
+            before_gather()
         if not self.gather or (self.world_size == 1 and not self.collective_when_alone):
             return GatheredBlocks(self.block[: self.hi - self.lo], [self.hi - self.lo])
         g = all_gather_blocks(self.block, self.n_global, self.world_size, self.group, out=self.outs[k], async_op=True)
