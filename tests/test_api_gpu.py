@@ -774,6 +774,23 @@ for t in range(40):
     torch.cuda.synchronize()
     assert torch.equal(obs, ref.obs_buf) and torch.equal(rew, ref.rew_buf) and torch.equal(done, ref.reset_buf) and torch.equal(tmo, ref.timeout_buf), t
 env.drain()
+# bench.py's overlapped loop (round 6): the previous step's gather is waited for between this step's kernel launch and this step's collective;
+# what each gather delivered is checked one step late, against a copy of the reference's buffers of THAT step
+pend, held = [], []
+def wait_previous():
+    while pend:
+        g_, want = pend.pop(0), held.pop(0)
+        rows_ = g_.wait().global_rows()
+        o_, r_, d_, t_ = unpack_block(rows_, env.len_obs)
+        torch.cuda.synchronize()
+        assert torch.equal(o_, want[0]) and torch.equal(r_, want[1]) and torch.equal(d_, want[2]) and torch.equal(t_, want[3]), "overlapped gather"
+for t in range(40, 70):
+    ref.step_raw(acts[t % 6])
+    want = (ref.obs_buf.clone(), ref.rew_buf.clone(), ref.reset_buf.clone(), ref.timeout_buf.clone())
+    g_ = env.step_async(acts[t % 6], before_gather=wait_previous)
+    pend.append(g_); held.append(want)
+wait_previous()
+env.drain()
 assert dist.get_backend() == "nccl"
 # ... and the collectives bench.py brackets its timed region with (barrier, MAX-reduction and all_gather of fp64 scalars on the device)
 t = torch.tensor([3.5], device=dev, dtype=torch.float64)
