@@ -560,6 +560,8 @@ def main():
     ap.add_argument("--gather", action="store_true", help="(the default since round 6; kept so that old command lines still parse)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the per-step all-gather out of the main timed region (the gather-free "
                     "sharded path becomes the headline; the gathered variants are still timed and reported)")
+    ap.add_argument("--direct-rccl", action="store_true", help="N > 1 over RCCL: the per-step all-gather as ONE ncclAllGather called directly on a comm stream "
+                    "(taco_amd/rccl.py; opt-in: its multi-rank initialisation has never run on real hardware) instead of torch.distributed's collective")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall-time budget of the all-cores CPU baseline sample of config 1")
     ap.add_argument("--no-large-n", action="store_true")
@@ -595,7 +597,7 @@ def main():
     finish_main = None
     if world > 1:
         from taco_amd.dist import ShardedEnv
-        env = ShardedEnv(cfg, rank=rank, world_size=world, device=dev, gather=gathered_main)
+        env = ShardedEnv(cfg, rank=rank, world_size=world, device=dev, gather=gathered_main, direct=bool(args.direct_rccl and backend_used == "nccl" and not solo))
         n_local = env.hi - env.lo
         pend = []
 
@@ -740,7 +742,11 @@ def main():
                 multi["with_allgather"] = {"value": n_global * args.steps / el_over, "unit": "env-steps/s", "ms_per_step": el_over / args.steps * 1e3,
                                            "what": "overlapped: step t + 1 is launched before the gather of step t is waited for (two alternating blocks)"}
             multi["allgather"] = {"collective": "1 all_gather_into_tensor of the kernel-filled [obs|rew|done|timeout] block per step",
-                                  "bytes_per_rank": int(env.block.numel() * 4), "backend": backend_used}
+                                  "bytes_per_rank": int(env.block.numel() * 4), "backend": backend_used,
+                                  "path": ("ncclAllGather called directly on a comm stream (--direct-rccl, taco_amd/rccl.py)" if env.direct_path else
+                                           "torch.distributed all_gather_into_tensor (async_op)"), "direct_reason": env.direct_reason,
+                                  "host_cost_note": "torch.distributed's collective costs 24-38 us of host time per call on this stack (profiles/r06_l_gather_host_cost.txt, one rank): "
+                                                    "at 4 096 envs per GPU the gathered headline is bound by that, not by the 11-us kernel"}
         except Exception as e:  # noqa: BLE001
             multi["allgather_legs_error"] = repr(e)[:300]
         env.gather = gathered_main

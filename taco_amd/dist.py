@@ -108,7 +108,12 @@ def all_gather_blocks(block, n_global, world_size, group=None, out=None, async_o
 class ShardedEnv:
     """This rank's slice of a `numEnvs`-wide job on its own MI355X."""
 
-    def __init__(self, cfg, rank, world_size, device, gather=True, group=None, collective_when_alone=False):
+    def __init__(self, cfg, rank, world_size, device, gather=True, group=None, collective_when_alone=False, direct=False):
+        """direct: False (default) -- the per-step all-gather is the process group's all_gather_into_tensor; True (opt-in) -- when the group's backend
+        is RCCL ("nccl") it is ONE ncclAllGather called directly on a comm stream (taco_amd/rccl.py), after a self-check every rank agrees on.
+        Measured with the one rank a one-GPU box allows (profiles/r06_l_gather_host_cost.txt): 23.3 us of host time per overlapped step against
+        29.4 through torch.distributed (5 without a collective).  Opt-in because its multi-rank initialisation has never run on real hardware
+        (RCCL refuses two ranks on one device, and no multi-GPU node was available to the builder).  `direct_path` / `direct_reason` tell which one runs."""
         from .vec_env import FpvBase
         self.rank, self.world_size, self.group, self.gather = rank, world_size, group, gather
         # a 1-rank job needs no collective; collective_when_alone issues it anyway -- what lets a ONE-GPU box execute the RCCL branch for real
@@ -130,6 +135,20 @@ class ShardedEnv:
         self.block = self.blocks[0]
         self._bound = None
         self._bind(self.block)
+        self.direct, self.direct_reason = None, "not asked for"
+        if direct and (world_size > 1 or self.collective_when_alone):
+            import torch.distributed as dist
+            if not (dist.is_available() and dist.is_initialized()):
+                self.direct_reason = "no process group"
+            elif dist.get_backend(group) != "nccl":
+                self.direct_reason = f"the process group's backend is {dist.get_backend(group)}, not RCCL"   # (gloo rehearsals: several ranks share a device)
+            else:
+                from . import rccl
+                self.direct, self.direct_reason = rccl.make_direct_comm(rank, world_size, self.env.device, group)
+
+    @property
+    def direct_path(self):
+        return self.direct is not None
 
     def _bind(self, block):
         """the block the step kernel fills besides its outputs (None: none -- the launch a single-GPU VecTask.step() makes)"""
@@ -162,7 +181,10 @@ class ShardedEnv:
             before_gather()
         if not self.gather or (self.world_size == 1 and not self.collective_when_alone):
             return GatheredBlocks(self.block[: self.hi - self.lo], [self.hi - self.lo])
-        g = all_gather_blocks(self.block, self.n_global, self.world_size, self.group, out=self.outs[k], async_op=True)
+        if self.direct is not None:   # one ncclAllGather on the comm stream, ordered behind the step kernel by an event
+            g = GatheredBlocks(self.outs[k], self.sizes, self.direct.all_gather(self.outs[k], self.block))
+        else:
+            g = all_gather_blocks(self.block, self.n_global, self.world_size, self.group, out=self.outs[k], async_op=True)
         self.pending[k] = g
         return g
 

@@ -735,11 +735,14 @@ def test_sharded_env_step_local_is_the_single_gpu_launch_and_rebinding_works():
     assert torch.equal(a.env.get_state(), b.env.get_state())
 
 
-def test_rccl_backend_runs_the_gather_path_on_one_rank():
+@pytest.mark.parametrize("direct", [True, False])
+def test_rccl_backend_runs_the_gather_path_on_one_rank(direct):
     """torch.distributed's "nccl" backend IS RCCL on ROCm.  The test box has ONE GPU and RCCL refuses two ranks on one device, so the N > 1 tests
     run over gloo -- here the RCCL branch itself executes, with a 1-rank group: communicator init, ShardedEnv.step_async / step_gathered issuing
     all_gather_into_tensor on the kernel-filled device block (async handle, the two alternating blocks, the stream-side wait), results equal to
-    the env's own buffers.  In a child process (a process group is process-wide state)."""
+    the env's own buffers.  direct=True (the default when the backend is RCCL, round 6): the gather is ONE ncclAllGather called directly on a comm
+    stream (taco_amd/rccl.py: unique id through the process group, self-check, event-ordered); False: the process group's collective.
+    In a child process (a process group is process-wide state)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -754,7 +757,8 @@ from taco_amd.vec_env import FpvBase
 dev = torch.device("cuda:0")
 n = 3000
 cfg = config.default_cfg("mix", n, env_lenObservations=2, env_lenStates=3, env_maxEpisodeLength=20, observation_noise=True)
-env = ShardedEnv(cfg, rank=0, world_size=1, device=dev, gather=True, collective_when_alone=True)
+env = ShardedEnv(cfg, rank=0, world_size=1, device=dev, gather=True, collective_when_alone=True, direct=DIRECT)
+assert env.direct_path == DIRECT, env.direct_reason     # round 6: ONE ncclAllGather called directly on a comm stream (taco_amd/rccl.py) / the process group's collective
 ref = FpvBase(config.default_cfg("mix", n, env_lenObservations=2, env_lenStates=3, env_maxEpisodeLength=20, observation_noise=True), copy_outputs=False)
 g = torch.Generator().manual_seed(2)
 acts = (0.3 * torch.randn((6, n, 4), generator=g)).clamp(-1, 1).to(dev)
@@ -804,5 +808,5 @@ dist.destroy_process_group()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    out = subprocess.run([sys.executable, "-c", code.replace("DIRECT", repr(bool(direct)))], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "RCCL-GATHER-OK" in out.stdout, (out.stdout + out.stderr)[-3000:]
