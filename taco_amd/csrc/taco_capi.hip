@@ -953,6 +953,10 @@ int taco_critic_values(const taco_policy_cfg *c, const float *blob, int64_t rows
     return launch_critic(c, blob, (size_t)rows, states, value, nullptr, (size_t)rows + 1, (float *)workspace, 0, stream, stamps);
 }
 
+#ifdef TACO_LSTM_STAMPS   // A/B probe builds only (never defined in the product build): where taco_critic_values_ring's split LSTM kernel leaves its segment stamps
+static uint64_t *g_lstm_stamps = nullptr;
+extern "C" void taco_debug_set_lstm_stamps(uint64_t *p) { g_lstm_stamps = p; }
+#endif
 int taco_critic_values_ring(const taco_policy_cfg *c, const float *blob, int64_t slots, int num_envs, const float *frames, float *value, void *workspace,
                             void *stream) {
     const int rc = policy_cfg_ok(c);
@@ -961,7 +965,11 @@ int taco_critic_values_ring(const taco_policy_cfg *c, const float *blob, int64_t
     if (slots < 1 || num_envs < 1) return fail(TACO_ERR_INVALID_ARG, "taco_critic_values_ring: slots and num_envs must be >= 1");
     if (((uintptr_t)blob & 15u) != 0) return fail(TACO_ERR_INVALID_ARG, "taco_critic_values_ring: the weight blob must be 16-byte aligned");
     const size_t rows = (size_t)slots * (size_t)num_envs;
+#ifdef TACO_LSTM_STAMPS
+    return launch_critic(c, blob, rows, frames, value, nullptr, rows + 1, (float *)workspace, 0, stream, g_lstm_stamps, num_envs);
+#else
     return launch_critic(c, blob, rows, frames, value, nullptr, rows + 1, (float *)workspace, 0, stream, nullptr, num_envs);
+#endif
 }
 
 int taco_policy_act_stamped(const taco_policy_cfg *c, const float *blob, int n, const float *obs, const float *states, uint64_t seed, uint32_t call,

@@ -1018,6 +1018,13 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_split_kerne
     const int r = lane & 15, g = lane >> 4;
     const int T = P.states_len, sd = P.states_dim, N = P.ring_n;
     if (tid < 2) tile_cnt[tid] = 0;   // (ordered ahead of every use by the barriers of the first block's staging)
+#ifdef TACO_LSTM_STAMPS   // A/B probe builds only: segment boundaries of wavefronts 0 and 4 of workgroup 0 (P.stamps: [2][128] shader-clock words)
+    int stamp_no = 0;
+    const bool stamping = P.stamps != nullptr && blockIdx.x == 0 && (wave & 3) == 0 && lane == 0;
+#define LSTM_STAMP() do { if (stamping && stamp_no < 128) P.stamps[(wave >> 2) * 128 + stamp_no++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define LSTM_STAMP() do { } while (0)
+#endif
     // One wavefront's LDS operations execute in order (h_t before the increment on the writer's side, the counter before h_t on the reader's), so the
     // fences only have to stop the compiler.  Bounded: a protocol bug ends in wrong values, never in a hang.
     auto post_tile = [&](int tile) __attribute__((always_inline)) {
@@ -1178,6 +1185,8 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_split_kerne
         const bool last = t + 1 >= T;
         const int row = 16 * tile + r;
         float hv[4];
+        // (two cells per call on gfx950's packed f32 multiply / add / fma -- 73 VALU instructions fewer per timestep, bit-identical -- bought nothing:
+        // 0.278 vs 0.278 ms, profiles/r06_n_ab_packed_cell.txt; v_pk_*_f32 issue at half rate, tools/ubench/mfma_valu "v_pk_fma_f32 | same")
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float cn;
@@ -1234,17 +1243,24 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_split_kerne
 #pragma unroll
             for (int q = 0; q < 4; ++q) am[q] = keep[q];        // tile A: bias + W_ih x(frame t), computed for tile B a timestep ago
             wait_tile(0, 8 * (k * T + t));                       // h_{t-1} of tile A is complete (all eight wavefronts' columns)
+            LSTM_STAMP();
             h_chain(hprev, 0);
+            LSTM_STAMP();
             cells(t, 0, cstA, false);
             post_tile(0);
+            LSTM_STAMP();
             x_chain(xh, t + 1);                                // tile B: frame t + 1
 #pragma unroll
             for (int q = 0; q < 4; ++q) keep[q] = am[q];
             wait_tile(1, 8 * (k * T + t));
+            LSTM_STAMP();
             h_chain(hprev, 1);
+            LSTM_STAMP();
             cells(t, 1, cstB, false);
             post_tile(1);
+            LSTM_STAMP();
             if constexpr (TACO_LSTM_SYNC == 0) __syncthreads();
+            LSTM_STAMP();
         }
     }
     if constexpr (TACO_LSTM_SYNC >= 1) { wait_tile(0, 8 * nb * T); wait_tile(1, 8 * nb * T); }
