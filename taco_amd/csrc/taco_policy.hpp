@@ -1155,6 +1155,7 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_split_kerne
     // -- tile A's start of the next timestep -- lives again instead of being parked in LDS).
     pf32x4 am[4], keep[4];
     float cstA[4], cstB[4];
+    // (fetching the frame's planes a cells() call ahead of this chain was tried with the h chain's prefetch below: no gain, profiles/r06_s_ab_hchain_prefetch.txt)
     auto x_chain = [&](const unsigned char *xh, int f) __attribute__((always_inline)) {   // am = bias + W_ih x(frame f) (combined), rows = the block's 16 envs
         const int at = (g * CR_XROWS + f * 16 + r) << 4;
         const V8 ah = *reinterpret_cast<const V8 *>(xh + at), al = *reinterpret_cast<const V8 *>(xh + 4 * CR_XROWS * 16 + at);
@@ -1167,6 +1168,30 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_split_kerne
     };
     auto h_chain = [&](const unsigned char *hprev, int tile) __attribute__((always_inline)) {   // am (= the x part) += W_hh h_{t-1}
         const unsigned char *rowh = hprev + (16 * tile + r) * CR_HLD, *rowl = rowh + CR_ROWS * CR_HLD;
+#ifndef TACO_AB_HCHAIN_NOPREFETCH
+        // the NEXT k block's two planes are on their way while this block's twelve MFMAs issue (round 6: left to itself the compiler read a block's
+        // operands right ahead of its MFMAs and waited -- ~80 clocks of LDS latency per k block on the chain's path: 1 090 -> 970 clocks for the 48 MFMAs, the timestep
+        // 6 180 -> 5 970; values_ring(37 x 4 096) 0.271 -> 0.268 ms, the critic at 557 056 rows 1.165 -> 1.135 ms, bit-identical: profiles/r06_s_ab_hchain_prefetch.txt)
+        const int pos0 = (g ^ cr_b(r)) << 4;
+        V8 nh = *reinterpret_cast<const V8 *>(rowh + pos0), nl = *reinterpret_cast<const V8 *>(rowl + pos0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+        for (int sb = 0; sb < 4; ++sb) {
+            const V8 ah = nh, al = nl;
+            if (sb + 1 < 4) {
+                const int pos = ((4 * (sb + 1) + g) ^ cr_b(r)) << 4;
+                nh = *reinterpret_cast<const V8 *>(rowh + pos); nl = *reinterpret_cast<const V8 *>(rowl + pos);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) am[q] = SK::mfma(whl[q][sb], ah, am[q]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) am[q] = SK::mfma(whh[q][sb], al, am[q]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) am[q] = SK::mfma(whh[q][sb], ah, am[q]);
+            if (sb + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // the next block's two reads FIRST ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);                  // ... then this block's twelve MFMAs
+        }
+#else
 #pragma unroll
         for (int sb = 0; sb < 4; ++sb) {
             const int pos = ((4 * sb + g) ^ cr_b(r)) << 4;
@@ -1178,6 +1203,7 @@ __global__ __launch_bounds__(64 * POL_NW) void taco_critic_lstm_pair_split_kerne
 #pragma unroll
             for (int q = 0; q < 4; ++q) am[q] = SK::mfma(whh[q][sb], ah, am[q]);
         }
+#endif
     };
     // this lane's cells: env row 16 tile + r, hidden columns c0 .. c0 + 3
     const int c0 = 16 * wave + 4 * g;
